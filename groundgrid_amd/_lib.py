@@ -1,0 +1,139 @@
+"""ctypes loader for libgroundgrid_hip.so (the C ABI of include/groundgrid_hip.h).
+
+The library is built in-tree by ``groundgrid_amd.build.build()`` (hipcc, gfx950).  Loading fails loudly
+if the .so is missing: the product has no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgroundgrid_hip.so")
+
+GG_OK = 0
+STATUS = {
+    0: "GG_OK",
+    -1: "GG_ERR_INVALID",
+    -2: "GG_ERR_GEOMETRY",
+    -3: "GG_ERR_NOMEM",
+    -4: "GG_ERR_HIP",
+    -5: "GG_ERR_CAPACITY",
+    -6: "GG_ERR_NO_DEVICE",
+}
+
+GG_POINT32, GG_POINT16 = 0, 1
+GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE = 1, 2
+GG_NUM_KERNELS = 7
+GG_NUM_LAYERS = 11
+
+LAYERS = [
+    "points", "ground", "groundpatch", "minGroundHeight", "maxGroundHeight", "groundCandidates",
+    "planeDist", "m2", "meanVariance", "pointsRaw", "variance",
+]
+
+# every symbol include/groundgrid_hip.h declares
+SYMBOLS = [
+    "gg_abi_version", "gg_kernel_name", "gg_default_config", "gg_default_geometry", "gg_create", "gg_destroy",
+    "gg_set_config", "gg_get_config", "gg_set_flags", "gg_get_size", "gg_get_geometry", "gg_last_error",
+    "gg_reset_map", "gg_set_map_position", "gg_set_layer", "gg_get_layer", "gg_get_expected_points",
+    "gg_filter_cloud", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
+]
+
+
+class GGConfig(C.Structure):
+    """gg_config == groundgrid::GroundGridConfig (cfg/GroundGrid.cfg:8-21)"""
+
+    _fields_ = [
+        ("point_count_cell_variance_threshold", C.c_int),
+        ("max_ring", C.c_int),
+        ("groundpatch_detection_minimum_threshold", C.c_double),
+        ("distance_factor", C.c_double),
+        ("minimum_distance_factor", C.c_double),
+        ("miminum_point_height_threshold", C.c_double),
+        ("minimum_point_height_obstacle_threshold", C.c_double),
+        ("outlier_tolerance", C.c_double),
+        ("ground_patch_detection_minimum_point_count_threshold", C.c_double),
+        ("patch_size_change_distance", C.c_double),
+        ("occupied_cells_decrease_factor", C.c_double),
+        ("occupied_cells_point_count_factor", C.c_double),
+        ("min_outlier_detection_ground_confidence", C.c_double),
+        ("thread_count", C.c_int),
+    ]
+
+
+class GGGeometry(C.Structure):
+    _fields_ = [
+        ("length", C.c_float),
+        ("resolution", C.c_float),
+        ("vertical_point_ang_dist", C.c_float),
+        ("min_dist_squared", C.c_float),
+    ]
+
+
+class GGBatch(C.Structure):
+    _fields_ = [
+        ("n_clouds", C.c_int),
+        ("first_slot", C.c_int),
+        ("point_format", C.c_int),
+        ("d_points", C.c_void_p),
+        ("cloud_stride", C.c_size_t),
+        ("n_points", C.POINTER(C.c_int32)),
+        ("origins", C.POINTER(C.c_float)),
+        ("base_z", C.POINTER(C.c_double)),
+        ("d_labels", C.c_void_p),
+        ("d_out_index", C.c_void_p),
+        ("d_out_clouds", C.c_void_p),
+        ("d_out_counts", C.c_void_p),
+    ]
+
+
+class GroundGridError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GroundGridError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    vp = C.c_void_p
+    L.gg_abi_version.restype = C.c_int
+    L.gg_kernel_name.restype = C.c_char_p
+    L.gg_kernel_name.argtypes = [C.c_int]
+    L.gg_default_config.argtypes = [P(GGConfig)]
+    L.gg_default_config.restype = None
+    L.gg_default_geometry.argtypes = [P(GGGeometry)]
+    L.gg_default_geometry.restype = None
+    L.gg_create.argtypes = [P(GGGeometry), C.c_int, C.c_size_t, C.c_int, P(vp)]
+    L.gg_destroy.argtypes = [vp]
+    L.gg_destroy.restype = None
+    L.gg_set_config.argtypes = [vp, P(GGConfig)]
+    L.gg_get_config.argtypes = [vp, P(GGConfig)]
+    L.gg_set_flags.argtypes = [vp, C.c_uint]
+    L.gg_get_size.argtypes = [vp, P(C.c_int), P(C.c_int)]
+    L.gg_get_geometry.argtypes = [vp, P(C.c_double), P(C.c_double), P(C.c_double)]
+    L.gg_last_error.argtypes = [vp]
+    L.gg_last_error.restype = C.c_char_p
+    L.gg_reset_map.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_float]
+    L.gg_set_map_position.argtypes = [vp, C.c_int, C.c_double, C.c_double]
+    L.gg_set_layer.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.gg_get_layer.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.gg_get_expected_points.argtypes = [vp, vp]
+    L.gg_filter_cloud.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_float), C.c_double, vp, P(C.c_size_t), vp, vp]
+    L.gg_filter_batch.argtypes = [vp, P(GGBatch), vp]
+    L.gg_synchronize.argtypes = [vp]
+    L.gg_get_point_classes.argtypes = [vp, C.c_int, C.c_size_t, vp, vp]
+    L.gg_get_kernel_times.argtypes = [vp, P(C.c_double), P(C.c_int64), C.c_int]
+    _lib = L
+    return L

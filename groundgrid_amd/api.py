@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's operator interface for the hot path, on top of the C ABI.
+
+``GroundSegmentation`` keeps the names and argument meaning of ``groundgrid::GroundSegmentation``
+(/root/reference/include/groundgrid/GroundSegmentation.h:48-71): ``init``, ``setConfig``,
+``filter_cloud``.  The grid map the reference borrows by reference (``grid_map::GridMap&``, owned by
+``GroundGrid``) lives in HBM inside the context; ``GridMap`` is a handle to one such map ("slot") with
+grid_map-like accessors.  ``filter_batch`` is the device-resident batched form (independent
+(cloud, map) pairs in one set of launches) used for throughput runs and multi-GPU sharding.
+
+PyTorch is used only for device buffers / streams in the batched path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import GGBatch, GGConfig, GGGeometry, GroundGridError, LAYERS
+from .synth import POINT_DTYPE
+
+# label / class codes (include/groundgrid_hip.h)
+DROPPED, GROUND, NONGROUND = 0, 49, 99
+OUTSIDE, IGNORED, OUTLIER, KEPT = 0, 1, 2, 3
+
+POINT16_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("ring", "<u2"), ("pad", "<u2")])
+
+
+def default_config() -> GGConfig:
+    c = GGConfig()
+    _lib.load().gg_default_config(C.byref(c))
+    return c
+
+
+def pack16(cloud: np.ndarray) -> np.ndarray:
+    """PointXYZIR (32 B) -> packed 16-B device records (x, y, z, ring)."""
+    out = np.zeros(cloud.shape[0], dtype=POINT16_DTYPE)
+    out["x"], out["y"], out["z"], out["ring"] = cloud["x"], cloud["y"], cloud["z"], cloud["ring"]
+    return out
+
+
+def _check(L, ctx, rc, what):
+    if rc != _lib.GG_OK:
+        msg = L.gg_last_error(ctx).decode() if ctx else ""
+        raise GroundGridError(f"{what}: {_lib.STATUS.get(rc, rc)} {msg}")
+
+
+class GridMap:
+    """Handle to one device-resident map state (the reference's grid_map::GridMap with its 11 layers)."""
+
+    def __init__(self, seg: "GroundSegmentation", slot: int):
+        self._seg = seg
+        self.slot = slot
+        self._pos = (0.0, 0.0)
+
+    # grid_map-like accessors
+    def getSize(self):
+        return self._seg.rows, self._seg.cols
+
+    def getResolution(self) -> float:
+        return self._seg.resolution
+
+    def getLength(self):
+        return self._seg.length
+
+    def getPosition(self):
+        return self._pos
+
+    def setPosition(self, x: float, y: float):
+        """Map position after grid_map::move (src/GroundGrid.cpp:97)."""
+        L, ctx = self._seg._L, self._seg._ctx
+        _check(L, ctx, L.gg_set_map_position(ctx, self.slot, float(x), float(y)), "gg_set_map_position")
+        self._pos = (float(x), float(y))
+
+    def reset(self, odom_z: float = 0.0, pos=(0.0, 0.0)):
+        """GroundGrid::initGroundGrid layer values (src/GroundGrid.cpp:71-75)."""
+        L, ctx = self._seg._L, self._seg._ctx
+        _check(L, ctx, L.gg_reset_map(ctx, self.slot, float(pos[0]), float(pos[1]), C.c_float(odom_z)), "gg_reset_map")
+        self._pos = (float(pos[0]), float(pos[1]))
+
+    def get(self, layer: str) -> np.ndarray:
+        """Layer as a (rows, cols) float32 array (element (i, j) == Eigen's matrix(i, j))."""
+        L, ctx = self._seg._L, self._seg._ctx
+        self._seg._sync_torch()
+        buf = np.empty(self._seg.rows * self._seg.cols, dtype=np.float32)
+        _check(L, ctx, L.gg_get_layer(ctx, self.slot, LAYERS.index(layer), buf.ctypes.data), "gg_get_layer")
+        return buf.reshape((self._seg.rows, self._seg.cols), order="F")
+
+    __getitem__ = get
+
+    def set(self, layer: str, arr: np.ndarray):
+        L, ctx = self._seg._L, self._seg._ctx
+        self._seg._sync_torch()
+        a = np.asfortranarray(np.asarray(arr, dtype=np.float32))
+        assert a.shape == (self._seg.rows, self._seg.cols)
+        flat = np.ascontiguousarray(a.reshape(-1, order="F"))
+        _check(L, ctx, L.gg_set_layer(ctx, self.slot, LAYERS.index(layer), flat.ctypes.data), "gg_set_layer")
+
+    def layers(self) -> dict:
+        return {n: self.get(n) for n in LAYERS}
+
+
+@dataclass
+class BatchOutputs:
+    labels: "object"      # torch.uint8 [B, stride]
+    out_index: "object"   # torch.int32 [B, stride]
+    counts: "object"      # torch.int32 [B, 4]: returned size, kept, ignored, outliers
+    out_clouds: "object" = None
+
+
+class GroundSegmentation:
+    """Mirror of groundgrid::GroundSegmentation (include/groundgrid/GroundSegmentation.h:48-71)."""
+
+    def __init__(self):
+        self._L = _lib.load()
+        self._ctx = None
+        self._torch_used = False
+
+    # -- GroundSegmentation::init(nodeHandle, dimension, resolution) (src/GroundSegmentation.cpp:37-48)
+    def init(self, dimension: float = 120.0, resolution: float = 0.33, *, n_slots: int = 1,
+             max_points: int = 150_000, device: int = 0, vertical_point_ang_dist: float = 0.0,
+             min_dist_squared: float = 0.0):
+        if self._ctx:
+            self.close()
+        geom = GGGeometry(float(dimension), float(resolution), float(vertical_point_ang_dist), float(min_dist_squared))
+        ctx = C.c_void_p()
+        rc = self._L.gg_create(C.byref(geom), int(n_slots), int(max_points), int(device), C.byref(ctx))
+        if rc != _lib.GG_OK:
+            raise GroundGridError(f"gg_create: {_lib.STATUS.get(rc, rc)}")
+        self._ctx = ctx
+        self.n_slots = n_slots
+        self.max_points = max_points
+        self.device = device
+        r, c = C.c_int(), C.c_int()
+        self._L.gg_get_size(ctx, C.byref(r), C.byref(c))
+        self.rows, self.cols = r.value, c.value
+        res, lx, ly = C.c_double(), C.c_double(), C.c_double()
+        self._L.gg_get_geometry(ctx, C.byref(res), C.byref(lx), C.byref(ly))
+        self.resolution, self.length = res.value, (lx.value, ly.value)
+        self._maps = [GridMap(self, s) for s in range(n_slots)]
+        return self
+
+    def close(self):
+        if self._ctx:
+            self._L.gg_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def map(self, slot: int = 0) -> GridMap:
+        return self._maps[slot]
+
+    # -- GroundSegmentation::setConfig (src/GroundSegmentation.cpp:468-471)
+    def setConfig(self, config: GGConfig):
+        _check(self._L, self._ctx, self._L.gg_set_config(self._ctx, C.byref(config)), "gg_set_config")
+
+    def getConfig(self) -> GGConfig:
+        c = GGConfig()
+        _check(self._L, self._ctx, self._L.gg_get_config(self._ctx, C.byref(c)), "gg_get_config")
+        return c
+
+    def set_flags(self, minimal_layers: bool = False, profile: bool = False):
+        f = (_lib.GG_FLAG_MINIMAL_LAYERS if minimal_layers else 0) | (_lib.GG_FLAG_PROFILE if profile else 0)
+        _check(self._L, self._ctx, self._L.gg_set_flags(self._ctx, f), "gg_set_flags")
+
+    def expected_points(self) -> np.ndarray:
+        buf = np.empty(self.rows * self.cols, dtype=np.float32)
+        _check(self._L, self._ctx, self._L.gg_get_expected_points(self._ctx, buf.ctypes.data), "gg_get_expected_points")
+        return buf.reshape((self.rows, self.cols), order="F")
+
+    # -- GroundSegmentation::filter_cloud (include/groundgrid/GroundSegmentation.h:54)
+    def filter_cloud(self, cloud: np.ndarray, cloudOrigin: Sequence[float], mapToBase_z: float, map: Optional[GridMap] = None,
+                     return_details: bool = False):
+        """cloud: POINT_DTYPE array in the map frame.  Returns the segmented cloud (intensity = 49 ground /
+        99 non-ground; order kept, ignored, outliers).  With return_details also (labels, out_index)."""
+        assert cloud.dtype == POINT_DTYPE, "cloud must use groundgrid_amd.synth.POINT_DTYPE (PointXYZIR, 32 B)"
+        gm = map if map is not None else self._maps[0]
+        cloud = np.ascontiguousarray(cloud)
+        n = cloud.shape[0]
+        out = np.zeros(max(n, 1) * 32, dtype=np.uint8).view(POINT_DTYPE)
+        labels = np.zeros(max(n, 1), dtype=np.uint8)
+        index = np.zeros(max(n, 1), dtype=np.int32)
+        out_n = C.c_size_t(0)
+        org = (C.c_float * 3)(*[float(v) for v in cloudOrigin])
+        self._sync_torch()
+        rc = self._L.gg_filter_cloud(self._ctx, gm.slot, cloud.ctypes.data, n, org, float(mapToBase_z),
+                                     out.ctypes.data, C.byref(out_n), labels.ctypes.data, index.ctypes.data)
+        _check(self._L, self._ctx, rc, "gg_filter_cloud")
+        seg = out[: out_n.value]
+        if return_details:
+            return seg, labels[:n], index[:n]
+        return seg
+
+    segment = filter_cloud  # BASELINE.json's north_star calls the entry point segment(); same thing
+
+    # -- insert_cloud's per-point decision (include/groundgrid/GroundSegmentation.h:55)
+    def point_classes(self, n: int, map: Optional[GridMap] = None):
+        gm = map if map is not None else self._maps[0]
+        cls = np.zeros(max(n, 1), dtype=np.uint8)
+        cell = np.zeros(max(n, 1), dtype=np.int32)
+        self._sync_torch()
+        rc = self._L.gg_get_point_classes(self._ctx, gm.slot, n, cls.ctypes.data, cell.ctypes.data)
+        _check(self._L, self._ctx, rc, "gg_get_point_classes")
+        return cls[:n], cell[:n]
+
+    # -- batched device-resident form
+    def filter_batch(self, points, n_points: Sequence[int], origins, base_z, *, first_slot: int = 0,
+                     out: Optional[BatchOutputs] = None, want_clouds: bool = False, stream=None) -> BatchOutputs:
+        """points: CUDA torch tensor [B, stride, 16] (packed gg_point16) or [B, stride, 32] (PointXYZIR), uint8.
+        Enqueues on the current torch stream and returns without synchronising."""
+        import torch
+
+        self._torch_used = True
+        assert points.is_cuda and points.dtype == torch.uint8 and points.dim() == 3 and points.is_contiguous()
+        B, stride, rec = points.shape
+        assert rec in (16, 32)
+        fmt = _lib.GG_POINT16 if rec == 16 else _lib.GG_POINT32
+        if out is None:
+            out = BatchOutputs(
+                labels=torch.empty((B, stride), dtype=torch.uint8, device=points.device),
+                out_index=torch.empty((B, stride), dtype=torch.int32, device=points.device),
+                counts=torch.empty((B, 4), dtype=torch.int32, device=points.device),
+                out_clouds=torch.empty((B, stride, 32), dtype=torch.uint8, device=points.device) if want_clouds else None,
+            )
+        npts = (C.c_int32 * B)(*[int(v) for v in n_points])
+        org = np.ascontiguousarray(np.asarray(origins, dtype=np.float32).reshape(B, 3))
+        bz = np.ascontiguousarray(np.asarray(base_z, dtype=np.float64).reshape(B))
+        b = GGBatch()
+        b.n_clouds, b.first_slot, b.point_format = B, first_slot, fmt
+        b.d_points, b.cloud_stride = points.data_ptr(), stride
+        b.n_points = npts
+        b.origins = org.ctypes.data_as(C.POINTER(C.c_float))
+        b.base_z = bz.ctypes.data_as(C.POINTER(C.c_double))
+        b.d_labels = out.labels.data_ptr()
+        b.d_out_index = out.out_index.data_ptr()
+        b.d_out_clouds = out.out_clouds.data_ptr() if out.out_clouds is not None else None
+        b.d_out_counts = out.counts.data_ptr()
+        s = stream if stream is not None else torch.cuda.current_stream(points.device).cuda_stream
+        rc = self._L.gg_filter_batch(self._ctx, C.byref(b), C.c_void_p(s))
+        _check(self._L, self._ctx, rc, "gg_filter_batch")
+        return out
+
+    def kernel_times(self, reset: bool = True):
+        """(ms[7], launches[7]) accumulated under set_flags(profile=True)."""
+        ms = (C.c_double * _lib.GG_NUM_KERNELS)()
+        ln = (C.c_int64 * _lib.GG_NUM_KERNELS)()
+        self._sync_torch()
+        _check(self._L, self._ctx, self._L.gg_get_kernel_times(self._ctx, ms, ln, 1 if reset else 0), "gg_get_kernel_times")
+        names = [self._L.gg_kernel_name(k).decode() for k in range(_lib.GG_NUM_KERNELS)]
+        return {names[k]: (ms[k], ln[k]) for k in range(_lib.GG_NUM_KERNELS)}
+
+    def synchronize(self):
+        self._sync_torch()
+        _check(self._L, self._ctx, self._L.gg_synchronize(self._ctx), "gg_synchronize")
+
+    def _sync_torch(self):
+        # batched calls run on torch's stream; host-path calls and layer copies run on the context's stream
+        if self._torch_used:
+            import torch
+
+            torch.cuda.synchronize(self.device)

@@ -1,0 +1,756 @@
+// gg_context.hip -- host side of libgroundgrid_hip.so: the C ABI of include/groundgrid_hip.h.
+//
+// One gg_context = one device arena (single hipMalloc, sized for n_slots independent map states and
+// max_points per cloud), one HIP stream, and the tables GroundSegmentation::init precomputes.
+// No CPU fallback: every failure is reported through gg_status / gg_last_error.
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "gg_internal.h"
+
+using namespace gg;
+
+namespace {
+
+constexpr int PARAM_RING = 4;
+
+struct EventPair {
+    hipEvent_t start, stop;
+    int kernel;
+};
+
+} // namespace
+
+struct gg_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Arena arena{};
+    gg_config cfg{};
+    gg_geometry geom{};
+    int n_slots = 0;
+    size_t max_points = 0;
+    unsigned flags = 0;
+    std::string last_error;
+
+    void *d_arena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<float> h_expected;
+    std::vector<double> pos_x, pos_y; // per slot map position
+
+    // per-call parameter ring (pinned host + device)
+    CloudParams *h_params = nullptr; // [PARAM_RING][n_slots] pinned
+    CloudParams *d_params = nullptr; // [PARAM_RING][n_slots]
+    hipEvent_t ring_done[PARAM_RING]{};
+    bool ring_used[PARAM_RING]{};
+    int ring_next = 0;
+
+    // staging for the host-buffer entry point
+    gg_point16 *h_stage_pts = nullptr; // pinned [max_points]
+    uint8_t *h_stage_labels = nullptr; // pinned
+    int32_t *h_stage_index = nullptr;  // pinned
+    int32_t *h_stage_counts = nullptr; // pinned [4]
+    gg_point16 *d_stage_pts = nullptr;
+    uint8_t *d_stage_labels = nullptr;
+    int32_t *d_stage_index = nullptr;
+    int32_t *d_stage_counts = nullptr;
+    uint8_t *d_stage_class = nullptr;
+    int32_t *d_stage_cell = nullptr;
+
+    // profiling
+    std::vector<EventPair> pending;
+    std::vector<EventPair> free_events;
+    double k_ms[GG_NUM_KERNELS]{};
+    int64_t k_launches[GG_NUM_KERNELS]{};
+};
+
+namespace {
+
+int fail(gg_context *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess)
+            snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else
+            snprintf(buf, sizeof buf, "%s", what);
+        ctx->last_error = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                      \
+    do {                                                                       \
+        hipError_t e__ = (call);                                               \
+        if (e__ != hipSuccess) return fail((ctx), GG_ERR_HIP, #call, e__);     \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+uint32_t morton2(uint32_t x, uint32_t y)
+{
+    auto spread = [](uint32_t v) {
+        v &= 0xFFFFu;
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1);
+}
+
+// Replay spiral_ground_interpolation's visit order (src/GroundSegmentation.cpp:413-440) and give every
+// visit the earliest level compatible with the in-place data hazards on its 3x3 neighbourhood:
+//   RAW  level > level of the last earlier visit that wrote any of the 9 cells it reads
+//   WAR  level > level of every earlier visit that read the cell it writes
+//   WAW  level > level of the earlier visit of the same cell (the two doubly-visited corners per ring)
+// Visits sharing a level are independent, so a barrier between levels reproduces the serial sweep exactly.
+void build_spiral_schedule(int n, std::vector<uint32_t> &visits_by_level, std::vector<uint32_t> &level_start, int &max_width)
+{
+    const int center = n / 2 - 1;
+    std::vector<uint32_t> cells;
+    for (int i = center - 1; i >= 1; --i) {
+        int rp = i;
+        const int sl = (center - rp) * 2;
+        for (int side = 0; side < 2; ++side)
+            for (int pos = rp; pos < rp + sl; ++pos) {
+                const int x = side % 2 ? pos : rp, y = side % 2 ? rp : pos;
+                cells.push_back((uint32_t)(x + y * n));
+            }
+        rp += sl;
+        for (int side = 0; side < 2; ++side)
+            for (int pos = rp; pos >= rp - sl; --pos) {
+                const int x = side % 2 ? pos : rp, y = side % 2 ? rp : pos;
+                cells.push_back((uint32_t)(x + y * n));
+            }
+    }
+    std::vector<int> last_write((size_t)n * n, 0), last_read((size_t)n * n, 0), level(cells.size());
+    int n_levels = 0;
+    for (size_t k = 0; k < cells.size(); ++k) {
+        const int x = (int)(cells[k] % (uint32_t)n), y = (int)(cells[k] / (uint32_t)n);
+        int lv = last_read[cells[k]];
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) lv = std::max(lv, last_write[(x + dx) + (y + dy) * n]);
+        lv += 1;
+        level[k] = lv;
+        last_write[cells[k]] = lv;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                int &r = last_read[(x + dx) + (y + dy) * n];
+                r = std::max(r, lv);
+            }
+        n_levels = std::max(n_levels, lv);
+    }
+    level_start.assign((size_t)n_levels + 1, 0);
+    for (size_t k = 0; k < cells.size(); ++k) level_start[level[k]]++; // level l (1-based) counted at index l
+    // exclusive prefix: level l occupies [level_start[l-1], level_start[l])
+    max_width = 0;
+    uint32_t run = 0;
+    for (int l = 1; l <= n_levels; ++l) {
+        const uint32_t c = level_start[l];
+        max_width = std::max(max_width, (int)c);
+        level_start[l] = run + c;
+        run += c;
+    }
+    level_start[0] = 0;
+    visits_by_level.resize(cells.size());
+    std::vector<uint32_t> cursor(level_start.begin(), level_start.end() - 1);
+    for (size_t k = 0; k < cells.size(); ++k) visits_by_level[cursor[level[k] - 1]++] = cells[k];
+}
+
+void make_dev_config(const gg_config &c, DevConfig &d)
+{
+    d.point_count_cell_variance_threshold = c.point_count_cell_variance_threshold;
+    d.max_ring = c.max_ring;
+    d.outlier_tolerance = c.outlier_tolerance;
+    d.gpd_min_point_count_threshold = c.ground_patch_detection_minimum_point_count_threshold;
+    d.patch_size_change_distance_sq = c.patch_size_change_distance * c.patch_size_change_distance; // pow(x, 2.0)
+    d.occupied_cells_decrease_factor = c.occupied_cells_decrease_factor;
+    d.occupied_cells_point_count_factor = c.occupied_cells_point_count_factor;
+    d.occupied_cells_point_count_factor_x2 = c.occupied_cells_point_count_factor * (double)2.0f; // :387
+    d.min_outlier_detection_ground_confidence = c.min_outlier_detection_ground_confidence;
+    d.distance_factor_sq = c.distance_factor * c.distance_factor;                                 // :369
+    d.minimum_distance_factor_sq = c.minimum_distance_factor * c.minimum_distance_factor;
+    const double m10 = c.minimum_distance_factor * 10;
+    d.minimum_distance_factor_x10_sq = m10 * m10;
+    d.min_dist_fac = c.minimum_distance_factor * 5; // :154
+    d.min_point_height_thres = c.miminum_point_height_threshold;
+    d.min_point_height_obs_thres = c.minimum_point_height_obstacle_threshold;
+}
+
+hipStream_t pick_stream(gg_context *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+struct Profiler {
+    gg_context *ctx;
+    hipStream_t s;
+    bool on;
+    EventPair cur{};
+    void begin(int k)
+    {
+        if (!on) return;
+        if (!ctx->free_events.empty()) {
+            cur = ctx->free_events.back();
+            ctx->free_events.pop_back();
+        } else {
+            hipEventCreate(&cur.start);
+            hipEventCreate(&cur.stop);
+        }
+        cur.kernel = k;
+        hipEventRecord(cur.start, s);
+    }
+    void end()
+    {
+        if (!on) return;
+        hipEventRecord(cur.stop, s);
+        ctx->pending.push_back(cur);
+    }
+};
+
+int drain_profile(gg_context *ctx)
+{
+    for (auto &p : ctx->pending) {
+        HIPCHK(ctx, hipEventSynchronize(p.stop));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, p.start, p.stop));
+        ctx->k_ms[p.kernel] += ms;
+        ctx->k_launches[p.kernel] += 1;
+        ctx->free_events.push_back(p);
+    }
+    ctx->pending.clear();
+    return GG_OK;
+}
+
+// enqueue the seven kernels of one batched filter_cloud call
+int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
+{
+    const int nb = b->n_clouds;
+    if (nb == 0) return GG_OK;
+    // parameter ring slot
+    const int g = ctx->ring_next;
+    ctx->ring_next = (g + 1) % PARAM_RING;
+    if (ctx->ring_used[g]) HIPCHK(ctx, hipEventSynchronize(ctx->ring_done[g]));
+    CloudParams *hp = ctx->h_params + (size_t)g * ctx->n_slots;
+    CloudParams *dp = ctx->d_params + (size_t)g * ctx->n_slots;
+    int max_n = 0;
+    for (int i = 0; i < nb; ++i) {
+        const int slot = b->first_slot + i;
+        CloudParams &p = hp[i];
+        p.slot = slot;
+        p.n_points = b->n_points[i];
+        p.ox = b->origins[i * 3 + 0];
+        p.oy = b->origins[i * 3 + 1];
+        p.oz = b->origins[i * 3 + 2];
+        p.base_z = (float)b->base_z[i];
+        p.pos_x = ctx->pos_x[slot];
+        p.pos_y = ctx->pos_y[slot];
+        max_n = std::max(max_n, p.n_points);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * nb, hipMemcpyHostToDevice, s));
+
+    BatchIO io;
+    io.d_points = b->d_points;
+    io.cloud_stride = b->cloud_stride;
+    io.point_format = b->point_format;
+    io.d_labels = b->d_labels;
+    io.d_out_index = b->d_out_index;
+    io.d_out_clouds = b->d_out_clouds;
+    io.d_out_counts = b->d_out_counts;
+
+    Arena a = ctx->arena;
+    a.flags = ctx->flags;
+    Profiler prof{ctx, s, (ctx->flags & GG_FLAG_PROFILE) != 0};
+
+    prof.begin(GG_K_CLASSIFY);
+    launch_classify(a, dp, io, nb, max_n, s);
+    prof.end();
+    prof.begin(GG_K_SCAN);
+    launch_scan(a, dp, nb, s);
+    prof.end();
+    prof.begin(GG_K_SCATTER);
+    launch_scatter(a, dp, nb, max_n, s);
+    prof.end();
+    prof.begin(GG_K_REDUCE);
+    launch_reduce(a, dp, nb, s);
+    prof.end();
+    prof.begin(GG_K_PATCH);
+    launch_patch(a, dp, nb, s);
+    prof.end();
+    prof.begin(GG_K_SPIRAL);
+    launch_spiral(a, dp, nb, s);
+    prof.end();
+    prof.begin(GG_K_LABEL);
+    launch_label(a, dp, io, nb, max_n, s);
+    prof.end();
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ring_done[g], s));
+    ctx->ring_used[g] = true;
+    return GG_OK;
+}
+
+bool slot_ok(const gg_context *ctx, int slot) { return ctx && slot >= 0 && slot < ctx->n_slots; }
+
+} // namespace
+
+extern "C" {
+
+int gg_abi_version(void) { return GG_ABI_VERSION; }
+
+const char *gg_kernel_name(int k)
+{
+    static const char *names[GG_NUM_KERNELS] = {"k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_spiral", "k_label"};
+    return (k >= 0 && k < GG_NUM_KERNELS) ? names[k] : "?";
+}
+
+void gg_default_config(gg_config *c)
+{
+    if (!c) return;
+    // cfg/GroundGrid.cfg:8-21
+    c->point_count_cell_variance_threshold = 10;
+    c->max_ring = 1024;
+    c->groundpatch_detection_minimum_threshold = 0.01;
+    c->distance_factor = 0.0001;
+    c->minimum_distance_factor = 0.0005;
+    c->miminum_point_height_threshold = 0.3;
+    c->minimum_point_height_obstacle_threshold = 0.1;
+    c->outlier_tolerance = 0.1;
+    c->ground_patch_detection_minimum_point_count_threshold = 0.25;
+    c->patch_size_change_distance = 20;
+    c->occupied_cells_decrease_factor = 5.0;
+    c->occupied_cells_point_count_factor = 20;
+    c->min_outlier_detection_ground_confidence = 1.25;
+    c->thread_count = 8;
+}
+
+void gg_default_geometry(gg_geometry *g)
+{
+    if (!g) return;
+    g->length = 120.0f;                                      // GroundGrid.h:71
+    g->resolution = .33f;                                    // GroundGrid.h:70
+    g->vertical_point_ang_dist = (float)(0.00174532925 * 2); // GroundSegmentation.h:69
+    g->min_dist_squared = 12.0f;                             // GroundSegmentation.h:70
+}
+
+int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int device, gg_context **out)
+{
+    if (!out) return GG_ERR_INVALID;
+    *out = nullptr;
+    if (n_slots <= 0 || max_points == 0 || max_points > (size_t)1 << 30) return GG_ERR_INVALID;
+    gg_geometry geom;
+    gg_default_geometry(&geom);
+    if (geom_in) {
+        if (geom_in->length > 0.f) geom.length = geom_in->length;
+        if (geom_in->resolution > 0.f) geom.resolution = geom_in->resolution;
+        if (geom_in->vertical_point_ang_dist > 0.f) geom.vertical_point_ang_dist = geom_in->vertical_point_ang_dist;
+        if (geom_in->min_dist_squared > 0.f) geom.min_dist_squared = geom_in->min_dist_squared;
+    }
+
+    // grid_map::GridMap::setGeometry (called at src/GroundGrid.cpp:58)
+    const double res = (double)geom.resolution;
+    const int n = (int)round((double)geom.length / res);
+    // GroundSegmentation::init (src/GroundSegmentation.cpp:38), dimension passed as size_t (Nodelet.cpp:95)
+    const size_t dimension = (size_t)geom.length;
+    const size_t cellCount = (size_t)roundf((float)dimension / geom.resolution);
+    if (n < 8 || (size_t)n != cellCount) return GG_ERR_GEOMETRY;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return GG_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GG_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return GG_ERR_NO_DEVICE; // this library carries gfx950 code only
+
+    gg_context *ctx = new (std::nothrow) gg_context();
+    if (!ctx) return GG_ERR_NOMEM;
+    ctx->device = device;
+    ctx->geom = geom;
+    ctx->n_slots = n_slots;
+    ctx->max_points = max_points;
+    gg_default_config(&ctx->cfg);
+    ctx->pos_x.assign(n_slots, 0.0);
+    ctx->pos_y.assign(n_slots, 0.0);
+
+#define CREATE_CHK(call)                                             \
+    do {                                                             \
+        hipError_t e__ = (call);                                     \
+        if (e__ != hipSuccess) {                                     \
+            fprintf(stderr, "groundgrid_hip: %s failed: %s\n", #call, hipGetErrorString(e__)); \
+            gg_destroy(ctx);                                         \
+            return e__ == hipErrorOutOfMemory ? GG_ERR_NOMEM : GG_ERR_HIP; \
+        }                                                            \
+    } while (0)
+
+    CREATE_CHK(hipSetDevice(device));
+    CREATE_CHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+
+    Arena &a = ctx->arena;
+    Geometry &g = a.g;
+    g.rows = g.cols = n;
+    g.C = n * n;
+    g.tiles_r = (n + TILE - 1) / TILE;
+    g.tiles_c = (n + TILE - 1) / TILE;
+    g.T = g.tiles_r * g.tiles_c;
+    g.resolution = res;
+    g.length0 = g.length1 = (double)n * res;
+    g.half0 = 0.5 * g.length0;
+    g.half1 = 0.5 * g.length1;
+    g.resolution_f = (float)res;
+    g.min_dist_squared = geom.min_dist_squared;
+    g.center = n / 2 - 1;
+    if (g.T > 65535 || (size_t)4 * g.T * sizeof(uint32_t) > 160 * 1024) {
+        gg_destroy(ctx);
+        return GG_ERR_GEOMETRY; // per-wave LDS tile histograms no longer fit
+    }
+    a.PW = g.T <= 1024 ? 1024 : 8192;
+    a.NCH = (int)((max_points + a.PW - 1) / a.PW);
+    make_dev_config(ctx->cfg, a.cfg);
+
+    // R1: expectedPoints (src/GroundSegmentation.cpp:40-46) -- host libm atanf, as in the reference
+    ctx->h_expected.resize((size_t)g.C);
+    for (size_t i = 0; i < cellCount; ++i)
+        for (size_t j = 0; j < cellCount; ++j) {
+            const float dist = (float)hypot((double)i - (double)cellCount / 2.0, (double)j - (double)cellCount / 2.0);
+            ctx->h_expected[i + j * cellCount] = atanf(1 / dist) / geom.vertical_point_ang_dist;
+        }
+
+    std::vector<uint32_t> visits, level_start;
+    int max_width = 0;
+    build_spiral_schedule(n, visits, level_start, max_width);
+    a.n_levels = (int)level_start.size() - 1;
+    a.max_level_width = max_width;
+
+    std::vector<uint16_t> tile_rank(g.T), rank_tile(g.T);
+    {
+        std::vector<std::pair<uint32_t, int>> order(g.T);
+        for (int tc = 0; tc < g.tiles_c; ++tc)
+            for (int tr = 0; tr < g.tiles_r; ++tr) order[tr + tc * g.tiles_r] = {morton2((uint32_t)tr, (uint32_t)tc), tr + tc * g.tiles_r};
+        std::sort(order.begin(), order.end());
+        for (int r = 0; r < g.T; ++r) {
+            rank_tile[r] = (uint16_t)order[r].second;
+            tile_rank[order[r].second] = (uint16_t)r;
+        }
+    }
+
+    // ---- carve the arena -----------------------------------------------------------------
+    const size_t A = 256;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes, A);
+        return o;
+    };
+    const size_t C = (size_t)g.C;
+    const size_t Cpad = align_up(C * 4, A) / 4;
+    const size_t Npad = align_up(max_points * 8, A) / 8;
+    const size_t o_expected = carve(C * 4);
+    const size_t o_visits = carve(visits.size() * 4);
+    const size_t o_lstart = carve(level_start.size() * 4);
+    const size_t o_trank = carve((size_t)g.T * 2);
+    const size_t o_rtile = carve((size_t)g.T * 2);
+    const size_t o_layers = carve((size_t)n_slots * GG_NUM_LAYERS * Cpad * 4);
+    const size_t o_rec = carve((size_t)n_slots * Npad * 8);
+    const size_t o_sorted = carve((size_t)n_slots * Npad * 8);
+    a.hist_stride = align_up((size_t)a.NCH * g.T * 4, A) / 4;
+    const size_t o_hist = carve((size_t)n_slots * a.hist_stride * 4);
+    a.emit_stride = align_up((size_t)a.NCH * 4 * 4, A) / 4;
+    const size_t o_emit = carve((size_t)n_slots * a.emit_stride * 4);
+    const size_t o_totals = carve((size_t)n_slots * 4 * 4);
+    a.tile_start_stride = align_up((size_t)(g.T + 1) * 4, A) / 4;
+    const size_t o_tstart = carve((size_t)n_slots * a.tile_start_stride * 4);
+    const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
+    const size_t o_spts = carve(max_points * sizeof(gg_point16));
+    const size_t o_slab = carve(max_points);
+    const size_t o_sidx = carve(max_points * 4);
+    const size_t o_scnt = carve(64);
+    const size_t o_scls = carve(max_points);
+    const size_t o_scell = carve(max_points * 4);
+    ctx->arena_bytes = off;
+    CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
+    char *base = (char *)ctx->d_arena;
+    CREATE_CHK(hipMemsetAsync(base, 0, ctx->arena_bytes, ctx->stream));
+
+    a.expected = (const float *)(base + o_expected);
+    a.visits = (const uint32_t *)(base + o_visits);
+    a.level_start = (const uint32_t *)(base + o_lstart);
+    a.tile_rank = (const uint16_t *)(base + o_trank);
+    a.rank_tile = (const uint16_t *)(base + o_rtile);
+    a.layers = (float *)(base + o_layers);
+    a.layer_stride = Cpad;
+    a.slot_layer_stride = Cpad * GG_NUM_LAYERS;
+    a.rec = (uint2 *)(base + o_rec);
+    a.sorted = (uint2 *)(base + o_sorted);
+    a.point_stride = Npad;
+    a.hist = (uint32_t *)(base + o_hist);
+    a.chunk_emit = (uint32_t *)(base + o_emit);
+    a.totals = (uint32_t *)(base + o_totals);
+    a.tile_start = (uint32_t *)(base + o_tstart);
+    a.flags = 0;
+    ctx->d_params = (CloudParams *)(base + o_params);
+    ctx->d_stage_pts = (gg_point16 *)(base + o_spts);
+    ctx->d_stage_labels = (uint8_t *)(base + o_slab);
+    ctx->d_stage_index = (int32_t *)(base + o_sidx);
+    ctx->d_stage_counts = (int32_t *)(base + o_scnt);
+    ctx->d_stage_class = (uint8_t *)(base + o_scls);
+    ctx->d_stage_cell = (int32_t *)(base + o_scell);
+
+    CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
+    CREATE_CHK(hipMemcpyAsync(base + o_visits, visits.data(), visits.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CREATE_CHK(hipMemcpyAsync(base + o_lstart, level_start.data(), level_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
+    CREATE_CHK(hipMemcpyAsync(base + o_rtile, rank_tile.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
+    CREATE_CHK(hipStreamSynchronize(ctx->stream)); // the host vectors above go out of scope
+
+    CREATE_CHK(hipHostMalloc((void **)&ctx->h_params, sizeof(CloudParams) * PARAM_RING * n_slots, hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void **)&ctx->h_stage_pts, max_points * sizeof(gg_point16), hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void **)&ctx->h_stage_labels, max_points, hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void **)&ctx->h_stage_index, max_points * 4, hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void **)&ctx->h_stage_counts, 64, hipHostMallocDefault));
+    for (int i = 0; i < PARAM_RING; ++i) CREATE_CHK(hipEventCreateWithFlags(&ctx->ring_done[i], hipEventDisableTiming));
+
+    for (int s = 0; s < n_slots; ++s) {
+        const int rc = gg_reset_map(ctx, s, 0.0, 0.0, 0.0f);
+        if (rc != GG_OK) {
+            gg_destroy(ctx);
+            return rc;
+        }
+    }
+    CREATE_CHK(hipStreamSynchronize(ctx->stream));
+#undef CREATE_CHK
+    *out = ctx;
+    return GG_OK;
+}
+
+void gg_destroy(gg_context *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) {
+        hipEventDestroy(p.start);
+        hipEventDestroy(p.stop);
+    }
+    for (auto &p : ctx->free_events) {
+        hipEventDestroy(p.start);
+        hipEventDestroy(p.stop);
+    }
+    for (int i = 0; i < PARAM_RING; ++i)
+        if (ctx->ring_done[i]) hipEventDestroy(ctx->ring_done[i]);
+    if (ctx->h_params) hipHostFree(ctx->h_params);
+    if (ctx->h_stage_pts) hipHostFree(ctx->h_stage_pts);
+    if (ctx->h_stage_labels) hipHostFree(ctx->h_stage_labels);
+    if (ctx->h_stage_index) hipHostFree(ctx->h_stage_index);
+    if (ctx->h_stage_counts) hipHostFree(ctx->h_stage_counts);
+    if (ctx->d_arena) hipFree(ctx->d_arena);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int gg_set_config(gg_context *ctx, const gg_config *cfg)
+{
+    if (!ctx || !cfg) return GG_ERR_INVALID;
+    ctx->cfg = *cfg; // src/GroundSegmentation.cpp:468-471
+    make_dev_config(ctx->cfg, ctx->arena.cfg);
+    return GG_OK;
+}
+
+int gg_get_config(const gg_context *ctx, gg_config *cfg)
+{
+    if (!ctx || !cfg) return GG_ERR_INVALID;
+    *cfg = ctx->cfg;
+    return GG_OK;
+}
+
+int gg_set_flags(gg_context *ctx, unsigned flags)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    ctx->flags = flags;
+    return GG_OK;
+}
+
+int gg_get_size(const gg_context *ctx, int *rows, int *cols)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    if (rows) *rows = ctx->arena.g.rows;
+    if (cols) *cols = ctx->arena.g.cols;
+    return GG_OK;
+}
+
+int gg_get_geometry(const gg_context *ctx, double *resolution, double *length_x, double *length_y)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    if (resolution) *resolution = ctx->arena.g.resolution;
+    if (length_x) *length_x = ctx->arena.g.length0;
+    if (length_y) *length_y = ctx->arena.g.length1;
+    return GG_OK;
+}
+
+const char *gg_last_error(const gg_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float odom_z)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pos_x[slot] = pos_x;
+    ctx->pos_y[slot] = pos_y;
+    const Arena &a = ctx->arena;
+    const size_t C = (size_t)a.g.C;
+    // src/GroundGrid.cpp:71-75; the layers filter_cloud adds later (:61-75) start at 0
+    const float init[GG_NUM_LAYERS] = {0.0f, odom_z, (float)0.0000001, (float)100.0, (float)-100.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < GG_NUM_LAYERS; ++l) launch_fill(layer_ptr(a, slot, l), C, init[l], ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return GG_OK;
+}
+
+int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    ctx->pos_x[slot] = pos_x;
+    ctx->pos_y[slot] = pos_y;
+    return GG_OK;
+}
+
+int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!src || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!dst || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, layer_ptr(ctx->arena, slot, layer), (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+int gg_get_expected_points(const gg_context *ctx, float *dst)
+{
+    if (!ctx || !dst) return GG_ERR_INVALID;
+    memcpy(dst, ctx->h_expected.data(), ctx->h_expected.size() * 4);
+    return GG_OK;
+}
+
+int gg_filter_batch(gg_context *ctx, const gg_batch *b, void *stream)
+{
+    if (!ctx || !b) return GG_ERR_INVALID;
+    if (b->n_clouds < 0 || b->first_slot < 0 || b->first_slot + b->n_clouds > ctx->n_slots) return fail(ctx, GG_ERR_CAPACITY, "slot range");
+    if (b->n_clouds == 0) return GG_OK;
+    if (!b->d_points || !b->n_points || !b->origins || !b->base_z) return fail(ctx, GG_ERR_INVALID, "null batch field");
+    if (b->point_format != GG_POINT32 && b->point_format != GG_POINT16) return fail(ctx, GG_ERR_INVALID, "point_format");
+    if (b->d_out_clouds && b->point_format != GG_POINT32) return fail(ctx, GG_ERR_INVALID, "d_out_clouds needs GG_POINT32 input");
+    for (int i = 0; i < b->n_clouds; ++i)
+        if (b->n_points[i] < 0 || (size_t)b->n_points[i] > ctx->max_points || (size_t)b->n_points[i] > b->cloud_stride)
+            return fail(ctx, GG_ERR_CAPACITY, "n_points exceeds max_points / cloud_stride");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return enqueue_batch(ctx, b, pick_stream(ctx, stream));
+}
+
+int gg_synchronize(gg_context *ctx)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+int gg_filter_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const float origin[3], double base_z,
+                    gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if ((!cloud && n) || !origin) return fail(ctx, GG_ERR_INVALID, "null cloud / origin");
+    if (n > ctx->max_points) return fail(ctx, GG_ERR_CAPACITY, "cloud larger than max_points");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+
+    // pack PointXYZIR -> 16-B records while copying into pinned staging (halves PCIe and HBM traffic)
+    for (size_t i = 0; i < n; ++i) {
+        gg_point16 &d = ctx->h_stage_pts[i];
+        d.x = cloud[i].x;
+        d.y = cloud[i].y;
+        d.z = cloud[i].z;
+        d.ring = cloud[i].ring;
+        d.pad = 0;
+    }
+    if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage_pts, ctx->h_stage_pts, n * sizeof(gg_point16), hipMemcpyHostToDevice, s));
+
+    const int32_t n32 = (int32_t)n;
+    gg_batch b{};
+    b.n_clouds = 1;
+    b.first_slot = slot;
+    b.point_format = GG_POINT16;
+    b.d_points = ctx->d_stage_pts;
+    b.cloud_stride = ctx->max_points;
+    b.n_points = &n32;
+    b.origins = origin;
+    b.base_z = &base_z;
+    b.d_labels = ctx->d_stage_labels;
+    b.d_out_index = ctx->d_stage_index;
+    b.d_out_clouds = nullptr;
+    b.d_out_counts = ctx->d_stage_counts;
+    const int rc = enqueue_batch(ctx, &b, s);
+    if (rc != GG_OK) return rc;
+
+    if (n) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage_labels, ctx->d_stage_labels, n, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage_index, ctx->d_stage_index, n * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage_counts, ctx->d_stage_counts, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+
+    if (out_n) *out_n = (size_t)ctx->h_stage_counts[0];
+    if (out_label && n) memcpy(out_label, ctx->h_stage_labels, n);
+    if (out_index && n) memcpy(out_index, ctx->h_stage_index, n * 4);
+    if (out_cloud) {
+        // the returned cloud (:173-189): the host owns the input, so it assembles the output from index + label
+        for (size_t i = 0; i < n; ++i) {
+            const int32_t k = ctx->h_stage_index[i];
+            if (k < 0) continue;
+            out_cloud[k] = cloud[i];
+            out_cloud[k].intensity = (float)ctx->h_stage_labels[i];
+        }
+    }
+    return GG_OK;
+}
+
+int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class, int32_t *out_cell)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (n > ctx->max_points) return GG_ERR_CAPACITY;
+    if (n == 0) return GG_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    launch_decode_classes(ctx->arena, slot, n, ctx->d_stage_class, ctx->d_stage_cell, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    if (out_class) HIPCHK(ctx, hipMemcpyAsync(out_class, ctx->d_stage_class, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_cell) HIPCHK(ctx, hipMemcpyAsync(out_cell, ctx->d_stage_cell, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+int gg_get_kernel_times(gg_context *ctx, double ms[GG_NUM_KERNELS], int64_t launches[GG_NUM_KERNELS], int reset)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = drain_profile(ctx);
+    if (rc != GG_OK) return rc;
+    for (int k = 0; k < GG_NUM_KERNELS; ++k) {
+        if (ms) ms[k] = ctx->k_ms[k];
+        if (launches) launches[k] = ctx->k_launches[k];
+        if (reset) {
+            ctx->k_ms[k] = 0.0;
+            ctx->k_launches[k] = 0;
+        }
+    }
+    return GG_OK;
+}
+
+} // extern "C"

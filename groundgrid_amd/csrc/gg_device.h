@@ -1,0 +1,89 @@
+// gg_device.h -- device-side scalar building blocks shared by the kernels.
+//
+// Every kernel file is compiled with -ffp-contract=off and without fast-math: the reference is
+// x86-64 SSE2 code with no FMA contraction and IEEE divide/sqrt, and ground / non-ground labels
+// are threshold tests on these values, so each float and double operation below is written in
+// exactly the order and precision of src/GroundSegmentation.cpp (see oracle/gg_oracle.c for the
+// same expressions on the CPU).
+#pragma once
+
+#include "gg_internal.h"
+
+namespace gg {
+
+#define GG_DEV __device__ __forceinline__
+
+// libstdc++ std::min / std::max (NaN: return the first argument when the comparison is false)
+GG_DEV double std_min(double a, double b) { return (b < a) ? b : a; }
+GG_DEV double std_max(double a, double b) { return (a < b) ? b : a; }
+GG_DEV float std_min(float a, float b) { return (b < a) ? b : a; }
+GG_DEV float std_max(float a, float b) { return (a < b) ? b : a; }
+
+// Eigen 3.3.7 redux_novec_unroller order for a 3x3 / 5x5 fixed-size block, e[] in column-major
+// linear order of the block (oracle/gg_oracle.c tree9 / tree25).
+GG_DEV float tree9(const float *e)
+{
+    return ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + (e[7] + e[8])));
+}
+GG_DEV float tree25(const float *e)
+{
+    const float a = (e[0] + (e[1] + e[2])) + (e[3] + (e[4] + e[5]));
+    const float b = (e[6] + (e[7] + e[8])) + (e[9] + (e[10] + e[11]));
+    const float c = (e[12] + (e[13] + e[14])) + (e[15] + (e[16] + e[17]));
+    const float d = (e[18] + (e[19] + e[20])) + ((e[21] + e[22]) + (e[23] + e[24]));
+    return (a + b) + (c + d);
+}
+
+// x86-64 cvttsd2si: truncation toward zero, INT_MIN for NaN / out of range
+GG_DEV int trunc_to_int(double v)
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
+// grid_map_core getIndexFromPosition (value part): index = (int)(-(((p - L/2) - mapPos) / res))
+GG_DEV void index_from_position(const Geometry &g, double pos_x, double pos_y, double px, double py, int &row, int &col)
+{
+    const double ivx = ((px - g.half0) - pos_x) / g.resolution;
+    const double ivy = ((py - g.half1) - pos_y) / g.resolution;
+    row = trunc_to_int(-ivx);
+    col = trunc_to_int(-ivy);
+}
+
+// grid_map_core checkIfPositionWithinMap: t = -I * ((p - mapPos) - L/2); 0 <= t < L per axis
+GG_DEV bool position_inside(const Geometry &g, double pos_x, double pos_y, double px, double py)
+{
+    const double ax = (px - pos_x) - g.half0;
+    const double ay = (py - pos_y) - g.half1;
+    const double tx = -1.0 * ax + 0.0 * ay;
+    const double ty = 0.0 * ax + -1.0 * ay;
+    return tx >= 0.0 && ty >= 0.0 && tx < g.length0 && ty < g.length1;
+}
+
+// glibc e_hypotf.c: (float)sqrt((double)x*x + (double)y*y) for finite arguments
+GG_DEV float ref_hypotf(float x, float y)
+{
+    if (isinf(x) || isinf(y)) return __builtin_inff();
+    if (isnan(x) || isnan(y)) return x + y;
+    const double dx = (double)x, dy = (double)y;
+    return (float)sqrt(dx * dx + dy * dy);
+}
+
+GG_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// number of set bits of `mask` below this lane
+GG_DEV int rank_below(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// cell (row, col) of a key
+GG_DEV void key_to_cell(const Arena &a, uint32_t key, int &row, int &col)
+{
+    const int tile = a.rank_tile[key >> KEY_TILE_SHIFT];
+    const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
+    row = tr * TILE + (int)(key & 15u);
+    col = tc * TILE + (int)((key >> 4) & 15u);
+}
+
+} // namespace gg

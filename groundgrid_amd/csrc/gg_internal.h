@@ -1,0 +1,120 @@
+// gg_internal.h -- device/host shared structures of libgroundgrid_hip (gfx950 only).
+//
+// HBM layout of one context (see DESIGN.md "Data layout"):
+//   shared   : expectedPoints[C]  spiral schedule  tile rank tables
+//   per slot : 11 layers [C] f32 (column-major, i + j*rows, as Eigen::MatrixXf)
+//              rec[Nmax]    (z, key)     cloud order     written by K1
+//              sorted[Nmax] (z, key)     Morton-tile order, cloud order inside a tile (stable)
+//              hist[NCH][T] per-wave-chunk tile histogram -> exclusive offsets after the scan
+//              chunk_emit[NCH][4], totals[4], tile_start[T+1]
+//              labels[Nmax], out_index[Nmax], pts16[Nmax] (host staging path)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "groundgrid_hip.h"
+
+namespace gg {
+
+constexpr int TILE = 16;             // cells per tile edge (K2 work-group = one tile, one thread per cell)
+constexpr int TILE_CELLS = TILE * TILE;
+constexpr uint32_t KEY_OUTSIDE = 0xFFFFFFFFu;
+// key = tile_rank << 12 | emit << 10 | class << 8 | cell_in_tile (row_in_tile | col_in_tile << 4)
+constexpr int KEY_TILE_SHIFT = 12;
+constexpr uint32_t KEY_EMIT_BIT = 1u << 10;
+constexpr int KEY_CLASS_SHIFT = 8;
+
+// device copy of gg_config plus the constants derived from it once per set_config
+struct DevConfig {
+    int point_count_cell_variance_threshold;
+    int max_ring;
+    double outlier_tolerance;
+    double gpd_min_point_count_threshold;   // ground_patch_detection_minimum_point_count_threshold
+    double patch_size_change_distance_sq;   // pow(patch_size_change_distance, 2.0)
+    double occupied_cells_decrease_factor;
+    double occupied_cells_point_count_factor;
+    double occupied_cells_point_count_factor_x2; // factor * (double)2.0f
+    double min_outlier_detection_ground_confidence;
+    double distance_factor_sq;              // pow(distance_factor, 2.0)
+    double minimum_distance_factor_sq;      // pow(minimum_distance_factor, 2.0)
+    double minimum_distance_factor_x10_sq;  // pow(minimum_distance_factor*10, 2.0)
+    double min_dist_fac;                    // minimum_distance_factor * 5   (:154)
+    double min_point_height_thres;          // :155
+    double min_point_height_obs_thres;      // :156
+};
+
+struct Geometry {
+    int rows, cols;          // grid_map size
+    int C;                   // rows * cols
+    int tiles_r, tiles_c, T; // tile grid
+    double resolution;       // (double)resolution_f
+    double length0, length1; // size * resolution
+    double half0, half1;     // 0.5 * length  (getVectorToOrigin)
+    float resolution_f;      // (float)map.getResolution()
+    float min_dist_squared;
+    int center;              // rows/2 - 1
+};
+
+// per-cloud parameters of one batched call (device array, one entry per cloud of the batch)
+struct CloudParams {
+    int slot;
+    int n_points;
+    float ox, oy, oz;
+    float base_z;   // (float)translation.z
+    double pos_x, pos_y;
+};
+
+// everything a kernel needs to find its data
+struct Arena {
+    Geometry g;
+    DevConfig cfg;
+    // shared
+    const float *expected;        // [C]
+    const uint32_t *visits;       // spiral visit list (cell linear index), grouped by level
+    const uint32_t *level_start;  // [n_levels + 1]
+    int n_levels;
+    int max_level_width;
+    const uint16_t *tile_rank;    // [T] tile (tr + tc*tiles_r) -> Morton rank
+    const uint16_t *rank_tile;    // [T] Morton rank -> tile
+    // per slot (slot s at base + s * stride)
+    float *layers;  size_t layer_stride;  size_t slot_layer_stride;  // layer l of slot s: layers + s*slot_layer_stride + l*layer_stride
+    uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
+    uint32_t *hist;        size_t hist_stride;   // NCH * T
+    uint32_t *chunk_emit;  size_t emit_stride;   // NCH * 4
+    uint32_t *totals;      // [slot][4]  (emitted kept, emitted ignored, outliers, in-map)
+    uint32_t *tile_start;  size_t tile_start_stride; // T + 1
+    int PW;    // points per wave-chunk
+    int NCH;   // chunks per cloud (capacity)
+    unsigned flags;
+};
+
+__host__ __device__ inline float *layer_ptr(const Arena &a, int slot, int layer)
+{
+    return a.layers + (size_t)slot * a.slot_layer_stride + (size_t)layer * a.layer_stride;
+}
+
+// I/O pointers of one batched call
+struct BatchIO {
+    const void *d_points;
+    size_t cloud_stride;
+    int point_format;
+    uint8_t *d_labels;
+    int32_t *d_out_index;
+    gg_point32 *d_out_clouds;
+    int32_t *d_out_counts;
+};
+
+// kernel launchers (one per .hip file)
+void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
+void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
+void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, int max_n, hipStream_t s);
+void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
+void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
+void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
+void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
+void launch_fill(float *dst, size_t n, float v, hipStream_t s);
+void launch_pack16(const gg_point32 *src, gg_point16 *dst, size_t n, hipStream_t s);
+void launch_decode_classes(const Arena &a, int slot, size_t n, uint8_t *d_class, int32_t *d_cell, hipStream_t s);
+
+} // namespace gg

@@ -1,0 +1,228 @@
+// K1 -- insert_cloud, per-point part (src/GroundSegmentation.cpp:219-279):
+//   map index + inside test (:222-231), ignore test (:237-240), line-of-sight outlier test (:243-275),
+//   and the Morton-tile key the ordered per-cell reduction (K2) is sorted by.
+//
+// One wavefront owns one contiguous chunk of PW points and walks it 64 points at a time with
+// coalesced 16-B loads (packed gg_point16) or 16+4-B loads (PointXYZIR).  Per wavefront it keeps a
+// tile histogram in LDS (ds_add, order-free counts) that is written out once per chunk; the stable
+// scatter (k_scatter) turns the scanned histograms into destinations.  No global atomics.
+//
+// HBM-bound: algorithmic bytes per point = 16 (point) + 4 (old ground gather) read, 8 (z,key) written.
+#include "gg_device.h"
+
+#include <algorithm>
+
+namespace gg {
+
+struct PointIn {
+    float x, y, z;
+    int ring;
+};
+
+template <int FMT>
+GG_DEV PointIn load_point(const void *base, size_t idx)
+{
+    PointIn p;
+    if (FMT == GG_POINT16) {
+        const uint4 v = reinterpret_cast<const uint4 *>(base)[idx];
+        p.x = __uint_as_float(v.x);
+        p.y = __uint_as_float(v.y);
+        p.z = __uint_as_float(v.z);
+        p.ring = (int)(v.w & 0xFFFFu);
+    } else {
+        const uint4 *q = reinterpret_cast<const uint4 *>(base) + idx * 2;
+        const uint4 v = q[0];
+        const uint32_t w = reinterpret_cast<const uint32_t *>(q + 1)[1]; // byte offset 20: ring (u16) + pad
+        p.x = __uint_as_float(v.x);
+        p.y = __uint_as_float(v.y);
+        p.z = __uint_as_float(v.z);
+        p.ring = (int)(w & 0xFFFFu);
+    }
+    return p;
+}
+
+// Returns the key (KEY_OUTSIDE if the point is not in the map).
+GG_DEV uint32_t classify_point(const Arena &a, const CloudParams &cp, const float *__restrict__ ground,
+                               const float *__restrict__ gpatch, const PointIn &pt)
+{
+    const Geometry &g = a.g;
+    const int rows = g.rows, cols = g.cols;
+    // :222-223
+    const double posx = (double)pt.x, posy = (double)pt.y;
+    const float dx = pt.x - cp.ox, dy = pt.y - cp.oy;
+    const float sqdist = (float)((double)dx * (double)dx + (double)dy * (double)dy);
+
+    // :228-231
+    if (!position_inside(g, cp.pos_x, cp.pos_y, posx, posy)) return KEY_OUTSIDE;
+    int gi0, gi1;
+    index_from_position(g, cp.pos_x, cp.pos_y, posx, posy, gi0, gi1);
+    if (gi0 < 0 || gi1 < 0 || gi0 >= rows || gi1 >= cols) return KEY_OUTSIDE; // UB in the reference; see DESIGN.md
+
+    int cls = GG_CLASS_KEPT;
+    if (pt.ring > a.cfg.max_ring || sqdist < g.min_dist_squared) { // :237
+        cls = GG_CLASS_IGNORED;
+    } else {
+        // Outlier detection test :243-275
+        const float oldgroundheight = ground[gi0 + gi1 * rows];
+        if ((double)pt.z < (double)oldgroundheight - 0.2) { // :244
+            float vx = pt.x - cp.ox, vy = pt.y - cp.oy, vz = pt.z - cp.oz; // :248-250
+            const float len = sqrtf(vx * vx + vy * vy + vz * vz);           // :252
+            vx /= len;                                                        // :253-255
+            vy /= len;
+            vz /= len;
+            const double len2 = (double)len * (double)len;
+            for (int step = 3;; ++step) { // :258
+                const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
+                const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
+                if (!(d2 < len2 && vz < -0.01f)) break;
+                const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
+                int I0, I1;
+                index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0, I1); // :261
+                if (I0 <= 0 || I1 <= 0 || I0 >= rows - 1 || I1 >= cols - 1) continue;         // :264-265
+                const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                            // :268
+                float e[9];
+#pragma unroll
+                for (int s = 0; s < 9; ++s) e[s] = gpatch[(r0 + s % 3) + (c0 + s / 3) * rows];
+                const float bsum = tree9(e);
+                if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gpatch[I0 + I1 * rows] > 0.01f &&
+                    (double)ground[I0 + I1 * rows] >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) { // :269
+                    cls = GG_CLASS_OUTLIER;
+                    break;
+                }
+            }
+        }
+    }
+    const uint32_t emit = (rows <= gi0 + 3 || cols <= gi1 + 3) ? 0u : KEY_EMIT_BIT; // :167-168 (decided by the cell only)
+    const uint32_t tile = (uint32_t)a.tile_rank[(gi0 / TILE) + (gi1 / TILE) * g.tiles_r];
+    return (tile << KEY_TILE_SHIFT) | emit | ((uint32_t)cls << KEY_CLASS_SHIFT) | (uint32_t)(gi0 % TILE) |
+           ((uint32_t)(gi1 % TILE) << 4);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
+{
+    extern __shared__ uint32_t lds_hist[]; // [4][T]
+    const int cloud = blockIdx.y;
+    const CloudParams cp = params[cloud];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + wave;
+    const int n = cp.n_points;
+    const int nch = (n + a.PW - 1) / a.PW;
+    if (chunk >= nch) return;
+
+    const int T = a.g.T;
+    uint32_t *hist = lds_hist + wave * T;
+    for (int t = lane; t < T; t += 64) hist[t] = 0u;
+
+    const float *ground = layer_ptr(a, cp.slot, GG_LAYER_GROUND);
+    const float *gpatch = layer_ptr(a, cp.slot, GG_LAYER_GROUNDPATCH);
+    const char *pts = reinterpret_cast<const char *>(io.d_points) +
+                      (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
+    uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
+
+    uint32_t n_kept = 0, n_ign = 0, n_outl = 0, n_inmap = 0;
+    const int base = chunk * a.PW;
+    const int end = min(base + a.PW, n);
+    for (int p0 = base; p0 < end; p0 += 64) {
+        const int p = p0 + lane;
+        const bool valid = p < end;
+        uint32_t key = KEY_OUTSIDE;
+        if (valid) {
+            const PointIn pt = load_point<FMT>(pts, (size_t)p);
+            key = classify_point(a, cp, ground, gpatch, pt);
+            rec[p] = make_uint2(__float_as_uint(pt.z), key);
+        }
+        const bool inmap = key != KEY_OUTSIDE;
+        if (inmap) atomicAdd(&hist[key >> KEY_TILE_SHIFT], 1u);
+        const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
+        const bool emit = inmap && (key & KEY_EMIT_BIT);
+        n_inmap += (uint32_t)__popcll(__ballot(inmap));
+        n_kept += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_KEPT));
+        n_ign += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_IGNORED));
+        n_outl += (uint32_t)__popcll(__ballot(inmap && cls == GG_CLASS_OUTLIER));
+    }
+
+    uint32_t *ghist = a.hist + (size_t)cp.slot * a.hist_stride + (size_t)chunk * T;
+    for (int t = lane; t < T; t += 64) ghist[t] = hist[t];
+    if (lane == 0) {
+        uint32_t *ce = a.chunk_emit + (size_t)cp.slot * a.emit_stride + (size_t)chunk * 4;
+        ce[0] = n_kept;
+        ce[1] = n_ign;
+        ce[2] = n_outl;
+        ce[3] = n_inmap;
+    }
+}
+
+void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s)
+{
+    const int nch = (max_n + a.PW - 1) / a.PW;
+    if (nch == 0 || n_clouds == 0) return;
+    dim3 grid((nch + 3) / 4, n_clouds);
+    const size_t lds = (size_t)4 * a.g.T * sizeof(uint32_t);
+    if (io.point_format == GG_POINT16)
+        hipLaunchKernelGGL(k_classify<GG_POINT16>, grid, dim3(256), lds, s, a, d_params, io);
+    else
+        hipLaunchKernelGGL(k_classify<GG_POINT32>, grid, dim3(256), lds, s, a, d_params, io);
+}
+
+// ---- small utility kernels ----------------------------------------------------------------
+
+__global__ void k_fill(float *dst, size_t n, float v)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+void launch_fill(float *dst, size_t n, float v, hipStream_t s)
+{
+    if (n == 0) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, dst, n, v);
+}
+
+// PointXYZIR (32 B) -> packed 16-B record, for callers that upload reference-layout clouds
+__global__ void k_pack16(const gg_point32 *__restrict__ src, gg_point16 *__restrict__ dst, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const PointIn p = load_point<GG_POINT32>(src, i);
+        uint4 o;
+        o.x = __float_as_uint(p.x);
+        o.y = __float_as_uint(p.y);
+        o.z = __float_as_uint(p.z);
+        o.w = (uint32_t)p.ring;
+        reinterpret_cast<uint4 *>(dst)[i] = o;
+    }
+}
+
+void launch_pack16(const gg_point32 *src, gg_point16 *dst, size_t n, hipStream_t s)
+{
+    if (n == 0) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(k_pack16, dim3(blocks), dim3(256), 0, s, src, dst, n);
+}
+
+// class + cell of every input point, decoded from the keys K1 wrote (gg_get_point_classes)
+__global__ void k_decode_classes(const Arena a, int slot, size_t n, uint8_t *d_class, int32_t *d_cell)
+{
+    const uint2 *rec = a.rec + (size_t)slot * a.point_stride;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t key = rec[i].y;
+        if (key == KEY_OUTSIDE) {
+            d_class[i] = GG_CLASS_OUTSIDE;
+            d_cell[i] = -1;
+        } else {
+            int row, col;
+            key_to_cell(a, key, row, col);
+            d_class[i] = (uint8_t)((key >> KEY_CLASS_SHIFT) & 3u);
+            d_cell[i] = row + col * a.g.rows;
+        }
+    }
+}
+
+void launch_decode_classes(const Arena &a, int slot, size_t n, uint8_t *d_class, int32_t *d_cell, hipStream_t s)
+{
+    if (n == 0) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(k_decode_classes, dim3(blocks), dim3(256), 0, s, a, slot, n, d_class, d_cell);
+}
+
+} // namespace gg

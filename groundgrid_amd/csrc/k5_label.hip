@@ -1,0 +1,133 @@
+// K5 -- filter_cloud's label loop and epilogue (src/GroundSegmentation.cpp:147-189).
+//
+// The reference returns a NEW cloud: kept points (cloud order), then ignored points (cloud order), then
+// outliers (cloud order), intensity overwritten with 99 (non-ground) / 49 (ground); points outside the
+// map or in the last 3 rows / cols are dropped.  This kernel produces, per INPUT point, the label and the
+// position in that returned cloud (and optionally the returned cloud itself): same wave <-> chunk
+// mapping as K1, per-chunk exclusive emission prefixes from k_scan, ranks inside a 64-point window from
+// ballots -> deterministic, identical order.  Non-ground points are counted back into `points` (:176)
+// with float atomics (exact: integer counts < 2^24, order-free).
+//
+// Algorithmic bytes per point: 8 (z,key) + 16 (x,y) + 8 (ground, variance gathers) read; 1 + 4 written.
+#include "gg_device.h"
+
+namespace gg {
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
+{
+    const int cloud = blockIdx.y;
+    const CloudParams cp = params[cloud];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + wave;
+    const int n = cp.n_points;
+    const int nch = (n + a.PW - 1) / a.PW;
+
+    const uint32_t *totals = a.totals + (size_t)cp.slot * 4;
+    if (io.d_out_counts && blockIdx.x == 0 && threadIdx.x == 0) {
+        int32_t *oc = io.d_out_counts + (size_t)cloud * 4;
+        oc[0] = (int32_t)(totals[0] + totals[1] + totals[2]);
+        oc[1] = (int32_t)totals[0];
+        oc[2] = (int32_t)totals[1];
+        oc[3] = (int32_t)totals[2];
+    }
+    if (chunk >= nch) return;
+
+    const int rows = a.g.rows;
+    const float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
+    const float *ground = L + GG_LAYER_GROUND * a.layer_stride;
+    const float *variance = L + GG_LAYER_VARIANCE * a.layer_stride;
+    float *points = const_cast<float *>(L) + GG_LAYER_POINTS * a.layer_stride;
+    const uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
+    const char *pts = reinterpret_cast<const char *>(io.d_points) + (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
+    uint8_t *labels = io.d_labels ? io.d_labels + (size_t)cloud * io.cloud_stride : nullptr;
+    int32_t *out_index = io.d_out_index ? io.d_out_index + (size_t)cloud * io.cloud_stride : nullptr;
+    gg_point32 *out_cloud = (FMT == GG_POINT32 && io.d_out_clouds) ? io.d_out_clouds + (size_t)cloud * io.cloud_stride : nullptr;
+
+    const uint32_t *ce = a.chunk_emit + (size_t)cp.slot * a.emit_stride + (size_t)chunk * 4;
+    uint32_t kept_base = ce[0];
+    uint32_t ign_base = totals[0] + ce[1];
+    uint32_t outl_base = totals[0] + totals[1] + ce[2];
+
+    const DevConfig &cfg = a.cfg;
+    const int base = chunk * a.PW;
+    const int end = min(base + a.PW, n);
+    for (int p0 = base; p0 < end; p0 += 64) {
+        const int p = p0 + lane;
+        const bool valid = p < end;
+        uint2 r = make_uint2(0u, KEY_OUTSIDE);
+        if (valid) r = rec[p];
+        const uint32_t key = r.y;
+        const bool inmap = key != KEY_OUTSIDE;
+        const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
+        const bool emit = inmap && (key & KEY_EMIT_BIT);
+        const bool is_kept = emit && cls == GG_CLASS_KEPT;
+        const bool is_ign = emit && cls == GG_CLASS_IGNORED;
+        const bool is_outl = inmap && cls == GG_CLASS_OUTLIER;
+
+        const unsigned long long mk = __ballot(is_kept), mi = __ballot(is_ign), mo = __ballot(is_outl);
+        int32_t idx = -1;
+        uint8_t label = GG_LABEL_DROPPED;
+        if (is_outl) { // :185-189
+            idx = (int32_t)(outl_base + (uint32_t)rank_below(mo));
+            label = GG_LABEL_GROUND;
+        } else if (is_kept || is_ign) { // :158-182
+            int row, col;
+            key_to_cell(a, key, row, col);
+            const size_t cidx = (size_t)row + (size_t)col * rows;
+            const double groundheight = (double)ground[cidx]; // :162
+            const float var = variance[cidx];                  // :165
+            float x, y;
+            if (FMT == GG_POINT16) {
+                const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)p * 2];
+                x = __uint_as_float(xy.x);
+                y = __uint_as_float(xy.y);
+            } else {
+                const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)p * 4];
+                x = __uint_as_float(xy.x);
+                y = __uint_as_float(xy.y);
+            }
+            const float z = __uint_as_float(r.x);
+            const float dist = ref_hypotf(x - cp.ox, y - cp.oy); // :170
+            const double tolerance = std_max(
+                std_min((cfg.min_dist_fac * (double)dist) / (double)var * cfg.min_point_height_thres, cfg.min_point_height_thres),
+                cfg.min_point_height_obs_thres); // :171
+            if (tolerance + groundheight < (double)z) { // :173
+                label = GG_LABEL_NONGROUND;
+                atomicAdd(&points[cidx], 1.0f); // :176
+            } else {
+                label = GG_LABEL_GROUND;
+            }
+            idx = is_kept ? (int32_t)(kept_base + (uint32_t)rank_below(mk)) : (int32_t)(ign_base + (uint32_t)rank_below(mi));
+        }
+        if (valid) {
+            if (labels) labels[p] = label;
+            if (out_index) out_index[p] = idx;
+            if (FMT == GG_POINT32 && out_cloud && idx >= 0) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(pts) + (size_t)p * 2;
+                uint4 lo = src[0], hi = src[1];
+                hi.x = __float_as_uint((float)label); // intensity := 49 / 99
+                uint4 *dst = reinterpret_cast<uint4 *>(out_cloud + idx);
+                dst[0] = lo;
+                dst[1] = hi;
+            }
+        }
+        kept_base += (uint32_t)__popcll(mk);
+        ign_base += (uint32_t)__popcll(mi);
+        outl_base += (uint32_t)__popcll(mo);
+    }
+}
+
+void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s)
+{
+    if (n_clouds == 0) return;
+    int nch = (max_n + a.PW - 1) / a.PW;
+    if (nch == 0) nch = 1; // still publish the (all-zero) counts
+    dim3 grid((nch + 3) / 4, n_clouds);
+    if (io.point_format == GG_POINT16)
+        hipLaunchKernelGGL(k_label<GG_POINT16>, grid, dim3(256), 0, s, a, d_params, io);
+    else
+        hipLaunchKernelGGL(k_label<GG_POINT32>, grid, dim3(256), 0, s, a, d_params, io);
+}
+
+} // namespace gg

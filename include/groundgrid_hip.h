@@ -1,0 +1,214 @@
+/*
+ * groundgrid_hip.h -- C ABI of libgroundgrid_hip.so: GroundGrid's per-cloud hot path on MI355X (gfx950).
+ *
+ * The reference has no FFI of its own for this path: it is the C++ class
+ * groundgrid::GroundSegmentation in the separately linked library
+ * groundgrid_groundsegmentation_lib (/root/reference/CMakeLists.txt:112-125), used by the nodelet
+ * at src/GroundGridNodelet.cpp:95 (init), :301 (setConfig) and :196 (filter_cloud).  A drop-in
+ * replacement of that library keeps the class (see groundgrid_amd/host/GroundSegmentation.hpp and
+ * INTEGRATION.md) and forwards to the entry points below.  Each entry point cites the reference
+ * interface it replaces.
+ *
+ * Conventions the reference never had: every function returns gg_status (0 = OK, negative =
+ * error), nothing throws across the boundary, all state lives in an opaque gg_context.  Calls on
+ * one context must be externally serialised (the reference's callbacks are serialised by the ROS
+ * spinner, src/GroundGridNode.cpp:42); different contexts are independent.
+ *
+ * Plain pointers and sizes only -- no torch / HIP types in any signature (a HIP stream is passed
+ * as void*).  The library fails loudly (GG_ERR_NO_DEVICE / GG_ERR_HIP): there is no CPU fallback.
+ */
+#ifndef GROUNDGRID_HIP_H
+#define GROUNDGRID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GG_ABI_VERSION 1
+
+typedef enum gg_status {
+    GG_OK = 0,
+    GG_ERR_INVALID = -1,   /* null pointer / bad argument                        */
+    GG_ERR_GEOMETRY = -2,  /* grid_map size and GroundSegmentation::init cell count disagree */
+    GG_ERR_NOMEM = -3,     /* device or host allocation failed                   */
+    GG_ERR_HIP = -4,       /* a HIP runtime call or kernel failed (see gg_last_error) */
+    GG_ERR_CAPACITY = -5,  /* cloud larger than max_points / slot out of range   */
+    GG_ERR_NO_DEVICE = -6  /* no gfx950 device visible                           */
+} gg_status;
+
+/* velodyne_pointcloud::PointXYZIR, include/velodyne_pointcloud/point_types.h:27-33 (32 B, 16-B aligned) */
+typedef struct gg_point32 {
+    float x, y, z, pad0;
+    float intensity;
+    uint16_t ring;
+    uint16_t pad1;
+    uint32_t pad2[2];
+} gg_point32;
+
+/* Device-native packed record (what the host staging path uploads: everything the algorithm
+ * reads of a point -- x, y, z, ring -- in one 16-B load). */
+typedef struct gg_point16 {
+    float x, y, z;
+    uint16_t ring;
+    uint16_t pad;
+} gg_point16;
+
+typedef enum gg_point_format { GG_POINT32 = 0, GG_POINT16 = 1 } gg_point_format;
+
+/* groundgrid::GroundGridConfig, generated from cfg/GroundGrid.cfg:8-21 (int_t -> int, double_t -> double) */
+typedef struct gg_config {
+    int point_count_cell_variance_threshold;
+    int max_ring;
+    double groundpatch_detection_minimum_threshold;
+    double distance_factor;
+    double minimum_distance_factor;
+    double miminum_point_height_threshold; /* sic */
+    double minimum_point_height_obstacle_threshold;
+    double outlier_tolerance;
+    double ground_patch_detection_minimum_point_count_threshold;
+    double patch_size_change_distance;
+    double occupied_cells_decrease_factor;
+    double occupied_cells_point_count_factor;
+    double min_outlier_detection_ground_confidence;
+    int thread_count; /* accepted and ignored: results are those of thread_count = 1 */
+} gg_config;
+
+/* Compile-time constants of the reference made run-time parameters:
+ * GroundGrid::mDimension / mResolution (include/groundgrid/GroundGrid.h:70-71) and
+ * GroundSegmentation::verticalPointAngDist / minDistSquared (include/groundgrid/GroundSegmentation.h:69-70).
+ * Zero selects the reference value. */
+typedef struct gg_geometry {
+    float length;                  /* 120.0f */
+    float resolution;              /* .33f   */
+    float vertical_point_ang_dist; /* (float)(0.00174532925*2) */
+    float min_dist_squared;        /* 12.0f  */
+} gg_geometry;
+
+/* grid_map layer names used by the path (src/GroundGrid.cpp:55, src/GroundSegmentation.cpp:61-75) */
+typedef enum gg_layer {
+    GG_LAYER_POINTS = 0,
+    GG_LAYER_GROUND = 1,
+    GG_LAYER_GROUNDPATCH = 2,
+    GG_LAYER_MINGROUNDHEIGHT = 3,
+    GG_LAYER_MAXGROUNDHEIGHT = 4,
+    GG_LAYER_GROUNDCANDIDATES = 5,
+    GG_LAYER_PLANEDIST = 6,
+    GG_LAYER_M2 = 7,
+    GG_LAYER_MEANVARIANCE = 8,
+    GG_LAYER_POINTSRAW = 9,
+    GG_LAYER_VARIANCE = 10,
+    GG_NUM_LAYERS = 11
+} gg_layer;
+
+/* per-input-point label: the intensity codes filter_cloud writes (src/GroundSegmentation.cpp:175,180,188);
+ * 0 = the point is not in the returned cloud (outside the map, :230-231, or border, :167-168). */
+enum { GG_LABEL_DROPPED = 0, GG_LABEL_GROUND = 49, GG_LABEL_NONGROUND = 99 };
+
+/* per-input-point class decided by insert_cloud (src/GroundSegmentation.cpp:230-279) */
+enum { GG_CLASS_OUTSIDE = 0, GG_CLASS_IGNORED = 1, GG_CLASS_OUTLIER = 2, GG_CLASS_KEPT = 3 };
+
+/* gg_set_flags bits */
+enum {
+    GG_FLAG_MINIMAL_LAYERS = 1, /* skip the four layers nothing in the path reads (groundCandidates, planeDist,
+                                   maxGroundHeight, meanVariance are still zero/initial-filled); default off */
+    GG_FLAG_PROFILE = 2         /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
+};
+
+typedef struct gg_context gg_context;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+void gg_default_config(gg_config *cfg);     /* cfg/GroundGrid.cfg defaults */
+void gg_default_geometry(gg_geometry *g);   /* GroundGrid.h:70-71, GroundSegmentation.h:69-70 */
+
+/* GroundSegmentation::init (src/GroundSegmentation.cpp:37-48) + the map geometry GroundGrid creates
+ * (grid_map::setGeometry, src/GroundGrid.cpp:58), for n_slots independent map states ("streams")
+ * that can be processed in one batched launch.  max_points = capacity per cloud. */
+int gg_create(const gg_geometry *geom, int n_slots, size_t max_points, int device, gg_context **out);
+void gg_destroy(gg_context *ctx);
+
+/* GroundSegmentation::setConfig (src/GroundSegmentation.cpp:468-471) */
+int gg_set_config(gg_context *ctx, const gg_config *cfg);
+int gg_get_config(const gg_context *ctx, gg_config *cfg);
+int gg_set_flags(gg_context *ctx, unsigned flags);
+
+int gg_get_size(const gg_context *ctx, int *rows, int *cols);          /* grid_map::GridMap::getSize */
+int gg_get_geometry(const gg_context *ctx, double *resolution, double *length_x, double *length_y);
+const char *gg_last_error(const gg_context *ctx);
+
+/* ---- map state (what GroundGrid owns; the path borrows it by reference, :50) --------------- */
+
+/* GroundGrid::initGroundGrid layer values (src/GroundGrid.cpp:71-75) + map position */
+int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float odom_z);
+/* map position after grid_map::move (src/GroundGrid.cpp:97); layers unchanged */
+int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y);
+/* any of the 11 layers, column-major rows x cols float32 (Eigen::MatrixXf), host memory */
+int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src);
+int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst);
+/* GroundSegmentation::expectedPoints (src/GroundSegmentation.cpp:40-46), host copy */
+int gg_get_expected_points(const gg_context *ctx, float *dst);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+
+/* GroundSegmentation::filter_cloud (include/groundgrid/GroundSegmentation.h:54,
+ * src/GroundSegmentation.cpp:50-197): host buffers in, host buffers out, synchronous.
+ *   cloud, n    : input cloud already in the map frame (Nodelet.cpp:166-181)
+ *   origin      : cloudOrigin x,y,z
+ *   base_z      : mapToBase.transform.translation.z (the only field of the transform the path uses, :406-411)
+ *   out_cloud   : capacity n (nullable); receives the returned cloud: kept, then ignored, then outliers
+ *   out_n       : number of points in the returned cloud
+ *   out_label   : per input point GG_LABEL_* (nullable)
+ *   out_index   : per input point position in the returned cloud, -1 if dropped (nullable) */
+int gg_filter_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const float origin[3],
+                    double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label,
+                    int32_t *out_index);
+
+/* Batched, device-resident form of the same call: n_clouds independent (cloud, map-state) pairs in
+ * one set of launches, slot first_slot + b for cloud b.  Pointers prefixed d_ are device memory.
+ * Enqueues on `stream` (a hipStream_t passed as void*, NULL = the context's own stream) and returns
+ * without waiting. */
+typedef struct gg_batch {
+    int n_clouds;
+    int first_slot;
+    int point_format;        /* gg_point_format */
+    const void *d_points;    /* [n_clouds][cloud_stride] records of point_format */
+    size_t cloud_stride;     /* in points; <= max_points */
+    const int32_t *n_points; /* host [n_clouds] */
+    const float *origins;    /* host [n_clouds][3] */
+    const double *base_z;    /* host [n_clouds] */
+    uint8_t *d_labels;       /* [n_clouds][cloud_stride], nullable */
+    int32_t *d_out_index;    /* [n_clouds][cloud_stride], nullable */
+    gg_point32 *d_out_clouds; /* [n_clouds][cloud_stride], nullable; needs point_format == GG_POINT32 */
+    int32_t *d_out_counts;   /* [n_clouds][4]: returned-cloud size, kept, ignored, outliers; nullable */
+} gg_batch;
+int gg_filter_batch(gg_context *ctx, const gg_batch *batch, void *stream);
+int gg_synchronize(gg_context *ctx);
+
+/* insert_cloud's per-point decision (include/groundgrid/GroundSegmentation.h:55): after a filter call,
+ * class (GG_CLASS_*) and cell (row + col*rows, -1 outside) of every input point of `slot`. */
+int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class, int32_t *out_cell);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+
+enum {
+    GG_K_CLASSIFY = 0, /* K1: insert_cloud classify + tile key (:219-279)                 */
+    GG_K_SCAN = 1,     /*     exclusive scan of tile histograms                            */
+    GG_K_SCATTER = 2,  /*     stable scatter into Morton-tile order                        */
+    GG_K_REDUCE = 3,   /* K2: ordered per-cell reductions (:282-309) + variance (:323)    */
+    GG_K_PATCH = 4,    /* K3: detect_ground_patch<3|5> stencil (:330-395)                 */
+    GG_K_SPIRAL = 5,   /* K4: spiral_ground_interpolation (:398-465)                       */
+    GG_K_LABEL = 6,    /* K5: label loop (:147-189)                                        */
+    GG_NUM_KERNELS = 7
+};
+/* With GG_FLAG_PROFILE: accumulated milliseconds and launch counts per kernel since the last reset. */
+int gg_get_kernel_times(gg_context *ctx, double ms[GG_NUM_KERNELS], int64_t launches[GG_NUM_KERNELS], int reset);
+const char *gg_kernel_name(int k);
+int gg_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -219,7 +219,8 @@ class OracleMap:
             self._m, C.byref(self.cfg), cloud.ctypes.data, n, org, float(base_z),
             out.ctypes.data, label.ctypes.data, index.ctypes.data, cls.ctypes.data, cell.ctypes.data,
         )
-        return dict(out_points=out[:out_n].copy(), label=label[:n], index=index[:n], cls=cls[:n], cell=cell[:n])
+        # NB: no .copy() -- numpy copies padded structured dtypes field by field and leaves the padding undefined
+        return dict(out_points=out[:out_n], label=label[:n], index=index[:n], cls=cls[:n], cell=cell[:n])
 
     # stage-wise entry points (for per-kernel parity tests)
     def stage_reset(self):
