@@ -1,0 +1,253 @@
+"""GPU parity tests (pytest -m gpu, on a real MI355X): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs and against the committed vectors in tests/golden/.
+
+Bar: integer results (class, cell, label, position in the returned cloud, counts) bit-exact; every float layer
+bit-exact too (NaN == NaN), which is stricter than the 1e-4 m the north star allows for terrain height.
+Nothing here reads /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from groundgrid_amd import api, synth  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ORIGIN0 = (0.0, 0.0, 0.0)
+
+
+def nan_equal(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def assert_same_state(seg_map, ref, tag=""):
+    for name in oracle.LAYERS:
+        a, b = seg_map[name], ref.layer(name)
+        if not nan_equal(a, b):
+            bad = np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b))))
+            raise AssertionError(f"{tag} layer {name}: {len(bad)} cells differ, first {bad[:3].tolist()} "
+                                 f"gpu={[float(a[tuple(i)]) for i in bad[:3]]} ref={[float(b[tuple(i)]) for i in bad[:3]]}")
+
+
+def run_pair(cloud, length=120.0, resolution=0.33, pos=(0.0, 0.0), origin=ORIGIN0, base_z=-1.73, frames=2, cfg_edit=None,
+             odom_z=0.0):
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=1, max_points=max(len(cloud), 1))
+    ref = oracle.OracleMap(length, resolution, pos=pos, odom_z=odom_z)
+    seg.map(0).reset(odom_z=odom_z, pos=pos)
+    if cfg_edit:
+        c = seg.getConfig()
+        cfg_edit(c)
+        seg.setConfig(c)
+        cfg_edit(ref.cfg)
+    for f in range(frames):
+        out, labels, index = seg.filter_cloud(cloud, origin, base_z, return_details=True)
+        r = ref.filter_cloud(cloud, origin, base_z)
+        cls, cell = seg.point_classes(len(cloud))
+        assert np.array_equal(cls, r["cls"]), f"frame {f}: classes differ at {np.nonzero(cls != r['cls'])[0][:5]}"
+        assert np.array_equal(cell, r["cell"]), f"frame {f}: cells differ"
+        assert np.array_equal(labels, r["label"]), f"frame {f}: {int((labels != r['label']).sum())} labels differ"
+        assert np.array_equal(index, r["index"]), f"frame {f}: returned-cloud order differs"
+        assert out.tobytes() == r["out_points"].tobytes(), f"frame {f}: returned cloud differs"
+        assert_same_state(seg.map(0), ref, f"frame {f}")
+    seg.close()
+    return r
+
+
+# ---------------------------------------------------------------- committed vectors
+
+@pytest.mark.parametrize("fname", sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz")))
+def test_golden_vectors(fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    cloud = np.frombuffer(g["cloud"].tobytes(), dtype=synth.POINT_DTYPE)
+    seg = api.GroundSegmentation().init(float(g["length"]), float(g["resolution"]), n_slots=1, max_points=len(cloud))
+    seg.map(0).reset(pos=tuple(g["pos"]))
+    for f in range(int(g["frames"])):
+        _, labels, index = seg.filter_cloud(cloud, tuple(g["origin"]), float(g["base_z"]), return_details=True)
+        cls, _ = seg.point_classes(len(cloud))
+        assert np.array_equal(labels, g[f"label_{f}"])
+        assert np.array_equal(index, g[f"index_{f}"])
+        assert np.array_equal(cls, g[f"cls_{f}"])
+        for layer in ("ground", "groundpatch", "variance"):
+            assert nan_equal(seg.map(0)[layer], g[f"{layer}_{f}"]), (f, layer)
+
+
+# ---------------------------------------------------------------- oracle on the same seeded inputs
+
+def test_expected_points_table_matches():
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=16)
+    assert np.array_equal(seg.expected_points(), oracle.OracleMap(120.0, 0.33).expected_points())
+
+
+def test_hdl64_full_size_three_frames():
+    r = run_pair(synth.hdl64_cloud(), frames=3)  # BASELINE configs[1]: ~125 k points, 364 x 364
+    assert (r["cls"] == oracle.OUTLIER).sum() > 0  # warm map: the line-of-sight test fired
+
+
+def test_hdl64_firing_order():
+    run_pair(synth.hdl64_cloud(seed=5, order="azimuth"), frames=2)  # every consecutive point in another cell/tile
+
+
+def test_unstructured_cloud_moved_map_and_origin():
+    run_pair(synth.random_cloud(60000, seed=9), pos=(4.29, -2.64), origin=(4.0, -2.5, 0.1), base_z=-1.6, frames=3)
+
+
+def test_dense_single_cells_and_ties():
+    # thousands of points in a handful of cells: long ordered Welford chains, LDS staging over several chunks
+    rng = np.random.default_rng(4)
+    n = 30000
+    xy = rng.choice(np.array([5.0, 5.2, 5.4, 7.7]), size=(n, 2)) + rng.uniform(0, 0.05, size=(n, 2))
+    z = rng.normal(-1.7, 0.05, size=n)
+    run_pair(synth.make_cloud(np.column_stack([xy, z]), ring=rng.integers(0, 64, n)), frames=2)
+
+
+def test_config_variations():
+    def edit(c):
+        c.max_ring = 40            # rings 41..63 ignored
+        c.point_count_cell_variance_threshold = 3
+        c.outlier_tolerance = 0.05
+        c.patch_size_change_distance = 10.0
+        c.occupied_cells_decrease_factor = 3.0
+        c.min_outlier_detection_ground_confidence = 0.8
+    r = run_pair(synth.hdl64_cloud(seed=21, n_az=700), frames=3, cfg_edit=edit)
+    assert (r["cls"] == oracle.IGNORED).sum() > 0
+
+
+def test_edge_cases():
+    pts = np.array([[5, 5, -1], [1, 1, -1], [5, 5, -1], [500, 0, -1], [np.nan, 0, -1], [5, 5, np.nan], [-59.9, -59.9, -1],
+                    [np.inf, 1, 0], [59.99, 59.99, 0.5], [0, 0, 3], [3, -59.5, -1.6], [5, 5, -np.inf], [-1e30, 2, 0]],
+                   dtype=np.float32)
+    cloud = synth.make_cloud(pts, ring=[0, 0, 2000, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5])
+    run_pair(cloud, frames=2)
+    run_pair(synth.empty_cloud(0), frames=2)
+    run_pair(synth.make_cloud(np.array([[900.0, 900.0, 0.0]], dtype=np.float32)), frames=1)  # everything outside
+
+
+def test_initial_ground_height_nonzero():
+    run_pair(synth.hdl64_cloud(seed=3, n_az=400), frames=2, odom_z=-1.5)
+
+
+def test_config4_geometry_dense_cloud():
+    # BASELINE configs[3] geometry: 200 m @ 0.2 m -> 1000 x 1000 cells; 128 beams x 2048 azimuths (~260 k points)
+    cloud = synth.os128_cloud(seed=1, n_az=2048)
+    seg = api.GroundSegmentation().init(200.0, 0.2, n_slots=1, max_points=len(cloud))
+    assert (seg.rows, seg.cols) == (1000, 1000)
+    seg.close()
+    run_pair(cloud, length=200.0, resolution=0.2, frames=2)
+
+
+# ---------------------------------------------------------------- batched, device-resident entry point
+
+def _batch_inputs(fmt, clouds, stride):
+    import torch
+
+    B = len(clouds)
+    if fmt == 16:
+        host = np.zeros((B, stride), dtype=api.POINT16_DTYPE)
+        for b, c in enumerate(clouds):
+            host[b, : len(c)] = api.pack16(c)
+        raw = host.view(np.uint8).reshape(B, stride, 16)
+    else:
+        raw = np.zeros((B, stride, 32), dtype=np.uint8)
+        for b, c in enumerate(clouds):
+            raw[b, : len(c)] = np.frombuffer(c.tobytes(), dtype=np.uint8).reshape(-1, 32)
+    return torch.from_numpy(raw).cuda()
+
+
+@pytest.mark.parametrize("fmt", [16, 32])
+def test_batched_independent_maps(fmt):
+    import torch
+
+    clouds = [synth.hdl64_cloud(seed=100 + k, n_az=300 + 37 * k) for k in range(5)] + [synth.empty_cloud(0)]
+    B, stride = len(clouds), max(len(c) for c in clouds) + 3
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B + 1, max_points=stride)
+    refs = [oracle.OracleMap(120.0, 0.33) for _ in clouds]
+    pts = _batch_inputs(fmt, clouds, stride)
+    origins = np.array([[0.1 * b, -0.05 * b, 0.02 * b] for b in range(B)], dtype=np.float32)
+    base_z = np.array([-1.73 + 0.01 * b for b in range(B)])
+    out = None
+    for frame in range(2):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], origins, base_z, first_slot=1, out=out, want_clouds=(fmt == 32))
+        torch.cuda.synchronize()
+        labels, index, counts = out.labels.cpu().numpy(), out.out_index.cpu().numpy(), out.counts.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, tuple(origins[b]), float(base_z[b]))
+            n = len(c)
+            assert np.array_equal(labels[b, :n], r["label"]), (frame, b)
+            assert np.array_equal(index[b, :n], r["index"]), (frame, b)
+            assert counts[b, 0] == len(r["out_points"])
+            assert counts[b, 3] == (r["cls"] == oracle.OUTLIER).sum()
+            assert_same_state(seg.map(b + 1), refs[b], f"frame {frame} cloud {b}")
+            if fmt == 32:
+                got = out.out_clouds[b, : counts[b, 0]].cpu().numpy().tobytes()
+                assert got == r["out_points"].tobytes(), (frame, b)
+    # slot 0 was never touched by the batch
+    assert (seg.map(0)["ground"] == 0).all()
+
+
+def test_minimal_layers_flag_keeps_labels_and_terrain():
+    cloud = synth.hdl64_cloud(seed=8, n_az=600)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    seg.set_flags(minimal_layers=True)
+    ref = oracle.OracleMap(120.0, 0.33)
+    for _ in range(2):
+        _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+        r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"])
+        for name in ("ground", "groundpatch", "points", "variance", "m2", "minGroundHeight", "pointsRaw", "meanVariance"):
+            assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+
+
+def test_run_to_run_determinism_and_reset():
+    cloud = synth.hdl64_cloud(seed=12, order="azimuth")
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    runs = []
+    for _ in range(3):
+        seg.map(0).reset()
+        for _ in range(2):
+            _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+        runs.append((labels.copy(), index.copy(), {k: v for k, v in seg.map(0).layers().items()}))
+    for lab, idx, layers in runs[1:]:
+        assert np.array_equal(lab, runs[0][0]) and np.array_equal(idx, runs[0][1])
+        for k in layers:
+            assert nan_equal(layers[k], runs[0][2][k]), k
+
+
+def test_full_size_properties_without_oracle():
+    """Size-independent properties at BASELINE's full size (also at the 2.1 M-point scale the oracle is slow on)."""
+    cloud = synth.hdl64_cloud(seed=31)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    for _ in range(2):
+        out, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+    cls, cell = seg.point_classes(len(cloud))
+    emitted = index >= 0
+    assert len(out) == emitted.sum()
+    assert np.array_equal(np.sort(index[emitted]), np.arange(emitted.sum()))  # a permutation
+    for k in (oracle.KEPT, oracle.IGNORED, oracle.OUTLIER):
+        sel = emitted & (cls == k)
+        assert (np.diff(index[sel]) > 0).all()                                 # cloud order inside each class
+    assert (labels[~emitted] == 0).all() and np.isin(labels[emitted], (49, 99)).all()
+    assert np.array_equal(out["intensity"], labels[emitted][np.argsort(index[emitted])].astype(np.float32))
+    pts_layer = seg.map(0)["points"]
+    cnt = np.bincount(cell[labels == 99], minlength=364 * 364).reshape((364, 364), order="F")
+    assert np.array_equal(pts_layer, cnt.astype(np.float32))                   # :176 non-ground count per cell
+    raw = seg.map(0)["pointsRaw"]
+    assert raw.sum() == (cls != oracle.OUTSIDE).sum()                          # :234 every in-map point counted once
+
+
+def test_capacity_and_argument_errors():
+    from groundgrid_amd._lib import GroundGridError
+
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=100)
+    with pytest.raises(GroundGridError):
+        seg.filter_cloud(synth.random_cloud(101, seed=1), ORIGIN0, -1.7)
+    with pytest.raises(GroundGridError):
+        api.GroundSegmentation().init(100.4, 0.4)  # GG_ERR_GEOMETRY
+
+
+def test_config4_full_2M_points_one_frame():
+    cloud = synth.os128_cloud(seed=2)  # ~2.1 M points, 1000 x 1000 grid (BASELINE configs[3])
+    assert len(cloud) > 1_900_000
+    run_pair(cloud, length=200.0, resolution=0.2, frames=1)

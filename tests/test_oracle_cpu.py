@@ -1,0 +1,273 @@
+"""CPU tests of the oracle (oracle/gg_oracle.c): hand-computed cases, an independent pure-Python
+restatement (tests/pyref.py) on small grids, the committed regression vectors (tests/golden/), and the
+edge cases the reference's control flow has.  The reference itself ships no tests or vectors
+ and cannot be built here, so nothing below is a reference output: PARITY UNPINNED.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from groundgrid_amd import synth
+from oracle import oracle
+from tests import pyref
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+F32 = np.float32
+
+
+def nan_equal(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+# ------------------------------------------------------------------ geometry / tables
+
+def test_geometry_matches_reference_constants():
+    m = oracle.OracleMap(120.0, 0.33)
+    assert (m.rows, m.cols) == (364, 364)  # round(120 / 0.33000001311) = 364, not 363
+    assert m.resolution == float(F32(0.33))
+    assert m.length[0] == 364 * float(F32(0.33))
+    assert oracle.spiral_visit_count(364) == 130680
+    assert oracle.spiral_visit_count(1000) == 995004
+
+
+def test_inconsistent_geometry_rejected():
+    # grid_map size round(100.4/0.4)=251 but init() sees size_t(100)/0.4 -> 250
+    with pytest.raises(ValueError):
+        oracle.OracleMap(100.4, 0.4)
+
+
+def test_get_index_against_plain_double_arithmetic():
+    m = oracle.OracleMap(120.0, 0.33, pos=(3.7, -11.2))
+    res, L = m.resolution, m.length[0]
+    rng = np.random.default_rng(0)
+    for x, y in rng.uniform(-80, 80, size=(2000, 2)):
+        inside, r, c = m.get_index(x, y)
+        half = 0.5 * L
+        er = int(-(((x - half) - 3.7) / res))
+        ec = int(-(((y - half) - (-11.2)) / res))
+        tx, ty = -((x - 3.7) - half), -((y + 11.2) - half)
+        assert (r, c) == (er, ec)
+        assert inside == (0.0 <= tx < L and 0.0 <= ty < L)
+    # index 0 is at +x/+y; NaN is never inside
+    assert m.get_index(3.7 + 60.0, -11.2 + 60.0)[1:] == (0, 0)
+    assert m.get_index(float("nan"), 0.0)[0] is False
+
+
+def test_expected_points_table():
+    m = oracle.OracleMap(120.0, 0.33)
+    e = m.expected_points()
+    vpad = F32(0.00174532925 * 2)
+    assert e[182, 182] == F32(np.arctan(F32(np.inf), dtype=np.float32)) / vpad  # dist 0 -> atan(inf)/vpad ~ 450
+    d = F32(math.hypot(10 - 182.0, 300 - 182.0))
+    assert abs(e[10, 300] - F32(math.atan(1.0 / float(d))) / vpad) <= 2 * np.spacing(e[10, 300])
+    assert e[0, 0] == e[0, 0].astype(np.float32) and np.isfinite(e).all()
+
+
+def test_tree_sum_order_is_eigen_unrolled_tree():
+    rng = np.random.default_rng(1)
+    for n in (9, 25):
+        for _ in range(50):
+            v = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 7, size=n)).astype(np.float32)
+            assert oracle.tree_sum(v) == float(pyref.tree_sum(list(v)))
+    # order sensitivity: a left-to-right sum gives a different float here
+    v = np.array([1e8, 1.0, -1e8, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], dtype=np.float32)
+    lr = F32(0)
+    for x in v:
+        lr = F32(lr + x)
+    t = ((F32(v[0] + v[1]) + F32(v[2] + v[3])) + (F32(v[4] + v[5]) + F32(v[6] + F32(v[7] + v[8]))))
+    assert oracle.tree_sum(v) == float(F32(t)) and float(lr) != float(F32(t))
+
+
+def test_hypotf_is_double_sqrt_rounded():
+    rng = np.random.default_rng(2)
+    for x, y in rng.uniform(-100, 100, size=(500, 2)).astype(np.float32):
+        assert oracle.hypotf(x, y) == float(F32(math.sqrt(float(x) * float(x) + float(y) * float(y))))
+    assert oracle.hypotf(0.0, -3.0) == 3.0
+
+
+# ------------------------------------------------------------------ hand-computed reductions
+
+def small_map():
+    return oracle.OracleMap(21.12, 0.33)  # 64 x 64 cells
+
+
+def test_single_cell_welford_by_hand():
+    m = small_map()
+    assert m.rows == 64
+    # three points in the same cell (5.0, 5.0), sensor origin z = 0.5
+    zs = np.array([-1.0, -0.8, -1.3], dtype=np.float32)
+    xyz = np.column_stack([np.full(3, 5.0), np.full(3, 5.0), zs]).astype(np.float32)
+    cloud = oracle.make_cloud(xyz, ring=[1, 2, 3])
+    m.stage_reset()
+    cls, cell = m.stage_insert(cloud, origin=(0.0, 0.0, 0.5))
+    assert (cls == oracle.KEPT).all() and len(set(cell)) == 1
+    r, c = int(cell[0]) % 64, int(cell[0]) // 64
+    inside, er, ec = m.get_index(5.0, 5.0)
+    assert inside and (r, c) == (er, ec)
+    # by hand (float32 steps of src/GroundSegmentation.cpp:295-309)
+    cnt, gc, mean, pdm, m2 = F32(0), F32(0), F32(0), F32(0), F32(0)
+    mx, mn = np.finfo(np.float32).tiny, np.finfo(np.float32).max
+    for z in zs:
+        pd = F32(z - F32(0.5))
+        gc = F32(np.float64(F32(z + F32(cnt * gc))) / (np.float64(cnt) + 1.0))
+        if mean == 0:
+            mean = pd
+        delta = F32(pd - mean)
+        mean = F32(mean + F32(delta / F32(cnt + F32(1))))
+        pdm = F32(np.float64(F32(pd + F32(cnt * pdm))) / (np.float64(cnt) + 1.0))
+        m2 = F32(m2 + F32(delta * F32(pd - mean)))
+        mx = max(mx, z)
+        mn = min(mn, F32(z - F32(0.0001)))
+        cnt = F32(cnt + 1)
+    assert m.layer("points")[r, c] == 3 and m.layer("pointsRaw")[r, c] == 3
+    assert m.layer("groundCandidates")[r, c] == gc
+    assert m.layer("meanVariance")[r, c] == mean
+    assert m.layer("planeDist")[r, c] == pdm
+    assert m.layer("m2")[r, c] == m2
+    assert m.layer("maxGroundHeight")[r, c] == mx
+    assert m.layer("minGroundHeight")[r, c] == mn
+    # untouched cells hold the reset values, including the reference's FLT_MIN (sic) for max
+    assert m.layer("minGroundHeight")[0, 0] == np.finfo(np.float32).max
+    assert m.layer("maxGroundHeight")[0, 0] == np.finfo(np.float32).tiny
+
+
+def test_welford_is_order_dependent():
+    """m2 depends on point order -> unordered atomics cannot reproduce it."""
+    rng = np.random.default_rng(5)
+    zs = rng.normal(-1.7, 0.05, size=40).astype(np.float32)
+    res = []
+    for order in (np.arange(40), np.arange(40)[::-1]):
+        m = small_map()
+        xyz = np.column_stack([np.full(40, 5.0), np.full(40, 5.0), zs[order]]).astype(np.float32)
+        m.stage_reset()
+        _, cell = m.stage_insert(oracle.make_cloud(xyz), origin=(0, 0, 0))
+        res.append(m.layer("m2").ravel(order="F")[cell[0]])
+    assert res[0] != res[1]
+    assert abs(res[0] - res[1]) < 1e-4
+
+
+def test_classification_rules():
+    m = small_map()
+    cfg = m.cfg
+    cfg.max_ring = 10
+    pts = np.array([
+        [5.0, 5.0, -1.0],     # kept
+        [1.0, 1.0, -1.0],     # sqdist 2 < 12 -> ignored
+        [5.0, 5.0, -1.0],     # ring 11 > max_ring -> ignored
+        [50.0, 0.0, -1.0],    # outside the 21 m map
+        [np.nan, 0.0, -1.0],  # NaN x -> outside
+        [5.0, 5.0, np.nan],   # NaN z is KEPT (no comparison is true), poisons the cell
+        [-10.3, -10.3, -1.0], # last rows/cols: kept by insert, dropped from the returned cloud (:167-168)
+    ], dtype=np.float32)
+    cloud = oracle.make_cloud(pts, ring=[0, 0, 11, 0, 0, 0, 0])
+    r = m.filter_cloud(cloud, (0, 0, 0), -1.7)
+    assert list(r["cls"]) == [3, 1, 1, 0, 0, 3, 3]
+    assert list(r["cell"][[3, 4]]) == [-1, -1]
+    assert r["label"][3] == 0 and r["label"][4] == 0 and r["index"][3] == -1
+    inside, row, col = m.get_index(-10.3, -10.3)
+    assert inside and (64 <= row + 3 or 64 <= col + 3)
+    assert r["label"][6] == 0 and r["index"][6] == -1
+    # order of the returned cloud: kept (cloud order) then ignored (cloud order)
+    assert list(r["index"][[0, 5, 1, 2]]) == [0, 1, 2, 3]
+    assert len(r["out_points"]) == 4
+    assert set(np.unique(r["out_points"]["intensity"])) <= {49.0, 99.0}
+    # NaN z: groundCandidates of that cell is NaN, points counted
+    rr, cc = int(r["cell"][0]) % 64, int(r["cell"][0]) // 64
+    assert np.isnan(m.layer("groundCandidates")[rr, cc])
+
+
+def test_empty_cloud_and_all_outside():
+    m = small_map()
+    r = m.filter_cloud(synth.empty_cloud(0), (0, 0, 0), -1.0)
+    assert len(r["out_points"]) == 0
+    c = m.n = m.rows // 2 - 1
+    assert m.layer("ground")[c, c] == F32(-1.0) and m.layer("groundpatch")[c, c] == 1.0
+    xyz = np.array([[500, 500, 0], [-500, 2, 0]], dtype=np.float32)
+    r = m.filter_cloud(oracle.make_cloud(xyz), (0, 0, 0), -1.0)
+    assert len(r["out_points"]) == 0 and (r["label"] == 0).all()
+
+
+def test_variance_zero_and_dist_zero_tolerance_branches():
+    """:171: variance 0 -> inf -> clamp 0.3; dist 0 and variance 0 -> NaN -> classified ground."""
+    m = small_map()
+    # one kept point far away: its cell has variance 0 -> tolerance 0.3
+    xyz = np.array([[6.0, 0.0, 5.0]], dtype=np.float32)
+    r = m.filter_cloud(oracle.make_cloud(xyz), (0, 0, 0), 0.0)
+    assert r["label"][0] in (49, 99)
+    # a point exactly at the origin (ignored: sqdist 0 < 12) with variance 0 in its cell and dist 0 -> NaN -> ground
+    xyz = np.array([[0.0, 0.0, 50.0]], dtype=np.float32)
+    m2 = small_map()
+    r = m2.filter_cloud(oracle.make_cloud(xyz), (0, 0, 0), 0.0)
+    assert r["cls"][0] == oracle.IGNORED and r["label"][0] == 49
+
+
+# ------------------------------------------------------------------ independent restatement
+
+@pytest.mark.parametrize("seed,origin,pos", [(0, (0.0, 0.0, 0.0), (0.0, 0.0)), (1, (0.4, -0.3, 0.2), (1.3, -2.1))])
+def test_oracle_matches_independent_python_restatement(seed, origin, pos):
+    rng = np.random.default_rng(seed)
+    n = 12000
+    xy = rng.uniform(-12, 12, size=(n, 2)) + np.array(pos)
+    z = -1.7 + 0.03 * xy[:, 0] + rng.normal(0, 0.02, size=n)
+    z[rng.random(n) < 0.2] += rng.uniform(0.2, 2.0)
+    z[rng.random(n) < 0.03] -= 1.0  # below ground: exercises the outlier ray march once the map is warm
+    cloud = oracle.make_cloud(np.column_stack([xy, z]).astype(np.float32), ring=rng.integers(0, 64, n))
+    m = oracle.OracleMap(21.12, 0.33, pos=pos)
+    p = pyref.PyRef(21.12, 0.33, pos=pos)
+    assert np.max(np.abs(p.expected - m.expected_points())) <= 1e-4 * np.max(p.expected)
+    p.expected = m.expected_points().copy()  # libm atanf vs numpy arctan may differ by an ulp; share the table
+    for frame in range(3):
+        r = m.filter_cloud(cloud, origin, -1.7)
+        q = p.filter_cloud(cloud, origin, -1.7)
+        assert np.array_equal(r["cls"], q["cls"]), frame
+        assert np.array_equal(r["cell"], q["cell"]), frame
+        for name in oracle.LAYERS:
+            assert nan_equal(m.layer(name), p.L[name]), (frame, name)
+        assert np.array_equal(r["label"], q["label"]) and np.array_equal(r["index"], q["index"]), frame
+    assert (r["cls"] == oracle.OUTLIER).sum() > 0  # the ray march fired
+
+
+# ------------------------------------------------------------------ committed regression vectors
+
+def golden_files():
+    return sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz")) if os.path.isdir(GOLDEN) else []
+
+
+@pytest.mark.parametrize("fname", golden_files())
+def test_oracle_reproduces_committed_vectors(fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    m = oracle.OracleMap(float(g["length"]), float(g["resolution"]), pos=tuple(g["pos"]))
+    cloud = np.frombuffer(g["cloud"].tobytes(), dtype=oracle.POINT_DTYPE)
+    for f in range(int(g["frames"])):
+        r = m.filter_cloud(cloud, tuple(g["origin"]), float(g["base_z"]))
+        assert np.array_equal(r["label"], g[f"label_{f}"])
+        assert np.array_equal(r["index"], g[f"index_{f}"])
+        assert nan_equal(m.layer("ground"), g[f"ground_{f}"])
+        assert nan_equal(m.layer("groundpatch"), g[f"groundpatch_{f}"])
+        assert nan_equal(m.layer("variance"), g[f"variance_{f}"])
+
+
+def test_golden_vectors_exist():
+    assert len(golden_files()) >= 3
+
+
+# ------------------------------------------------------------------ whole-cloud properties
+
+def test_full_size_cloud_properties():
+    cloud = synth.hdl64_cloud(seed=11, n_az=520)
+    m = oracle.OracleMap(120.0, 0.33)
+    for _ in range(2):
+        r = m.filter_cloud(cloud, (0, 0, 0), -1.73)
+    lab, idx = r["label"], r["index"]
+    emitted = idx >= 0
+    assert (lab[emitted] != 0).all() and (lab[~emitted] == 0).all()
+    assert sorted(idx[emitted]) == list(range(int(emitted.sum())))          # a permutation of the returned cloud
+    kept = (r["cls"] == 3) & emitted
+    assert (np.diff(idx[kept]) > 0).all()                                    # cloud order preserved inside a class
+    # `points` layer now holds the non-ground count per cell (:176)
+    cnt = np.bincount(r["cell"][(lab == 99)], minlength=364 * 364).reshape((364, 364), order="F")
+    assert np.array_equal(m.layer("points"), cnt.astype(np.float32))
+    # flat synthetic terrain: most returns are ground
+    assert (lab == 49).sum() > (lab == 99).sum()
