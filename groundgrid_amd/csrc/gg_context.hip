@@ -105,13 +105,20 @@ uint32_t morton2(uint32_t x, uint32_t y)
     return spread(x) | (spread(y) << 1);
 }
 
-// Replay spiral_ground_interpolation's visit order (src/GroundSegmentation.cpp:413-440) and give every
-// visit the earliest level compatible with the in-place data hazards on its 3x3 neighbourhood:
-//   RAW  level > level of the last earlier visit that wrote any of the 9 cells it reads
-//   WAR  level > level of every earlier visit that read the cell it writes
-//   WAW  level > level of the earlier visit of the same cell (the two doubly-visited corners per ring)
-// Visits sharing a level are independent, so a barrier between levels reproduces the serial sweep exactly.
-void build_spiral_schedule(int n, std::vector<uint32_t> &visits_by_level, std::vector<uint32_t> &level_start, int &max_width)
+// Replay spiral_ground_interpolation's visit order (src/GroundSegmentation.cpp:413-440) once and turn the serial,
+// in-place sweep into an exact level schedule:
+//   * every visit gets the earliest level compatible with the in-place data hazards on its 3x3 neighbourhood
+//       RAW  level > level of the last earlier visit that wrote any of the 9 cells it reads
+//       WAR  level > level of every earlier visit that read the cell it writes
+//       WAW  level > level of the earlier visit of the same cell (the two doubly-visited corners per ring)
+//     so visits sharing a level are independent and a barrier between levels reproduces the serial sweep;
+//   * for each of the 9 cells a visit reads, the replay knows whether an EARLIER visit rewrote it (fresh value) or
+//     not (pre-sweep value).  Fresh values are handed over through LDS: each written value gets a slot that stays
+//     allocated until the level of its last reader (lifetime <= 8 levels, 1723 slots for n = 364), pre-sweep values
+//     are read from the layer in global memory, which nobody has touched yet at that point.  The choice is made
+//     here, from the serial order -- never from timing on the device.
+void build_spiral_schedule(int n, double res, float min_dist_sq, std::vector<SpiralVisit> &visits_by_level,
+                           std::vector<uint32_t> &level_start, int &max_width, int &n_slots)
 {
     const int center = n / 2 - 1;
     std::vector<uint32_t> cells;
@@ -130,26 +137,32 @@ void build_spiral_schedule(int n, std::vector<uint32_t> &visits_by_level, std::v
                 cells.push_back((uint32_t)(x + y * n));
             }
     }
-    std::vector<int> last_write((size_t)n * n, 0), last_read((size_t)n * n, 0), level(cells.size());
+    const size_t V = cells.size();
+    const size_t C = (size_t)n * n;
+    std::vector<int> last_write(C, 0), last_read(C, 0), level(V), last_reader_level(V, 0);
+    std::vector<int64_t> last_writer(C, -1);
+    std::vector<int64_t> src_visit(V * 9, -1);
     int n_levels = 0;
-    for (size_t k = 0; k < cells.size(); ++k) {
+    for (size_t k = 0; k < V; ++k) {
         const int x = (int)(cells[k] % (uint32_t)n), y = (int)(cells[k] / (uint32_t)n);
         int lv = last_read[cells[k]];
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) lv = std::max(lv, last_write[(x + dx) + (y + dy) * n]);
+        for (int q = 0; q < 9; ++q) lv = std::max(lv, last_write[(x - 1 + q % 3) + (y - 1 + q / 3) * n]);
         lv += 1;
         level[k] = lv;
+        for (int q = 0; q < 9; ++q) {
+            const size_t nb = (size_t)((x - 1 + q % 3) + (y - 1 + q / 3) * n);
+            const int64_t w = last_writer[nb];
+            src_visit[k * 9 + q] = w;
+            if (w >= 0) last_reader_level[w] = std::max(last_reader_level[w], lv);
+            last_read[nb] = std::max(last_read[nb], lv);
+        }
         last_write[cells[k]] = lv;
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                int &r = last_read[(x + dx) + (y + dy) * n];
-                r = std::max(r, lv);
-            }
+        last_writer[cells[k]] = (int64_t)k;
         n_levels = std::max(n_levels, lv);
     }
+    // group by level (stable)
     level_start.assign((size_t)n_levels + 1, 0);
-    for (size_t k = 0; k < cells.size(); ++k) level_start[level[k]]++; // level l (1-based) counted at index l
-    // exclusive prefix: level l occupies [level_start[l-1], level_start[l])
+    for (size_t k = 0; k < V; ++k) level_start[level[k]]++;
     max_width = 0;
     uint32_t run = 0;
     for (int l = 1; l <= n_levels; ++l) {
@@ -159,9 +172,51 @@ void build_spiral_schedule(int n, std::vector<uint32_t> &visits_by_level, std::v
         run += c;
     }
     level_start[0] = 0;
-    visits_by_level.resize(cells.size());
-    std::vector<uint32_t> cursor(level_start.begin(), level_start.end() - 1);
-    for (size_t k = 0; k < cells.size(); ++k) visits_by_level[cursor[level[k] - 1]++] = cells[k];
+    std::vector<uint32_t> order(V);
+    {
+        std::vector<uint32_t> cursor(level_start.begin(), level_start.end() - 1);
+        for (size_t k = 0; k < V; ++k) order[cursor[level[k] - 1]++] = (uint32_t)k;
+    }
+    // LDS slot allocation, level by level: a slot is free again at (last reader level + 1)
+    std::vector<uint16_t> wslot(V, SPIRAL_NONE);
+    std::vector<std::vector<uint16_t>> release((size_t)n_levels + 2);
+    std::vector<uint16_t> free_slots;
+    n_slots = 0;
+    size_t pos = 0;
+    for (int l = 1; l <= n_levels; ++l) {
+        for (uint16_t s : release[l]) free_slots.push_back(s);
+        for (; pos < V && level[order[pos]] == l; ++pos) {
+            const uint32_t v = order[pos];
+            if (last_reader_level[v] == 0) continue;
+            uint16_t s;
+            if (!free_slots.empty()) {
+                s = free_slots.back();
+                free_slots.pop_back();
+            } else {
+                s = (uint16_t)n_slots++;
+            }
+            wslot[v] = s;
+            release[(size_t)last_reader_level[v] + 1].push_back(s);
+        }
+    }
+    visits_by_level.resize(V);
+    const double res2 = res * res;
+    for (size_t i = 0; i < V; ++i) {
+        const uint32_t v = order[i];
+        SpiralVisit d{};
+        d.cell = cells[v];
+        d.wslot = wslot[v];
+        const int x = (int)(cells[v] % (uint32_t)n), y = (int)(cells[v] / (uint32_t)n);
+        // :463 (pow((float)x - center_idx, 2.0) + pow((float)y - center_idx, 2.0)) * pow(resolution, 2.0f) > minDistSquared
+        const float fx = (float)x - (float)center, fy = (float)y - (float)center;
+        const double d2 = ((double)fx * (double)fx + (double)fy * (double)fy) * res2;
+        d.flags = (uint16_t)((last_writer[cells[v]] == (int64_t)v ? SPIRAL_STORE : 0) | (d2 > (double)min_dist_sq ? SPIRAL_DECAY : 0));
+        for (int q = 0; q < 9; ++q) {
+            const int64_t w = src_visit[(size_t)v * 9 + q];
+            d.src[q] = w >= 0 ? wslot[w] : SPIRAL_NONE;
+        }
+        visits_by_level[i] = d;
+    }
 }
 
 void make_dev_config(const gg_config &c, DevConfig &d)
@@ -417,11 +472,17 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
             ctx->h_expected[i + j * cellCount] = atanf(1 / dist) / geom.vertical_point_ang_dist;
         }
 
-    std::vector<uint32_t> visits, level_start;
-    int max_width = 0;
-    build_spiral_schedule(n, visits, level_start, max_width);
+    std::vector<SpiralVisit> visits;
+    std::vector<uint32_t> level_start;
+    int max_width = 0, spiral_slots = 0;
+    build_spiral_schedule(n, res, geom.min_dist_squared, visits, level_start, max_width, spiral_slots);
     a.n_levels = (int)level_start.size() - 1;
     a.max_level_width = max_width;
+    a.spiral_slots = spiral_slots;
+    if (spiral_slots >= 0xFFFF || (size_t)spiral_slots * 8 + level_start.size() * 4 > 150 * 1024 || max_width > 1024) {
+        gg_destroy(ctx);
+        return GG_ERR_GEOMETRY; // the spiral's fresh-value window no longer fits LDS
+    }
 
     std::vector<uint16_t> tile_rank(g.T), rank_tile(g.T);
     {
@@ -447,10 +508,11 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t Cpad = align_up(C * 4, A) / 4;
     const size_t Npad = align_up(max_points * 8, A) / 8;
     const size_t o_expected = carve(C * 4);
-    const size_t o_visits = carve(visits.size() * 4);
+    const size_t o_visits = carve(visits.size() * sizeof(SpiralVisit));
     const size_t o_lstart = carve(level_start.size() * 4);
     const size_t o_trank = carve((size_t)g.T * 2);
     const size_t o_rtile = carve((size_t)g.T * 2);
+    const size_t o_dummy = carve(2 * 1024 * 4);
     const size_t o_layers = carve((size_t)n_slots * GG_NUM_LAYERS * Cpad * 4);
     const size_t o_rec = carve((size_t)n_slots * Npad * 8);
     const size_t o_sorted = carve((size_t)n_slots * Npad * 8);
@@ -474,10 +536,11 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipMemsetAsync(base, 0, ctx->arena_bytes, ctx->stream));
 
     a.expected = (const float *)(base + o_expected);
-    a.visits = (const uint32_t *)(base + o_visits);
+    a.visits = (const SpiralVisit *)(base + o_visits);
     a.level_start = (const uint32_t *)(base + o_lstart);
     a.tile_rank = (const uint16_t *)(base + o_trank);
     a.rank_tile = (const uint16_t *)(base + o_rtile);
+    a.spiral_dummy = (float *)(base + o_dummy);
     a.layers = (float *)(base + o_layers);
     a.layer_stride = Cpad;
     a.slot_layer_stride = Cpad * GG_NUM_LAYERS;
@@ -498,7 +561,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_stage_cell = (int32_t *)(base + o_scell);
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
-    CREATE_CHK(hipMemcpyAsync(base + o_visits, visits.data(), visits.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CREATE_CHK(hipMemcpyAsync(base + o_visits, visits.data(), visits.size() * sizeof(SpiralVisit), hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_lstart, level_start.data(), level_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_rtile, rank_tile.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));

@@ -56,6 +56,20 @@ struct Geometry {
     int center;              // rows/2 - 1
 };
 
+// One visit of spiral_ground_interpolation (src/GroundSegmentation.cpp:413-440), 32 bytes.  Built on the host by
+// replaying the serial sweep once (gg_context.hip build_spiral_schedule): which of the 9 cells it reads were
+// already rewritten earlier in the serial order ("fresh": taken from an LDS slot) and which still hold their
+// pre-sweep value (read from the layer).
+struct SpiralVisit {
+    uint32_t cell;    // row + col * rows
+    uint16_t wslot;   // LDS slot receiving this visit's (ground, confidence); SPIRAL_NONE: nobody reads it during the sweep
+    uint16_t flags;   // bit0: last visit of the cell -> store to the layers; bit1: confidence decay applies (:463)
+    uint16_t src[9];  // 3x3 block, column-major: LDS slot holding the fresh value, SPIRAL_NONE: read the layer
+    uint16_t pad[3];
+};
+constexpr uint16_t SPIRAL_NONE = 0xFFFFu;
+constexpr uint16_t SPIRAL_STORE = 1u, SPIRAL_DECAY = 2u;
+
 // per-cloud parameters of one batched call (device array, one entry per cloud of the batch)
 struct CloudParams {
     int slot;
@@ -71,10 +85,12 @@ struct Arena {
     DevConfig cfg;
     // shared
     const float *expected;        // [C]
-    const uint32_t *visits;       // spiral visit list (cell linear index), grouped by level
+    const SpiralVisit *visits;    // spiral visit descriptors, grouped by level
     const uint32_t *level_start;  // [n_levels + 1]
     int n_levels;
     int max_level_width;
+    int spiral_slots;             // LDS slots the fresh-value window needs
+    float *spiral_dummy;          // [2 * 1024] write-only sink for idle lanes of k_spiral
     const uint16_t *tile_rank;    // [T] tile (tr + tc*tiles_r) -> Morton rank
     const uint16_t *rank_tile;    // [T] Morton rank -> tile
     // per slot (slot s at base + s * stride)

@@ -1,34 +1,51 @@
 // K2 -- insert_cloud, per-cell part (src/GroundSegmentation.cpp:282-309) fused with the per-call layer
 // reset (:61-75) and the variance layer (:323).
 //
-// One work-group per (cloud, tile); one thread per cell of the 16x16 tile.  The tile's records arrive
-// in cloud order (stable tile sort).  They are staged through LDS in chunks of CH records: every record
-// sets bit `position` in a per-cell bitmask with an LDS atomic OR (order-free), then each cell thread
-// walks its own mask from the lowest bit upwards -- i.e. in cloud order -- and runs the reference's
-// float32 recurrence (count, groundCandidates, running mean, planeDist, m2, min, max) in registers.
-// Running state stays in registers across chunks; the 9 per-call layers are written exactly once, which
-// also performs the reset of cells that received no point (points = 0, min = FLT_MAX, max = FLT_MIN...).
+// One work-group per (cloud, tile); one thread per cell of the 16x16 tile.  The tile's records arrive in
+// cloud order (stable tile sort).  They are staged through LDS in chunks of CH records and counting-sorted
+// by cell INSIDE LDS, stably:
+//   1. every record sets bit `position` in its cell's bitmask (LDS atomic OR: order-free),
+//   2. each cell thread turns its 32 mask words into per-word exclusive popcount prefixes and its total,
+//      a block scan of the 256 totals gives each cell a contiguous segment,
+//   3. every KEPT record computes its rank = prefix[word] + popc(mask[word] & bits below) -- the number of
+//      earlier records of the same cell, i.e. cloud order -- and drops its z into the cell's segment,
+//   4. each cell thread walks its own segment front to back and runs the reference's float32 recurrence
+//      (count, groundCandidates, running mean, planeDist, m2, min, max) in registers.
+// Lanes advance independently inside a chunk (a cell with 300 points does not stall its neighbours' words);
+// running state stays in registers across chunks; the 9 per-call layers are written exactly once, which also
+// performs the reset of cells that received no point (points = 0, min = FLT_MAX, max = FLT_MIN ...).
 //
-// Algorithmic bytes: 8 per in-map record read; 9 (full) or 4 (minimal) layers x 4 B per cell written.
+// Double rounding: the reference computes groundCandidates and planeDist as (float)((double)num / ((double)c + 1.0))
+// with num and c + 1 exactly representable floats (:296, :303).  For binary32 operands a quotient rounded to
+// binary64 (53 >= 2*24 + 2 bits) and then to binary32 equals the correctly rounded binary32 quotient (Figueroa,
+// "When is double rounding innocuous?", 1995), so the IEEE float division below is bit-identical and keeps the
+// 150-cycle f64 divide off the per-point dependency chain (tests/test_oracle_cpu.py::test_double_rounding_identity).
+//
+// Algorithmic bytes: 8 per in-map record read; 9 (full) or 5 (minimal) layers x 4 B per cell written.
 #include "gg_device.h"
 
 #include <float.h>
 
 namespace gg {
 
-constexpr int CH = 1024; // records staged per pass
+constexpr int CH = 1024;          // records staged per pass
+constexpr int NW = CH / 32;       // mask words per cell
+constexpr int RPT = CH / TILE_CELLS; // records per thread per pass
 
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams *__restrict__ params)
 {
-    __shared__ uint32_t mask[CH / 32][TILE_CELLS]; // 32 KiB: bit p of word [p/32][cell] <=> staged record p is a KEPT point of cell
-    __shared__ float zs[CH];                        // 4 KiB
-    __shared__ uint32_t raw_cnt[TILE_CELLS];        // pointsRaw (:234): every in-map point of the cell
+    __shared__ uint32_t mask[NW][TILE_CELLS];   // 32 KiB  bit p%32 of [p/32][cell] <=> staged record p is a KEPT point of cell
+    __shared__ uint16_t wprefix[NW][TILE_CELLS]; // 16 KiB  segment start of the cell + its KEPT records in words < w
+    __shared__ float zsorted[CH];                // 4 KiB   z, grouped by cell, cloud order inside a cell
+    __shared__ uint32_t raw_cnt[TILE_CELLS];     // pointsRaw (:234): every in-map point of the cell
+    __shared__ uint32_t wave_tot[4];
 
     const int cloud = blockIdx.y;
     const CloudParams cp = params[cloud];
     const int rank = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int tile = a.rank_tile[rank];
     const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
 
@@ -38,53 +55,100 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     const float oz = cp.oz;
 
     // per-cell running state == the layer values after :61-75
-    float c = 0.0f;        // points
-    float gc = 0.0f;       // groundCandidates
-    float mean = 0.0f;     // meanVariance
-    float pdm = 0.0f;      // planeDist
-    float m2 = 0.0f;       // m2
-    float mx = FLT_MIN;    // maxGroundHeight  (numeric_limits<float>::min(), sic, :73)
-    float mn = FLT_MAX;    // minGroundHeight  (:72)
+    float c = 0.0f;     // points
+    float gc = 0.0f;    // groundCandidates
+    float mean = 0.0f;  // meanVariance
+    float pdm = 0.0f;   // planeDist
+    float m2 = 0.0f;    // m2
+    float mx = FLT_MIN; // maxGroundHeight  (numeric_limits<float>::min(), sic, :73)
+    float mn = FLT_MAX; // minGroundHeight  (:72)
 
     raw_cnt[tid] = 0u;
 #pragma unroll
-    for (int w = 0; w < CH / 32; ++w) mask[w][tid] = 0u;
+    for (int w = 0; w < NW; ++w) mask[w][tid] = 0u;
     __syncthreads();
 
     for (uint32_t base = start; base < end; base += CH) {
         const int cnt = (int)min((uint32_t)CH, end - base);
-        for (int k = tid; k < cnt; k += 256) {
-            const uint2 r = sorted[base + k];
-            zs[k] = __uint_as_float(r.x);
-            const uint32_t cit = r.y & 255u;
-            atomicAdd(&raw_cnt[cit], 1u);
-            if (((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT) atomicOr(&mask[k >> 5][cit], 1u << (k & 31));
+        // ---- 1. stage: bitmask per cell ----
+        uint2 r[RPT];
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int k = j * TILE_CELLS + tid;
+            r[j] = make_uint2(0u, KEY_OUTSIDE);
+            if (k < cnt) {
+                r[j] = sorted[base + k];
+                const uint32_t cit = r[j].y & 255u;
+                atomicAdd(&raw_cnt[cit], 1u);
+                if (((r[j].y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT)
+                    atomicOr(&mask[k >> 5][cit], 1u << (k & 31));
+                else
+                    r[j].y = KEY_OUTSIDE; // not a KEPT record: nothing to place
+            }
         }
         __syncthreads();
-        const int nw = (cnt + 31) >> 5;
-        for (int w = 0; w < nw; ++w) {
-            uint32_t m = mask[w][tid];
-            if (m) {
-                mask[w][tid] = 0u;
-                do {
-                    const int b = __ffs((int)m) - 1;
-                    m &= m - 1u;
-                    const float z = zs[(w << 5) + b];
-                    // ---- src/GroundSegmentation.cpp:295-309, one KEPT point, `c` = points before it ----
-                    const float planeDist = z - oz; // :295
-                    if (FULL) gc = (float)((double)(z + c * gc) / ((double)c + 1.0)); // :296
-                    if ((double)mean == 0.0) mean = planeDist;                          // :298-299
-                    if (!isnan(planeDist)) {                                            // :300
-                        const float delta = planeDist - mean;                           // :301
-                        mean += delta / (c + 1.0f);                                     // :302
-                        if (FULL) pdm = (float)((double)(planeDist + c * pdm) / ((double)c + 1.0)); // :303
-                        m2 += delta * (planeDist - mean);                               // :304
-                    }
-                    if (FULL) mx = std_max(mx, z);   // :307
-                    mn = std_min(mn, z - 0.0001f);   // :308
-                    c = (float)((double)c + 1.0);    // :309
-                } while (m);
+        // ---- 2. per-cell word prefixes + block scan of the cell totals ----
+        uint32_t tot = 0;
+        uint32_t pc[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            pc[w] = (uint32_t)__popc(mask[w][tid]);
+            tot += pc[w];
+        }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            if (w < wave) wbase += wave_tot[w];
+        const uint32_t my_start = wbase + inc - tot;
+        {
+            uint32_t run = my_start;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                wprefix[w][tid] = (uint16_t)run;
+                run += pc[w];
             }
+        }
+        __syncthreads();
+        // ---- 3. stable placement ----
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            if (r[j].y != KEY_OUTSIDE) {
+                const int k = j * TILE_CELLS + tid;
+                const uint32_t cit = r[j].y & 255u;
+                const uint32_t m = mask[k >> 5][cit];
+                const uint32_t rk = (uint32_t)wprefix[k >> 5][cit] + (uint32_t)__popc(m & ((1u << (k & 31)) - 1u));
+                zsorted[rk] = __uint_as_float(r[j].x);
+            }
+        }
+        __syncthreads();
+        // ---- 4. ordered per-cell recurrence; clear this cell's masks for the next pass ----
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mask[w][tid] = 0u;
+        float znext = tot ? zsorted[my_start] : 0.0f;
+        for (uint32_t i = 0; i < tot; ++i) {
+            const float z = znext;
+            if (i + 1 < tot) znext = zsorted[my_start + i + 1];
+            // ---- src/GroundSegmentation.cpp:295-309, one KEPT point, `c` = points before it ----
+            const float planeDist = z - oz;                                      // :295
+            if (FULL) gc = (z + c * gc) / (c + 1.0f);                            // :296 (see note on double rounding above)
+            if ((double)mean == 0.0) mean = planeDist;                           // :298-299
+            if (!isnan(planeDist)) {                                             // :300
+                const float delta = planeDist - mean;                            // :301
+                mean += delta / (c + 1.0f);                                      // :302
+                if (FULL) pdm = (planeDist + c * pdm) / (c + 1.0f);              // :303
+                m2 += delta * (planeDist - mean);                                // :304
+            }
+            if (FULL) mx = std_max(mx, z);  // :307
+            mn = std_min(mn, z - 0.0001f);  // :308
+            c = (float)((double)c + 1.0);   // :309
         }
         __syncthreads();
     }

@@ -87,6 +87,17 @@ def test_hypotf_is_double_sqrt_rounded():
     assert oracle.hypotf(0.0, -3.0) == 3.0
 
 
+def test_double_rounding_identity():
+    """(float)((double)a / (double)b) == a / b in binary32 for float a, b (53 >= 2*24+2): lets K2 use f32 division."""
+    rng = np.random.default_rng(7)
+    a = (rng.standard_normal(2_000_000) * 10.0 ** rng.integers(-3, 4, size=2_000_000)).astype(np.float32)
+    b = rng.integers(1, 5000, size=2_000_000).astype(np.float32)
+    via_double = (a.astype(np.float64) / b.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(via_double, a / b)
+    b2 = (rng.random(2_000_000) * 100 + 0.01).astype(np.float32)
+    assert np.array_equal((a.astype(np.float64) / b2.astype(np.float64)).astype(np.float32), a / b2)
+
+
 # ------------------------------------------------------------------ hand-computed reductions
 
 def small_map():
