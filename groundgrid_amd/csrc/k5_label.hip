@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                 cfg.min_point_height_obs_thres); // :171
             if (tolerance + groundheight < (double)z) { // :173
                 label = GG_LABEL_NONGROUND;
-                atomicAdd(&points[cidx], 1.0f); // :176
+                unsafeAtomicAdd(&points[cidx], 1.0f); // :176 hardware global_atomic_add_f32 (exact: integer-valued counts)
             } else {
                 label = GG_LABEL_GROUND;
             }
