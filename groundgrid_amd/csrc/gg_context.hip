@@ -450,6 +450,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     g.tiles_c = (n + TILE - 1) / TILE;
     g.T = g.tiles_r * g.tiles_c;
     g.resolution = res;
+    g.inv_resolution = 1.0 / res;
     g.length0 = g.length1 = (double)n * res;
     g.half0 = 0.5 * g.length0;
     g.half1 = 0.5 * g.length1;

@@ -41,13 +41,23 @@ GG_DEV int trunc_to_int(double v)
     return (int)v;
 }
 
+// trunc_to_int(-(a / res)) without the f64 divide on the common path.  q = a * (1/res) differs from the correctly
+// rounded quotient fl(a / res) by less than |q| * 2^-51 (one rounding in 1/res, one in the product, half an ulp in the
+// true division), so whenever q is further than |q| * 2^-49 from the nearest integer both values truncate to the same
+// integer; otherwise (probability ~1e-13 per point, or a == 0, NaN, inf) the exact IEEE division decides.
+GG_DEV int index_of(double a, double res, double inv_res)
+{
+    const double q = a * inv_res;
+    const double r = rint(q);
+    if (fabs(q - r) > fabs(q) * 0x1p-49) return trunc_to_int(-q);
+    return trunc_to_int(-(a / res));
+}
+
 // grid_map_core getIndexFromPosition (value part): index = (int)(-(((p - L/2) - mapPos) / res))
 GG_DEV void index_from_position(const Geometry &g, double pos_x, double pos_y, double px, double py, int &row, int &col)
 {
-    const double ivx = ((px - g.half0) - pos_x) / g.resolution;
-    const double ivy = ((py - g.half1) - pos_y) / g.resolution;
-    row = trunc_to_int(-ivx);
-    col = trunc_to_int(-ivy);
+    row = index_of((px - g.half0) - pos_x, g.resolution, g.inv_resolution);
+    col = index_of((py - g.half1) - pos_y, g.resolution, g.inv_resolution);
 }
 
 // grid_map_core checkIfPositionWithinMap: t = -I * ((p - mapPos) - L/2); 0 <= t < L per axis

@@ -49,6 +49,7 @@ struct Geometry {
     int C;                   // rows * cols
     int tiles_r, tiles_c, T; // tile grid
     double resolution;       // (double)resolution_f
+    double inv_resolution;   // 1.0 / resolution (fast path of the index division, gg_device.h)
     double length0, length1; // size * resolution
     double half0, half1;     // 0.5 * length  (getVectorToOrigin)
     float resolution_f;      // (float)map.getResolution()

@@ -41,54 +41,53 @@ GG_DEV PointIn load_point(const void *base, size_t idx)
     return p;
 }
 
-// Returns the key (KEY_OUTSIDE if the point is not in the map).
-GG_DEV uint32_t classify_point(const Arena &a, const CloudParams &cp, const float *__restrict__ ground,
-                               const float *__restrict__ gpatch, const PointIn &pt)
+// :222-231 -- map index + inside test (branch-free part, so that several points per lane can be in flight)
+GG_DEV bool locate_point(const Arena &a, const CloudParams &cp, const PointIn &pt, int &gi0, int &gi1)
+{
+    const Geometry &g = a.g;
+    const double posx = (double)pt.x, posy = (double)pt.y;
+    const bool inside = position_inside(g, cp.pos_x, cp.pos_y, posx, posy);
+    index_from_position(g, cp.pos_x, cp.pos_y, posx, posy, gi0, gi1);
+    // an index outside the grid while isInside is true is UB in the reference; treated as outside
+    return inside && gi0 >= 0 && gi1 >= 0 && gi0 < g.rows && gi1 < g.cols;
+}
+
+// :237-279 -- ignore test, line-of-sight outlier test, key.  `oldgroundheight` = ground(gi) before this cloud.
+GG_DEV uint32_t finish_point(const Arena &a, const CloudParams &cp, const float *__restrict__ ground,
+                             const float *__restrict__ gpatch, const PointIn &pt, int gi0, int gi1, float oldgroundheight)
 {
     const Geometry &g = a.g;
     const int rows = g.rows, cols = g.cols;
-    // :222-223
-    const double posx = (double)pt.x, posy = (double)pt.y;
     const float dx = pt.x - cp.ox, dy = pt.y - cp.oy;
-    const float sqdist = (float)((double)dx * (double)dx + (double)dy * (double)dy);
-
-    // :228-231
-    if (!position_inside(g, cp.pos_x, cp.pos_y, posx, posy)) return KEY_OUTSIDE;
-    int gi0, gi1;
-    index_from_position(g, cp.pos_x, cp.pos_y, posx, posy, gi0, gi1);
-    if (gi0 < 0 || gi1 < 0 || gi0 >= rows || gi1 >= cols) return KEY_OUTSIDE; // UB in the reference; see DESIGN.md
+    const float sqdist = (float)((double)dx * (double)dx + (double)dy * (double)dy); // :223
 
     int cls = GG_CLASS_KEPT;
     if (pt.ring > a.cfg.max_ring || sqdist < g.min_dist_squared) { // :237
         cls = GG_CLASS_IGNORED;
-    } else {
-        // Outlier detection test :243-275
-        const float oldgroundheight = ground[gi0 + gi1 * rows];
-        if ((double)pt.z < (double)oldgroundheight - 0.2) { // :244
-            float vx = pt.x - cp.ox, vy = pt.y - cp.oy, vz = pt.z - cp.oz; // :248-250
-            const float len = sqrtf(vx * vx + vy * vy + vz * vz);           // :252
-            vx /= len;                                                        // :253-255
-            vy /= len;
-            vz /= len;
-            const double len2 = (double)len * (double)len;
-            for (int step = 3;; ++step) { // :258
-                const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
-                const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
-                if (!(d2 < len2 && vz < -0.01f)) break;
-                const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
-                int I0, I1;
-                index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0, I1); // :261
-                if (I0 <= 0 || I1 <= 0 || I0 >= rows - 1 || I1 >= cols - 1) continue;         // :264-265
-                const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                            // :268
-                float e[9];
+    } else if ((double)pt.z < (double)oldgroundheight - 0.2) { // :243-244 Outlier detection test
+        float vx = pt.x - cp.ox, vy = pt.y - cp.oy, vz = pt.z - cp.oz; // :248-250
+        const float len = sqrtf(vx * vx + vy * vy + vz * vz);           // :252
+        vx /= len;                                                        // :253-255
+        vy /= len;
+        vz /= len;
+        const double len2 = (double)len * (double)len;
+        for (int step = 3;; ++step) { // :258
+            const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
+            const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
+            if (!(d2 < len2 && vz < -0.01f)) break;
+            const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
+            int I0, I1;
+            index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0, I1); // :261
+            if (I0 <= 0 || I1 <= 0 || I0 >= rows - 1 || I1 >= cols - 1) continue;         // :264-265
+            const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                            // :268
+            float e[9];
 #pragma unroll
-                for (int s = 0; s < 9; ++s) e[s] = gpatch[(r0 + s % 3) + (c0 + s / 3) * rows];
-                const float bsum = tree9(e);
-                if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gpatch[I0 + I1 * rows] > 0.01f &&
-                    (double)ground[I0 + I1 * rows] >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) { // :269
-                    cls = GG_CLASS_OUTLIER;
-                    break;
-                }
+            for (int s = 0; s < 9; ++s) e[s] = gpatch[(r0 + s % 3) + (c0 + s / 3) * rows];
+            const float bsum = tree9(e);
+            if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gpatch[I0 + I1 * rows] > 0.01f &&
+                (double)ground[I0 + I1 * rows] >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) { // :269
+                cls = GG_CLASS_OUTLIER;
+                break;
             }
         }
     }
@@ -99,7 +98,7 @@ GG_DEV uint32_t classify_point(const Arena &a, const CloudParams &cp, const floa
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
+__global__ __launch_bounds__(256, 8) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
 {
     extern __shared__ uint32_t lds_hist[]; // [4][T]
     const int cloud = blockIdx.y;
@@ -123,23 +122,41 @@ __global__ __launch_bounds__(256) void k_classify(const Arena a, const CloudPara
     uint32_t n_kept = 0, n_ign = 0, n_outl = 0, n_inmap = 0;
     const int base = chunk * a.PW;
     const int end = min(base + a.PW, n);
-    for (int p0 = base; p0 < end; p0 += 64) {
-        const int p = p0 + lane;
-        const bool valid = p < end;
-        uint32_t key = KEY_OUTSIDE;
-        if (valid) {
-            const PointIn pt = load_point<FMT>(pts, (size_t)p);
-            key = classify_point(a, cp, ground, gpatch, pt);
-            rec[p] = make_uint2(__float_as_uint(pt.z), key);
+    // ITEMS independent 64-point windows per trip: all point loads are issued before the first classification, so
+    // several HBM / L2 round trips (point record, then the old-ground gather) are in flight per lane.
+    constexpr int ITEMS = 4;
+    for (int p0 = base; p0 < end; p0 += 64 * ITEMS) {
+        PointIn pt[ITEMS];
+        bool valid[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int p = p0 + j * 64 + lane;
+            valid[j] = p < end;
+            pt[j] = load_point<FMT>(pts, (size_t)(valid[j] ? p : base));
         }
-        const bool inmap = key != KEY_OUTSIDE;
-        if (inmap) atomicAdd(&hist[key >> KEY_TILE_SHIFT], 1u);
-        const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
-        const bool emit = inmap && (key & KEY_EMIT_BIT);
-        n_inmap += (uint32_t)__popcll(__ballot(inmap));
-        n_kept += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_KEPT));
-        n_ign += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_IGNORED));
-        n_outl += (uint32_t)__popcll(__ballot(inmap && cls == GG_CLASS_OUTLIER));
+        int gi0[ITEMS], gi1[ITEMS];
+        bool inmap_[ITEMS];
+        float og[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { // index math for all windows, then all old-ground gathers in flight together
+            inmap_[j] = locate_point(a, cp, pt[j], gi0[j], gi1[j]) && valid[j];
+            og[j] = ground[inmap_[j] ? gi0[j] + gi1[j] * a.g.rows : 0]; // :243
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int p = p0 + j * 64 + lane;
+            uint32_t key = KEY_OUTSIDE;
+            if (inmap_[j]) key = finish_point(a, cp, ground, gpatch, pt[j], gi0[j], gi1[j], og[j]);
+            if (valid[j]) rec[p] = make_uint2(__float_as_uint(pt[j].z), key);
+            const bool inmap = key != KEY_OUTSIDE;
+            if (inmap) atomicAdd(&hist[key >> KEY_TILE_SHIFT], 1u);
+            const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
+            const bool emit = inmap && (key & KEY_EMIT_BIT);
+            n_inmap += (uint32_t)__popcll(__ballot(inmap));
+            n_kept += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_KEPT));
+            n_ign += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_IGNORED));
+            n_outl += (uint32_t)__popcll(__ballot(inmap && cls == GG_CLASS_OUTLIER));
+        }
     }
 
     uint32_t *ghist = a.hist + (size_t)cp.slot * a.hist_stride + (size_t)chunk * T;

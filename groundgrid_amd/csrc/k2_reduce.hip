@@ -28,16 +28,16 @@
 
 namespace gg {
 
-constexpr int CH = 1024;          // records staged per pass
+constexpr int CH = 512;           // records staged per pass (27 KiB of LDS per work-group -> 5 work-groups per CU)
 constexpr int NW = CH / 32;       // mask words per cell
 constexpr int RPT = CH / TILE_CELLS; // records per thread per pass
 
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams *__restrict__ params)
 {
-    __shared__ uint32_t mask[NW][TILE_CELLS];   // 32 KiB  bit p%32 of [p/32][cell] <=> staged record p is a KEPT point of cell
-    __shared__ uint16_t wprefix[NW][TILE_CELLS]; // 16 KiB  segment start of the cell + its KEPT records in words < w
-    __shared__ float zsorted[CH];                // 4 KiB   z, grouped by cell, cloud order inside a cell
+    __shared__ uint32_t mask[NW][TILE_CELLS];   // 16 KiB  bit p%32 of [p/32][cell] <=> staged record p is a KEPT point of cell
+    __shared__ uint16_t wprefix[NW][TILE_CELLS]; // 8 KiB   segment start of the cell + its KEPT records in words < w
+    __shared__ float zsorted[CH];                // 2 KiB   z, grouped by cell, cloud order inside a cell
     __shared__ uint32_t raw_cnt[TILE_CELLS];     // pointsRaw (:234): every in-map point of the cell
     __shared__ uint32_t wave_tot[4];
 
@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     float mn = FLT_MAX; // minGroundHeight  (:72)
 
     raw_cnt[tid] = 0u;
+    if (start != end) { // (uniform) tiles without any point only write the reset values below
 #pragma unroll
-    for (int w = 0; w < NW; ++w) mask[w][tid] = 0u;
+        for (int w = 0; w < NW; ++w) mask[w][tid] = 0u;
+    }
     __syncthreads();
 
     for (uint32_t base = start; base < end; base += CH) {

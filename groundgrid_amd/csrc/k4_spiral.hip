@@ -83,13 +83,22 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const CloudParam
         d.lo = V[(size_t)vi * 2];
         d.hi = V[(size_t)vi * 2 + 1];
     };
+    // The lanes of a wave sit on different rings, so every load instruction touches 64 different cache lines and the
+    // per-CU vector-memory pipeline (one line per clock), not arithmetic, paces a level.  The three cells of one
+    // block column are contiguous (column-major layers): one 12-byte load per column and layer = 6 instead of 18.
     auto load_old = [&](const VisitRegs &d, float (&gw)[9], float (&gg_)[9]) {
         const uint32_t cell = d.lo.x;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { // :453,458 block<3,3>(x-1, y-1), column-major linear index
-            const int idx = (int)cell + (q % 3 - 1) + (q / 3 - 1) * rows;
-            gw[q] = gpatch[idx];
-            gg_[q] = ground[idx];
+        for (int col = 0; col < 3; ++col) { // :453,458 block<3,3>(x-1, y-1), column-major linear index
+            const uint32_t idx = cell - 1u + (uint32_t)((col - 1) * rows);
+            const float3 w3 = *reinterpret_cast<const float3 *>(gpatch + idx);
+            const float3 g3 = *reinterpret_cast<const float3 *>(ground + idx);
+            gw[col * 3 + 0] = w3.x;
+            gw[col * 3 + 1] = w3.y;
+            gw[col * 3 + 2] = w3.z;
+            gg_[col * 3 + 0] = g3.x;
+            gg_[col * 3 + 1] = g3.y;
+            gg_[col * 3 + 2] = g3.z;
         }
     };
 
@@ -121,14 +130,10 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const CloudParam
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
                         const uint32_t s = visit_src(d0, q);
-                        if (s != (uint32_t)SPIRAL_NONE) {
-                            const float2 f = fresh[s];
-                            g[q] = f.x;
-                            w[q] = f.y;
-                        } else {
-                            g[q] = G[u % 2][q];
-                            w[q] = W[u % 2][q];
-                        }
+                        const bool is_fresh = s != (uint32_t)SPIRAL_NONE;
+                        const float2 f = fresh[is_fresh ? s : 0u]; // unconditional read + select: no branch per input
+                        g[q] = is_fresh ? f.x : G[u % 2][q];
+                        w[q] = is_fresh ? f.y : W[u % 2][q];
                     }
                     const float height = g[4], occupied = w[4]; // :455-456
                     const float gvlSum = tree9(w) + FLT_MIN;    // :457

@@ -52,69 +52,107 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
     const DevConfig &cfg = a.cfg;
     const int base = chunk * a.PW;
     const int end = min(base + a.PW, n);
-    for (int p0 = base; p0 < end; p0 += 64) {
-        const int p = p0 + lane;
-        const bool valid = p < end;
-        uint2 r = make_uint2(0u, KEY_OUTSIDE);
-        if (valid) r = rec[p];
-        const uint32_t key = r.y;
-        const bool inmap = key != KEY_OUTSIDE;
-        const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
-        const bool emit = inmap && (key & KEY_EMIT_BIT);
-        const bool is_kept = emit && cls == GG_CLASS_KEPT;
-        const bool is_ign = emit && cls == GG_CLASS_IGNORED;
-        const bool is_outl = inmap && cls == GG_CLASS_OUTLIER;
+    // :171 tolerance = max(min(t, thres), obs), t = (5 mdf * dist) / variance * thres.  On real data t is far above
+    // thres (variance ~1e-4 m^2), so the clamp decides; a float estimate of t with a 1e-3 safety band selects the clamp
+    // without the f64 sqrt and divide, and only estimates inside the band (or NaN / odd configs) take the exact path.
+    const double thres = cfg.min_point_height_thres, obs = cfg.min_point_height_obs_thres;
+    const bool normal_cfg = obs <= thres && thres > 0.0 && obs > 0.0 && cfg.min_dist_fac > 0.0;
+    const double tol_hi = std_max(thres, obs); // value of the expression when t > thres
+    const float thres_f = (float)thres, obs_f = (float)obs, fac_f = (float)cfg.min_dist_fac;
 
-        const unsigned long long mk = __ballot(is_kept), mi = __ballot(is_ign), mo = __ballot(is_outl);
-        int32_t idx = -1;
-        uint8_t label = GG_LABEL_DROPPED;
-        if (is_outl) { // :185-189
-            idx = (int32_t)(outl_base + (uint32_t)rank_below(mo));
-            label = GG_LABEL_GROUND;
-        } else if (is_kept || is_ign) { // :158-182
-            int row, col;
-            key_to_cell(a, key, row, col);
-            const size_t cidx = (size_t)row + (size_t)col * rows;
-            const double groundheight = (double)ground[cidx]; // :162
-            const float var = variance[cidx];                  // :165
-            float x, y;
-            if (FMT == GG_POINT16) {
-                const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)p * 2];
-                x = __uint_as_float(xy.x);
-                y = __uint_as_float(xy.y);
-            } else {
-                const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)p * 4];
-                x = __uint_as_float(xy.x);
-                y = __uint_as_float(xy.y);
-            }
-            const float z = __uint_as_float(r.x);
-            const float dist = ref_hypotf(x - cp.ox, y - cp.oy); // :170
-            const double tolerance = std_max(
-                std_min((cfg.min_dist_fac * (double)dist) / (double)var * cfg.min_point_height_thres, cfg.min_point_height_thres),
-                cfg.min_point_height_obs_thres); // :171
-            if (tolerance + groundheight < (double)z) { // :173
-                label = GG_LABEL_NONGROUND;
-                unsafeAtomicAdd(&points[cidx], 1.0f); // :176 hardware global_atomic_add_f32 (exact: integer-valued counts)
-            } else {
+    constexpr int ITEMS = 4;
+    for (int p0 = base; p0 < end; p0 += 64 * ITEMS) {
+        uint2 r[ITEMS];
+        bool valid[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int p = p0 + j * 64 + lane;
+            valid[j] = p < end;
+            r[j] = rec[valid[j] ? p : base];
+            if (!valid[j]) r[j].y = KEY_OUTSIDE;
+        }
+        size_t cidx[ITEMS];
+        float gh[ITEMS], var[ITEMS], x[ITEMS], y[ITEMS];
+        bool lab[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { // all gathers of all windows in flight together
+            const int p = p0 + j * 64 + lane;
+            const uint32_t key = r[j].y;
+            const bool inmap = key != KEY_OUTSIDE;
+            const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
+            lab[j] = inmap && (key & KEY_EMIT_BIT) && cls != GG_CLASS_OUTLIER; // kept or ignored, not on the border (:167)
+            int row = 0, col = 0;
+            if (lab[j]) key_to_cell(a, key, row, col);
+            cidx[j] = (size_t)row + (size_t)col * rows;
+            gh[j] = ground[cidx[j]];   // :162
+            var[j] = variance[cidx[j]]; // :165
+            const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)(valid[j] ? p : base) * (FMT == GG_POINT16 ? 2 : 4)];
+            x[j] = __uint_as_float(xy.x);
+            y[j] = __uint_as_float(xy.y);
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int p = p0 + j * 64 + lane;
+            const uint32_t key = r[j].y;
+            const bool inmap = key != KEY_OUTSIDE;
+            const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
+            const bool emit = inmap && (key & KEY_EMIT_BIT);
+            const bool is_kept = emit && cls == GG_CLASS_KEPT;
+            const bool is_ign = emit && cls == GG_CLASS_IGNORED;
+            const bool is_outl = inmap && cls == GG_CLASS_OUTLIER;
+
+            const unsigned long long mk = __ballot(is_kept), mi = __ballot(is_ign), mo = __ballot(is_outl);
+            int32_t idx = -1;
+            uint8_t label = GG_LABEL_DROPPED;
+            if (is_outl) { // :185-189
+                idx = (int32_t)(outl_base + (uint32_t)rank_below(mo));
                 label = GG_LABEL_GROUND;
+            } else if (lab[j]) { // :158-182
+                const float z = __uint_as_float(r[j].x);
+                const float dxf = x[j] - cp.ox, dyf = y[j] - cp.oy;
+                double tolerance;
+                const float t_est = (fac_f * sqrtf(dxf * dxf + dyf * dyf)) / var[j] * thres_f;
+                if (normal_cfg && t_est > thres_f * 1.001f) {
+                    tolerance = tol_hi;
+                } else if (normal_cfg && t_est >= 0.0f && t_est < obs_f * 0.999f) {
+                    tolerance = obs;
+                } else {
+                    const float dist = ref_hypotf(dxf, dyf); // :170
+                    tolerance = std_max(std_min((cfg.min_dist_fac * (double)dist) / (double)var[j] * thres, thres), obs); // :171
+                }
+                label = (tolerance + (double)gh[j] < (double)z) ? GG_LABEL_NONGROUND : GG_LABEL_GROUND; // :173
+                idx = is_kept ? (int32_t)(kept_base + (uint32_t)rank_below(mk)) : (int32_t)(ign_base + (uint32_t)rank_below(mi));
             }
-            idx = is_kept ? (int32_t)(kept_base + (uint32_t)rank_below(mk)) : (int32_t)(ign_base + (uint32_t)rank_below(mi));
-        }
-        if (valid) {
-            if (labels) labels[p] = label;
-            if (out_index) out_index[p] = idx;
-            if (FMT == GG_POINT32 && out_cloud && idx >= 0) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(pts) + (size_t)p * 2;
-                uint4 lo = src[0], hi = src[1];
-                hi.x = __float_as_uint((float)label); // intensity := 49 / 99
-                uint4 *dst = reinterpret_cast<uint4 *>(out_cloud + idx);
-                dst[0] = lo;
-                dst[1] = hi;
+            // :176 points(gi) += 1 per non-ground point.  Neighbouring lanes mostly hit the same cell, and same-address
+            // atomics serialise in L2: one hardware float atomic per distinct cell of the window, adding the lane count
+            // (exact: integer-valued floats < 2^24, order-free).
+            {
+                const bool ng = label == GG_LABEL_NONGROUND;
+                unsigned long long todo = __ballot(ng);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cidx[j], leader);
+                    const unsigned long long same = __ballot(ng && (uint32_t)cidx[j] == c0);
+                    if (lane == leader) unsafeAtomicAdd(&points[c0], (float)__popcll(same));
+                    todo &= ~same;
+                }
             }
+            if (valid[j]) {
+                if (labels) labels[p] = label;
+                if (out_index) out_index[p] = idx;
+                if (FMT == GG_POINT32 && out_cloud && idx >= 0) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(pts) + (size_t)p * 2;
+                    uint4 lo = src[0], hi = src[1];
+                    hi.x = __float_as_uint((float)label); // intensity := 49 / 99
+                    uint4 *dst = reinterpret_cast<uint4 *>(out_cloud + idx);
+                    dst[0] = lo;
+                    dst[1] = hi;
+                }
+            }
+            kept_base += (uint32_t)__popcll(mk);
+            ign_base += (uint32_t)__popcll(mi);
+            outl_base += (uint32_t)__popcll(mo);
         }
-        kept_base += (uint32_t)__popcll(mk);
-        ign_base += (uint32_t)__popcll(mi);
-        outl_base += (uint32_t)__popcll(mo);
     }
 }
 

@@ -251,3 +251,23 @@ def test_config4_full_2M_points_one_frame():
     cloud = synth.os128_cloud(seed=2)  # ~2.1 M points, 1000 x 1000 grid (BASELINE configs[3])
     assert len(cloud) > 1_900_000
     run_pair(cloud, length=200.0, resolution=0.2, frames=1)
+
+
+def test_index_fast_path_boundaries():
+    """K1 replaces the f64 divide of getIndex by a multiply + exactness check (gg_device.h index_of); points that sit
+    exactly on / next to cell boundaries (where the exact division must decide) have to match the oracle too."""
+    m = oracle.OracleMap(120.0, 0.33)
+    half, res = 0.5 * m.length[0], m.resolution
+    xs = []
+    for k in (0, 1, 2, 17, 181, 182, 183, 300, 362, 363):
+        edge = half - k * res  # x of the boundary between rows k-1 and k (exact in double)
+        f = np.float32(edge)
+        xs += [f, np.nextafter(f, np.float32(np.inf)), np.nextafter(f, np.float32(-np.inf))]
+    xs = np.array(xs, dtype=np.float32)
+    X, Y = np.meshgrid(xs, xs)
+    pts = np.column_stack([X.ravel(), Y.ravel(), np.full(X.size, -1.7, dtype=np.float32)])
+    run_pair(synth.make_cloud(pts), frames=1)
+    # a == 0 exactly: map position chosen so that (x - L/2) - pos == 0 for x = 5 -> the exact-division path
+    pos = (float(np.float64(np.float32(5.0)) - half), float(np.float64(np.float32(-7.25)) - half))
+    pts = np.array([[5.0, -7.25, -1.0], [5.0, -7.0, -1.0], [4.9, -7.25, -1.2], [3.0, -9.0, -1.1]], dtype=np.float32)
+    run_pair(synth.make_cloud(pts), pos=pos, origin=(pos[0], pos[1], 0.0), frames=1)

@@ -4,10 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from groundgrid_amd import api, synth
 
-def run(name, clouds, steps=10, warm=3, minimal=False, length=120.0, res=0.33):
+def run(name, clouds, steps=10, warm=3, minimal=False, length=120.0, res=0.33, dbg=0):
     B = len(clouds); stride = max(len(c) for c in clouds)
     seg = api.GroundSegmentation().init(length, res, n_slots=B, max_points=stride)
     seg.set_flags(minimal_layers=minimal, profile=True)
+    if dbg:
+        from groundgrid_amd import _lib
+        seg._L.gg_set_flags(seg._ctx, _lib.GG_FLAG_PROFILE | dbg)
     host = np.zeros((B, stride), dtype=api.POINT16_DTYPE)
     for b, c in enumerate(clouds): host[b, :len(c)] = api.pack16(c)
     pts = torch.from_numpy(host.view(np.uint8).reshape(B, stride, 16)).cuda()
@@ -29,4 +32,8 @@ if __name__ == "__main__":
     if "hdlaz" in which: run("hdl64 azimuth-major", [synth.hdl64_cloud(order="azimuth")])
     if "rand" in which: run("uniform random 120k", [synth.random_cloud(125000, seed=1, extent=59.0)])
     if "b8" in which: run("hdl64 x8", [synth.hdl64_cloud(seed=s) for s in range(8)])
+    if "dbg" in which:
+        cl = [synth.hdl64_cloud(seed=s) for s in range(8)] * 8
+        for d, nm in ((0, "base"), (0x100, "no LDS atomics"), (0x200, "no ground gather"), (0x400, "no rec store"), (0x800, "no hist flush"), (0xF00, "none of them")):
+            run("B64 " + nm, cl, dbg=d)
     if "os" in which: run("os128 2.1M 1000^2", [synth.os128_cloud()], steps=3, warm=1, length=200.0, res=0.2)
