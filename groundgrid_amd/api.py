@@ -74,6 +74,19 @@ class GridMap:
         _check(L, ctx, L.gg_set_map_position(ctx, self.slot, float(x), float(y)), "gg_set_map_position")
         self._pos = (float(x), float(y))
 
+    def move(self, odom_x: float, odom_y: float, base_to_map=(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0)):
+        """GroundGrid::update (src/GroundGrid.cpp:83-147) on the device.  base_to_map = (tx, ty, tz, qx, qy, qz, qw).
+        Returns the index shift (rows, cols)."""
+        L, ctx = self._seg._L, self._seg._ctx
+        self._seg._sync_torch()
+        tf = (C.c_double * 7)(*[float(v) for v in base_to_map])
+        sh = (C.c_int * 2)()
+        _check(L, ctx, L.gg_move_map(ctx, self.slot, float(odom_x), float(odom_y), tf, sh), "gg_move_map")
+        x, y = C.c_double(), C.c_double()
+        L.gg_get_map_position(ctx, self.slot, C.byref(x), C.byref(y))
+        self._pos = (x.value, y.value)
+        return sh[0], sh[1]
+
     def reset(self, odom_z: float = 0.0, pos=(0.0, 0.0)):
         """GroundGrid::initGroundGrid layer values (src/GroundGrid.cpp:71-75)."""
         L, ctx = self._seg._L, self._seg._ctx

@@ -61,6 +61,7 @@ struct gg_context {
     int32_t *d_stage_counts = nullptr;
     uint8_t *d_stage_class = nullptr;
     int32_t *d_stage_cell = nullptr;
+    float *d_scroll_scratch = nullptr; // 2 layers
 
     // profiling
     std::vector<EventPair> pending;
@@ -531,6 +532,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_scnt = carve(64);
     const size_t o_scls = carve(max_points);
     const size_t o_scell = carve(max_points * 4);
+    const size_t o_scroll = carve(2 * Cpad * 4);
     ctx->arena_bytes = off;
     CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
     char *base = (char *)ctx->d_arena;
@@ -560,6 +562,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_stage_counts = (int32_t *)(base + o_scnt);
     ctx->d_stage_class = (uint8_t *)(base + o_scls);
     ctx->d_stage_cell = (int32_t *)(base + o_scell);
+    ctx->d_scroll_scratch = (float *)(base + o_scroll);
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_visits, visits.data(), visits.size() * sizeof(SpiralVisit), hipMemcpyHostToDevice, ctx->stream));
@@ -674,6 +677,41 @@ int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y)
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     ctx->pos_x[slot] = pos_x;
     ctx->pos_y[slot] = pos_y;
+    return GG_OK;
+}
+
+int gg_move_map(gg_context *ctx, int slot, double odom_x, double odom_y, const double base_to_map[7], int shift_out[2])
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!base_to_map) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double res = ctx->arena.g.resolution;
+    // grid_map_core getIndexShiftFromPositionShift: round half away from zero, map frame -> buffer order (sign flip)
+    const double odom[2] = {odom_x, odom_y};
+    const double pos[2] = {ctx->pos_x[slot], ctx->pos_y[slot]};
+    int s[2];
+    for (int i = 0; i < 2; ++i) {
+        const double tmp = (odom[i] - pos[i]) / res;
+        s[i] = -(int)(tmp + 0.5 * (tmp > 0 ? 1 : -1));
+    }
+    if (shift_out) {
+        shift_out[0] = s[0];
+        shift_out[1] = s[1];
+    }
+    if (s[0] == 0 && s[1] == 0) return GG_OK; // src/GroundGrid.cpp:135-137
+    // getPositionShiftFromIndexShift: the position advances by whole cells, not to the odometry position
+    ctx->pos_x[slot] += (double)(-s[0]) * res;
+    ctx->pos_y[slot] += (double)(-s[1]) * res;
+    launch_scroll(ctx->arena, slot, ctx->d_scroll_scratch, s[0], s[1], ctx->pos_x[slot], ctx->pos_y[slot], base_to_map, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return GG_OK;
+}
+
+int gg_get_map_position(const gg_context *ctx, int slot, double *pos_x, double *pos_y)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (pos_x) *pos_x = ctx->pos_x[slot];
+    if (pos_y) *pos_y = ctx->pos_y[slot];
     return GG_OK;
 }
 

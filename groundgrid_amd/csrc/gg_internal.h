@@ -131,6 +131,7 @@ void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hip
 void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
+void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double tf[7], hipStream_t s);
 void launch_pack16(const gg_point32 *src, gg_point16 *dst, size_t n, hipStream_t s);
 void launch_decode_classes(const Arena &a, int slot, size_t n, uint8_t *d_class, int32_t *d_cell, hipStream_t s);
 

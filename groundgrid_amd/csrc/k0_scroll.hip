@@ -1,0 +1,83 @@
+// K0 -- GroundGrid::update (src/GroundGrid.cpp:83-147) on the device: the map follows the vehicle.
+//
+// grid_map::GridMap::move shifts the map by a whole number of cells (the host computes the shift with grid_map's
+// rounding, gg_context.hip gg_move_map), drops the rows / columns that fall out and exposes new ones;
+// GroundGrid::update fills the exposed cells with ground = -(z of the cell centre expressed in base_link) and
+// groundpatch = 0 (:121-131) and re-linearises the ring buffer (:143), which the hot path relies on (it indexes raw
+// matrices).  In default-start-index terms that is one gather per cell:
+//     new(i, j) = exposed(i, j) ? fill(i, j) : old((i + s0) mod n, (j + s1) mod n)
+// Only `ground` and `groundpatch` persist across clouds (every other layer is rewritten by the next filter_cloud
+// before anyone can observe it), so only those two are moved: 4 layer-passes per cloud instead of 22.
+#include "gg_device.h"
+
+namespace gg {
+
+struct ScrollParams {
+    int s0, s1;          // index shift (rows, cols), buffer order
+    double pos_x, pos_y; // map position AFTER the move
+    double first0, first1; // L/2 - res/2  (getVectorToFirstCell)
+    double res;
+    double m20, m21, m22, tz; // third row of the base_link<-map rotation (tf2::Matrix3x3::setRotation) and translation z
+};
+
+__global__ __launch_bounds__(256) void k_scroll(const float *__restrict__ ground, const float *__restrict__ gpatch,
+                                                float *__restrict__ out_ground, float *__restrict__ out_gpatch, int rows,
+                                                int cols, const ScrollParams sp)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= rows || j >= cols) return;
+    const bool all = abs(sp.s0) >= rows || abs(sp.s1) >= cols;
+    int bi = (i + sp.s0) % rows, bj = (j + sp.s1) % cols;
+    if (bi < 0) bi += rows;
+    if (bj < 0) bj += cols;
+    const bool new0 = sp.s0 > 0 ? bi < sp.s0 : (sp.s0 < 0 ? bi >= rows + sp.s0 : false);
+    const bool new1 = sp.s1 > 0 ? bj < sp.s1 : (sp.s1 < 0 ? bj >= cols + sp.s1 : false);
+    float g, w;
+    if (all || new0 || new1) {
+        // grid_map getPositionFromIndex: position = mapPosition + offset + resolution * (-index)
+        const double px = (sp.pos_x + sp.first0) + sp.res * (double)(-i);
+        const double py = (sp.pos_y + sp.first1) + sp.res * (double)(-j);
+        // tf2: v_out.z = (m20 * x + m21 * y + m22 * 0) + origin.z ; ground = -z (:130), groundpatch = 0 (:131)
+        const double z = ((sp.m20 * px + sp.m21 * py) + sp.m22 * 0.0) + sp.tz;
+        g = (float)(-z);
+        w = 0.0f;
+    } else {
+        g = ground[(size_t)bi + (size_t)bj * rows];
+        w = gpatch[(size_t)bi + (size_t)bj * rows];
+    }
+    out_ground[(size_t)i + (size_t)j * rows] = g;
+    out_gpatch[(size_t)i + (size_t)j * rows] = w;
+}
+
+void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double tf[7],
+                   hipStream_t s)
+{
+    ScrollParams sp;
+    sp.s0 = s0;
+    sp.s1 = s1;
+    sp.pos_x = pos_x;
+    sp.pos_y = pos_y;
+    sp.res = a.g.resolution;
+    sp.first0 = a.g.half0 - 0.5 * a.g.resolution;
+    sp.first1 = a.g.half1 - 0.5 * a.g.resolution;
+    // tf2::Matrix3x3::setRotation(q), third row
+    const double qx = tf[3], qy = tf[4], qz = tf[5], qw = tf[6];
+    const double d = qx * qx + qy * qy + qz * qz + qw * qw;
+    const double sc = 2.0 / d;
+    const double xs = qx * sc, ys = qy * sc, zs = qz * sc;
+    const double wx = qw * xs, wy = qw * ys;
+    const double xx = qx * xs, xz = qx * zs, yy = qy * ys, yz = qy * zs;
+    sp.m20 = xz - wy;
+    sp.m21 = yz + wx;
+    sp.m22 = 1.0 - (xx + yy);
+    sp.tz = tf[2];
+    float *ground = layer_ptr(a, slot, GG_LAYER_GROUND), *gpatch = layer_ptr(a, slot, GG_LAYER_GROUNDPATCH);
+    float *og = scratch, *ow = scratch + a.layer_stride;
+    dim3 grid((a.g.rows + 63) / 64, (a.g.cols + 3) / 4);
+    hipLaunchKernelGGL(k_scroll, grid, dim3(256), 0, s, ground, gpatch, og, ow, a.g.rows, a.g.cols, sp);
+    hipMemcpyAsync(ground, og, (size_t)a.g.C * 4, hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(gpatch, ow, (size_t)a.g.C * 4, hipMemcpyDeviceToDevice, s);
+}
+
+} // namespace gg

@@ -145,6 +145,13 @@ const char *gg_last_error(const gg_context *ctx);
 int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float odom_z);
 /* map position after grid_map::move (src/GroundGrid.cpp:97); layers unchanged */
 int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y);
+/* GroundGrid::update for an initialised map (src/GroundGrid.cpp:83-147): grid_map::GridMap::move to the odometry
+ * position (whole cells; the map position is snapped), newly exposed cells get ground = -(z of the cell centre in
+ * base_link) and groundpatch = 0 (:121-131), then convertToDefaultStartIndex (:143) -- on the device, so that the two
+ * persistent layers never leave HBM between clouds.  base_to_map = {tx, ty, tz, qx, qy, qz, qw} of
+ * lookupTransform("base_link", "map") (:103).  shift (nullable) receives the index shift (rows, cols). */
+int gg_move_map(gg_context *ctx, int slot, double odom_x, double odom_y, const double base_to_map[7], int shift[2]);
+int gg_get_map_position(const gg_context *ctx, int slot, double *pos_x, double *pos_y);
 /* any of the 11 layers, column-major rows x cols float32 (Eigen::MatrixXf), host memory */
 int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src);
 int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst);

@@ -198,6 +198,83 @@ void ggo_map_destroy(ggo_map *m)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* N1: GroundGrid::update (src/GroundGrid.cpp:83-147) + grid_map::GridMap::move / getPosition /  */
+/*     convertToDefaultStartIndex (grid_map_core 1.6.x) + tf2 doTransform of a point            */
+/* ------------------------------------------------------------------------------------------ */
+int ggo_map_update(ggo_map *m, double odom_x, double odom_y, const double tf[7], int shift[2])
+{
+    const int n[2] = {m->rows, m->cols};
+    const double res = m->resolution;
+    /* GridMapMath.cpp getIndexShiftFromPositionShift: round half away from zero, then map frame -> buffer order */
+    const double odom[2] = {odom_x, odom_y};
+    int s[2];
+    for (int i = 0; i < 2; ++i) {
+        const double tmp = (odom[i] - m->position[i]) / res;
+        const int v = (int)(tmp + 0.5 * (tmp > 0 ? 1 : -1));
+        s[i] = -v;
+    }
+    if (shift) {
+        shift[0] = s[0];
+        shift[1] = s[1];
+    }
+    if (s[0] == 0 && s[1] == 0) return 0; /* GroundGrid.cpp:135-137: damage empty, nothing to do */
+
+    /* getPositionShiftFromIndexShift: position += (-indexShift) * resolution (snapped, not the odometry position) */
+    m->position[0] += (double)(-s[0]) * res;
+    m->position[1] += (double)(-s[1]) * res;
+
+    /* tf2::Matrix3x3::setRotation, third row only (Matrix3x3.h) */
+    const double qx = tf[3], qy = tf[4], qz = tf[5], qw = tf[6];
+    const double d = qx * qx + qy * qy + qz * qz + qw * qw;
+    const double sc = 2.0 / d;
+    const double xs = qx * sc, ys = qy * sc, zs = qz * sc;
+    const double wx = qw * xs, wy = qw * ys;
+    const double xx = qx * xs, xz = qx * zs, yy = qy * ys, yz = qy * zs;
+    (void)zs;
+    const double m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+
+    const size_t C = (size_t)n[0] * (size_t)n[1];
+    float *tmp = (float *)malloc(C * sizeof(float));
+    const double first0 = 0.5 * m->length[0] - 0.5 * res, first1 = 0.5 * m->length[1] - 0.5 * res; /* getVectorToFirstCell */
+    for (int l = 0; l < GGO_NUM_LAYERS; ++l) {
+        float *L = m->layer[l];
+        for (int j = 0; j < n[1]; ++j) {
+            for (int i = 0; i < n[0]; ++i) {
+                /* convertToDefaultStartIndex: new (unwrapped) index (i,j) <- buffer index ((i + s0) mod n, (j + s1) mod n);
+                 * the rows / cols move() dropped from the buffer are the newly exposed cells */
+                const int all0 = abs(s[0]) >= n[0], all1 = abs(s[1]) >= n[1];
+                int bi = (i + s[0]) % n[0], bj = (j + s[1]) % n[1];
+                if (bi < 0) bi += n[0];
+                if (bj < 0) bj += n[1];
+                const int new0 = all0 || all1 || (s[0] > 0 ? bi < s[0] : (s[0] < 0 ? bi >= n[0] + s[0] : 0));
+                const int new1 = all0 || all1 || (s[1] > 0 ? bj < s[1] : (s[1] < 0 ? bj >= n[1] + s[1] : 0));
+                float v;
+                if (new0 || new1) {
+                    if (l == GGO_GROUND) {
+                        /* getPositionFromIndex: position = mapPosition + offset + resolution * (-index) */
+                        const double px = (m->position[0] + first0) + res * (double)(-i);
+                        const double py = (m->position[1] + first1) + res * (double)(-j);
+                        /* tf2: v_out.z = (m20 * x + m21 * y + m22 * 0) + origin.z; ground = -z (:130) */
+                        const double z = ((m20 * px + m21 * py) + m22 * 0.0) + tf[2];
+                        v = (float)(-z);
+                    } else if (l == GGO_GROUNDPATCH) {
+                        v = 0.0f; /* :131 */
+                    } else {
+                        v = NAN; /* grid_map::GridMap::clearRows / clearCols on every layer */
+                    }
+                } else {
+                    v = L[(size_t)bi + (size_t)bj * n[0]];
+                }
+                tmp[(size_t)i + (size_t)j * n[0]] = v;
+            }
+        }
+        memcpy(L, tmp, C * sizeof(float));
+    }
+    free(tmp);
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* R2: filter_cloud prologue (src/GroundSegmentation.cpp:61-75)                               */
 /* ------------------------------------------------------------------------------------------ */
 void ggo_stage_reset(ggo_map *m)

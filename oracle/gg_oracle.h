@@ -117,6 +117,14 @@ void ggo_stage_insert(ggo_map *m, const ggo_config *cfg, const ggo_point *cloud,
 void ggo_stage_detect(ggo_map *m, const ggo_config *cfg);           /* :314-395 */
 void ggo_stage_spiral(ggo_map *m, const ggo_config *cfg, double base_z); /* :398-465 */
 
+/* GroundGrid::update (src/GroundGrid.cpp:83-147) on an already initialised map: grid_map::GridMap::move to the odometry
+ * position (snapped to whole cells), newly exposed cells get ground = -(z of (cell centre, 0) in base_link) and
+ * groundpatch = 0 (:121-131), every other layer NaN there (grid_map clears dropped rows/cols of all layers),
+ * then convertToDefaultStartIndex (:143).  base_to_map = {tx, ty, tz, qx, qy, qz, qw} of the transform
+ * lookupTransform("base_link", "map") returns (:103).  shift[2] receives the index shift (rows, cols); returns 1 if
+ * the map moved. */
+int ggo_map_update(ggo_map *m, double odom_x, double odom_y, const double base_to_map[7], int shift[2]);
+
 /* helpers exported for unit tests */
 int ggo_get_index(const ggo_map *m, double px, double py, int *row, int *col); /* returns isInside */
 float ggo_tree_sum(const float *e, int len);   /* Eigen 3.3.7 redux_novec_unroller order */

@@ -115,6 +115,8 @@ def lib():
         ]
         L.ggo_stage_detect.argtypes = [C.POINTER(_Map), C.POINTER(Config)]
         L.ggo_stage_spiral.argtypes = [C.POINTER(_Map), C.POINTER(Config), C.c_double]
+        L.ggo_map_update.restype = C.c_int
+        L.ggo_map_update.argtypes = [C.POINTER(_Map), C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.ggo_get_index.restype = C.c_int
         L.ggo_get_index.argtypes = [C.POINTER(_Map), C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ggo_tree_sum.restype = C.c_float
@@ -181,6 +183,13 @@ class OracleMap:
 
     def reset_state(self, pos=(0.0, 0.0), odom_z=0.0):
         self._L.ggo_map_reset_state(self._m, pos[0], pos[1], C.c_float(odom_z))
+
+    def update(self, odom_x: float, odom_y: float, base_to_map):
+        """GroundGrid::update.  base_to_map = (tx, ty, tz, qx, qy, qz, qw).  Returns (moved, (shift_rows, shift_cols))."""
+        tf = (C.c_double * 7)(*[float(v) for v in base_to_map])
+        sh = (C.c_int * 2)()
+        moved = self._L.ggo_map_update(self._m, float(odom_x), float(odom_y), tf, sh)
+        return bool(moved), (sh[0], sh[1])
 
     def layer(self, name: str) -> np.ndarray:
         """View (no copy) of a layer as (rows, cols) Fortran-ordered float32 (Eigen column-major)."""

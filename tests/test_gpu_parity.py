@@ -271,3 +271,71 @@ def test_index_fast_path_boundaries():
     pos = (float(np.float64(np.float32(5.0)) - half), float(np.float64(np.float32(-7.25)) - half))
     pts = np.array([[5.0, -7.25, -1.0], [5.0, -7.0, -1.0], [4.9, -7.25, -1.2], [3.0, -9.0, -1.1]], dtype=np.float32)
     run_pair(synth.make_cloud(pts), pos=pos, origin=(pos[0], pos[1], 0.0), frames=1)
+
+
+# ---------------------------------------------------------------- N1: map follows the vehicle (GroundGrid::update)
+
+def drive_frames(n_frames=6, n_az=500, seed=77):
+    """A vehicle driving a curve: per frame (cloud in the map frame, odom xy, sensor origin, base_link<-map transform)."""
+    base = synth.hdl64_cloud(seed=seed, n_az=n_az)
+    frames = []
+    for f in range(n_frames):
+        yaw = 0.15 * f
+        x, y = 1.3 * f, 0.45 * f * f * 0.3 - 0.7 * f
+        c, s = np.float32(np.cos(yaw)), np.float32(np.sin(yaw))
+        cloud = base.copy()
+        cloud["x"] = (c * base["x"] - s * base["y"] + np.float32(x)).astype(np.float32)
+        cloud["y"] = (s * base["x"] + c * base["y"] + np.float32(y)).astype(np.float32)
+        cloud["z"], cloud["ring"], cloud["intensity"] = base["z"], base["ring"], base["intensity"]
+        # base_link pose in map: (x, y, -1.73, yaw)  ->  base_link<-map = inverse
+        tx = -(np.cos(yaw) * x + np.sin(yaw) * y)
+        ty = -(-np.sin(yaw) * x + np.cos(yaw) * y)
+        tf = (tx, ty, 1.73, 0.0, 0.0, -np.sin(yaw / 2), np.cos(yaw / 2))
+        frames.append((cloud, (x, y), (np.float32(x), np.float32(y), np.float32(0.0)), tf))
+    return frames
+
+
+def test_driving_sequence_with_device_map_scroll():
+    frames = drive_frames()
+    n = max(len(f[0]) for f in frames)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=n)
+    x0, y0 = frames[0][1]
+    ref = oracle.OracleMap(120.0, 0.33, pos=(x0, y0), odom_z=-1.73)
+    seg.map(0).reset(odom_z=-1.73, pos=(x0, y0))  # GroundGrid::initGroundGrid on the first odometry message
+    moved_any = False
+    for k, (cloud, odom, origin, tf) in enumerate(frames):
+        if k > 0:  # odom_callback -> GroundGrid::update
+            moved, shift = ref.update(odom[0], odom[1], tf)
+            dshift = seg.map(0).move(odom[0], odom[1], tf)
+            assert tuple(dshift) == tuple(shift)
+            assert seg.map(0).getPosition() == ref.position
+            moved_any |= moved
+            for name in ("ground", "groundpatch"):
+                assert nan_equal(seg.map(0)[name], ref.layer(name)), (k, name)
+        out, labels, index = seg.filter_cloud(cloud, origin, -1.73, return_details=True)
+        r = ref.filter_cloud(cloud, origin, -1.73)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), k
+        assert out.tobytes() == r["out_points"].tobytes()
+        assert_same_state(seg.map(0), ref, f"frame {k}")
+    assert moved_any
+
+
+def test_map_scroll_edge_cases():
+    seg = api.GroundSegmentation().init(21.12, 0.33, n_slots=1, max_points=16)
+    ref = oracle.OracleMap(21.12, 0.33)
+    rng = np.random.default_rng(3)
+    g0, w0 = rng.normal(size=(64, 64)).astype(np.float32), rng.random((64, 64)).astype(np.float32)
+    for odom, tf in [((0.1, -0.1), (0, 0, 1, 0, 0, 0, 1)),            # less than half a cell: no move at all
+                     ((0.17, 0.0), (0.3, 0.2, 1.5, 0.02, -0.01, 0.3, 0.95)),  # exactly past the rounding point, tilted base
+                     ((-3.0, 5.2), (1, 2, 3, 0, 0, 0.7071, 0.7071)),
+                     ((40.0, 5.2), (0, 0, 0.5, 0, 0, 0, 1)),               # more than the whole map in x: everything is new
+                     ((40.0, -90.0), (0, 0, 0.5, 0.1, 0.2, 0.3, 0.9))]:
+        ref.set_layer("ground", g0)
+        ref.set_layer("groundpatch", w0)
+        seg.map(0).set("ground", g0)
+        seg.map(0).set("groundpatch", w0)
+        moved, shift = ref.update(odom[0], odom[1], tf)
+        assert tuple(seg.map(0).move(odom[0], odom[1], tf)) == tuple(shift)
+        assert seg.map(0).getPosition() == ref.position
+        for name in ("ground", "groundpatch"):
+            assert nan_equal(seg.map(0)[name], ref.layer(name)), (odom, name)

@@ -282,3 +282,39 @@ def test_full_size_cloud_properties():
     assert np.array_equal(m.layer("points"), cnt.astype(np.float32))
     # flat synthetic terrain: most returns are ground
     assert (lab == 49).sum() > (lab == 99).sum()
+
+
+# ------------------------------------------------------------------ N1: GroundGrid::update
+
+def test_map_update_semantics():
+    m = oracle.OracleMap(21.12, 0.33)
+    g = np.arange(64 * 64, dtype=np.float32).reshape((64, 64), order="F")
+    m.set_layer("ground", g)
+    m.set_layer("groundpatch", np.full((64, 64), 0.5, dtype=np.float32))
+    res = m.resolution
+    # less than half a cell: nothing moves, position unchanged (src/GroundGrid.cpp:135-137)
+    moved, shift = m.update(0.16, -0.16, (0, 0, 1, 0, 0, 0, 1))
+    assert not moved and shift == (0, 0) and m.position == (0.0, 0.0)
+    # +0.7 m in x = 2.12 cells -> 2 cells; row index 0 is at +x, so two NEW rows appear at rows 0..1
+    moved, shift = m.update(0.7, -0.34, (0.0, 0.0, 1.25, 0, 0, 0, 1))
+    assert moved and shift == (-2, 1)
+    assert m.position == (2 * res, -1 * res)                       # snapped to whole cells, not to the odometry
+    G, W = m.layer("ground"), m.layer("groundpatch")
+    assert np.array_equal(G[2:, :63], g[:62, 1:])                  # old content shifted by (+2 rows, -1 col)
+    assert (G[:2, :] == np.float32(-1.25)).all() and (G[:, 63] == np.float32(-1.25)).all()   # -(z in base_link), identity rotation
+    assert (W[:2, :] == 0).all() and (W[:, 63] == 0).all() and (W[2:, :63] == 0.5).all()
+    assert np.isnan(m.layer("points")[:2, :]).all() and np.isnan(m.layer("minGroundHeight")[:, 63]).all()
+    assert not np.isnan(m.layer("points")[2:, :63]).any()
+    # a pitched base: the fill is a plane -(m20 x + m21 y + tz) over the cell centres
+    q = (0.0, np.sin(0.05), 0.0, np.cos(0.05))
+    m2 = oracle.OracleMap(21.12, 0.33)
+    m2.update(5.0, 0.0, (0.2, 0.0, 1.0) + q)
+    L = m2.length[0]
+    xs = m2.position[0] + (0.5 * L - 0.5 * res) - res * np.arange(64)
+    m20 = 2 * (q[0] * q[2] - q[3] * q[1])
+    expect = -(m20 * xs[:15] + 1.0)
+    assert np.allclose(m2.layer("ground")[:15, 10], expect, atol=1e-6)
+    # a jump larger than the map: every cell is new
+    m3 = oracle.OracleMap(21.12, 0.33)
+    m3.update(500.0, 0.0, (0, 0, 2, 0, 0, 0, 1))
+    assert (m3.layer("ground") == -2).all() and (m3.layer("groundpatch") == 0).all()
