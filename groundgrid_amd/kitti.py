@@ -1,0 +1,177 @@
+"""SemanticKITTI sequence reader and the frame wiring of the reference's evaluation pipeline, without ROS.
+
+Restates what /root/reference/scripts/kitti_data_publisher.py and launch/KITTIEvaluate.launch feed the nodelet:
+
+* file formats (kitti_data_publisher.py:117-161): ``velodyne/%06d.bin`` float32 x,y,z,remission; ``labels/%06d.label``
+  uint32 whose low 16 bits are the semantic label -- the player stores it in the cloud's ``ring`` field (:124,:130);
+  ``poses.txt`` 3x4 row-major per line; ``times.txt``;
+* pose math (:164-180): pose_i = calib^-1 . P_i . calib with the hard-coded calibration string (:168);
+* frames: the player broadcasts map <- kitti_base_link = pose_i (:207-215) and publishes the odometry position
+  = pose translation (:193-195); static transforms (KITTIEvaluate.launch:13-16): base_link = kitti_base_link +
+  (1.95, 0, -1.73), velodyne = kitti_base_link;
+* what the nodelet derives per cloud (src/GroundGridNodelet.cpp:129-195): the cloud transformed point by point into the
+  map frame in double precision and cast back to float (:166-181), the sensor origin = map <- velodyne applied to 0,
+  mapToBase = map <- base_link (only translation.z is used by the path), and in odom_callback
+  (src/GroundGrid.cpp:83-147) the base_link <- map transform used to seed newly exposed cells.
+
+tf timing / interpolation effects of the live ROS pipeline are not modelled: every cloud uses its own pose exactly, so
+aggregate results are a close match to README.md:57-94, not a bit-exact one.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Iterator, List, Optional
+
+import numpy as np
+
+from .synth import POINT_DTYPE, empty_cloud
+
+# scripts/kitti_data_publisher.py:168
+CALIB_STRING = ("4.276802385584e-04 -9.999672484946e-01 -8.084491683471e-03 -1.198459927713e-02 -7.210626507497e-03 "
+                "8.081198471645e-03 -9.999413164504e-01 -5.403984729748e-02 9.999738645903e-01 4.859485810390e-04 "
+                "-7.206933692422e-03 -2.921968648686e-01")
+# launch/KITTIEvaluate.launch:13,16
+KITTI_BASE_TO_BASE_LINK = (1.95, 0.0, -1.73)
+KITTI_BASE_TO_VELODYNE = (0.0, 0.0, 0.0)
+
+
+def read_bin(path: str) -> np.ndarray:
+    """velodyne/%06d.bin -> (n, 4) float32 x, y, z, remission (kitti_data_publisher.py:120-121)."""
+    return np.fromfile(path, dtype=np.float32).reshape((-1, 4))
+
+
+def read_labels(path: str) -> np.ndarray:
+    """labels/%06d.label -> semantic label = low 16 bits (kitti_data_publisher.py:156-161)."""
+    return (np.fromfile(path, dtype=np.uint32).reshape(-1) & 0xFFFF).astype(np.uint16)
+
+
+def make_cloud(scan: np.ndarray, labels: Optional[np.ndarray]) -> np.ndarray:
+    """PointXYZIR records as the nodelet receives them: intensity = remission, ring = semantic label (:124-130)."""
+    pts = empty_cloud(scan.shape[0])
+    pts["x"], pts["y"], pts["z"], pts["intensity"] = scan[:, 0], scan[:, 1], scan[:, 2], scan[:, 3]
+    if labels is not None:
+        pts["ring"] = labels
+    return pts
+
+
+def read_poses(path: str) -> List[np.ndarray]:
+    """poses.txt -> list of 4x4 float64 calib^-1 . P . calib (kitti_data_publisher.py:164-180)."""
+    calib = np.vstack((np.array(CALIB_STRING.split(), dtype=np.float64).reshape(3, 4), [0, 0, 0, 1]))
+    calib_inv = np.linalg.inv(calib)
+    poses = []
+    with open(path) as f:
+        for line in f:
+            if not line.strip():
+                continue
+            P = np.vstack((np.array(line.split(), dtype=np.float64).reshape(3, 4), [0, 0, 0, 1]))
+            poses.append(np.matmul(calib_inv, np.matmul(P, calib)))
+    return poses
+
+
+def quaternion_from_matrix(M: np.ndarray) -> np.ndarray:
+    """tf.transformations.quaternion_from_matrix (x, y, z, w), the branchy trace form used by ROS Noetic's tf."""
+    M = np.asarray(M, dtype=np.float64)[:4, :4]
+    q = np.empty(4)
+    t = np.trace(M)
+    if t > M[3, 3]:
+        q[3] = t
+        q[2] = M[1, 0] - M[0, 1]
+        q[1] = M[0, 2] - M[2, 0]
+        q[0] = M[2, 1] - M[1, 2]
+    else:
+        i, j, k = 0, 1, 2
+        if M[1, 1] > M[0, 0]:
+            i, j, k = 1, 2, 0
+        if M[2, 2] > M[i, i]:
+            i, j, k = 2, 0, 1
+        t = M[i, i] - (M[j, j] + M[k, k]) + M[3, 3]
+        q[i] = t
+        q[j] = M[i, j] + M[j, i]
+        q[k] = M[k, i] + M[i, k]
+        q[3] = M[k, j] - M[j, k]
+    q *= 0.5 / np.sqrt(t * M[3, 3])
+    return q
+
+
+def matrix_from_quaternion(q) -> np.ndarray:
+    """tf2::Matrix3x3::setRotation (what tf2::doTransform builds from the message quaternion)."""
+    x, y, z, w = (float(v) for v in q)
+    d = x * x + y * y + z * z + w * w
+    s = 2.0 / d
+    xs, ys, zs = x * s, y * s, z * s
+    wx, wy, wz = w * xs, w * ys, w * zs
+    xx, xy, xz = x * xs, x * ys, x * zs
+    yy, yz, zz = y * ys, y * zs, z * zs
+    return np.array([[1.0 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1.0 - (xx + zz), yz - wx], [xz - wy, yz + wx, 1.0 - (xx + yy)]])
+
+
+def transform_cloud(cloud: np.ndarray, R: np.ndarray, t: np.ndarray) -> np.ndarray:
+    """src/GroundGridNodelet.cpp:166-181: tf2::doTransform per point in double (dot products left to right,
+    then + origin), cast back to float; everything else of the record is copied."""
+    x, y, z = (cloud[k].astype(np.float64) for k in ("x", "y", "z"))
+    out = cloud.copy()
+    for name, row, off in (("x", R[0], t[0]), ("y", R[1], t[1]), ("z", R[2], t[2])):
+        out[name] = (((row[0] * x + row[1] * y) + row[2] * z) + off).astype(np.float32)
+    out["intensity"], out["ring"] = cloud["intensity"], cloud["ring"]
+    return out
+
+
+@dataclass
+class Frame:
+    index: int
+    cloud_sensor: np.ndarray      # PointXYZIR in the kitti_base_link (= velodyne) frame, ring = semantic label
+    cloud_map: np.ndarray         # the same cloud in the map frame (what filter_cloud receives)
+    origin: tuple                 # cloudOrigin: map <- velodyne applied to (0, 0, 0), as floats
+    odom: tuple                   # odometry position x, y, z (GroundGrid::update / initGroundGrid)
+    map_to_base_z: float          # mapToBase.transform.translation.z
+    base_to_map: tuple            # (tx, ty, tz, qx, qy, qz, qw) of base_link <- map
+
+
+class KittiSequence:
+    """Iterates a SemanticKITTI sequence directory (``.../sequences/00``) in the reference pipeline's conventions."""
+
+    def __init__(self, directory: str):
+        self.dir = directory
+        self.poses = read_poses(os.path.join(directory, "poses.txt"))
+        self.n = len(self.poses)
+        self.have_labels = os.path.isdir(os.path.join(directory, "labels"))
+
+    def __len__(self):
+        return self.n
+
+    def frame(self, i: int) -> Frame:
+        scan = read_bin(os.path.join(self.dir, "velodyne", f"{i:06d}.bin"))
+        labels = read_labels(os.path.join(self.dir, "labels", f"{i:06d}.label")) if self.have_labels else None
+        return make_frame(i, make_cloud(scan, labels), self.poses[i])
+
+    def __iter__(self) -> Iterator[Frame]:
+        for i in range(self.n):
+            yield self.frame(i)
+
+
+def make_frame(i: int, cloud_sensor: np.ndarray, pose: np.ndarray) -> Frame:
+    q = quaternion_from_matrix(pose)                  # player: quaternion of the pose (:199)
+    R = matrix_from_quaternion(q)                     # nodelet: tf2 rebuilds the rotation from the quaternion
+    t = np.array([pose[0, 3], pose[1, 3], pose[2, 3]])
+    cloud_map = transform_cloud(cloud_sensor, R, t)
+    origin = tuple(np.float32(v) for v in t)          # Nodelet.cpp:139-146,192-195 (velodyne == kitti_base_link)
+    # map <- base_link = pose . static(1.95, 0, -1.73)
+    sb = np.array(KITTI_BASE_TO_BASE_LINK)
+    base_in_map = R @ sb + t
+    # base_link <- map = inverse: rotation conj(q), translation -R^T . base_in_map
+    tb = -(R.T @ base_in_map)
+    base_to_map = (tb[0], tb[1], tb[2], -q[0], -q[1], -q[2], q[3])
+    return Frame(i, cloud_sensor, cloud_map, origin, (t[0], t[1], t[2]), float(base_in_map[2]), base_to_map)
+
+
+def write_synthetic_sequence(directory: str, clouds: List[np.ndarray], poses_cam: List[np.ndarray]):
+    """Writes clouds (POINT_DTYPE, ring = label) + camera-frame 3x4 poses in SemanticKITTI layout (tests / demos)."""
+    os.makedirs(os.path.join(directory, "velodyne"), exist_ok=True)
+    os.makedirs(os.path.join(directory, "labels"), exist_ok=True)
+    with open(os.path.join(directory, "poses.txt"), "w") as fp, open(os.path.join(directory, "times.txt"), "w") as ft:
+        for i, (c, P) in enumerate(zip(clouds, poses_cam)):
+            np.column_stack([c["x"], c["y"], c["z"], c["intensity"]]).astype(np.float32).tofile(os.path.join(directory, "velodyne", f"{i:06d}.bin"))
+            c["ring"].astype(np.uint32).tofile(os.path.join(directory, "labels", f"{i:06d}.label"))
+            fp.write(" ".join(f"{v:.12e}" for v in np.asarray(P, dtype=np.float64)[:3, :4].reshape(-1)) + "\n")
+            ft.write(f"{0.1 * i:.6e}\n")

@@ -339,3 +339,20 @@ def test_map_scroll_edge_cases():
         assert seg.map(0).getPosition() == ref.position
         for name in ("ground", "groundpatch"):
             assert nan_equal(seg.map(0)[name], ref.layer(name)), (odom, name)
+
+
+# ---------------------------------------------------------------- N3: KITTI-format sequence replay (configs[4] harness)
+
+def test_kitti_format_sequence_replay_matches_cpu_path(tmp_path):
+    from groundgrid_amd import kitti, replay
+    from tests.test_kitti_cpu import OracleBackend, _synthetic_sequence
+
+    d, _ = _synthetic_sequence(tmp_path, n_frames=5)
+    seq = kitti.KittiSequence(d)
+    per_frame = {"gpu": [], "cpu": []}
+    ev_gpu, _ = replay.replay(seq, replay.DeviceBackend(max_points=20000), on_frame=lambda fr, lab, idx: per_frame["gpu"].append((lab.copy(), idx.copy())))
+    ev_cpu, _ = replay.replay(seq, OracleBackend(), on_frame=lambda fr, lab, idx: per_frame["cpu"].append((lab.copy(), idx.copy())))
+    for k, ((lg, ig), (lc, ic)) in enumerate(zip(per_frame["gpu"], per_frame["cpu"])):
+        assert np.array_equal(lg, lc) and np.array_equal(ig, ic), k
+    assert ev_gpu.total == ev_cpu.total and ev_gpu.non_ground == ev_cpu.non_ground
+    assert ev_gpu.summary() == ev_cpu.summary() and ev_gpu.table() == ev_cpu.table()
