@@ -43,10 +43,9 @@ def make_clouds(batch: int, rank: int, n_scenes: int = 8):
             continue
         ang = np.float32(2.0 * np.pi * rot / max(1, (batch + len(scenes) - 1) // len(scenes)) + 0.01 * b)
         c, s = np.cos(ang), np.sin(ang)
-        out = base.copy()
+        out = synth.clone_cloud(base)
         out["x"] = (c * base["x"] - s * base["y"]).astype(np.float32)
         out["y"] = (s * base["x"] + c * base["y"]).astype(np.float32)
-        out["z"], out["ring"], out["intensity"] = base["z"], base["ring"], base["intensity"]
         clouds.append(out)
     return clouds
 

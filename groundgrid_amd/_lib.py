@@ -37,7 +37,7 @@ SYMBOLS = [
     "gg_abi_version", "gg_kernel_name", "gg_default_config", "gg_default_geometry", "gg_create", "gg_destroy",
     "gg_set_config", "gg_get_config", "gg_set_flags", "gg_get_size", "gg_get_geometry", "gg_last_error",
     "gg_reset_map", "gg_set_map_position", "gg_move_map", "gg_get_map_position", "gg_set_layer", "gg_get_layer", "gg_get_expected_points",
-    "gg_filter_cloud", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
+    "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
 ]
 
 
@@ -81,6 +81,7 @@ class GGBatch(C.Structure):
         ("n_points", C.POINTER(C.c_int32)),
         ("origins", C.POINTER(C.c_float)),
         ("base_z", C.POINTER(C.c_double)),
+        ("transforms", C.POINTER(C.c_double)),
         ("d_labels", C.c_void_p),
         ("d_out_index", C.c_void_p),
         ("d_out_clouds", C.c_void_p),
@@ -133,6 +134,7 @@ def load():
     L.gg_get_layer.argtypes = [vp, C.c_int, C.c_int, vp]
     L.gg_get_expected_points.argtypes = [vp, vp]
     L.gg_filter_cloud.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_float), C.c_double, vp, P(C.c_size_t), vp, vp]
+    L.gg_filter_cloud_tf.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, vp, P(C.c_size_t), vp, vp]
     L.gg_filter_batch.argtypes = [vp, P(GGBatch), vp]
     L.gg_synchronize.argtypes = [vp]
     L.gg_get_point_classes.argtypes = [vp, C.c_int, C.c_size_t, vp, vp]

@@ -305,6 +305,9 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
         p.base_z = (float)b->base_z[i];
         p.pos_x = ctx->pos_x[slot];
         p.pos_y = ctx->pos_y[slot];
+        p.has_tf = b->transforms ? 1 : 0;
+        p.pad_ = 0;
+        for (int k = 0; k < 12; ++k) p.tf[k] = b->transforms ? b->transforms[(size_t)i * 12 + k] : 0.0;
         max_n = std::max(max_n, p.n_points);
     }
     HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * nb, hipMemcpyHostToDevice, s));
@@ -765,8 +768,8 @@ int gg_synchronize(gg_context *ctx)
     return GG_OK;
 }
 
-int gg_filter_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const float origin[3], double base_z,
-                    gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index)
+static int filter_cloud_impl(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *tf, const float origin[3],
+                             double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index)
 {
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if ((!cloud && n) || !origin) return fail(ctx, GG_ERR_INVALID, "null cloud / origin");
@@ -795,6 +798,7 @@ int gg_filter_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n
     b.n_points = &n32;
     b.origins = origin;
     b.base_z = &base_z;
+    b.transforms = tf;
     b.d_labels = ctx->d_stage_labels;
     b.d_out_index = ctx->d_stage_index;
     b.d_out_clouds = nullptr;
@@ -818,10 +822,30 @@ int gg_filter_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n
             const int32_t k = ctx->h_stage_index[i];
             if (k < 0) continue;
             out_cloud[k] = cloud[i];
+            if (tf) { // map-frame coordinates, same arithmetic as the device (this file is built with -ffp-contract=off)
+                const double dx = (double)cloud[i].x, dy = (double)cloud[i].y, dz = (double)cloud[i].z;
+                out_cloud[k].x = (float)(((tf[0] * dx + tf[1] * dy) + tf[2] * dz) + tf[3]);
+                out_cloud[k].y = (float)(((tf[4] * dx + tf[5] * dy) + tf[6] * dz) + tf[7]);
+                out_cloud[k].z = (float)(((tf[8] * dx + tf[9] * dy) + tf[10] * dz) + tf[11]);
+            }
             out_cloud[k].intensity = (float)ctx->h_stage_labels[i];
         }
     }
     return GG_OK;
+}
+
+int gg_filter_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const float origin[3], double base_z,
+                    gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index)
+{
+    return filter_cloud_impl(ctx, slot, cloud, n, nullptr, origin, base_z, out_cloud, out_n, out_label, out_index);
+}
+
+int gg_filter_cloud_tf(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double map_from_cloud[12],
+                       const float origin[3], double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label,
+                       int32_t *out_index)
+{
+    if (!map_from_cloud) return GG_ERR_INVALID;
+    return filter_cloud_impl(ctx, slot, cloud, n, map_from_cloud, origin, base_z, out_cloud, out_n, out_label, out_index);
 }
 
 int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class, int32_t *out_cell)

@@ -79,6 +79,19 @@ GG_DEV float ref_hypotf(float x, float y)
     return (float)sqrt(dx * dx + dy * dy);
 }
 
+// tf2::doTransform of one point (src/GroundGridNodelet.cpp:166-181): v_out = basis * v + origin with the dot products
+// evaluated left to right in double, each coordinate cast back to float.
+GG_DEV void transform_point(const double (&tf)[12], float &x, float &y, float &z)
+{
+    const double dx = (double)x, dy = (double)y, dz = (double)z;
+    const double ox = ((tf[0] * dx + tf[1] * dy) + tf[2] * dz) + tf[3];
+    const double oy = ((tf[4] * dx + tf[5] * dy) + tf[6] * dz) + tf[7];
+    const double oz = ((tf[8] * dx + tf[9] * dy) + tf[10] * dz) + tf[11];
+    x = (float)ox;
+    y = (float)oy;
+    z = (float)oz;
+}
+
 GG_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // number of set bits of `mask` below this lane

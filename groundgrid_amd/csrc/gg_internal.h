@@ -78,6 +78,9 @@ struct CloudParams {
     float ox, oy, oz;
     float base_z;   // (float)translation.z
     double pos_x, pos_y;
+    int has_tf;     // points are in the sensor frame: p_map = (float)(R p + t) first (src/GroundGridNodelet.cpp:166-181)
+    int pad_;
+    double tf[12];  // map <- cloud frame, 3x4 row-major (R | t)
 };
 
 // everything a kernel needs to find its data

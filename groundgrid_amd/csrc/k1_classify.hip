@@ -134,6 +134,10 @@ __global__ __launch_bounds__(256, 8) void k_classify(const Arena a, const CloudP
             valid[j] = p < end;
             pt[j] = load_point<FMT>(pts, (size_t)(valid[j] ? p : base));
         }
+        if (cp.has_tf) { // N2: cloud still in the sensor frame (uniform branch)
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) transform_point(cp.tf, pt[j].x, pt[j].y, pt[j].z);
+        }
         int gi0[ITEMS], gi1[ITEMS];
         bool inmap_[ITEMS];
         float og[ITEMS];

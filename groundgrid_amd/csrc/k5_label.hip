@@ -89,6 +89,13 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)(valid[j] ? p : base) * (FMT == GG_POINT16 ? 2 : 4)];
             x[j] = __uint_as_float(xy.x);
             y[j] = __uint_as_float(xy.y);
+            if (cp.has_tf) { // N2: same arithmetic as K1 -> the same map-frame x, y (z travels in rec)
+                const double dx = (double)x[j], dy = (double)y[j];
+                const double dz = (double)__uint_as_float(
+                    reinterpret_cast<const uint32_t *>(pts)[(size_t)(valid[j] ? p : base) * (FMT == GG_POINT16 ? 4 : 8) + 2]);
+                x[j] = (float)(((cp.tf[0] * dx + cp.tf[1] * dy) + cp.tf[2] * dz) + cp.tf[3]);
+                y[j] = (float)(((cp.tf[4] * dx + cp.tf[5] * dy) + cp.tf[6] * dz) + cp.tf[7]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -143,6 +150,11 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                 if (FMT == GG_POINT32 && out_cloud && idx >= 0) {
                     const uint4 *src = reinterpret_cast<const uint4 *>(pts) + (size_t)p * 2;
                     uint4 lo = src[0], hi = src[1];
+                    if (cp.has_tf) { // the returned cloud is in the map frame
+                        lo.x = __float_as_uint(x[j]);
+                        lo.y = __float_as_uint(y[j]);
+                        lo.z = r[j].x;
+                    }
                     hi.x = __float_as_uint((float)label); // intensity := 49 / 99
                     uint4 *dst = reinterpret_cast<uint4 *>(out_cloud + idx);
                     dst[0] = lo;

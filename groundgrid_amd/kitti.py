@@ -25,7 +25,7 @@ from typing import Iterator, List, Optional
 
 import numpy as np
 
-from .synth import POINT_DTYPE, empty_cloud
+from .synth import POINT_DTYPE, clone_cloud, empty_cloud
 
 # scripts/kitti_data_publisher.py:168
 CALIB_STRING = ("4.276802385584e-04 -9.999672484946e-01 -8.084491683471e-03 -1.198459927713e-02 -7.210626507497e-03 "
@@ -110,10 +110,9 @@ def transform_cloud(cloud: np.ndarray, R: np.ndarray, t: np.ndarray) -> np.ndarr
     """src/GroundGridNodelet.cpp:166-181: tf2::doTransform per point in double (dot products left to right,
     then + origin), cast back to float; everything else of the record is copied."""
     x, y, z = (cloud[k].astype(np.float64) for k in ("x", "y", "z"))
-    out = cloud.copy()
+    out = clone_cloud(cloud)
     for name, row, off in (("x", R[0], t[0]), ("y", R[1], t[1]), ("z", R[2], t[2])):
         out[name] = (((row[0] * x + row[1] * y) + row[2] * z) + off).astype(np.float32)
-    out["intensity"], out["ring"] = cloud["intensity"], cloud["ring"]
     return out
 
 

@@ -27,6 +27,12 @@ def empty_cloud(n: int) -> np.ndarray:
     return np.zeros(n * 32, dtype=np.uint8).view(POINT_DTYPE)
 
 
+def clone_cloud(cloud: np.ndarray) -> np.ndarray:
+    """Byte-exact copy.  (ndarray.copy() of a padded structured dtype copies field by field and leaves the 14 padding
+    bytes of each record undefined; the reference copies whole 32-byte points.)"""
+    return np.frombuffer(cloud.tobytes(), dtype=np.uint8).copy().view(POINT_DTYPE)
+
+
 def make_cloud(xyz, ring=None, intensity=None) -> np.ndarray:
     xyz = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
     pts = empty_cloud(xyz.shape[0])

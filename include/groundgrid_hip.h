@@ -173,6 +173,13 @@ int gg_filter_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n
                     double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label,
                     int32_t *out_index);
 
+/* filter_cloud for a cloud that is still in the sensor frame: the per-point transform of points_callback
+ * (src/GroundGridNodelet.cpp:148-184) is fused into the first kernel.  map_from_cloud = 3x4 row-major (R | t) of
+ * lookupTransform("map", cloud frame).  The returned cloud is in the map frame, as in the reference. */
+int gg_filter_cloud_tf(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double map_from_cloud[12],
+                       const float origin[3], double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label,
+                       int32_t *out_index);
+
 /* Batched, device-resident form of the same call: n_clouds independent (cloud, map-state) pairs in
  * one set of launches, slot first_slot + b for cloud b.  Pointers prefixed d_ are device memory.
  * Enqueues on `stream` (a hipStream_t passed as void*, NULL = the context's own stream) and returns
@@ -186,6 +193,10 @@ typedef struct gg_batch {
     const int32_t *n_points; /* host [n_clouds] */
     const float *origins;    /* host [n_clouds][3] */
     const double *base_z;    /* host [n_clouds] */
+    const double *transforms; /* host [n_clouds][12], nullable: map <- cloud frame as 3x4 row-major (R | t).  When given,
+                                the points are still in the sensor frame and are transformed on the device exactly like
+                                the nodelet does per point (tf2::doTransform in double, cast to float,
+                                src/GroundGridNodelet.cpp:166-181); labels / returned clouds refer to map-frame points */
     uint8_t *d_labels;       /* [n_clouds][cloud_stride], nullable */
     int32_t *d_out_index;    /* [n_clouds][cloud_stride], nullable */
     gg_point32 *d_out_clouds; /* [n_clouds][cloud_stride], nullable; needs point_format == GG_POINT32 */

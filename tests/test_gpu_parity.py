@@ -356,3 +356,35 @@ def test_kitti_format_sequence_replay_matches_cpu_path(tmp_path):
         assert np.array_equal(lg, lc) and np.array_equal(ig, ic), k
     assert ev_gpu.total == ev_cpu.total and ev_gpu.non_ground == ev_cpu.non_ground
     assert ev_gpu.summary() == ev_cpu.summary() and ev_gpu.table() == ev_cpu.table()
+
+
+# ---------------------------------------------------------------- N2: cloud -> map transform fused into the first kernel
+
+def test_sensor_frame_cloud_transformed_on_device():
+    import torch
+    from groundgrid_amd import kitti
+
+    base = synth.hdl64_cloud(seed=9, n_az=700)
+    q = np.array([0.01, -0.02, np.sin(0.4), np.cos(0.4)])
+    q /= np.linalg.norm(q)
+    R, t = kitti.matrix_from_quaternion(q), np.array([3.25, -1.5, 0.07])
+    cloud_map = kitti.transform_cloud(base, R, t)          # what the nodelet computes on the CPU (Nodelet.cpp:166-181)
+    tf = np.hstack([R, t[:, None]])
+    origin = tuple(np.float32(v) for v in t)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=2, max_points=len(base))
+    ref = oracle.OracleMap(120.0, 0.33)
+    for frame in range(2):
+        out, labels, index = seg.filter_cloud(base, origin, -1.66, return_details=True, map_from_cloud=tf)
+        r = ref.filter_cloud(cloud_map, origin, -1.66)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), frame
+        assert out.tobytes() == r["out_points"].tobytes(), frame   # the returned cloud is in the map frame
+        assert_same_state(seg.map(0), ref, f"frame {frame}")
+    # batched entry point, PointXYZIR records, returned clouds materialised on the device
+    raw = torch.from_numpy(np.frombuffer(base.tobytes(), dtype=np.uint8).reshape(1, -1, 32).copy()).cuda()
+    ref2 = oracle.OracleMap(120.0, 0.33)
+    o = seg.filter_batch(raw, [len(base)], [origin], [-1.66], first_slot=1, want_clouds=True, transforms=tf[None])
+    torch.cuda.synchronize()
+    r = ref2.filter_cloud(cloud_map, origin, -1.66)
+    n_out = int(o.counts[0, 0])
+    assert np.array_equal(o.labels[0, : len(base)].cpu().numpy(), r["label"])
+    assert o.out_clouds[0, :n_out].cpu().numpy().tobytes() == r["out_points"].tobytes()
