@@ -23,7 +23,7 @@ STATUS = {
 }
 
 GG_POINT32, GG_POINT16 = 0, 1
-GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE = 1, 2
+GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE, GG_FLAG_SPIRAL_NARROW = 1, 2, 4
 GG_NUM_KERNELS = 7
 GG_NUM_LAYERS = 11
 

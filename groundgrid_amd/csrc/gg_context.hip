@@ -118,7 +118,11 @@ uint32_t morton2(uint32_t x, uint32_t y)
 //     allocated until the level of its last reader (lifetime <= 8 levels, 1723 slots for n = 364), pre-sweep values
 //     are read from the layer in global memory, which nobody has touched yet at that point.  The choice is made
 //     here, from the serial order -- never from timing on the device.
-void build_spiral_schedule(int n, double res, float min_dist_sq, std::vector<SpiralVisit> &visits_by_level,
+//   * `cap` bounds the visits per level (a level that is full pushes later visits to the next one -- visits of one level
+//     stay independent, so any split is legal).  cap = 1024 gives the shortest chain (903 levels, n = 364: lowest
+//     latency for one cloud); cap = 64 gives levels of one wavefront (no idle waves, no work-group barrier: the least
+//     vector-memory work per cloud, best when many clouds are in flight).
+void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::vector<SpiralVisit> &visits_by_level,
                            std::vector<uint32_t> &level_start, int &max_width, int &n_slots)
 {
     const int center = n / 2 - 1;
@@ -143,12 +147,19 @@ void build_spiral_schedule(int n, double res, float min_dist_sq, std::vector<Spi
     std::vector<int> last_write(C, 0), last_read(C, 0), level(V), last_reader_level(V, 0);
     std::vector<int64_t> last_writer(C, -1);
     std::vector<int64_t> src_visit(V * 9, -1);
+    std::vector<int> level_count(64, 0);
     int n_levels = 0;
     for (size_t k = 0; k < V; ++k) {
         const int x = (int)(cells[k] % (uint32_t)n), y = (int)(cells[k] / (uint32_t)n);
         int lv = last_read[cells[k]];
         for (int q = 0; q < 9; ++q) lv = std::max(lv, last_write[(x - 1 + q % 3) + (y - 1 + q / 3) * n]);
         lv += 1;
+        if ((size_t)lv >= level_count.size()) level_count.resize((size_t)lv + 64, 0);
+        while (level_count[lv] >= cap) {
+            ++lv;
+            if ((size_t)lv >= level_count.size()) level_count.resize((size_t)lv + 64, 0);
+        }
+        level_count[lv]++;
         level[k] = lv;
         for (int q = 0; q < 9; ++q) {
             const size_t nb = (size_t)((x - 1 + q % 3) + (y - 1 + q / 3) * n);
@@ -445,6 +456,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 
     CREATE_CHK(hipSetDevice(device));
     CREATE_CHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    gg::configure_kernels();
 
     Arena &a = ctx->arena;
     Geometry &g = a.g;
@@ -477,16 +489,20 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
             ctx->h_expected[i + j * cellCount] = atanf(1 / dist) / geom.vertical_point_ang_dist;
         }
 
-    std::vector<SpiralVisit> visits;
-    std::vector<uint32_t> level_start;
-    int max_width = 0, spiral_slots = 0;
-    build_spiral_schedule(n, res, geom.min_dist_squared, visits, level_start, max_width, spiral_slots);
-    a.n_levels = (int)level_start.size() - 1;
-    a.max_level_width = max_width;
-    a.spiral_slots = spiral_slots;
-    if (spiral_slots >= 0xFFFF || (size_t)spiral_slots * 8 + level_start.size() * 4 > 150 * 1024 || max_width > 1024) {
-        gg_destroy(ctx);
-        return GG_ERR_GEOMETRY; // the spiral's fresh-value window no longer fits LDS
+    std::vector<SpiralVisit> visits[2];
+    std::vector<uint32_t> level_start[2];
+    const int caps[2] = {1024, 64};
+    for (int v = 0; v < 2; ++v) {
+        int max_width = 0, spiral_slots = 0;
+        build_spiral_schedule(n, res, geom.min_dist_squared, caps[v], visits[v], level_start[v], max_width, spiral_slots);
+        a.sched[v].n_levels = (int)level_start[v].size() - 1;
+        a.sched[v].max_level_width = max_width;
+        a.sched[v].slots = spiral_slots;
+        a.sched[v].pad_ = 0;
+        if (spiral_slots >= 0xFFFF || (size_t)spiral_slots * 8 + level_start[v].size() * 4 > 150 * 1024 || max_width > 1024) {
+            gg_destroy(ctx);
+            return GG_ERR_GEOMETRY; // the spiral's fresh-value window no longer fits LDS
+        }
     }
 
     std::vector<uint16_t> tile_rank(g.T), rank_tile(g.T);
@@ -513,8 +529,11 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t Cpad = align_up(C * 4, A) / 4;
     const size_t Npad = align_up(max_points * 8, A) / 8;
     const size_t o_expected = carve(C * 4);
-    const size_t o_visits = carve(visits.size() * sizeof(SpiralVisit));
-    const size_t o_lstart = carve(level_start.size() * 4);
+    size_t o_visits[2], o_lstart[2];
+    for (int v = 0; v < 2; ++v) {
+        o_visits[v] = carve(visits[v].size() * sizeof(SpiralVisit));
+        o_lstart[v] = carve(level_start[v].size() * 4);
+    }
     const size_t o_trank = carve((size_t)g.T * 2);
     const size_t o_rtile = carve((size_t)g.T * 2);
     const size_t o_dummy = carve(2 * 1024 * 4);
@@ -542,8 +561,10 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipMemsetAsync(base, 0, ctx->arena_bytes, ctx->stream));
 
     a.expected = (const float *)(base + o_expected);
-    a.visits = (const SpiralVisit *)(base + o_visits);
-    a.level_start = (const uint32_t *)(base + o_lstart);
+    for (int v = 0; v < 2; ++v) {
+        a.sched[v].visits = (const SpiralVisit *)(base + o_visits[v]);
+        a.sched[v].level_start = (const uint32_t *)(base + o_lstart[v]);
+    }
     a.tile_rank = (const uint16_t *)(base + o_trank);
     a.rank_tile = (const uint16_t *)(base + o_rtile);
     a.spiral_dummy = (float *)(base + o_dummy);
@@ -568,8 +589,10 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_scroll_scratch = (float *)(base + o_scroll);
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
-    CREATE_CHK(hipMemcpyAsync(base + o_visits, visits.data(), visits.size() * sizeof(SpiralVisit), hipMemcpyHostToDevice, ctx->stream));
-    CREATE_CHK(hipMemcpyAsync(base + o_lstart, level_start.data(), level_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (int v = 0; v < 2; ++v) {
+        CREATE_CHK(hipMemcpyAsync(base + o_visits[v], visits[v].data(), visits[v].size() * sizeof(SpiralVisit), hipMemcpyHostToDevice, ctx->stream));
+        CREATE_CHK(hipMemcpyAsync(base + o_lstart[v], level_start[v].data(), level_start[v].size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_rtile, rank_tile.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipStreamSynchronize(ctx->stream)); // the host vectors above go out of scope

@@ -71,6 +71,16 @@ struct SpiralVisit {
 constexpr uint16_t SPIRAL_NONE = 0xFFFFu;
 constexpr uint16_t SPIRAL_STORE = 1u, SPIRAL_DECAY = 2u;
 
+// One level schedule of the terrain sweep (built by gg_context.hip build_spiral_schedule)
+struct SpiralSched {
+    const SpiralVisit *visits;    // visit descriptors, grouped by level
+    const uint32_t *level_start;  // [n_levels + 1]
+    int n_levels;
+    int max_level_width;          // visits per level <= this (the work-group size is its round-up to 64)
+    int slots;                    // LDS slots the fresh-value window needs
+    int pad_;
+};
+
 // per-cloud parameters of one batched call (device array, one entry per cloud of the batch)
 struct CloudParams {
     int slot;
@@ -89,11 +99,7 @@ struct Arena {
     DevConfig cfg;
     // shared
     const float *expected;        // [C]
-    const SpiralVisit *visits;    // spiral visit descriptors, grouped by level
-    const uint32_t *level_start;  // [n_levels + 1]
-    int n_levels;
-    int max_level_width;
-    int spiral_slots;             // LDS slots the fresh-value window needs
+    SpiralSched sched[2];         // [0] widest levels (lowest latency), [1] levels capped at one wavefront (throughput)
     float *spiral_dummy;          // [2 * 1024] write-only sink for idle lanes of k_spiral
     const uint16_t *tile_rank;    // [T] tile (tr + tc*tiles_r) -> Morton rank
     const uint16_t *rank_tile;    // [T] Morton rank -> tile
@@ -134,6 +140,7 @@ void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hip
 void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
+void configure_kernels(); // one-time function attributes (dynamic LDS above 64 KiB)
 void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double tf[7], hipStream_t s);
 void launch_pack16(const gg_point32 *src, gg_point16 *dst, size_t n, hipStream_t s);
 void launch_decode_classes(const Arena &a, int slot, size_t n, uint8_t *d_class, int32_t *d_cell, hipStream_t s);

@@ -70,16 +70,30 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     }
     __syncthreads();
 
+    // the records of the NEXT chunk are loaded into registers before the current chunk is processed
+    uint2 nxt[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const uint32_t k = start + (uint32_t)(j * TILE_CELLS + tid);
+        nxt[j] = make_uint2(0u, KEY_OUTSIDE);
+        if (k < end) nxt[j] = sorted[k];
+    }
     for (uint32_t base = start; base < end; base += CH) {
         const int cnt = (int)min((uint32_t)CH, end - base);
         // ---- 1. stage: bitmask per cell ----
         uint2 r[RPT];
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
+            r[j] = nxt[j];
+            const uint32_t kn = base + CH + (uint32_t)(j * TILE_CELLS + tid);
+            nxt[j] = make_uint2(0u, KEY_OUTSIDE);
+            if (kn < end) nxt[j] = sorted[kn];
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
             const int k = j * TILE_CELLS + tid;
-            r[j] = make_uint2(0u, KEY_OUTSIDE);
+            if (k >= cnt) r[j].y = KEY_OUTSIDE;
             if (k < cnt) {
-                r[j] = sorted[base + k];
                 const uint32_t cit = r[j].y & 255u;
                 atomicAdd(&raw_cnt[cit], 1u);
                 if (((r[j].y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT)

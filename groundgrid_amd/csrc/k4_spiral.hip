@@ -25,6 +25,9 @@
 #include "gg_device.h"
 
 #include <float.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 namespace gg {
 
@@ -40,10 +43,10 @@ GG_DEV uint32_t visit_src(const VisitRegs &d, int q)
     return (q & 1) ? (w >> 16) : (w & 0xFFFFu);
 }
 
-__global__ __launch_bounds__(1024) void k_spiral(const Arena a, const CloudParams *__restrict__ params)
+__global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSched sc, const CloudParams *__restrict__ params)
 {
     extern __shared__ float2 fresh[];                                                // [spiral_slots] (ground, confidence)
-    uint32_t *lstart = reinterpret_cast<uint32_t *>(fresh + a.spiral_slots);         // [n_levels + 2]
+    uint32_t *lstart = reinterpret_cast<uint32_t *>(fresh + sc.slots);         // [n_levels + 2]
 
     const int cloud = blockIdx.x;
     const CloudParams cp = params[cloud];
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const CloudParam
     float *gpatch = L + GG_LAYER_GROUNDPATCH * a.layer_stride;
     float *points = L + GG_LAYER_POINTS * a.layer_stride;
     const double decrease = a.cfg.occupied_cells_decrease_factor;
-    const int n_levels = a.n_levels;
+    const int n_levels = sc.n_levels;
 
     if (threadIdx.x == 0) {
         gpatch[center + center * rows] = 1.0f;      // :405
@@ -63,11 +66,11 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const CloudParam
     }
     // :147 map["points"].setConstant(0.0) -- K3 was the last reader of the KEPT counts; K5 re-counts non-ground points
     for (int k = threadIdx.x; k < a.g.C; k += nthreads) points[k] = 0.0f;
-    for (int k = threadIdx.x; k <= n_levels; k += nthreads) lstart[k] = a.level_start[k];
-    if (threadIdx.x == 0) lstart[n_levels + 1] = a.level_start[n_levels];
+    for (int k = threadIdx.x; k <= n_levels; k += nthreads) lstart[k] = sc.level_start[k];
+    if (threadIdx.x == 0) lstart[n_levels + 1] = sc.level_start[n_levels];
     __syncthreads(); // full barrier: the centre cell's new values are read from the layers by ring 1
 
-    const uint4 *__restrict__ V = reinterpret_cast<const uint4 *>(a.visits);
+    const uint4 *__restrict__ V = reinterpret_cast<const uint4 *>(sc.visits);
 
     // Every thread issues the SAME number of vector-memory operations per level, active or not (idle lanes re-read
     // the level's first descriptor and store to a dummy line): with a fixed count the compiler can wait for "the
@@ -159,14 +162,25 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const CloudParam
     }
 }
 
+void configure_kernels()
+{
+    // dynamic LDS requests above the 64 KiB default need an explicit opt-in (large grids: more fresh-value slots)
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_spiral), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)
 {
     if (n_clouds == 0) return;
-    int threads = (a.max_level_width + 63) / 64 * 64;
+    // Few clouds in flight: the widest levels (shortest dependent chain, lowest latency).  Very large batches: levels of
+    // one wavefront (no idle waves, no work-group barrier) move ~8 % less through the memory path; measured equal at
+    // 256 clouds, ahead at 512.  GG_FLAG_SPIRAL_NARROW forces the narrow schedule (tests).
+    const int v = ((a.flags & GG_FLAG_SPIRAL_NARROW) || n_clouds >= 384) ? 1 : 0;
+    const SpiralSched &sc = a.sched[v];
+    int threads = (sc.max_level_width + 63) / 64 * 64;
     if (threads < 64) threads = 64;
     // gg_create guarantees max_level_width <= 1024 (one visit per thread per level)
-    const size_t lds = (size_t)a.spiral_slots * sizeof(float2) + ((size_t)a.n_levels + 2) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_spiral, dim3(n_clouds), dim3(threads), lds, s, a, d_params);
+    const size_t lds = (size_t)sc.slots * sizeof(float2) + ((size_t)sc.n_levels + 2) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_spiral, dim3(n_clouds), dim3(threads), lds, s, a, sc, d_params);
 }
 
 } // namespace gg

@@ -200,6 +200,26 @@ def test_minimal_layers_flag_keeps_labels_and_terrain():
             assert nan_equal(seg.map(0)[name], ref.layer(name)), name
 
 
+def test_one_wavefront_spiral_schedule_is_exact_too():
+    """The terrain sweep has two exact level schedules (gg_context.hip build_spiral_schedule, cap 1024 / 64)."""
+    cloud = synth.hdl64_cloud(seed=41, n_az=900)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    seg.set_flags(spiral_narrow=True)
+    ref = oracle.OracleMap(120.0, 0.33)
+    for _ in range(3):
+        _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+        r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"])
+        assert_same_state(seg.map(0), ref)
+    big = api.GroundSegmentation().init(200.0, 0.2, n_slots=1, max_points=1000)  # 1000 x 1000: 2493 / ~7000 levels
+    big.set_flags(spiral_narrow=True)
+    refb = oracle.OracleMap(200.0, 0.2)
+    c = synth.random_cloud(1000, seed=2, extent=90.0)
+    big.filter_cloud(c, ORIGIN0, -1.7)
+    refb.filter_cloud(c, ORIGIN0, -1.7)
+    assert_same_state(big.map(0), refb)
+
+
 def test_run_to_run_determinism_and_reset():
     cloud = synth.hdl64_cloud(seed=12, order="azimuth")
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
