@@ -114,6 +114,23 @@ class GridMap:
     def layers(self) -> dict:
         return {n: self.get(n) for n in LAYERS}
 
+    def image_u8(self, layer: str):
+        """GridMapCvConverter::toImage<unsigned char,1> (Nodelet.cpp:239): (rows x cols uint8 image, lower, upper)."""
+        L, ctx = self._seg._L, self._seg._ctx
+        self._seg._sync_torch()
+        img = np.empty((self._seg.rows, self._seg.cols), dtype=np.uint8)
+        lo, hi = C.c_float(), C.c_float()
+        _check(L, ctx, L.gg_get_layer_image_u8(ctx, self.slot, LAYERS.index(layer), img.ctypes.data, C.byref(lo), C.byref(hi)), "gg_get_layer_image_u8")
+        return img, lo.value, hi.value
+
+    def terrain_image(self) -> np.ndarray:
+        """The 32FC3 terrain image of Nodelet.cpp:247-268: rows x cols x (ground, visited flag, pointsRaw)."""
+        L, ctx = self._seg._L, self._seg._ctx
+        self._seg._sync_torch()
+        img = np.empty((self._seg.rows, self._seg.cols, 3), dtype=np.float32)
+        _check(L, ctx, L.gg_get_terrain_image(ctx, self.slot, img.ctypes.data), "gg_get_terrain_image")
+        return img
+
 
 @dataclass
 class BatchOutputs:
@@ -217,6 +234,26 @@ class GroundSegmentation:
         return seg
 
     segment = filter_cloud  # BASELINE.json's north_star calls the entry point segment(); same thing
+
+    def filter_cloud_pc2(self, data: bytes, n: int, point_step: int, offsets, cloudOrigin, mapToBase_z: float,
+                         map: Optional[GridMap] = None, map_from_cloud=None):
+        """filter_cloud straight from a sensor_msgs/PointCloud2 payload; offsets = (x, y, z, ring) byte offsets.
+        Returns (labels, out_index, n_returned) per input point."""
+        gm = map if map is not None else self._maps[0]
+        buf = np.frombuffer(data, dtype=np.uint8)
+        assert buf.size >= n * point_step
+        labels = np.zeros(max(n, 1), dtype=np.uint8)
+        index = np.zeros(max(n, 1), dtype=np.int32)
+        out_n = C.c_size_t(0)
+        org = (C.c_float * 3)(*[float(v) for v in cloudOrigin])
+        tf = None
+        if map_from_cloud is not None:
+            tf = (C.c_double * 12)(*[float(v) for v in np.asarray(map_from_cloud, dtype=np.float64).reshape(-1)[:12]])
+        self._sync_torch()
+        rc = self._L.gg_filter_cloud_pc2(self._ctx, gm.slot, buf.ctypes.data, n, point_step, offsets[0], offsets[1], offsets[2], offsets[3],
+                                         tf, org, float(mapToBase_z), labels.ctypes.data, index.ctypes.data, C.byref(out_n))
+        _check(self._L, self._ctx, rc, "gg_filter_cloud_pc2")
+        return labels[:n], index[:n], out_n.value
 
     # -- insert_cloud's per-point decision (include/groundgrid/GroundSegmentation.h:55)
     def point_classes(self, n: int, map: Optional[GridMap] = None):

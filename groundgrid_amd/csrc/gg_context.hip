@@ -62,6 +62,8 @@ struct gg_context {
     uint8_t *d_stage_class = nullptr;
     int32_t *d_stage_cell = nullptr;
     float *d_scroll_scratch = nullptr; // 2 layers
+    float *d_image = nullptr;          // 3 * C floats (wire-format images)
+    float *d_bounds = nullptr;         // 2 floats
 
     // profiling
     std::vector<EventPair> pending;
@@ -555,6 +557,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_scls = carve(max_points);
     const size_t o_scell = carve(max_points * 4);
     const size_t o_scroll = carve(2 * Cpad * 4);
+    const size_t o_image = carve(3 * Cpad * 4);
+    const size_t o_bounds = carve(64);
     ctx->arena_bytes = off;
     CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
     char *base = (char *)ctx->d_arena;
@@ -587,6 +591,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_stage_class = (uint8_t *)(base + o_scls);
     ctx->d_stage_cell = (int32_t *)(base + o_scell);
     ctx->d_scroll_scratch = (float *)(base + o_scroll);
+    ctx->d_image = (float *)(base + o_image);
+    ctx->d_bounds = (float *)(base + o_bounds);
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
     for (int v = 0; v < 2; ++v) {
@@ -758,6 +764,85 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(dst, layer_ptr(ctx->arena, slot, layer), (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, float *lower, float *upper)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!dst || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const Geometry &g = ctx->arena.g;
+    uint8_t *d_img = reinterpret_cast<uint8_t *>(ctx->d_image);
+    launch_layer_to_u8(layer_ptr(ctx->arena, slot, layer), g.rows, g.cols, ctx->d_bounds, d_img, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    float b[2];
+    HIPCHK(ctx, hipMemcpyAsync(dst, d_img, (size_t)g.C, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b, ctx->d_bounds, sizeof b, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (lower) *lower = b[0];
+    if (upper) *upper = b[1];
+    return GG_OK;
+}
+
+int gg_get_terrain_image(gg_context *ctx, int slot, float *dst)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!dst) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const Geometry &g = ctx->arena.g;
+    launch_terrain_image(layer_ptr(ctx->arena, slot, GG_LAYER_GROUND), layer_ptr(ctx->arena, slot, GG_LAYER_POINTSRAW), g.rows, g.cols,
+                         ctx->d_image, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(dst, ctx->d_image, (size_t)g.C * 3 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+// sensor_msgs/PointCloud2 payload -> the packed records the device reads, in one host pass (the reference goes
+// wire -> 32-byte PCL points first, pcl::fromROSMsg at src/GroundGridNodelet.cpp:120)
+int gg_filter_cloud_pc2(gg_context *ctx, int slot, const uint8_t *data, size_t n, size_t point_step, size_t off_x, size_t off_y,
+                        size_t off_z, size_t off_ring, const double *map_from_cloud, const float origin[3], double base_z,
+                        uint8_t *out_label, int32_t *out_index, size_t *out_n)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if ((!data && n) || !origin) return fail(ctx, GG_ERR_INVALID, "null data / origin");
+    if (n > ctx->max_points) return fail(ctx, GG_ERR_CAPACITY, "cloud larger than max_points");
+    if (off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step || off_ring + 2 > point_step)
+        return fail(ctx, GG_ERR_INVALID, "field offset outside point_step");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t *p = data + i * point_step;
+        gg_point16 &d = ctx->h_stage_pts[i];
+        memcpy(&d.x, p + off_x, 4);
+        memcpy(&d.y, p + off_y, 4);
+        memcpy(&d.z, p + off_z, 4);
+        memcpy(&d.ring, p + off_ring, 2);
+        d.pad = 0;
+    }
+    if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage_pts, ctx->h_stage_pts, n * sizeof(gg_point16), hipMemcpyHostToDevice, s));
+    const int32_t n32 = (int32_t)n;
+    gg_batch b{};
+    b.n_clouds = 1;
+    b.first_slot = slot;
+    b.point_format = GG_POINT16;
+    b.d_points = ctx->d_stage_pts;
+    b.cloud_stride = ctx->max_points;
+    b.n_points = &n32;
+    b.origins = origin;
+    b.base_z = &base_z;
+    b.transforms = map_from_cloud;
+    b.d_labels = ctx->d_stage_labels;
+    b.d_out_index = ctx->d_stage_index;
+    b.d_out_counts = ctx->d_stage_counts;
+    const int rc = enqueue_batch(ctx, &b, s);
+    if (rc != GG_OK) return rc;
+    if (n && out_label) HIPCHK(ctx, hipMemcpyAsync(out_label, ctx->d_stage_labels, n, hipMemcpyDeviceToHost, s));
+    if (n && out_index) HIPCHK(ctx, hipMemcpyAsync(out_index, ctx->d_stage_index, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage_counts, ctx->d_stage_counts, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (out_n) *out_n = (size_t)ctx->h_stage_counts[0];
     return GG_OK;
 }
 

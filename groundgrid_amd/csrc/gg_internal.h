@@ -140,6 +140,8 @@ void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hip
 void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
+void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds, uint8_t *d_img, hipStream_t s);
+void launch_terrain_image(const float *ground, const float *raw, int rows, int cols, float *d_img, hipStream_t s);
 void configure_kernels(); // one-time function attributes (dynamic LDS above 64 KiB)
 void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double tf[7], hipStream_t s);
 void launch_pack16(const gg_point32 *src, gg_point16 *dst, size_t n, hipStream_t s);

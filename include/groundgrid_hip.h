@@ -206,6 +206,22 @@ typedef struct gg_batch {
 int gg_filter_batch(gg_context *ctx, const gg_batch *batch, void *stream);
 int gg_synchronize(gg_context *ctx);
 
+/* ---- wire formats around the path (src/GroundGridNodelet.cpp:120, :211-291) -------------------------------------- */
+
+/* filter_cloud straight from a sensor_msgs/PointCloud2 payload (e.g. the KITTI player's 18-byte records,
+ * scripts/kitti_data_publisher.py:139-150: x@0 y@4 z@8 intensity@12 ring@16): one host pass packs the fields the path
+ * reads, instead of pcl::fromROSMsg into 32-byte points first (Nodelet.cpp:120).  map_from_cloud (nullable) as in
+ * gg_filter_cloud_tf.  Results per input point; the caller owns the payload and can assemble whatever message it needs. */
+int gg_filter_cloud_pc2(gg_context *ctx, int slot, const uint8_t *data, size_t n, size_t point_step, size_t off_x, size_t off_y,
+                        size_t off_z, size_t off_ring, const double *map_from_cloud, const float origin[3], double base_z,
+                        uint8_t *out_label, int32_t *out_index, size_t *out_n);
+/* grid_map::GridMapCvConverter::toImage<unsigned char, 1> of one layer (Nodelet.cpp:239): rows x cols row-major bytes,
+ * the layer normalised between the min and max of its finite cells (returned in lower / upper), non-finite cells 0.
+ * cv::applyColorMap (:240) is left to the host. */
+int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, float *lower, float *upper);
+/* the 32FC3 terrain image (Nodelet.cpp:247-268): rows x cols x 3 floats (ground, 3x3 pointsRaw sum >= 27, pointsRaw) */
+int gg_get_terrain_image(gg_context *ctx, int slot, float *dst);
+
 /* insert_cloud's per-point decision (include/groundgrid/GroundSegmentation.h:55): after a filter call,
  * class (GG_CLASS_*) and cell (row + col*rows, -1 outside) of every input point of `slot`. */
 int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class, int32_t *out_cell);

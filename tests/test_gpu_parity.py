@@ -408,3 +408,43 @@ def test_sensor_frame_cloud_transformed_on_device():
     n_out = int(o.counts[0, 0])
     assert np.array_equal(o.labels[0, : len(base)].cpu().numpy(), r["label"])
     assert o.out_clouds[0, :n_out].cpu().numpy().tobytes() == r["out_points"].tobytes()
+
+
+# ---------------------------------------------------------------- N4: wire formats around the path
+
+def test_wire_formats_pointcloud2_ingest_and_images():
+    cloud = synth.hdl64_cloud(seed=13, n_az=500)
+    n = len(cloud)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=n)
+    ref = oracle.OracleMap(120.0, 0.33)
+    # the KITTI player's PointCloud2 payload: 18-byte records x, y, z, intensity (f32) + ring (u16)  (kitti_data_publisher.py:139-150)
+    wire = np.zeros(n, dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4"), ("ring", "<u2")]))
+    assert wire.dtype.itemsize == 18
+    for k in ("x", "y", "z", "intensity", "ring"):
+        wire[k] = cloud[k]
+    for frame in range(2):
+        labels, index, n_out = seg.filter_cloud_pc2(wire.tobytes(), n, 18, (0, 4, 8, 16), ORIGIN0, -1.73)
+        r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]) and n_out == len(r["out_points"])
+    assert_same_state(seg.map(0), ref)
+
+    # grid_map::GridMapCvConverter::toImage<unsigned char, 1> (src/GroundGridNodelet.cpp:239), restated with numpy
+    for layer in ("ground", "groundpatch", "points", "variance", "minGroundHeight"):
+        img, lo, hi = seg.map(0).image_u8(layer)
+        L = ref.layer(layer)
+        fin = np.isfinite(L)
+        elo, ehi = np.float32(L[fin].min()), np.float32(L[fin].max())
+        assert (np.float32(lo), np.float32(hi)) == (elo, ehi), layer
+        with np.errstate(all="ignore"):
+            expect = (((np.clip(L, elo, ehi) - elo) / (ehi - elo)) * np.float32(255.0))
+            expect = np.where(fin & np.isfinite(expect), expect, 0).astype(np.uint8)
+        assert np.array_equal(img, expect), layer
+    # the 32FC3 terrain image (src/GroundGridNodelet.cpp:247-268)
+    t = seg.map(0).terrain_image()
+    g, raw = ref.layer("ground"), ref.layer("pointsRaw")
+    assert np.array_equal(t[:, :, 0], g) and np.array_equal(t[:, :, 2], raw)
+    s = np.zeros_like(raw)
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            s[1:-1, 1:-1] += raw[1 + di : raw.shape[0] - 1 + di, 1 + dj : raw.shape[1] - 1 + dj]   # integer-valued: order-free
+    assert np.array_equal(t[1:-1, 1:-1, 1], (s[1:-1, 1:-1] >= 27).astype(np.float32))
