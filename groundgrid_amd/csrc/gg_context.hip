@@ -699,7 +699,9 @@ int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float od
     const size_t C = (size_t)a.g.C;
     // src/GroundGrid.cpp:71-75; the layers filter_cloud adds later (:61-75) start at 0
     const float init[GG_NUM_LAYERS] = {0.0f, odom_z, (float)0.0000001, (float)100.0, (float)-100.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < GG_NUM_LAYERS; ++l) launch_fill(layer_ptr(a, slot, l), C, init[l], ctx->stream);
+    for (int l = 0; l < GG_NUM_LAYERS; ++l)
+        if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH) launch_fill(layer_ptr(a, slot, l), C, init[l], ctx->stream);
+    launch_fill2(gp2_ptr(a, slot), C, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], ctx->stream); // interleaved pair
     HIPCHK(ctx, hipGetLastError());
     return GG_OK;
 }
@@ -752,7 +754,13 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if (!src || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) { // de-interleave at the host boundary
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
+        launch_plane_insert(gp2_ptr(ctx->arena, slot), layer == GG_LAYER_GROUNDPATCH, ctx->d_image, (size_t)ctx->arena.g.C, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
@@ -762,7 +770,13 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if (!dst || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(dst, layer_ptr(ctx->arena, slot, layer), (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const float *plane = layer_ptr(ctx->arena, slot, layer);
+    if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) {
+        launch_plane_extract(gp2_ptr(ctx->arena, slot), layer == GG_LAYER_GROUNDPATCH, ctx->d_image, (size_t)ctx->arena.g.C, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        plane = ctx->d_image;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dst, plane, (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
@@ -774,7 +788,12 @@ int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, fl
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const Geometry &g = ctx->arena.g;
     uint8_t *d_img = reinterpret_cast<uint8_t *>(ctx->d_image);
-    launch_layer_to_u8(layer_ptr(ctx->arena, slot, layer), g.rows, g.cols, ctx->d_bounds, d_img, ctx->stream);
+    const float *plane = layer_ptr(ctx->arena, slot, layer);
+    if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) {
+        launch_plane_extract(gp2_ptr(ctx->arena, slot), layer == GG_LAYER_GROUNDPATCH, ctx->d_scroll_scratch, (size_t)g.C, ctx->stream);
+        plane = ctx->d_scroll_scratch;
+    }
+    launch_layer_to_u8(plane, g.rows, g.cols, ctx->d_bounds, d_img, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     float b[2];
     HIPCHK(ctx, hipMemcpyAsync(dst, d_img, (size_t)g.C, hipMemcpyDeviceToHost, ctx->stream));
@@ -791,7 +810,7 @@ int gg_get_terrain_image(gg_context *ctx, int slot, float *dst)
     if (!dst) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const Geometry &g = ctx->arena.g;
-    launch_terrain_image(layer_ptr(ctx->arena, slot, GG_LAYER_GROUND), layer_ptr(ctx->arena, slot, GG_LAYER_POINTSRAW), g.rows, g.cols,
+    launch_terrain_image(gp2_ptr(ctx->arena, slot), layer_ptr(ctx->arena, slot, GG_LAYER_POINTSRAW), g.rows, g.cols,
                          ctx->d_image, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(dst, ctx->d_image, (size_t)g.C * 3 * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -120,6 +120,15 @@ __host__ __device__ inline float *layer_ptr(const Arena &a, int slot, int layer)
     return a.layers + (size_t)slot * a.slot_layer_stride + (size_t)layer * a.layer_stride;
 }
 
+// `ground` and `groundpatch` (confidence) are always used together -- confidence-weighted height -- and are the only
+// state that persists from cloud to cloud.  They are stored INTERLEAVED as float2 (x = ground, y = confidence) in the two
+// adjacent plane slots GG_LAYER_GROUND / GG_LAYER_GROUNDPATCH: one 8-byte request instead of two 4-byte ones everywhere
+// (the terrain sweep is bound by request count).  gg_get_layer / gg_set_layer de-interleave at the host boundary.
+__host__ __device__ inline float2 *gp2_ptr(const Arena &a, int slot)
+{
+    return reinterpret_cast<float2 *>(layer_ptr(a, slot, GG_LAYER_GROUND));
+}
+
 // I/O pointers of one batched call
 struct BatchIO {
     const void *d_points;
@@ -140,8 +149,11 @@ void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hip
 void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
+void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
+void launch_plane_extract(const float2 *src, int comp, float *dst, size_t n, hipStream_t s);
+void launch_plane_insert(float2 *dst, int comp, const float *src, size_t n, hipStream_t s);
 void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds, uint8_t *d_img, hipStream_t s);
-void launch_terrain_image(const float *ground, const float *raw, int rows, int cols, float *d_img, hipStream_t s);
+void launch_terrain_image(const float2 *gp2, const float *raw, int rows, int cols, float *d_img, hipStream_t s);
 void configure_kernels(); // one-time function attributes (dynamic LDS above 64 KiB)
 void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double tf[7], hipStream_t s);
 void launch_pack16(const gg_point32 *src, gg_point16 *dst, size_t n, hipStream_t s);

@@ -20,9 +20,8 @@ struct ScrollParams {
     double m20, m21, m22, tz; // third row of the base_link<-map rotation (tf2::Matrix3x3::setRotation) and translation z
 };
 
-__global__ __launch_bounds__(256) void k_scroll(const float *__restrict__ ground, const float *__restrict__ gpatch,
-                                                float *__restrict__ out_ground, float *__restrict__ out_gpatch, int rows,
-                                                int cols, const ScrollParams sp)
+__global__ __launch_bounds__(256) void k_scroll(const float2 *__restrict__ gp2, float2 *__restrict__ out, int rows, int cols,
+                                                const ScrollParams sp)
 {
     const int i = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -43,11 +42,11 @@ __global__ __launch_bounds__(256) void k_scroll(const float *__restrict__ ground
         g = (float)(-z);
         w = 0.0f;
     } else {
-        g = ground[(size_t)bi + (size_t)bj * rows];
-        w = gpatch[(size_t)bi + (size_t)bj * rows];
+        const float2 v = gp2[(size_t)bi + (size_t)bj * rows];
+        g = v.x;
+        w = v.y;
     }
-    out_ground[(size_t)i + (size_t)j * rows] = g;
-    out_gpatch[(size_t)i + (size_t)j * rows] = w;
+    out[(size_t)i + (size_t)j * rows] = make_float2(g, w);
 }
 
 void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double tf[7],
@@ -72,12 +71,11 @@ void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, dou
     sp.m21 = yz + wx;
     sp.m22 = 1.0 - (xx + yy);
     sp.tz = tf[2];
-    float *ground = layer_ptr(a, slot, GG_LAYER_GROUND), *gpatch = layer_ptr(a, slot, GG_LAYER_GROUNDPATCH);
-    float *og = scratch, *ow = scratch + a.layer_stride;
+    float2 *gp2 = gp2_ptr(a, slot);
+    float2 *out = reinterpret_cast<float2 *>(scratch);
     dim3 grid((a.g.rows + 63) / 64, (a.g.cols + 3) / 4);
-    hipLaunchKernelGGL(k_scroll, grid, dim3(256), 0, s, ground, gpatch, og, ow, a.g.rows, a.g.cols, sp);
-    hipMemcpyAsync(ground, og, (size_t)a.g.C * 4, hipMemcpyDeviceToDevice, s);
-    hipMemcpyAsync(gpatch, ow, (size_t)a.g.C * 4, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_scroll, grid, dim3(256), 0, s, gp2, out, a.g.rows, a.g.cols, sp);
+    hipMemcpyAsync(gp2, out, (size_t)a.g.C * 8, hipMemcpyDeviceToDevice, s);
 }
 
 } // namespace gg

@@ -53,8 +53,8 @@ GG_DEV bool locate_point(const Arena &a, const CloudParams &cp, const PointIn &p
 }
 
 // :237-279 -- ignore test, line-of-sight outlier test, key.  `oldgroundheight` = ground(gi) before this cloud.
-GG_DEV uint32_t finish_point(const Arena &a, const CloudParams &cp, const float *__restrict__ ground,
-                             const float *__restrict__ gpatch, const PointIn &pt, int gi0, int gi1, float oldgroundheight)
+GG_DEV uint32_t finish_point(const Arena &a, const CloudParams &cp, const float2 *__restrict__ gp2, const PointIn &pt, int gi0, int gi1,
+                             float oldgroundheight)
 {
     const Geometry &g = a.g;
     const int rows = g.rows, cols = g.cols;
@@ -82,10 +82,11 @@ GG_DEV uint32_t finish_point(const Arena &a, const CloudParams &cp, const float 
             const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                            // :268
             float e[9];
 #pragma unroll
-            for (int s = 0; s < 9; ++s) e[s] = gpatch[(r0 + s % 3) + (c0 + s / 3) * rows];
+            for (int s = 0; s < 9; ++s) e[s] = gp2[(r0 + s % 3) + (c0 + s / 3) * rows].y;
             const float bsum = tree9(e);
-            if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gpatch[I0 + I1 * rows] > 0.01f &&
-                (double)ground[I0 + I1 * rows] >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) { // :269
+            const float2 gI = gp2[I0 + I1 * rows];
+            if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gI.y > 0.01f &&
+                (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) { // :269
                 cls = GG_CLASS_OUTLIER;
                 break;
             }
@@ -113,8 +114,7 @@ __global__ __launch_bounds__(256, 8) void k_classify(const Arena a, const CloudP
     uint32_t *hist = lds_hist + wave * T;
     for (int t = lane; t < T; t += 64) hist[t] = 0u;
 
-    const float *ground = layer_ptr(a, cp.slot, GG_LAYER_GROUND);
-    const float *gpatch = layer_ptr(a, cp.slot, GG_LAYER_GROUNDPATCH);
+    const float2 *gp2 = gp2_ptr(a, cp.slot);
     const char *pts = reinterpret_cast<const char *>(io.d_points) +
                       (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
     uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(256, 8) void k_classify(const Arena a, const CloudP
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { // index math for all windows, then all old-ground gathers in flight together
             inmap_[j] = locate_point(a, cp, pt[j], gi0[j], gi1[j]) && valid[j];
-            og[j] = ground[inmap_[j] ? gi0[j] + gi1[j] * a.g.rows : 0]; // :243
+            og[j] = gp2[inmap_[j] ? gi0[j] + gi1[j] * a.g.rows : 0].x; // :243
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int p = p0 + j * 64 + lane;
             uint32_t key = KEY_OUTSIDE;
-            if (inmap_[j]) key = finish_point(a, cp, ground, gpatch, pt[j], gi0[j], gi1[j], og[j]);
+            if (inmap_[j]) key = finish_point(a, cp, gp2, pt[j], gi0[j], gi1[j], og[j]);
             if (valid[j]) rec[p] = make_uint2(__float_as_uint(pt[j].z), key);
             const bool inmap = key != KEY_OUTSIDE;
             if (inmap) atomicAdd(&hist[key >> KEY_TILE_SHIFT], 1u);
@@ -191,6 +191,43 @@ void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO 
 __global__ void k_fill(float *dst, size_t n, float v)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+__global__ void k_fill2(float2 *dst, size_t n, float x, float y)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = make_float2(x, y);
+}
+void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s)
+{
+    if (n == 0) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(k_fill2, dim3(blocks), dim3(256), 0, s, dst, n, x, y);
+}
+
+// one plane of the interleaved (ground, confidence) pair <-> a plain float layer (host boundary, K6)
+__global__ void k_plane_extract(const float2 *__restrict__ src, int comp, float *__restrict__ dst, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 v = src[i];
+        dst[i] = comp ? v.y : v.x;
+    }
+}
+__global__ void k_plane_insert(float2 *__restrict__ dst, int comp, const float *__restrict__ src, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (comp) dst[i].y = src[i];
+        else dst[i].x = src[i];
+    }
+}
+void launch_plane_extract(const float2 *src, int comp, float *dst, size_t n, hipStream_t s)
+{
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(k_plane_extract, dim3(blocks), dim3(256), 0, s, src, comp, dst, n);
+}
+void launch_plane_insert(float2 *dst, int comp, const float *src, size_t n, hipStream_t s)
+{
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(k_plane_insert, dim3(blocks), dim3(256), 0, s, dst, comp, src, n);
 }
 
 void launch_fill(float *dst, size_t n, float v, hipStream_t s)

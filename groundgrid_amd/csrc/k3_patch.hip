@@ -18,7 +18,7 @@ constexpr int LR = PR + 2 * HALO, LC = PC + 2 * HALO; // 36 x 12
 
 template <int S>
 GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const float (*var)[LR], const float (*mnl)[LR],
-                                int lr, int lc, int i, int j, float sqdist, float *ground, float *gpatch)
+                                int lr, int lc, int i, int j, float sqdist, float2 *gp2)
 {
     constexpr int SS = S * S;
     constexpr int ci = S / 2; // :352
@@ -35,8 +35,9 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
     // :364-365
     if ((double)pointsblockSum < std_max(floor(cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) return;
 
-    const float oldConfidence = gpatch[idx];   // :360
-    const float oldGroundheight = ground[idx]; // :361
+    const float2 old = gp2[idx];
+    const float oldConfidence = old.y;   // :360
+    const float oldGroundheight = old.x; // :361
 
     // :369
     const float varThresholdsq =
@@ -73,12 +74,12 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
     if ((double)varThresholdsq > (double)maxVar * (double)maxVar && maxVar > 0.0f &&
         (double)pointsblockSum > (double)((groundDiff * expected) * (float)S) * cfg.gpd_min_point_count_threshold) {
         const float newConfidence = (float)std_min((double)pointsblockSum / cfg.occupied_cells_point_count_factor, 1.0); // :383
-        ground[idx] = (groundlevel * newConfidence + (oldConfidence * oldGroundheight) * 2.0f) / (newConfidence + oldConfidence * 2.0f); // :385
-        gpatch[idx] =
+        const float G = (groundlevel * newConfidence + (oldConfidence * oldGroundheight) * 2.0f) / (newConfidence + oldConfidence * 2.0f); // :385
+        const float Cf =
             (float)std_min(((double)pointsblockSum / cfg.occupied_cells_point_count_factor_x2 + (double)oldConfidence) / 2.0, 1.0); // :387
+        gp2[idx] = make_float2(G, Cf);
     } else if (localmin < oldGroundheight) { // :389
-        ground[idx] = localmin;                               // :391
-        gpatch[idx] = std_min(oldConfidence + 0.1f, 0.5f);   // :393
+        gp2[idx] = make_float2(localmin, std_min(oldConfidence + 0.1f, 0.5f)); // :391, :393
     }
 }
 
@@ -118,12 +119,11 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     // :332
     const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
     const float sqdist = (float)((di * di + dj * dj) * ((double)a.g.resolution_f * (double)a.g.resolution_f));
-    float *ground = const_cast<float *>(L) + GG_LAYER_GROUND * a.layer_stride;
-    float *gpatch = const_cast<float *>(L) + GG_LAYER_GROUNDPATCH * a.layer_stride;
+    float2 *gp2 = gp2_ptr(a, cp.slot);
     if ((double)sqdist <= a.cfg.patch_size_change_distance_sq) // :334
-        detect_ground_patch<3>(a, pts, var, mnl, tr + HALO, tcl + HALO, i, j, sqdist, ground, gpatch);
+        detect_ground_patch<3>(a, pts, var, mnl, tr + HALO, tcl + HALO, i, j, sqdist, gp2);
     else
-        detect_ground_patch<5>(a, pts, var, mnl, tr + HALO, tcl + HALO, i, j, sqdist, ground, gpatch);
+        detect_ground_patch<5>(a, pts, var, mnl, tr + HALO, tcl + HALO, i, j, sqdist, gp2);
 }
 
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)

@@ -31,6 +31,11 @@
 
 namespace gg {
 
+// two consecutive (ground, confidence) cells; only 8-byte alignment may be assumed
+struct __attribute__((aligned(8))) Pair2 {
+    float x, y, z, w;
+};
+
 struct VisitRegs {
     uint4 lo, hi; // the 32-byte SpiralVisit
 };
@@ -54,15 +59,13 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
     const int center = a.g.center;
     const int nthreads = blockDim.x;
     float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
-    float *ground = L + GG_LAYER_GROUND * a.layer_stride;
-    float *gpatch = L + GG_LAYER_GROUNDPATCH * a.layer_stride;
+    float2 *gp2 = gp2_ptr(a, cp.slot);
     float *points = L + GG_LAYER_POINTS * a.layer_stride;
     const double decrease = a.cfg.occupied_cells_decrease_factor;
     const int n_levels = sc.n_levels;
 
     if (threadIdx.x == 0) {
-        gpatch[center + center * rows] = 1.0f;      // :405
-        ground[center + center * rows] = cp.base_z; // :406-411
+        gp2[center + center * rows] = make_float2(cp.base_z, 1.0f); // :405, :406-411
     }
     // :147 map["points"].setConstant(0.0) -- K3 was the last reader of the KEPT counts; K5 re-counts non-ground points
     for (int k = threadIdx.x; k < a.g.C; k += nthreads) points[k] = 0.0f;
@@ -94,14 +97,14 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
 #pragma unroll
         for (int col = 0; col < 3; ++col) { // :453,458 block<3,3>(x-1, y-1), column-major linear index
             const uint32_t idx = cell - 1u + (uint32_t)((col - 1) * rows);
-            const float3 w3 = *reinterpret_cast<const float3 *>(gpatch + idx);
-            const float3 g3 = *reinterpret_cast<const float3 *>(ground + idx);
-            gw[col * 3 + 0] = w3.x;
-            gw[col * 3 + 1] = w3.y;
-            gw[col * 3 + 2] = w3.z;
-            gg_[col * 3 + 0] = g3.x;
-            gg_[col * 3 + 1] = g3.y;
-            gg_[col * 3 + 2] = g3.z;
+            const Pair2 c01 = *reinterpret_cast<const Pair2 *>(gp2 + idx); // rows x-1, x in one 16-byte request (8-byte aligned)
+            const float2 c2 = gp2[idx + 2];                                  // row  x+1
+            gg_[col * 3 + 0] = c01.x;
+            gw[col * 3 + 0] = c01.y;
+            gg_[col * 3 + 1] = c01.z;
+            gw[col * 3 + 1] = c01.w;
+            gg_[col * 3 + 2] = c2.x;
+            gw[col * 3 + 2] = c2.y;
         }
     };
 
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
                 load_old(D[(u + 1) % 3], W[(u + 1) % 2], G[(u + 1) % 2]);
 
                 const uint32_t cell = d0.lo.x;
-                float *dst_g = dummy, *dst_w = dummy + 1;
+                float2 *dst = reinterpret_cast<float2 *>(dummy);
                 float new_g = 0.0f, new_w = 0.0f;
                 if (act[u % 3]) {
                     float w[9], g[9], pr[9];
@@ -149,12 +152,10 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
                     if (flags & SPIRAL_DECAY) new_w = (float)std_max((double)occupied - (double)occupied / decrease, 0.001); // :463-464
                     if (wslot != (uint32_t)SPIRAL_NONE) fresh[wslot] = make_float2(new_g, new_w);
                     if (flags & SPIRAL_STORE) {
-                        dst_g = ground + cell;
-                        dst_w = gpatch + cell;
+                        dst = gp2 + cell;
                     }
                 }
-                *dst_g = new_g;
-                *dst_w = new_w;
+                *dst = make_float2(new_g, new_w);
                 // order LDS only: global stores are never read back inside this kernel
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
 
     const int rows = a.g.rows;
     const float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
-    const float *ground = L + GG_LAYER_GROUND * a.layer_stride;
+    const float2 *gp2 = gp2_ptr(a, cp.slot);
     const float *variance = L + GG_LAYER_VARIANCE * a.layer_stride;
     float *points = const_cast<float *>(L) + GG_LAYER_POINTS * a.layer_stride;
     const uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             int row = 0, col = 0;
             if (lab[j]) key_to_cell(a, key, row, col);
             cidx[j] = (size_t)row + (size_t)col * rows;
-            gh[j] = ground[cidx[j]];   // :162
+            gh[j] = gp2[cidx[j]].x;    // :162
             var[j] = variance[cidx[j]]; // :165
             const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)(valid[j] ? p : base) * (FMT == GG_POINT16 ? 2 : 4)];
             x[j] = __uint_as_float(xy.x);

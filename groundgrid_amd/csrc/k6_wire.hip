@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_layer_to_u8(const float *__restrict__ l
 }
 
 // Nodelet.cpp:258-268; the reference reads block<3,3>(i-1, j-1) also on the border (UB): border cells get 0 for the flag.
-__global__ __launch_bounds__(256) void k_terrain_image(const float *__restrict__ ground, const float *__restrict__ raw, int rows, int cols,
+__global__ __launch_bounds__(256) void k_terrain_image(const float2 *__restrict__ gp2, const float *__restrict__ raw, int rows, int cols,
                                                        float *__restrict__ img)
 {
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_terrain_image(const float *__restrict__
         flag = tree9(e) >= 27.0f ? 1.0f : 0.0f;
     }
     float *px = img + ((size_t)i * cols + j) * 3;
-    px[0] = ground[(size_t)i + (size_t)j * rows];
+    px[0] = gp2[(size_t)i + (size_t)j * rows].x;
     px[1] = flag;
     px[2] = raw[(size_t)i + (size_t)j * rows];
 }
@@ -87,10 +87,10 @@ void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds,
     hipLaunchKernelGGL(k_layer_to_u8, grid, dim3(256), 0, s, layer, rows, cols, d_bounds, d_img);
 }
 
-void launch_terrain_image(const float *ground, const float *raw, int rows, int cols, float *d_img, hipStream_t s)
+void launch_terrain_image(const float2 *gp2, const float *raw, int rows, int cols, float *d_img, hipStream_t s)
 {
     dim3 grid((cols + 63) / 64, (rows + 3) / 4);
-    hipLaunchKernelGGL(k_terrain_image, grid, dim3(256), 0, s, ground, raw, rows, cols, d_img);
+    hipLaunchKernelGGL(k_terrain_image, grid, dim3(256), 0, s, gp2, raw, rows, cols, d_img);
 }
 
 } // namespace gg
