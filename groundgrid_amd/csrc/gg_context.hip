@@ -117,14 +117,16 @@ uint32_t morton2(uint32_t x, uint32_t y)
 //     so visits sharing a level are independent and a barrier between levels reproduces the serial sweep;
 //   * for each of the 9 cells a visit reads, the replay knows whether an EARLIER visit rewrote it (fresh value) or
 //     not (pre-sweep value).  Fresh values are handed over through LDS: each written value gets a slot that stays
-//     allocated until the level of its last reader (lifetime <= 8 levels, 1723 slots for n = 364), pre-sweep values
-//     are read from the layer in global memory, which nobody has touched yet at that point.  The choice is made
-//     here, from the serial order -- never from timing on the device.
-//   * `cap` bounds the visits per level (a level that is full pushes later visits to the next one -- visits of one level
-//     stay independent, so any split is legal).  cap = 1024 gives the shortest chain (903 levels, n = 364: lowest
-//     latency for one cloud); cap = 64 gives levels of one wavefront (no idle waves, no work-group barrier: the least
-//     vector-memory work per cloud, best when many clouds are in flight).
-void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::vector<SpiralVisit> &visits_by_level,
+//     allocated until the level of its last reader.  Pre-sweep values come from the interleaved (ground, confidence)
+//     layer with a LOAD PLAN of at most three 16-byte requests per visit: the not-yet-visited cells of a block column
+//     are vertically adjacent, and a request covers two consecutive rows.  98.6 % of the visits need exactly three
+//     pairs; the few that need more (ring corners) get "helper" entries one level earlier that fetch the extra pair
+//     and park it in LDS slots, so that the kernel's instruction stream is identical for every visit.
+//     All of this is decided here, from the serial order -- never from timing on the device;
+//   * `cap` bounds the visits per level (a full level spills into the next one; visits of one level are independent,
+//     so any split is legal).  cap = 1024: shortest chain (lowest latency for one cloud); cap = 64: levels of one
+//     wavefront (no idle waves, no work-group barrier).
+void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::vector<SpiralVisit> &out_visits,
                            std::vector<uint32_t> &level_start, int &max_width, int &n_slots)
 {
     const int center = n / 2 - 1;
@@ -146,90 +148,169 @@ void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::v
     }
     const size_t V = cells.size();
     const size_t C = (size_t)n * n;
-    std::vector<int> last_write(C, 0), last_read(C, 0), level(V), last_reader_level(V, 0);
+
+    // ---- 1. hazard levels (uncapped), sources --------------------------------------------------------------
+    struct Entry {
+        uint32_t cell;
+        int level;          // uncapped level, >= 2 for real visits (level 1 is left for helpers of level-2 visits)
+        int64_t src[9];     // entry index producing the value (>= 0), or -1: pre-sweep value
+        int plan[3];        // load plan: pair p = column c (0..2) * 2 + row offset r (0..1)
+        int stage_of[9];    // for pre-sweep inputs served by the own load plan: staging element 0..5, else -1
+        bool helper;
+        int64_t helper_src_elem[2]; // helper: consumers read its staged elements as entries (filled below)
+        uint16_t flags;
+    };
+    std::vector<Entry> E(V);
+    std::vector<int> last_write(C, 0), last_read(C, 0);
     std::vector<int64_t> last_writer(C, -1);
-    std::vector<int64_t> src_visit(V * 9, -1);
-    std::vector<int> level_count(64, 0);
-    int n_levels = 0;
     for (size_t k = 0; k < V; ++k) {
+        Entry &e = E[k];
+        e.cell = cells[k];
+        e.helper = false;
         const int x = (int)(cells[k] % (uint32_t)n), y = (int)(cells[k] / (uint32_t)n);
         int lv = last_read[cells[k]];
         for (int q = 0; q < 9; ++q) lv = std::max(lv, last_write[(x - 1 + q % 3) + (y - 1 + q / 3) * n]);
-        lv += 1;
-        if ((size_t)lv >= level_count.size()) level_count.resize((size_t)lv + 64, 0);
-        while (level_count[lv] >= cap) {
-            ++lv;
-            if ((size_t)lv >= level_count.size()) level_count.resize((size_t)lv + 64, 0);
-        }
-        level_count[lv]++;
-        level[k] = lv;
+        lv = std::max(lv + 1, 2);
+        e.level = lv;
         for (int q = 0; q < 9; ++q) {
             const size_t nb = (size_t)((x - 1 + q % 3) + (y - 1 + q / 3) * n);
-            const int64_t w = last_writer[nb];
-            src_visit[k * 9 + q] = w;
-            if (w >= 0) last_reader_level[w] = std::max(last_reader_level[w], lv);
+            e.src[q] = last_writer[nb];
             last_read[nb] = std::max(last_read[nb], lv);
         }
         last_write[cells[k]] = lv;
         last_writer[cells[k]] = (int64_t)k;
-        n_levels = std::max(n_levels, lv);
+        // :463 (pow((float)x - center_idx, 2.0) + pow((float)y - center_idx, 2.0)) * pow(resolution, 2.0f) > minDistSquared
+        const float fx = (float)x - (float)center, fy = (float)y - (float)center;
+        const double d2 = ((double)fx * (double)fx + (double)fy * (double)fy) * (res * res);
+        e.flags = (uint16_t)(d2 > (double)min_dist_sq ? SPIRAL_DECAY : 0);
     }
-    // group by level (stable)
-    level_start.assign((size_t)n_levels + 1, 0);
-    for (size_t k = 0; k < V; ++k) level_start[level[k]]++;
+    for (size_t k = 0; k < V; ++k)
+        if (last_writer[E[k].cell] == (int64_t)k) E[k].flags |= SPIRAL_STORE; // only the last visit of a cell stores
+
+    // ---- 2. load plans; helpers for visits that need more than three pairs ----------------------------------
+    // a helper is an Entry with helper = true: it loads ONE pair (plan[0]) relative to `cell` and parks both cells in LDS
+    std::vector<Entry> H;
+    struct HelperRef { size_t reader; int q; size_t helper; int elem; };
+    std::vector<HelperRef> href;
+    for (size_t k = 0; k < V; ++k) {
+        Entry &e = E[k];
+        std::vector<int> pairs;
+        for (int c = 0; c < 3; ++c) {
+            bool old_[3];
+            int cnt = 0;
+            for (int r = 0; r < 3; ++r) cnt += (old_[r] = e.src[c * 3 + r] < 0);
+            if (!cnt) continue;
+            if (!old_[2]) pairs.push_back(c * 2 + 0);
+            else if (!old_[0]) pairs.push_back(c * 2 + 1);
+            else { pairs.push_back(c * 2 + 0); pairs.push_back(c * 2 + 1); }
+        }
+        for (int q = 0; q < 9; ++q) e.stage_of[q] = -1;
+        for (int p = 0; p < 3; ++p) e.plan[p] = p < (int)pairs.size() ? pairs[p] : (pairs.empty() ? 2 : pairs[0]);
+        // inputs covered by the first three pairs
+        for (int p = 0; p < 3 && p < (int)pairs.size(); ++p) {
+            const int c = pairs[p] / 2, r = pairs[p] % 2;
+            for (int el = 0; el < 2; ++el) {
+                const int q = c * 3 + r + el;
+                if (e.src[q] < 0 && e.stage_of[q] < 0) e.stage_of[q] = p * 2 + el;
+            }
+        }
+        // the rest: one helper per extra pair, one level earlier
+        for (size_t p = 3; p < pairs.size(); ++p) {
+            Entry h{};
+            h.cell = e.cell;
+            h.level = e.level - 1;
+            h.helper = true;
+            h.flags = SPIRAL_HELPER;
+            for (int q = 0; q < 9; ++q) { h.src[q] = -1; h.stage_of[q] = -1; }
+            h.plan[0] = h.plan[1] = h.plan[2] = pairs[p];
+            const int c = pairs[p] / 2, r = pairs[p] % 2;
+            for (int el = 0; el < 2; ++el) {
+                const int q = c * 3 + r + el;
+                if (e.src[q] < 0 && e.stage_of[q] == -1) {
+                    href.push_back({k, q, H.size(), el});
+                    e.stage_of[q] = -2; // served by a helper
+                }
+            }
+            H.push_back(h);
+        }
+    }
+
+    // ---- 3. final levels: uncapped levels split into chunks of at most `cap` entries (helpers included) ------
+    const size_t NE = V + H.size();
+    auto entry = [&](size_t i) -> Entry & { return i < V ? E[i] : H[i - V]; };
+    int max_level = 0;
+    for (size_t i = 0; i < NE; ++i) max_level = std::max(max_level, entry(i).level);
+    std::vector<std::vector<uint32_t>> by_level((size_t)max_level + 1);
+    for (size_t i = V; i < NE; ++i) by_level[entry(i).level].push_back((uint32_t)i); // helpers first (any order is legal)
+    for (size_t i = 0; i < V; ++i) by_level[entry(i).level].push_back((uint32_t)i);
+    std::vector<uint32_t> order;       // entries in final order
+    std::vector<int> final_level(NE);  // 1-based final level of each entry
+    level_start.assign(1, 0);
     max_width = 0;
-    uint32_t run = 0;
-    for (int l = 1; l <= n_levels; ++l) {
-        const uint32_t c = level_start[l];
-        max_width = std::max(max_width, (int)c);
-        level_start[l] = run + c;
-        run += c;
+    for (int l = 1; l <= max_level; ++l) {
+        const auto &v = by_level[l];
+        for (size_t b = 0; b < v.size(); b += (size_t)cap) {
+            const size_t cnt = std::min((size_t)cap, v.size() - b);
+            for (size_t j = 0; j < cnt; ++j) {
+                final_level[v[b + j]] = (int)level_start.size();
+                order.push_back(v[b + j]);
+            }
+            max_width = std::max(max_width, (int)cnt);
+            level_start.push_back((uint32_t)order.size());
+        }
     }
-    level_start[0] = 0;
-    std::vector<uint32_t> order(V);
-    {
-        std::vector<uint32_t> cursor(level_start.begin(), level_start.end() - 1);
-        for (size_t k = 0; k < V; ++k) order[cursor[level[k] - 1]++] = (uint32_t)k;
-    }
-    // LDS slot allocation, level by level: a slot is free again at (last reader level + 1)
-    std::vector<uint16_t> wslot(V, SPIRAL_NONE);
+    const int n_levels = (int)level_start.size() - 1;
+
+    // ---- 4. LDS slots: one per value that somebody reads through LDS, alive until its last reader's level -----
+    // value id: entry i produces value (i, 0) [a visit's result] or (i, el) [a helper's staged element el]
+    std::vector<int> last_reader(NE * 2, 0);
+    for (size_t k = 0; k < V; ++k)
+        for (int q = 0; q < 9; ++q)
+            if (E[k].src[q] >= 0) last_reader[(size_t)E[k].src[q] * 2] = std::max(last_reader[(size_t)E[k].src[q] * 2], final_level[k]);
+    for (const auto &r : href) last_reader[(V + r.helper) * 2 + r.elem] = std::max(last_reader[(V + r.helper) * 2 + r.elem], final_level[r.reader]);
+    std::vector<uint16_t> slot(NE * 2, SPIRAL_NONE);
     std::vector<std::vector<uint16_t>> release((size_t)n_levels + 2);
     std::vector<uint16_t> free_slots;
     n_slots = 0;
-    size_t pos = 0;
-    for (int l = 1; l <= n_levels; ++l) {
-        for (uint16_t s : release[l]) free_slots.push_back(s);
-        for (; pos < V && level[order[pos]] == l; ++pos) {
-            const uint32_t v = order[pos];
-            if (last_reader_level[v] == 0) continue;
-            uint16_t s;
-            if (!free_slots.empty()) {
-                s = free_slots.back();
-                free_slots.pop_back();
-            } else {
-                s = (uint16_t)n_slots++;
+    for (size_t oi = 0, l = 1; l <= (size_t)n_levels; ++l) {
+        for (uint16_t s_ : release[l]) free_slots.push_back(s_);
+        for (; oi < order.size() && final_level[order[oi]] == (int)l; ++oi)
+            for (int el = 0; el < 2; ++el) {
+                const size_t id = (size_t)order[oi] * 2 + el;
+                if (last_reader[id] == 0) continue;
+                uint16_t s_;
+                if (!free_slots.empty()) { s_ = free_slots.back(); free_slots.pop_back(); }
+                else s_ = (uint16_t)n_slots++;
+                slot[id] = s_;
+                release[(size_t)last_reader[id] + 1].push_back(s_);
             }
-            wslot[v] = s;
-            release[(size_t)last_reader_level[v] + 1].push_back(s);
-        }
     }
-    visits_by_level.resize(V);
-    const double res2 = res * res;
-    for (size_t i = 0; i < V; ++i) {
-        const uint32_t v = order[i];
+
+    // ---- 5. descriptors ---------------------------------------------------------------------------------------
+    std::vector<uint16_t> helper_code(V * 9, 0);
+    for (const auto &r : href) helper_code[r.reader * 9 + r.q] = slot[(V + r.helper) * 2 + r.elem];
+    out_visits.resize(NE);
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+        const size_t i = order[oi];
+        const Entry &e = entry(i);
         SpiralVisit d{};
-        d.cell = cells[v];
-        d.wslot = wslot[v];
-        const int x = (int)(cells[v] % (uint32_t)n), y = (int)(cells[v] / (uint32_t)n);
-        // :463 (pow((float)x - center_idx, 2.0) + pow((float)y - center_idx, 2.0)) * pow(resolution, 2.0f) > minDistSquared
-        const float fx = (float)x - (float)center, fy = (float)y - (float)center;
-        const double d2 = ((double)fx * (double)fx + (double)fy * (double)fy) * res2;
-        d.flags = (uint16_t)((last_writer[cells[v]] == (int64_t)v ? SPIRAL_STORE : 0) | (d2 > (double)min_dist_sq ? SPIRAL_DECAY : 0));
-        for (int q = 0; q < 9; ++q) {
-            const int64_t w = src_visit[(size_t)v * 9 + q];
-            d.src[q] = w >= 0 ? wslot[w] : SPIRAL_NONE;
+        d.cell = e.cell;
+        d.wslot = e.helper ? SPIRAL_NONE : slot[i * 2];
+        uint16_t plan = 0;
+        for (int p = 0; p < 3; ++p) plan |= (uint16_t)(e.plan[p] << (3 * p)); // pair = column * 2 + row offset, 3 bits each
+        d.flags = (uint16_t)(e.flags | (plan << 4));
+        if (e.helper) {
+            d.src[0] = slot[i * 2 + 0]; // where staged element 0 / 1 go (SPIRAL_NONE: nobody reads it)
+            d.src[1] = slot[i * 2 + 1];
+            for (int q = 2; q < 9; ++q) d.src[q] = SPIRAL_NONE;
+        } else {
+            for (int q = 0; q < 9; ++q) {
+                if (e.src[q] >= 0) d.src[q] = slot[(size_t)e.src[q] * 2];
+                else if (e.stage_of[q] >= 0) d.src[q] = (uint16_t)(SPIRAL_STAGED + e.stage_of[q]);
+                else d.src[q] = helper_code[i * 9 + q];
+            }
         }
-        visits_by_level[i] = d;
+        out_visits[oi] = d;
     }
 }
 
@@ -501,7 +582,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         a.sched[v].max_level_width = max_width;
         a.sched[v].slots = spiral_slots;
         a.sched[v].pad_ = 0;
-        if (spiral_slots >= 0xFFFF || (size_t)spiral_slots * 8 + level_start[v].size() * 4 > 150 * 1024 || max_width > 1024) {
+        if (spiral_slots >= (int)SPIRAL_STAGED || ((size_t)spiral_slots + (size_t)((max_width + 63) / 64 * 64) * 6) * 8 + level_start[v].size() * 4 > 150 * 1024 ||
+            max_width > 1024) {
             gg_destroy(ctx);
             return GG_ERR_GEOMETRY; // the spiral's fresh-value window no longer fits LDS
         }

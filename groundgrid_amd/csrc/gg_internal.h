@@ -64,12 +64,15 @@ struct Geometry {
 struct SpiralVisit {
     uint32_t cell;    // row + col * rows
     uint16_t wslot;   // LDS slot receiving this visit's (ground, confidence); SPIRAL_NONE: nobody reads it during the sweep
-    uint16_t flags;   // bit0: last visit of the cell -> store to the layers; bit1: confidence decay applies (:463)
-    uint16_t src[9];  // 3x3 block, column-major: LDS slot holding the fresh value, SPIRAL_NONE: read the layer
+    uint16_t flags;   // bit0 STORE (last visit of the cell), bit1 DECAY (:463), bit2 HELPER; bits 4..12: load plan,
+                      // three pairs of 3 bits = block column (0..2) * 2 + row offset (0..1) of a 2-cell (16-byte) load
+    uint16_t src[9];  // 3x3 block, column-major: LDS slot of the value, or SPIRAL_STAGED + k = k-th cell of the own load plan
+                      // (helper: src[0], src[1] = LDS slots that receive its two loaded cells)
     uint16_t pad[3];
 };
 constexpr uint16_t SPIRAL_NONE = 0xFFFFu;
-constexpr uint16_t SPIRAL_STORE = 1u, SPIRAL_DECAY = 2u;
+constexpr uint16_t SPIRAL_STAGED = 0xFFF0u; // .. 0xFFF5
+constexpr uint16_t SPIRAL_STORE = 1u, SPIRAL_DECAY = 2u, SPIRAL_HELPER = 4u;
 
 // One level schedule of the terrain sweep (built by gg_context.hip build_spiral_schedule)
 struct SpiralSched {

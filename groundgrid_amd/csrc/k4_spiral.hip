@@ -50,35 +50,36 @@ GG_DEV uint32_t visit_src(const VisitRegs &d, int q)
 
 __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSched sc, const CloudParams *__restrict__ params)
 {
-    extern __shared__ float2 fresh[];                                                // [spiral_slots] (ground, confidence)
-    uint32_t *lstart = reinterpret_cast<uint32_t *>(fresh + sc.slots);         // [n_levels + 2]
+    // LDS: [slots] fresh values | [threads][6] private staging of the cells this thread loaded | [n_levels + 2] level starts
+    extern __shared__ float2 fresh[];
+    const int nthreads = blockDim.x;
+    float2 *stage = fresh + sc.slots + (size_t)threadIdx.x * 6;
+    uint32_t *lstart = reinterpret_cast<uint32_t *>(fresh + sc.slots + (size_t)nthreads * 6); // [n_levels + 2]
 
     const int cloud = blockIdx.x;
     const CloudParams cp = params[cloud];
     const int rows = a.g.rows;
     const int center = a.g.center;
-    const int nthreads = blockDim.x;
     float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
     float2 *gp2 = gp2_ptr(a, cp.slot);
     float *points = L + GG_LAYER_POINTS * a.layer_stride;
     const double decrease = a.cfg.occupied_cells_decrease_factor;
     const int n_levels = sc.n_levels;
+    const uint32_t stage_base = (uint32_t)sc.slots + threadIdx.x * 6u;
 
-    if (threadIdx.x == 0) {
-        gp2[center + center * rows] = make_float2(cp.base_z, 1.0f); // :405, :406-411
-    }
+    if (threadIdx.x == 0) gp2[center + center * rows] = make_float2(cp.base_z, 1.0f); // :405, :406-411
     // :147 map["points"].setConstant(0.0) -- K3 was the last reader of the KEPT counts; K5 re-counts non-ground points
     for (int k = threadIdx.x; k < a.g.C; k += nthreads) points[k] = 0.0f;
     for (int k = threadIdx.x; k <= n_levels; k += nthreads) lstart[k] = sc.level_start[k];
     if (threadIdx.x == 0) lstart[n_levels + 1] = sc.level_start[n_levels];
-    __syncthreads(); // full barrier: the centre cell's new values are read from the layers by ring 1
+    __syncthreads(); // full barrier: the centre cell's new values are read from the layer by ring 1
 
     const uint4 *__restrict__ V = reinterpret_cast<const uint4 *>(sc.visits);
 
-    // Every thread issues the SAME number of vector-memory operations per level, active or not (idle lanes re-read
-    // the level's first descriptor and store to a dummy line): with a fixed count the compiler can wait for "the
-    // loads issued one level ago" with s_waitcnt vmcnt(N > 0) and leave this level's prefetches in flight; a
-    // conditional load or store would make N unknowable and degrade every wait to vmcnt(0).
+    // Every thread issues the SAME number of vector-memory operations per level, active or not (idle lanes re-read the
+    // level's first descriptor and store to a dummy line): with a fixed count the compiler can wait for "the loads
+    // issued one level ago" with s_waitcnt vmcnt(N > 0) and leave this level's prefetches in flight; a conditional load
+    // or store would make N unknowable and degrade every wait to vmcnt(0).
     const uint32_t n_visits = lstart[n_levels];
     auto load_desc = [&](int lvl, VisitRegs &d, bool &active) {
         const int l = min(lvl, n_levels - 1);
@@ -89,22 +90,17 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
         d.lo = V[(size_t)vi * 2];
         d.hi = V[(size_t)vi * 2 + 1];
     };
-    // The lanes of a wave sit on different rings, so every load instruction touches 64 different cache lines and the
-    // per-CU vector-memory pipeline (one line per clock), not arithmetic, paces a level.  The three cells of one
-    // block column are contiguous (column-major layers): one 12-byte load per column and layer = 6 instead of 18.
-    auto load_old = [&](const VisitRegs &d, float (&gw)[9], float (&gg_)[9]) {
+    // The memory path retires about one lane-request per clock whatever the width, so the sweep is paced by the NUMBER of
+    // requests: the load plan fetches the not-yet-visited cells of the 3x3 block with three 16-byte requests (two
+    // vertically adjacent interleaved cells each) instead of 18 scalar ones.
+    auto load_pairs = [&](const VisitRegs &d, Pair2 (&P)[3]) {
         const uint32_t cell = d.lo.x;
+        const uint32_t plan = d.lo.y >> 20;
 #pragma unroll
-        for (int col = 0; col < 3; ++col) { // :453,458 block<3,3>(x-1, y-1), column-major linear index
-            const uint32_t idx = cell - 1u + (uint32_t)((col - 1) * rows);
-            const Pair2 c01 = *reinterpret_cast<const Pair2 *>(gp2 + idx); // rows x-1, x in one 16-byte request (8-byte aligned)
-            const float2 c2 = gp2[idx + 2];                                  // row  x+1
-            gg_[col * 3 + 0] = c01.x;
-            gw[col * 3 + 0] = c01.y;
-            gg_[col * 3 + 1] = c01.z;
-            gw[col * 3 + 1] = c01.w;
-            gg_[col * 3 + 2] = c2.x;
-            gw[col * 3 + 2] = c2.y;
+        for (int p = 0; p < 3; ++p) {
+            const uint32_t pr = (plan >> (3 * p)) & 7u; // block column * 2 + row offset
+            const uint32_t idx = cell - 1u + (pr & 1u) + (uint32_t)(((int)(pr >> 1) - 1) * rows);
+            P[p] = *reinterpret_cast<const Pair2 *>(gp2 + idx);
         }
     };
 
@@ -113,11 +109,11 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
     // the destination registers of loads issued in the same iteration and force a full vmcnt(0) wait per level.
     VisitRegs D[3];
     bool act[3];
-    float W[2][9], G[2][9];
+    Pair2 P[2][3];
     load_desc(0, D[0], act[0]);
     load_desc(1, D[1], act[1]);
-    load_old(D[0], W[0], G[0]);
-    float *const dummy = a.spiral_dummy + 2 * threadIdx.x;
+    load_pairs(D[0], P[0]);
+    float2 *const dummy = reinterpret_cast<float2 *>(a.spiral_dummy) + threadIdx.x;
 
     for (int base = 0; base < n_levels; base += 6) {
 #pragma unroll
@@ -126,36 +122,48 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
             if (lvl < n_levels) { // uniform
                 VisitRegs &d0 = D[u % 3];
                 load_desc(lvl + 2, D[(u + 2) % 3], act[(u + 2) % 3]);
-                load_old(D[(u + 1) % 3], W[(u + 1) % 2], G[(u + 1) % 2]);
+                load_pairs(D[(u + 1) % 3], P[(u + 1) % 2]);
 
                 const uint32_t cell = d0.lo.x;
-                float2 *dst = reinterpret_cast<float2 *>(dummy);
-                float new_g = 0.0f, new_w = 0.0f;
+                float2 *dst = dummy;
+                float2 result = make_float2(0.0f, 0.0f);
                 if (act[u % 3]) {
-                    float w[9], g[9], pr[9];
+                    // park the six cells of this level's load plan in the thread's private LDS staging: from here on
+                    // every input, fresh or pre-sweep, is "an LDS address" and needs no per-input select logic
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) {
-                        const uint32_t s = visit_src(d0, q);
-                        const bool is_fresh = s != (uint32_t)SPIRAL_NONE;
-                        const float2 f = fresh[is_fresh ? s : 0u]; // unconditional read + select: no branch per input
-                        g[q] = is_fresh ? f.x : G[u % 2][q];
-                        w[q] = is_fresh ? f.y : W[u % 2][q];
+                    for (int p = 0; p < 3; ++p) {
+                        stage[2 * p] = make_float2(P[u % 2][p].x, P[u % 2][p].y);
+                        stage[2 * p + 1] = make_float2(P[u % 2][p].z, P[u % 2][p].w);
                     }
-                    const float height = g[4], occupied = w[4]; // :455-456
-                    const float gvlSum = tree9(w) + FLT_MIN;    // :457
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) pr[q] = w[q] * g[q];
-                    const float avg = tree9(pr) / gvlSum;                            // :458
-                    new_g = (1.0f - occupied) * avg + occupied * height; // :460
                     const uint32_t flags = d0.lo.y >> 16, wslot = d0.lo.y & 0xFFFFu;
-                    new_w = occupied;
-                    if (flags & SPIRAL_DECAY) new_w = (float)std_max((double)occupied - (double)occupied / decrease, 0.001); // :463-464
-                    if (wslot != (uint32_t)SPIRAL_NONE) fresh[wslot] = make_float2(new_g, new_w);
-                    if (flags & SPIRAL_STORE) {
-                        dst = gp2 + cell;
+                    if (flags & SPIRAL_HELPER) {
+                        // a helper only forwards its pair to the slots a later visit will read
+                        const uint32_t s0 = visit_src(d0, 0), s1 = visit_src(d0, 1);
+                        if (s0 != (uint32_t)SPIRAL_NONE) fresh[s0] = stage[0];
+                        if (s1 != (uint32_t)SPIRAL_NONE) fresh[s1] = stage[1];
+                    } else {
+                        float w[9], g[9], pr[9];
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) { // :453,458 block<3,3>(x-1, y-1), column-major linear index
+                            const uint32_t s = visit_src(d0, q);
+                            const float2 f = fresh[s >= (uint32_t)SPIRAL_STAGED ? stage_base + (s - (uint32_t)SPIRAL_STAGED) : s];
+                            g[q] = f.x;
+                            w[q] = f.y;
+                        }
+                        const float height = g[4], occupied = w[4]; // :455-456
+                        const float gvlSum = tree9(w) + FLT_MIN;    // :457
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) pr[q] = w[q] * g[q];
+                        const float avg = tree9(pr) / gvlSum;                            // :458
+                        const float new_g = (1.0f - occupied) * avg + occupied * height; // :460
+                        float new_w = occupied;
+                        if (flags & SPIRAL_DECAY) new_w = (float)std_max((double)occupied - (double)occupied / decrease, 0.001); // :463-464
+                        result = make_float2(new_g, new_w);
+                        if (wslot != (uint32_t)SPIRAL_NONE) fresh[wslot] = result;
+                        if (flags & SPIRAL_STORE) dst = gp2 + cell;
                     }
                 }
-                *dst = make_float2(new_g, new_w);
+                *dst = result;
                 // order LDS only: global stores are never read back inside this kernel
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
@@ -180,7 +188,7 @@ void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hi
     int threads = (sc.max_level_width + 63) / 64 * 64;
     if (threads < 64) threads = 64;
     // gg_create guarantees max_level_width <= 1024 (one visit per thread per level)
-    const size_t lds = (size_t)sc.slots * sizeof(float2) + ((size_t)sc.n_levels + 2) * sizeof(uint32_t);
+    const size_t lds = ((size_t)sc.slots + (size_t)threads * 6) * sizeof(float2) + ((size_t)sc.n_levels + 2) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_spiral, dim3(n_clouds), dim3(threads), lds, s, a, sc, d_params);
 }
 
