@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgroundgrid_hip.so")
+LIB_PATH = os.environ.get("GROUNDGRID_HIP_LIB") or os.path.join(_HERE, "libgroundgrid_hip.so")  # override: side-by-side builds
 
 GG_OK = 0
 STATUS = {

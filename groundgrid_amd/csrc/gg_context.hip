@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -296,9 +298,12 @@ void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::v
         SpiralVisit d{};
         d.cell = e.cell;
         d.wslot = e.helper ? SPIRAL_NONE : slot[i * 2];
-        uint16_t plan = 0;
-        for (int p = 0; p < 3; ++p) plan |= (uint16_t)(e.plan[p] << (3 * p)); // pair = column * 2 + row offset, 3 bits each
-        d.flags = (uint16_t)(e.flags | (plan << 4));
+        d.flags = (uint16_t)e.flags;
+        for (int p = 0; p < 3; ++p) // pair code = block column * 2 + row offset  ->  index delta from the centre cell
+            d.pair[p] = (int16_t)(-1 + (e.plan[p] & 1) + ((e.plan[p] >> 1) - 1) * n);
+        // the visit runs on thread (position inside its level): its private staging slots are known here
+        const uint32_t thread = (uint32_t)(oi - level_start[(size_t)final_level[i] - 1]);
+        const uint32_t stage0 = (uint32_t)n_slots + thread * 6u;
         if (e.helper) {
             d.src[0] = slot[i * 2 + 0]; // where staged element 0 / 1 go (SPIRAL_NONE: nobody reads it)
             d.src[1] = slot[i * 2 + 1];
@@ -306,7 +311,7 @@ void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::v
         } else {
             for (int q = 0; q < 9; ++q) {
                 if (e.src[q] >= 0) d.src[q] = slot[(size_t)e.src[q] * 2];
-                else if (e.stage_of[q] >= 0) d.src[q] = (uint16_t)(SPIRAL_STAGED + e.stage_of[q]);
+                else if (e.stage_of[q] >= 0) d.src[q] = (uint16_t)(stage0 + (uint32_t)e.stage_of[q]);
                 else d.src[q] = helper_code[i * 9 + q];
             }
         }
@@ -574,7 +579,14 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 
     std::vector<SpiralVisit> visits[2];
     std::vector<uint32_t> level_start[2];
-    const int caps[2] = {1024, 64};
+    int caps[2] = {512, 64}; // k_spiral runs two wave sets of `cap` lanes: 2 * 512 = the largest work-group
+    if (const char *e = getenv("GG_SPIRAL_CAPS")) { // tuning knob: "<latency schedule cap>,<throughput schedule cap>"
+        int c0 = 0, c1 = 0;
+        if (sscanf(e, "%d,%d", &c0, &c1) == 2 && c0 >= 64 && c0 <= 512 && c1 >= 64 && c1 <= 512) {
+            caps[0] = c0;
+            caps[1] = c1;
+        }
+    }
     for (int v = 0; v < 2; ++v) {
         int max_width = 0, spiral_slots = 0;
         build_spiral_schedule(n, res, geom.min_dist_squared, caps[v], visits[v], level_start[v], max_width, spiral_slots);
@@ -582,8 +594,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         a.sched[v].max_level_width = max_width;
         a.sched[v].slots = spiral_slots;
         a.sched[v].pad_ = 0;
-        if (spiral_slots >= (int)SPIRAL_STAGED || ((size_t)spiral_slots + (size_t)((max_width + 63) / 64 * 64) * 6) * 8 + level_start[v].size() * 4 > 150 * 1024 ||
-            max_width > 1024) {
+        if (spiral_slots + 512 * 6 >= (int)SPIRAL_NONE || n + 1 > 32767 || ((size_t)spiral_slots + (size_t)((max_width + 63) / 64 * 64) * 6) * 8 + level_start[v].size() * 4 > 150 * 1024 ||
+            max_width > 512) {
             gg_destroy(ctx);
             return GG_ERR_GEOMETRY; // the spiral's fresh-value window no longer fits LDS
         }
@@ -614,13 +626,13 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t Npad = align_up(max_points * 8, A) / 8;
     const size_t o_expected = carve(C * 4);
     size_t o_visits[2], o_lstart[2];
+    std::vector<char> soa[2]; // must outlive the async copies below
     for (int v = 0; v < 2; ++v) {
         o_visits[v] = carve(visits[v].size() * sizeof(SpiralVisit));
         o_lstart[v] = carve(level_start[v].size() * 4);
     }
     const size_t o_trank = carve((size_t)g.T * 2);
     const size_t o_rtile = carve((size_t)g.T * 2);
-    const size_t o_dummy = carve(2 * 1024 * 4);
     const size_t o_layers = carve((size_t)n_slots * GG_NUM_LAYERS * Cpad * 4);
     const size_t o_rec = carve((size_t)n_slots * Npad * 8);
     const size_t o_sorted = carve((size_t)n_slots * Npad * 8);
@@ -653,7 +665,6 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     }
     a.tile_rank = (const uint16_t *)(base + o_trank);
     a.rank_tile = (const uint16_t *)(base + o_rtile);
-    a.spiral_dummy = (float *)(base + o_dummy);
     a.layers = (float *)(base + o_layers);
     a.layer_stride = Cpad;
     a.slot_layer_stride = Cpad * GG_NUM_LAYERS;
@@ -678,7 +689,17 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
     for (int v = 0; v < 2; ++v) {
-        CREATE_CHK(hipMemcpyAsync(base + o_visits[v], visits[v].data(), visits[v].size() * sizeof(SpiralVisit), hipMemcpyHostToDevice, ctx->stream));
+        {
+            // device layout: the first 16 bytes of all descriptors, then the second 16 bytes of all descriptors -- a
+            // wavefront's 16-byte loads then cover whole cache lines instead of every other half line
+            const size_t ne = visits[v].size();
+            soa[v].resize(ne * sizeof(SpiralVisit));
+            for (size_t i = 0; i < ne; ++i) {
+                memcpy(soa[v].data() + i * 16, reinterpret_cast<const char *>(&visits[v][i]), 16);
+                memcpy(soa[v].data() + (ne + i) * 16, reinterpret_cast<const char *>(&visits[v][i]) + 16, 16);
+            }
+        }
+        CREATE_CHK(hipMemcpyAsync(base + o_visits[v], soa[v].data(), soa[v].size(), hipMemcpyHostToDevice, ctx->stream));
         CREATE_CHK(hipMemcpyAsync(base + o_lstart[v], level_start[v].data(), level_start[v].size() * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));

@@ -64,14 +64,13 @@ struct Geometry {
 struct SpiralVisit {
     uint32_t cell;    // row + col * rows
     uint16_t wslot;   // LDS slot receiving this visit's (ground, confidence); SPIRAL_NONE: nobody reads it during the sweep
-    uint16_t flags;   // bit0 STORE (last visit of the cell), bit1 DECAY (:463), bit2 HELPER; bits 4..12: load plan,
-                      // three pairs of 3 bits = block column (0..2) * 2 + row offset (0..1) of a 2-cell (16-byte) load
-    uint16_t src[9];  // 3x3 block, column-major: LDS slot of the value, or SPIRAL_STAGED + k = k-th cell of the own load plan
+    uint16_t flags;   // bit0 STORE (last visit of the cell), bit1 DECAY (:463), bit2 HELPER
+    uint16_t src[9];  // 3x3 block, column-major: LDS slot holding the value -- a fresh-value slot, or a slot of the visiting
+                      // thread's own staging area (slots + thread * 6 + k: the host knows which thread runs the visit)
                       // (helper: src[0], src[1] = LDS slots that receive its two loaded cells)
-    uint16_t pad[3];
+    int16_t pair[3];  // load plan: three 16-byte loads of two vertically adjacent interleaved cells, as cell-index deltas
 };
 constexpr uint16_t SPIRAL_NONE = 0xFFFFu;
-constexpr uint16_t SPIRAL_STAGED = 0xFFF0u; // .. 0xFFF5
 constexpr uint16_t SPIRAL_STORE = 1u, SPIRAL_DECAY = 2u, SPIRAL_HELPER = 4u;
 
 // One level schedule of the terrain sweep (built by gg_context.hip build_spiral_schedule)
@@ -103,7 +102,6 @@ struct Arena {
     // shared
     const float *expected;        // [C]
     SpiralSched sched[2];         // [0] widest levels (lowest latency), [1] levels capped at one wavefront (throughput)
-    float *spiral_dummy;          // [2 * 1024] write-only sink for idle lanes of k_spiral
     const uint16_t *tile_rank;    // [T] tile (tr + tc*tiles_r) -> Morton rank
     const uint16_t *rank_tile;    // [T] Morton rank -> tile
     // per slot (slot s at base + s * stride)

@@ -36,6 +36,8 @@ struct __attribute__((aligned(8))) Pair2 {
     float x, y, z, w;
 };
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 struct VisitRegs {
     uint4 lo, hi; // the 32-byte SpiralVisit
 };
@@ -43,18 +45,26 @@ struct VisitRegs {
 GG_DEV uint32_t visit_src(const VisitRegs &d, int q)
 {
     // SpiralVisit layout: cell u32 | wslot u16 flags u16 | src[0..8] u16 | pad
-    // dwords: lo.x = cell, lo.y = wslot | flags << 16, lo.z = src0|src1<<16, lo.w = src2|src3, hi.x = src4|src5, hi.y = src6|src7, hi.z = src8|pad
+    // dwords: lo.x = cell, lo.y = wslot | flags << 16, lo.z = src0|src1<<16, lo.w = src2|src3, hi.x = src4|src5, hi.y = src6|src7,
+    //         hi.z = src8 | pair0 << 16, hi.w = pair1 | pair2 << 16
     const uint32_t w = (q < 2) ? d.lo.z : (q < 4) ? d.lo.w : (q < 6) ? d.hi.x : (q < 8) ? d.hi.y : d.hi.z;
     return (q & 1) ? (w >> 16) : (w & 0xFFFFu);
 }
 
 __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSched sc, const CloudParams *__restrict__ params)
 {
-    // LDS: [slots] fresh values | [threads][6] private staging of the cells this thread loaded | [n_levels + 2] level starts
+    // LDS: [slots] fresh values | [threads][6] private staging of the cells this thread loaded
     extern __shared__ float2 fresh[];
     const int nthreads = blockDim.x;
-    float2 *stage = fresh + sc.slots + (size_t)threadIdx.x * 6;
-    uint32_t *lstart = reinterpret_cast<uint32_t *>(fresh + sc.slots + (size_t)nthreads * 6); // [n_levels + 2]
+    // Two wave sets take turns: while one set computes level L (LDS reads, arithmetic, LDS write -- the dependent chain of
+    // the sweep), the other set issues ALL of its vector-memory work (descriptor / pre-sweep prefetches for its coming
+    // levels, the store of its previous result).  A wave that issues scattered 16-byte loads is held at the texture
+    // addresser for ~1 clock per lane-request; with one set doing both, that issue time (~900 clocks per level) sat in
+    // series with the chain (~500 clocks).  Set s owns levels s, s + 2, s + 4, ...
+    const int W = nthreads >> 1;                 // lanes per set = widest level, a multiple of 64: sets are whole waves
+    const int set = __builtin_amdgcn_readfirstlane((int)threadIdx.x >= W ? 1 : 0); // wave-uniform: level bounds stay in SGPRs
+    const uint32_t lane = threadIdx.x - (uint32_t)(set * W); // position inside the level
+    float2 *stage = fresh + sc.slots + (size_t)lane * 6;
 
     const int cloud = blockIdx.x;
     const CloudParams cp = params[cloud];
@@ -64,76 +74,112 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
     float2 *gp2 = gp2_ptr(a, cp.slot);
     float *points = L + GG_LAYER_POINTS * a.layer_stride;
     const double decrease = a.cfg.occupied_cells_decrease_factor;
+    // The confidence decay (:463-464) is (float)max(x - x / decrease, 0.001) in double.  The f64 divide is the longest
+    // dependent stretch of a visit, so it is replaced by a multiply with 1/decrease whenever that provably rounds alike:
+    // for decrease >= 1.25 the product form differs from the quotient form by < 2^-49 relative, both the max and the
+    // float conversion are monotonic, so if the two ends of the +-2^-48 interval convert to the same float the exact
+    // value does too; otherwise (about 1 visit in 10^7, NaN, or an unusual config) the divide decides.
+    const double inv_decrease = 1.0 / decrease;
+    const bool decay_fast = decrease >= 1.25 && decrease < 1e300;
     const int n_levels = sc.n_levels;
-    const uint32_t stage_base = (uint32_t)sc.slots + threadIdx.x * 6u;
 
     if (threadIdx.x == 0) gp2[center + center * rows] = make_float2(cp.base_z, 1.0f); // :405, :406-411
     // :147 map["points"].setConstant(0.0) -- K3 was the last reader of the KEPT counts; K5 re-counts non-ground points
     for (int k = threadIdx.x; k < a.g.C; k += nthreads) points[k] = 0.0f;
-    for (int k = threadIdx.x; k <= n_levels; k += nthreads) lstart[k] = sc.level_start[k];
-    if (threadIdx.x == 0) lstart[n_levels + 1] = sc.level_start[n_levels];
     __syncthreads(); // full barrier: the centre cell's new values are read from the layer by ring 1
 
-    const uint4 *__restrict__ V = reinterpret_cast<const uint4 *>(sc.visits);
 
-    // Every thread issues the SAME number of vector-memory operations per level, active or not (idle lanes re-read the
-    // level's first descriptor and store to a dummy line): with a fixed count the compiler can wait for "the loads
-    // issued one level ago" with s_waitcnt vmcnt(N > 0) and leave this level's prefetches in flight; a conditional load
-    // or store would make N unknowable and degrade every wait to vmcnt(0).
-    const uint32_t n_visits = lstart[n_levels];
-    auto load_desc = [&](int lvl, VisitRegs &d, bool &active) {
+    // Every thread issues the SAME number of vector-memory operations per level, active or not: with a fixed count the
+    // compiler can wait for "the loads issued N levels ago" with s_waitcnt vmcnt(N > 0) and leave the younger prefetches
+    // in flight; a conditional load or store would make N unknowable and degrade every wait to vmcnt(0).
+    // Level bounds are wave-uniform: scalar loads (SGPRs), requested one level before the descriptor request that
+    // needs them so that no wait for them sits behind the barrier.
+    // (constant address space: the table is never written while kernels run, which lets the loads be scalar)
+    typedef const __attribute__((address_space(4))) uint32_t *ConstU32Ptr;
+    const ConstU32Ptr LS = (ConstU32Ptr)(uintptr_t)sc.level_start;
+    const uint32_t n_visits = LS[n_levels];
+    uint32_t nb0 = 0, nb1 = 0; // [start, end) of the next level to request descriptors for
+    auto level_bounds = [&](int lvl) {
         const int l = min(lvl, n_levels - 1);
-        const uint32_t s0 = lstart[l], e0 = lstart[l + 1];
-        const uint32_t v = s0 + threadIdx.x;
-        active = lvl < n_levels && v < e0;
-        const uint32_t vi = active ? v : min(s0, n_visits - 1);
-        d.lo = V[(size_t)vi * 2];
-        d.hi = V[(size_t)vi * 2 + 1];
+        nb0 = LS[l];
+        nb1 = LS[l + 1];
+    };
+    // All vector-memory traffic of the level loop goes through BUFFER instructions with hardware range checking: an idle
+    // lane passes an out-of-range offset, which returns zeros / drops the store without touching L1 -- the instruction
+    // count per level stays uniform (see above) but only active lanes cost bandwidth.  Measured: with plain global
+    // loads the 1024 lanes of the work-group moved ~90 KB through the CU's 64 B/clk L1 path per level for ~13 KB of
+    // useful data, and that, not latency or arithmetic, set the time per level.
+    constexpr uint32_t OOR = 0x80000000u; // beyond any buffer here, also after the +16 / +8 immediate offsets
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<SpiralVisit *>(sc.visits), 0, (int)(n_visits * 32u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, a.g.C * 8, 0x00020000);
+    auto load_desc = [&](int lvl, VisitRegs &d, bool &active) { // nb0 / nb1 hold the bounds of `lvl`
+        const uint32_t v = nb0 + lane;
+        active = lvl < n_levels && v < nb1;
+        const uint32_t off = active ? v * 16u : OOR; // halves are stored as two arrays (gg_context.hip)
+        d.lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, off, 0, 0));
+        d.hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, off, n_visits * 16u, 0));
     };
     // The memory path retires about one lane-request per clock whatever the width, so the sweep is paced by the NUMBER of
     // requests: the load plan fetches the not-yet-visited cells of the 3x3 block with three 16-byte requests (two
     // vertically adjacent interleaved cells each) instead of 18 scalar ones.
-    auto load_pairs = [&](const VisitRegs &d, Pair2 (&P)[3]) {
-        const uint32_t cell = d.lo.x;
-        const uint32_t plan = d.lo.y >> 20;
+    auto load_pairs = [&](const VisitRegs &d, bool active, Pair2 (&P)[3]) {
+        const int cell = (int)d.lo.x;
+        const int delta[3] = {(int)d.hi.z >> 16, (int)(d.hi.w << 16) >> 16, (int)d.hi.w >> 16}; // SpiralVisit::pair, int16
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const uint32_t pr = (plan >> (3 * p)) & 7u; // block column * 2 + row offset
-            const uint32_t idx = cell - 1u + (pr & 1u) + (uint32_t)(((int)(pr >> 1) - 1) * rows);
-            P[p] = *reinterpret_cast<const Pair2 *>(gp2 + idx);
-        }
+        for (int p = 0; p < 3; ++p)
+            P[p] = __builtin_bit_cast(Pair2, __builtin_amdgcn_raw_buffer_load_b128(rsrc_g, active ? (uint32_t)(cell + delta[p]) * 8u : OOR, 0, 0));
     };
 
-    // Software pipeline: descriptor two levels ahead, pre-sweep values one level ahead.  The register sets rotate by
-    // NAME (the loop is unrolled by 6 = lcm(3 descriptor sets, 2 value sets)), never by copying: a copy would read
-    // the destination registers of loads issued in the same iteration and force a full vmcnt(0) wait per level.
-    VisitRegs D[3];
-    bool act[3];
-    Pair2 P[2][3];
-    load_desc(0, D[0], act[0]);
-    load_desc(1, D[1], act[1]);
-    load_pairs(D[0], P[0]);
-    float2 *const dummy = reinterpret_cast<float2 *>(a.spiral_dummy) + threadIdx.x;
-
-    for (int base = 0; base < n_levels; base += 6) {
+    // Software pipeline, in units of a set's OWN levels (every second level): descriptors are requested DESC_AHEAD own
+    // levels early and pre-sweep pairs PAIR_AHEAD own levels early (pre-sweep cells are by definition not rewritten before
+    // their visit, so any lead is legal).  The register sets rotate by NAME (the loop is unrolled by lcm(ND, NP)), never by
+    // copying: a copy would read the destination registers of loads issued in the same iteration and force a full
+    // vmcnt(0) wait per level.
+    constexpr int DESC_AHEAD = 5, PAIR_AHEAD = 2, ND = DESC_AHEAD + 1, NP = PAIR_AHEAD + 1, UNROLL = 6;
+    static_assert(UNROLL % ND == 0 && UNROLL % NP == 0, "register sets must rotate back after one unrolled body");
+    VisitRegs D[ND];
+    bool act[ND];
+    Pair2 P[NP][3];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int lvl = base + u;
-            if (lvl < n_levels) { // uniform
-                VisitRegs &d0 = D[u % 3];
-                load_desc(lvl + 2, D[(u + 2) % 3], act[(u + 2) % 3]);
-                load_pairs(D[(u + 1) % 3], P[(u + 1) % 2]);
+    for (int k = 0; k < DESC_AHEAD; ++k) {
+        level_bounds(2 * k + set);
+        load_desc(2 * k + set, D[k], act[k]);
+    }
+    level_bounds(2 * DESC_AHEAD + set);
+#pragma unroll
+    for (int k = 0; k < PAIR_AHEAD; ++k) load_pairs(D[k], act[k], P[k]);
 
+    uint32_t dst = OOR; // byte offset of the cell the pending result goes to; out of range = no store
+    float2 result = make_float2(0.0f, 0.0f);
+    // barrier interval k = level k: set 0 computes in the even intervals and talks to memory in the odd ones, set 1 the
+    // other way round (shifted by one barrier)
+    if (set) asm volatile("s_barrier" ::: "memory");
+    const int own_levels = (n_levels + 1) / 2;
+    for (int base = 0; base < own_levels; base += UNROLL) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int lvl = 2 * (base + u) + set; // levels past n_levels are empty (load_desc): no branch, no control-flow join
+            {
+                // ---- memory phase (the other set computes) ----
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, result), rsrc_g, dst, 0, 0); // previous own level
+                load_desc(lvl + 2 * DESC_AHEAD, D[(u + DESC_AHEAD) % ND], act[(u + DESC_AHEAD) % ND]);
+                level_bounds(lvl + 2 * DESC_AHEAD + 2);
+                load_pairs(D[(u + PAIR_AHEAD) % ND], act[(u + PAIR_AHEAD) % ND], P[(u + PAIR_AHEAD) % NP]);
+                asm volatile("s_barrier" ::: "memory");
+
+                // ---- compute phase: level `lvl` ----
+                VisitRegs &d0 = D[u % ND];
+                const Pair2 (&p0)[3] = P[u % NP];
+                const bool active = act[u % ND];
                 const uint32_t cell = d0.lo.x;
-                float2 *dst = dummy;
-                float2 result = make_float2(0.0f, 0.0f);
-                if (act[u % 3]) {
+                dst = OOR;
+                if (active) {
                     // park the six cells of this level's load plan in the thread's private LDS staging: from here on
                     // every input, fresh or pre-sweep, is "an LDS address" and needs no per-input select logic
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
-                        stage[2 * p] = make_float2(P[u % 2][p].x, P[u % 2][p].y);
-                        stage[2 * p + 1] = make_float2(P[u % 2][p].z, P[u % 2][p].w);
+                        stage[2 * p] = make_float2(p0[p].x, p0[p].y);
+                        stage[2 * p + 1] = make_float2(p0[p].z, p0[p].w);
                     }
                     const uint32_t flags = d0.lo.y >> 16, wslot = d0.lo.y & 0xFFFFu;
                     if (flags & SPIRAL_HELPER) {
@@ -145,8 +191,7 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
                         float w[9], g[9], pr[9];
 #pragma unroll
                         for (int q = 0; q < 9; ++q) { // :453,458 block<3,3>(x-1, y-1), column-major linear index
-                            const uint32_t s = visit_src(d0, q);
-                            const float2 f = fresh[s >= (uint32_t)SPIRAL_STAGED ? stage_base + (s - (uint32_t)SPIRAL_STAGED) : s];
+                            const float2 f = fresh[visit_src(d0, q)]; // fresh-value slot or own staging slot, resolved by the host
                             g[q] = f.x;
                             w[q] = f.y;
                         }
@@ -157,18 +202,25 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
                         const float avg = tree9(pr) / gvlSum;                            // :458
                         const float new_g = (1.0f - occupied) * avg + occupied * height; // :460
                         float new_w = occupied;
-                        if (flags & SPIRAL_DECAY) new_w = (float)std_max((double)occupied - (double)occupied / decrease, 0.001); // :463-464
+                        if (flags & SPIRAL_DECAY) { // :463-464
+                            const double x = (double)occupied;
+                            const double t = x - x * inv_decrease;
+                            const float lo = (float)std_max(t * (1.0 - 0x1p-48), 0.001);
+                            const float hi = (float)std_max(t * (1.0 + 0x1p-48), 0.001);
+                            new_w = lo;
+                            if (!(decay_fast && lo == hi)) new_w = (float)std_max(x - x / decrease, 0.001);
+                        }
                         result = make_float2(new_g, new_w);
                         if (wslot != (uint32_t)SPIRAL_NONE) fresh[wslot] = result;
-                        if (flags & SPIRAL_STORE) dst = gp2 + cell;
+                        if (flags & SPIRAL_STORE) dst = cell * 8u;
                     }
                 }
-                *dst = result;
                 // order LDS only: global stores are never read back inside this kernel
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
     }
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, result), rsrc_g, dst, 0, 0);
 }
 
 void configure_kernels()
@@ -185,10 +237,11 @@ void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hi
     // 256 clouds, ahead at 512.  GG_FLAG_SPIRAL_NARROW forces the narrow schedule (tests).
     const int v = ((a.flags & GG_FLAG_SPIRAL_NARROW) || n_clouds >= 384) ? 1 : 0;
     const SpiralSched &sc = a.sched[v];
-    int threads = (sc.max_level_width + 63) / 64 * 64;
-    if (threads < 64) threads = 64;
+    int width = (sc.max_level_width + 63) / 64 * 64;
+    if (width < 64) width = 64;
+    const int threads = 2 * width; // two wave sets (see k_spiral)
     // gg_create guarantees max_level_width <= 1024 (one visit per thread per level)
-    const size_t lds = ((size_t)sc.slots + (size_t)threads * 6) * sizeof(float2) + ((size_t)sc.n_levels + 2) * sizeof(uint32_t);
+    const size_t lds = ((size_t)sc.slots + (size_t)width * 6) * sizeof(float2);
     hipLaunchKernelGGL(k_spiral, dim3(n_clouds), dim3(threads), lds, s, a, sc, d_params);
 }
 

@@ -115,6 +115,15 @@ def test_config_variations():
     assert (r["cls"] == oracle.IGNORED).sum() > 0
 
 
+@pytest.mark.parametrize("factor", [1.1, 1.25, 0.5, 7.3, 1e6])
+def test_confidence_decay_factor_fast_and_exact_branches(factor):
+    """k_spiral replaces the f64 divide of :463-464 by a guarded multiply for factors >= 1.25 (tests/test_oracle_cpu.py
+    proves the guard); smaller factors take the divide.  Both must reproduce the CPU path over several frames."""
+    def edit(c):
+        c.occupied_cells_decrease_factor = factor
+    run_pair(synth.hdl64_cloud(seed=33, n_az=500), frames=4, cfg_edit=edit)
+
+
 def test_edge_cases():
     pts = np.array([[5, 5, -1], [1, 1, -1], [5, 5, -1], [500, 0, -1], [np.nan, 0, -1], [5, 5, np.nan], [-59.9, -59.9, -1],
                     [np.inf, 1, 0], [59.99, 59.99, 0.5], [0, 0, 3], [3, -59.5, -1.6], [5, 5, -np.inf], [-1e30, 2, 0]],

@@ -318,3 +318,20 @@ def test_map_update_semantics():
     m3 = oracle.OracleMap(21.12, 0.33)
     m3.update(500.0, 0.0, (0, 0, 2, 0, 0, 0, 1))
     assert (m3.layer("ground") == -2).all() and (m3.layer("groundpatch") == 0).all()
+
+
+def test_decay_multiply_guard_is_exact():
+    """k4_spiral.hip computes (float)max(x - x/d, 0.001) (GroundSegmentation.cpp:463-464, double arithmetic) as
+    x - x*(1/d) when both ends of the +-2^-48 interval around that value convert to the same float.  Whenever the guard
+    accepts, the result must equal the divide form bit for bit."""
+    rng = np.random.default_rng(5)
+    for d in (1.25, 1.3, 2.0, 3.0, 5.0, 7.3, 1e6):
+        x = np.concatenate([rng.random(2_000_000, dtype=np.float32), np.float32(10.0) ** rng.uniform(-30, 3, 500_000).astype(np.float32),
+                            np.array([0.0, 1.0, 0.5, 1e-7, 0.001, 0.00125, 0.0012500001], dtype=np.float32)]).astype(np.float64)
+        exact = np.maximum(x - x / d, 0.001).astype(np.float32)
+        t = x - x * (1.0 / d)
+        lo = np.maximum(t * (1.0 - 2.0 ** -48), 0.001).astype(np.float32)
+        hi = np.maximum(t * (1.0 + 2.0 ** -48), 0.001).astype(np.float32)
+        ok = lo == hi
+        assert ok.mean() > 0.999
+        assert np.array_equal(lo[ok], exact[ok])

@@ -37,3 +37,7 @@ if __name__ == "__main__":
         for d, nm in ((0, "base"), (0x100, "no LDS atomics"), (0x200, "no ground gather"), (0x400, "no rec store"), (0x800, "no hist flush"), (0xF00, "none of them")):
             run("B64 " + nm, cl, dbg=d)
     if "os" in which: run("os128 2.1M 1000^2", [synth.os128_cloud()], steps=3, warm=1, length=200.0, res=0.2)
+    if "small" in which:
+        run("hdl64 on 60 m map (182^2)", [hdl], length=60.0)
+        run("hdl64 on 30 m map (90^2)", [hdl], length=30.0)
+        run("hdl64 on 240 m map (728^2)", [hdl], length=240.0)
