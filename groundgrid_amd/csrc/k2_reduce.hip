@@ -10,9 +10,10 @@
 //   3. every KEPT record computes its rank = prefix[word] + popc(mask[word] & bits below) -- the number of
 //      earlier records of the same cell, i.e. cloud order -- and drops its z into the cell's segment,
 //   4. each cell thread walks its own segment front to back and runs the reference's float32 recurrence
-//      (count, groundCandidates, running mean, planeDist, m2, min, max) in registers.
-// Lanes advance independently inside a chunk (a cell with 300 points does not stall its neighbours' words);
-// running state stays in registers across chunks; the 9 per-call layers are written exactly once, which also
+//      (count, groundCandidates, running mean, planeDist, m2, min, max) in registers -- except for "heavy" cells
+//      (more than LIGHT_MAX points in the pass), whose recurrences are delegated to the lanes of one wave so that
+//      the other three waves do not idle behind one full cell each.
+// Running state stays in registers across chunks (delegated cells: parked in LDS for the pass); the 9 per-call layers are written exactly once, which also
 // performs the reset of cells that received no point (points = 0, min = FLT_MAX, max = FLT_MIN ...).
 //
 // Double rounding: the reference computes groundCandidates and planeDist as (float)((double)num / ((double)c + 1.0))
@@ -31,6 +32,8 @@ namespace gg {
 constexpr int CH = 512;           // records staged per pass (27 KiB of LDS per work-group -> 5 work-groups per CU)
 constexpr int NW = CH / 32;       // mask words per cell
 constexpr int RPT = CH / TILE_CELLS; // records per thread per pass
+constexpr int LIGHT_MAX = 2;      // a cell with more KEPT points in a pass is "heavy": its recurrence is delegated (step 4)
+constexpr int HMAX = 64;          // heavy cells delegated per pass (one wavefront of runners)
 
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams *__restrict__ params)
@@ -39,7 +42,9 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     __shared__ uint16_t wprefix[NW][TILE_CELLS]; // 8 KiB   segment start of the cell + its KEPT records in words < w
     __shared__ float zsorted[CH];                // 2 KiB   z, grouped by cell, cloud order inside a cell
     __shared__ uint32_t raw_cnt[TILE_CELLS];     // pointsRaw (:234): every in-map point of the cell
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t wave_tot[4], wave_heavy[4];
+    __shared__ float hst[7][HMAX];               // running state of the delegated heavy cells (step 4)
+    __shared__ uint16_t hseg[2][HMAX];           // their segment start / length in zsorted
 
     const int cloud = blockIdx.y;
     const CloudParams cp = params[cloud];
@@ -118,12 +123,33 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
             if (lane >= d) inc += o;
         }
         if (lane == 63) wave_tot[wave] = inc;
+        const bool heavy = tot > (uint32_t)LIGHT_MAX;
+        const unsigned long long hb = __ballot(heavy);
+        if (lane == 0) wave_heavy[wave] = (uint32_t)__popcll(hb);
         __syncthreads();
-        uint32_t wbase = 0;
+        uint32_t wbase = 0, hpos = (uint32_t)__popcll(hb & ((1ull << lane) - 1ull)), n_heavy = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < 4; ++w) {
             if (w < wave) wbase += wave_tot[w];
+            if (w < wave) hpos += wave_heavy[w];
+            n_heavy += wave_heavy[w];
+        }
+        n_heavy = min(n_heavy, (uint32_t)HMAX);
         const uint32_t my_start = wbase + inc - tot;
+        const bool delegated = heavy && hpos < (uint32_t)HMAX;
+        if (delegated) { // hand the cell's state to the runner (read after the next barrier)
+            hst[0][hpos] = c;
+            hst[1][hpos] = mean;
+            hst[2][hpos] = m2;
+            hst[3][hpos] = mn;
+            if (FULL) {
+                hst[4][hpos] = gc;
+                hst[5][hpos] = pdm;
+                hst[6][hpos] = mx;
+            }
+            hseg[0][hpos] = (uint16_t)my_start;
+            hseg[1][hpos] = (uint16_t)tot;
+        }
         {
             uint32_t run = my_start;
 #pragma unroll
@@ -148,25 +174,66 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
         // ---- 4. ordered per-cell recurrence; clear this cell's masks for the next pass ----
 #pragma unroll
         for (int w = 0; w < NW; ++w) mask[w][tid] = 0u;
-        float znext = tot ? zsorted[my_start] : 0.0f;
-        for (uint32_t i = 0; i < tot; ++i) {
-            const float z = znext;
-            if (i + 1 < tot) znext = zsorted[my_start + i + 1];
-            // ---- src/GroundSegmentation.cpp:295-309, one KEPT point, `c` = points before it ----
-            const float planeDist = z - oz;                                      // :295
-            if (FULL) gc = (z + c * gc) / (c + 1.0f);                            // :296 (see note on double rounding above)
-            if ((double)mean == 0.0) mean = planeDist;                           // :298-299
-            if (!isnan(planeDist)) {                                             // :300
-                const float delta = planeDist - mean;                            // :301
-                mean += delta / (c + 1.0f);                                      // :302
-                if (FULL) pdm = (planeDist + c * pdm) / (c + 1.0f);              // :303
-                m2 += delta * (planeDist - mean);                                // :304
+        // Load balance.  A wavefront is busy for as long as its fullest cell, and point counts per cell are very uneven
+        // (a few cells next to the sensor hold hundreds of points, most a handful): with a strict "thread = cell" every
+        // wave of the tile waited for one of the full cells.  So a cell thread runs its own recurrence only when the
+        // cell is light (<= LIGHT_MAX points in this pass); up to HMAX heavy cells per pass were compacted in step 2 and
+        // are run by the lanes of ONE wave from state parked in LDS, so the other three waves retire after at
+        // most LIGHT_MAX steps.  The order INSIDE a cell is untouched.
+        auto recur = [&](uint32_t s0, uint32_t n, float &c_, float &gc_, float &mean_, float &pdm_, float &m2_, float &mx_, float &mn_) {
+            float znext = n ? zsorted[s0] : 0.0f;
+            for (uint32_t i = 0; i < n; ++i) {
+                const float z = znext;
+                if (i + 1 < n) znext = zsorted[s0 + i + 1];
+                // ---- src/GroundSegmentation.cpp:295-309, one KEPT point, `c_` = points before it ----
+                const float planeDist = z - oz;                                       // :295
+                if (FULL) gc_ = (z + c_ * gc_) / (c_ + 1.0f);                         // :296 (see note on double rounding above)
+                if ((double)mean_ == 0.0) mean_ = planeDist;                          // :298-299
+                if (!isnan(planeDist)) {                                              // :300
+                    const float delta = planeDist - mean_;                            // :301
+                    mean_ += delta / (c_ + 1.0f);                                     // :302
+                    if (FULL) pdm_ = (planeDist + c_ * pdm_) / (c_ + 1.0f);           // :303
+                    m2_ += delta * (planeDist - mean_);                               // :304
+                }
+                if (FULL) mx_ = std_max(mx_, z);  // :307
+                mn_ = std_min(mn_, z - 0.0001f);  // :308
+                c_ = (float)((double)c_ + 1.0);   // :309
             }
-            if (FULL) mx = std_max(mx, z);  // :307
-            mn = std_min(mn, z - 0.0001f);  // :308
-            c = (float)((double)c + 1.0);   // :309
+        };
+        if (!delegated) recur(my_start, tot, c, gc, mean, pdm, m2, mx, mn);
+        // the runner wave rotates with the tile so that concurrent work-groups of a CU keep different SIMDs busy
+        const uint32_t rt = (uint32_t)(tid - (rank & 3) * 64) & (TILE_CELLS - 1);
+        if (rt < n_heavy) { // (one wave: n_heavy <= HMAX = 64)
+            float hc = hst[0][rt], hmean = hst[1][rt], hm2 = hst[2][rt], hmn = hst[3][rt];
+            float hgc = 0.0f, hpdm = 0.0f, hmx = 0.0f;
+            if (FULL) {
+                hgc = hst[4][rt];
+                hpdm = hst[5][rt];
+                hmx = hst[6][rt];
+            }
+            recur((uint32_t)hseg[0][rt], (uint32_t)hseg[1][rt], hc, hgc, hmean, hpdm, hm2, hmx, hmn);
+            hst[0][rt] = hc;
+            hst[1][rt] = hmean;
+            hst[2][rt] = hm2;
+            hst[3][rt] = hmn;
+            if (FULL) {
+                hst[4][rt] = hgc;
+                hst[5][rt] = hpdm;
+                hst[6][rt] = hmx;
+            }
         }
         __syncthreads();
+        if (delegated) { // take the state back
+            c = hst[0][hpos];
+            mean = hst[1][hpos];
+            m2 = hst[2][hpos];
+            mn = hst[3][hpos];
+            if (FULL) {
+                gc = hst[4][hpos];
+                pdm = hst[5][hpos];
+                mx = hst[6][hpos];
+            }
+        }
     }
 
     const int row = tr * TILE + (tid & 15), col = tc * TILE + (tid >> 4);
