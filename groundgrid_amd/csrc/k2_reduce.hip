@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     __shared__ float zsorted[CH];                // 2 KiB   z, grouped by cell, cloud order inside a cell
     __shared__ uint32_t raw_cnt[TILE_CELLS];     // pointsRaw (:234): every in-map point of the cell
     __shared__ uint32_t wave_tot[4], wave_heavy[4];
-    __shared__ float hst[7][HMAX];               // running state of the delegated heavy cells (step 4)
+    __shared__ float hst[8][HMAX];               // running state of the delegated heavy cells (step 4); row 7 = count after the pass
     __shared__ uint16_t hseg[2][HMAX];           // their segment start / length in zsorted
 
     const int cloud = blockIdx.y;
@@ -178,8 +178,7 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
         // (a few cells next to the sensor hold hundreds of points, most a handful): with a strict "thread = cell" every
         // wave of the tile waited for one of the full cells.  So a cell thread runs its own recurrence only when the
         // cell is light (<= LIGHT_MAX points in this pass); up to HMAX heavy cells per pass were compacted in step 2 and
-        // are run by the lanes of ONE wave from state parked in LDS, so the other three waves retire after at
-        // most LIGHT_MAX steps.  The order INSIDE a cell is untouched.
+        // are run from state parked in LDS by dedicated waves (below), so no wave idles behind one full cell.  The order INSIDE a cell is untouched.
         auto recur = [&](uint32_t s0, uint32_t n, float &c_, float &gc_, float &mean_, float &pdm_, float &m2_, float &mx_, float &mn_) {
             float znext = n ? zsorted[s0] : 0.0f;
             for (uint32_t i = 0; i < n; ++i) {
@@ -201,30 +200,60 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
             }
         };
         if (!delegated) recur(my_start, tot, c, gc, mean, pdm, m2, mx, mn);
-        // the runner wave rotates with the tile so that concurrent work-groups of a CU keep different SIMDs busy
-        const uint32_t rt = (uint32_t)(tid - (rank & 3) * 64) & (TILE_CELLS - 1);
-        if (rt < n_heavy) { // (one wave: n_heavy <= HMAX = 64)
-            float hc = hst[0][rt], hmean = hst[1][rt], hm2 = hst[2][rt], hmn = hst[3][rt];
-            float hgc = 0.0f, hpdm = 0.0f, hmx = 0.0f;
-            if (FULL) {
-                hgc = hst[4][rt];
-                hpdm = hst[5][rt];
-                hmx = hst[6][rt];
-            }
-            recur((uint32_t)hseg[0][rt], (uint32_t)hseg[1][rt], hc, hgc, hmean, hpdm, hm2, hmx, hmn);
-            hst[0][rt] = hc;
-            hst[1][rt] = hmean;
-            hst[2][rt] = hm2;
-            hst[3][rt] = hmn;
-            if (FULL) {
-                hst[4][rt] = hgc;
-                hst[5][rt] = hpdm;
-                hst[6][rt] = hmx;
+        // Delegated cells: the recurrence of one point consists of three chains that only share the point count --
+        // (mean, m2, min), (groundCandidates, max), (planeDist) -- so three waves each run ONE chain for all heavy cells
+        // (lane = heavy cell): a third of the dependent instructions per point on the tile's critical path.  The
+        // roles rotate with the tile so that concurrent work-groups of a CU keep different SIMDs busy.
+        const int role = (wave - rank) & 3; // wave-uniform
+        if ((uint32_t)lane < n_heavy && role < (FULL ? 3 : 1)) {
+            const uint32_t s0 = (uint32_t)hseg[0][lane], n = (uint32_t)hseg[1][lane];
+            float hc = hst[0][lane]; // points before this pass
+            float znext = zsorted[s0];
+            if (role == 0) {
+                float hmean = hst[1][lane], hm2 = hst[2][lane], hmn = hst[3][lane];
+                for (uint32_t i = 0; i < n; ++i) {
+                    const float z = znext;
+                    if (i + 1 < n) znext = zsorted[s0 + i + 1];
+                    const float planeDist = z - oz;                   // :295
+                    if ((double)hmean == 0.0) hmean = planeDist;      // :298-299
+                    if (!isnan(planeDist)) {                          // :300
+                        const float delta = planeDist - hmean;        // :301
+                        hmean += delta / (hc + 1.0f);                 // :302
+                        hm2 += delta * (planeDist - hmean);           // :304
+                    }
+                    hmn = std_min(hmn, z - 0.0001f);                  // :308
+                    hc = (float)((double)hc + 1.0);                   // :309
+                }
+                hst[1][lane] = hmean;
+                hst[2][lane] = hm2;
+                hst[3][lane] = hmn;
+                hst[7][lane] = hc; // points after this pass (row 0 is still being read by the other two chains)
+            } else if (role == 1) {
+                float hgc = hst[4][lane], hmx = hst[6][lane];
+                for (uint32_t i = 0; i < n; ++i) {
+                    const float z = znext;
+                    if (i + 1 < n) znext = zsorted[s0 + i + 1];
+                    hgc = (z + hc * hgc) / (hc + 1.0f);               // :296
+                    hmx = std_max(hmx, z);                            // :307
+                    hc = (float)((double)hc + 1.0);
+                }
+                hst[4][lane] = hgc;
+                hst[6][lane] = hmx;
+            } else {
+                float hpdm = hst[5][lane];
+                for (uint32_t i = 0; i < n; ++i) {
+                    const float z = znext;
+                    if (i + 1 < n) znext = zsorted[s0 + i + 1];
+                    const float planeDist = z - oz;
+                    if (!isnan(planeDist)) hpdm = (planeDist + hc * hpdm) / (hc + 1.0f); // :300, :303
+                    hc = (float)((double)hc + 1.0);
+                }
+                hst[5][lane] = hpdm;
             }
         }
         __syncthreads();
         if (delegated) { // take the state back
-            c = hst[0][hpos];
+            c = hst[7][hpos];
             mean = hst[1][hpos];
             m2 = hst[2][hpos];
             mn = hst[3][hpos];
