@@ -131,6 +131,7 @@ uint32_t morton2(uint32_t x, uint32_t y)
 void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::vector<SpiralVisit> &out_visits,
                            std::vector<uint32_t> &level_start, int &max_width, int &n_slots)
 {
+    int n_result_slots = 0;
     const int center = n / 2 - 1;
     std::vector<uint32_t> cells;
     for (int i = center - 1; i >= 1; --i) {
@@ -156,10 +157,10 @@ void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::v
         uint32_t cell;
         int level;          // uncapped level, >= 2 for real visits (level 1 is left for helpers of level-2 visits)
         int64_t src[9];     // entry index producing the value (>= 0), or -1: pre-sweep value
-        int plan[3];        // load plan: pair p = column c (0..2) * 2 + row offset r (0..1)
-        int stage_of[9];    // for pre-sweep inputs served by the own load plan: staging element 0..5, else -1
+        int plan[3];        // load plan: pair p = column c (0..2) * 2 + row offset r (0..1), -1 = unused
+        int64_t rd_entry[9]; // pre-sweep inputs: the loader (entry index; may be the visit itself) whose block holds the value
+        int rd_elem[9];     //                    and the element 0..5 inside that block
         bool helper;
-        int64_t helper_src_elem[2]; // helper: consumers read its staged elements as entries (filled below)
         uint16_t flags;
     };
     std::vector<Entry> E(V);
@@ -189,49 +190,81 @@ void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::v
     for (size_t k = 0; k < V; ++k)
         if (last_writer[E[k].cell] == (int64_t)k) E[k].flags |= SPIRAL_STORE; // only the last visit of a cell stores
 
-    // ---- 2. load plans; helpers for visits that need more than three pairs ----------------------------------
-    // a helper is an Entry with helper = true: it loads ONE pair (plan[0]) relative to `cell` and parks both cells in LDS
+    // ---- 2. pre-sweep inputs: read them from LDS if an EARLIER level already fetched the cell, else fetch them --------
+    // An entry that fetches cells ("loader": a visit, or a helper = fetch-only entry one level before the visit that
+    // needs it) parks them in a block of 6 LDS slots (3 pairs x 2 cells); `staged` remembers, per cell, the latest block
+    // element holding its pre-sweep value.  Entries are handled in level order, so "earlier level" is decided on the
+    // uncapped hazard levels and stays true under any split of a level.
+    struct Staged { int64_t entry = -1; int elem = 0; int level = 0; };
+    std::vector<Staged> staged(C);
     std::vector<Entry> H;
-    struct HelperRef { size_t reader; int q; size_t helper; int elem; };
-    std::vector<HelperRef> href;
-    for (size_t k = 0; k < V; ++k) {
+    std::vector<size_t> by_lvl(V);
+    for (size_t k = 0; k < V; ++k) by_lvl[k] = k;
+    std::stable_sort(by_lvl.begin(), by_lvl.end(), [&](size_t a_, size_t b_) { return E[a_].level < E[b_].level; });
+    for (size_t kk = 0; kk < V; ++kk) {
+        const size_t k = by_lvl[kk];
         Entry &e = E[k];
-        std::vector<int> pairs;
+        const int x = (int)(e.cell % (uint32_t)n), y = (int)(e.cell / (uint32_t)n);
+        auto cell_of = [&](int q) { return (size_t)((x - 1 + q % 3) + (y - 1 + q / 3) * n); };
+        bool need[9];
+        for (int q = 0; q < 9; ++q) {
+            e.rd_entry[q] = -1;
+            e.rd_elem[q] = 0;
+            need[q] = false;
+            if (e.src[q] >= 0) continue; // fresh value: comes from the producing visit's slot
+            const Staged &sb = staged[cell_of(q)];
+            if (sb.entry >= 0 && sb.level < e.level) {
+                e.rd_entry[q] = sb.entry;
+                e.rd_elem[q] = sb.elem;
+            } else {
+                need[q] = true;
+            }
+        }
+        std::vector<int> pairs; // pair code = block column * 2 + row offset (rows ro, ro + 1 of that column)
         for (int c = 0; c < 3; ++c) {
-            bool old_[3];
-            int cnt = 0;
-            for (int r = 0; r < 3; ++r) cnt += (old_[r] = e.src[c * 3 + r] < 0);
-            if (!cnt) continue;
-            if (!old_[2]) pairs.push_back(c * 2 + 0);
-            else if (!old_[0]) pairs.push_back(c * 2 + 1);
+            const bool n0 = need[c * 3 + 0], n1 = need[c * 3 + 1], n2 = need[c * 3 + 2];
+            if (!n0 && !n1 && !n2) continue;
+            if (!n2) pairs.push_back(c * 2 + 0);
+            else if (!n0) pairs.push_back(c * 2 + 1);
             else { pairs.push_back(c * 2 + 0); pairs.push_back(c * 2 + 1); }
         }
-        for (int q = 0; q < 9; ++q) e.stage_of[q] = -1;
-        for (int p = 0; p < 3; ++p) e.plan[p] = p < (int)pairs.size() ? pairs[p] : (pairs.empty() ? 2 : pairs[0]);
-        // inputs covered by the first three pairs
+        // a pair element may be handed on to later readers only if it is a pre-sweep value for the loader itself (a cell an
+        // earlier visit already rewrote may or may not have reached memory when the prefetch executes)
+        auto publish = [&](int64_t entry_id, int elem, int q, int level) {
+            if (e.src[q] < 0) staged[cell_of(q)] = Staged{entry_id, elem, level};
+        };
+        for (int p = 0; p < 3; ++p) e.plan[p] = p < (int)pairs.size() ? pairs[p] : -1;
         for (int p = 0; p < 3 && p < (int)pairs.size(); ++p) {
             const int c = pairs[p] / 2, r = pairs[p] % 2;
             for (int el = 0; el < 2; ++el) {
                 const int q = c * 3 + r + el;
-                if (e.src[q] < 0 && e.stage_of[q] < 0) e.stage_of[q] = p * 2 + el;
+                if (need[q]) {
+                    e.rd_entry[q] = (int64_t)k;
+                    e.rd_elem[q] = p * 2 + el;
+                    need[q] = false;
+                }
+                publish((int64_t)k, p * 2 + el, q, e.level);
             }
         }
-        // the rest: one helper per extra pair, one level earlier
-        for (size_t p = 3; p < pairs.size(); ++p) {
+        for (size_t p = 3; p < pairs.size(); ++p) { // the rest: one fetch-only helper per extra pair, one level earlier
             Entry h{};
             h.cell = e.cell;
             h.level = e.level - 1;
             h.helper = true;
             h.flags = SPIRAL_HELPER;
-            for (int q = 0; q < 9; ++q) { h.src[q] = -1; h.stage_of[q] = -1; }
-            h.plan[0] = h.plan[1] = h.plan[2] = pairs[p];
+            for (int q = 0; q < 9; ++q) { h.src[q] = -1; h.rd_entry[q] = -1; h.rd_elem[q] = 0; }
+            h.plan[0] = pairs[p];
+            h.plan[1] = h.plan[2] = -1;
+            const int64_t hid = (int64_t)(V + H.size());
             const int c = pairs[p] / 2, r = pairs[p] % 2;
             for (int el = 0; el < 2; ++el) {
                 const int q = c * 3 + r + el;
-                if (e.src[q] < 0 && e.stage_of[q] == -1) {
-                    href.push_back({k, q, H.size(), el});
-                    e.stage_of[q] = -2; // served by a helper
+                if (need[q]) {
+                    e.rd_entry[q] = hid;
+                    e.rd_elem[q] = el;
+                    need[q] = false;
                 }
+                publish(hid, el, q, h.level);
             }
             H.push_back(h);
         }
@@ -263,57 +296,74 @@ void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::v
     }
     const int n_levels = (int)level_start.size() - 1;
 
-    // ---- 4. LDS slots: one per value that somebody reads through LDS, alive until its last reader's level -----
-    // value id: entry i produces value (i, 0) [a visit's result] or (i, el) [a helper's staged element el]
-    std::vector<int> last_reader(NE * 2, 0);
+    // ---- 4. LDS slots ------------------------------------------------------------------------------------------
+    // two kinds of values live in LDS until the level of their last reader: a visit's result (one slot) and a
+    // loader's block of fetched cells (6 slots).  Both are recycled through free lists, in final level order.
+    std::vector<int> last_res(NE, 0), last_blk(NE, 0);
     for (size_t k = 0; k < V; ++k)
-        for (int q = 0; q < 9; ++q)
-            if (E[k].src[q] >= 0) last_reader[(size_t)E[k].src[q] * 2] = std::max(last_reader[(size_t)E[k].src[q] * 2], final_level[k]);
-    for (const auto &r : href) last_reader[(V + r.helper) * 2 + r.elem] = std::max(last_reader[(V + r.helper) * 2 + r.elem], final_level[r.reader]);
-    std::vector<uint16_t> slot(NE * 2, SPIRAL_NONE);
-    std::vector<std::vector<uint16_t>> release((size_t)n_levels + 2);
-    std::vector<uint16_t> free_slots;
-    n_slots = 0;
-    for (size_t oi = 0, l = 1; l <= (size_t)n_levels; ++l) {
-        for (uint16_t s_ : release[l]) free_slots.push_back(s_);
-        for (; oi < order.size() && final_level[order[oi]] == (int)l; ++oi)
-            for (int el = 0; el < 2; ++el) {
-                const size_t id = (size_t)order[oi] * 2 + el;
-                if (last_reader[id] == 0) continue;
-                uint16_t s_;
-                if (!free_slots.empty()) { s_ = free_slots.back(); free_slots.pop_back(); }
-                else s_ = (uint16_t)n_slots++;
-                slot[id] = s_;
-                release[(size_t)last_reader[id] + 1].push_back(s_);
+        for (int q = 0; q < 9; ++q) {
+            if (E[k].src[q] >= 0) last_res[(size_t)E[k].src[q]] = std::max(last_res[(size_t)E[k].src[q]], final_level[k]);
+            else last_blk[(size_t)E[k].rd_entry[q]] = std::max(last_blk[(size_t)E[k].rd_entry[q]], final_level[k]);
+        }
+    std::vector<uint16_t> res_slot(NE, SPIRAL_NONE);
+    std::vector<int> blk_base_of(NE, -1); // first slot of the entry's block, relative to the block region
+    {
+        // blocks come in three sizes (2 slots per pair of the load plan); block region = [size-2 | size-4 | size-6] arenas,
+        // each arena recycles its own blocks
+        std::vector<std::vector<uint16_t>> rel_res((size_t)n_levels + 2);
+        std::vector<std::vector<std::pair<int, int>>> rel_blk((size_t)n_levels + 2); // (size class, index)
+        std::vector<uint16_t> free_res;
+        std::vector<int> free_blk[3];
+        int n_res = 0, n_blk[3] = {0, 0, 0};
+        std::vector<int> blk_cls(NE, -1), blk_idx(NE, -1);
+        for (size_t oi = 0, l = 1; l <= (size_t)n_levels; ++l) {
+            for (uint16_t s_ : rel_res[l]) free_res.push_back(s_);
+            for (const auto &b_ : rel_blk[l]) free_blk[b_.first].push_back(b_.second);
+            for (; oi < order.size() && final_level[order[oi]] == (int)l; ++oi) {
+                const size_t id = order[oi];
+                if (last_res[id] > 0) {
+                    uint16_t s_;
+                    if (!free_res.empty()) { s_ = free_res.back(); free_res.pop_back(); }
+                    else s_ = (uint16_t)n_res++;
+                    res_slot[id] = s_;
+                    rel_res[(size_t)last_res[id] + 1].push_back(s_);
+                }
+                if (last_blk[id] > 0) { // (a loader nobody reads -- not even itself -- needs no block)
+                    int npairs = 0;
+                    for (int p = 0; p < 3; ++p) npairs += entry(id).plan[p] >= 0;
+                    const int cls = std::max(npairs, 1) - 1;
+                    int b_;
+                    if (!free_blk[cls].empty()) { b_ = free_blk[cls].back(); free_blk[cls].pop_back(); }
+                    else b_ = n_blk[cls]++;
+                    blk_cls[id] = cls;
+                    blk_idx[id] = b_;
+                    rel_blk[(size_t)std::max(last_blk[id], (int)l) + 1].push_back({cls, b_});
+                }
             }
+        }
+        const int arena0 = 0, arena1 = 2 * n_blk[0], arena2 = arena1 + 4 * n_blk[1];
+        for (size_t id = 0; id < NE; ++id)
+            if (blk_idx[id] >= 0) blk_base_of[id] = (blk_cls[id] == 0 ? arena0 : blk_cls[id] == 1 ? arena1 : arena2) + 2 * (blk_cls[id] + 1) * blk_idx[id];
+        n_slots = n_res + arena2 + 6 * n_blk[2];
+        n_result_slots = n_res;
     }
 
     // ---- 5. descriptors ---------------------------------------------------------------------------------------
-    std::vector<uint16_t> helper_code(V * 9, 0);
-    for (const auto &r : href) helper_code[r.reader * 9 + r.q] = slot[(V + r.helper) * 2 + r.elem];
+    auto blk_base = [&](size_t id) { return (uint32_t)n_result_slots + (uint32_t)blk_base_of[id]; };
     out_visits.resize(NE);
     for (size_t oi = 0; oi < order.size(); ++oi) {
         const size_t i = order[oi];
         const Entry &e = entry(i);
         SpiralVisit d{};
-        d.cell = e.cell;
-        d.wslot = e.helper ? SPIRAL_NONE : slot[i * 2];
-        d.flags = (uint16_t)e.flags;
+        d.cell_flags = e.cell | ((uint32_t)e.flags << 24);
+        d.wslot = e.helper ? SPIRAL_NONE : res_slot[i];
+        d.stage = blk_base_of[i] >= 0 ? (uint16_t)blk_base(i) : SPIRAL_NONE;
         for (int p = 0; p < 3; ++p) // pair code = block column * 2 + row offset  ->  index delta from the centre cell
-            d.pair[p] = (int16_t)(-1 + (e.plan[p] & 1) + ((e.plan[p] >> 1) - 1) * n);
-        // the visit runs on thread (position inside its level): its private staging slots are known here
-        const uint32_t thread = (uint32_t)(oi - level_start[(size_t)final_level[i] - 1]);
-        const uint32_t stage0 = (uint32_t)n_slots + thread * 6u;
-        if (e.helper) {
-            d.src[0] = slot[i * 2 + 0]; // where staged element 0 / 1 go (SPIRAL_NONE: nobody reads it)
-            d.src[1] = slot[i * 2 + 1];
-            for (int q = 2; q < 9; ++q) d.src[q] = SPIRAL_NONE;
-        } else {
-            for (int q = 0; q < 9; ++q) {
-                if (e.src[q] >= 0) d.src[q] = slot[(size_t)e.src[q] * 2];
-                else if (e.stage_of[q] >= 0) d.src[q] = (uint16_t)(stage0 + (uint32_t)e.stage_of[q]);
-                else d.src[q] = helper_code[i * 9 + q];
-            }
+            d.pair[p] = e.plan[p] < 0 ? SPIRAL_NO_PAIR : (int16_t)(-1 + (e.plan[p] & 1) + ((e.plan[p] >> 1) - 1) * n);
+        for (int q = 0; q < 9; ++q) {
+            if (e.helper) d.src[q] = SPIRAL_NONE;
+            else if (e.src[q] >= 0) d.src[q] = res_slot[(size_t)e.src[q]];
+            else d.src[q] = (uint16_t)(blk_base((size_t)e.rd_entry[q]) + (uint32_t)e.rd_elem[q]);
         }
         out_visits[oi] = d;
     }
@@ -590,11 +640,14 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     for (int v = 0; v < 2; ++v) {
         int max_width = 0, spiral_slots = 0;
         build_spiral_schedule(n, res, geom.min_dist_squared, caps[v], visits[v], level_start[v], max_width, spiral_slots);
+        if (getenv("GG_DEBUG_SCHEDULE"))
+            fprintf(stderr, "groundgrid_hip: spiral schedule %d (cap %d): %zu entries (%zu visits), %zu levels, widest %d, %d LDS slots\n", v, caps[v],
+                    visits[v].size(), (size_t)((size_t)(n / 2 - 2) * ((size_t)(n / 2 - 2) + 1) * 4 + 2 * (size_t)(n / 2 - 2)), level_start[v].size() - 1, max_width, spiral_slots);
         a.sched[v].n_levels = (int)level_start[v].size() - 1;
         a.sched[v].max_level_width = max_width;
         a.sched[v].slots = spiral_slots;
         a.sched[v].pad_ = 0;
-        if (spiral_slots + 512 * 6 >= (int)SPIRAL_NONE || n + 1 > 32767 || ((size_t)spiral_slots + (size_t)((max_width + 63) / 64 * 64) * 6) * 8 + level_start[v].size() * 4 > 150 * 1024 ||
+        if (spiral_slots >= (int)SPIRAL_NONE || n + 1 > 32766 || (size_t)spiral_slots * 8 > 150 * 1024 || (size_t)n * n >= (1u << 24) ||
             max_width > 512) {
             gg_destroy(ctx);
             return GG_ERR_GEOMETRY; // the spiral's fresh-value window no longer fits LDS

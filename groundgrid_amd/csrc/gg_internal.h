@@ -62,15 +62,18 @@ struct Geometry {
 // already rewritten earlier in the serial order ("fresh": taken from an LDS slot) and which still hold their
 // pre-sweep value (read from the layer).
 struct SpiralVisit {
-    uint32_t cell;    // row + col * rows
-    uint16_t wslot;   // LDS slot receiving this visit's (ground, confidence); SPIRAL_NONE: nobody reads it during the sweep
-    uint16_t flags;   // bit0 STORE (last visit of the cell), bit1 DECAY (:463), bit2 HELPER
-    uint16_t src[9];  // 3x3 block, column-major: LDS slot holding the value -- a fresh-value slot, or a slot of the visiting
-                      // thread's own staging area (slots + thread * 6 + k: the host knows which thread runs the visit)
-                      // (helper: src[0], src[1] = LDS slots that receive its two loaded cells)
-    int16_t pair[3];  // load plan: three 16-byte loads of two vertically adjacent interleaved cells, as cell-index deltas
+    uint32_t cell_flags; // bits 0..23: row + col * rows; bit 24 STORE (last visit of the cell), 25 DECAY (:463), 26 HELPER
+    uint16_t wslot;      // LDS slot receiving this visit's (ground, confidence); SPIRAL_NONE: nobody reads it during the sweep
+    uint16_t stage;      // first LDS slot of the block (2 slots per used pair) that receives the cells of this entry's load plan;
+                         // SPIRAL_NONE: none
+    uint16_t src[9];     // 3x3 block, column-major: LDS slot holding the value -- a visit's result slot, or an element of a
+                         // loader's block (this entry's own, or one an earlier level fetched: each pre-sweep cell is fetched
+                         // about once per sweep, not once per reader)
+    int16_t pair[3];     // load plan: three 16-byte loads of two vertically adjacent interleaved cells, as cell-index deltas;
+                         // SPIRAL_NO_PAIR: unused
 };
 constexpr uint16_t SPIRAL_NONE = 0xFFFFu;
+constexpr int16_t SPIRAL_NO_PAIR = -32768;
 constexpr uint16_t SPIRAL_STORE = 1u, SPIRAL_DECAY = 2u, SPIRAL_HELPER = 4u;
 
 // One level schedule of the terrain sweep (built by gg_context.hip build_spiral_schedule)

@@ -44,8 +44,8 @@ struct VisitRegs {
 
 GG_DEV uint32_t visit_src(const VisitRegs &d, int q)
 {
-    // SpiralVisit layout: cell u32 | wslot u16 flags u16 | src[0..8] u16 | pad
-    // dwords: lo.x = cell, lo.y = wslot | flags << 16, lo.z = src0|src1<<16, lo.w = src2|src3, hi.x = src4|src5, hi.y = src6|src7,
+    // SpiralVisit layout: cell_flags u32 | wslot u16 stage u16 | src[0..8] u16 | pair[0..2] i16
+    // dwords: lo.x = cell | flags << 24, lo.y = wslot | stage << 16, lo.z = src0|src1<<16, lo.w = src2|src3, hi.x = src4|src5, hi.y = src6|src7,
     //         hi.z = src8 | pair0 << 16, hi.w = pair1 | pair2 << 16
     const uint32_t w = (q < 2) ? d.lo.z : (q < 4) ? d.lo.w : (q < 6) ? d.hi.x : (q < 8) ? d.hi.y : d.hi.z;
     return (q & 1) ? (w >> 16) : (w & 0xFFFFu);
@@ -53,7 +53,7 @@ GG_DEV uint32_t visit_src(const VisitRegs &d, int q)
 
 __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSched sc, const CloudParams *__restrict__ params)
 {
-    // LDS: [slots] fresh values | [threads][6] private staging of the cells this thread loaded
+    // LDS: [slots] results of visits and blocks of fetched cells, both recycled by the host-side allocator
     extern __shared__ float2 fresh[];
     const int nthreads = blockDim.x;
     // Two wave sets take turns: while one set computes level L (LDS reads, arithmetic, LDS write -- the dependent chain of
@@ -64,7 +64,6 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
     const int W = nthreads >> 1;                 // lanes per set = widest level, a multiple of 64: sets are whole waves
     const int set = __builtin_amdgcn_readfirstlane((int)threadIdx.x >= W ? 1 : 0); // wave-uniform: level bounds stay in SGPRs
     const uint32_t lane = threadIdx.x - (uint32_t)(set * W); // position inside the level
-    float2 *stage = fresh + sc.slots + (size_t)lane * 6;
 
     const int cloud = blockIdx.x;
     const CloudParams cp = params[cloud];
@@ -123,11 +122,12 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
     // requests: the load plan fetches the not-yet-visited cells of the 3x3 block with three 16-byte requests (two
     // vertically adjacent interleaved cells each) instead of 18 scalar ones.
     auto load_pairs = [&](const VisitRegs &d, bool active, Pair2 (&P)[3]) {
-        const int cell = (int)d.lo.x;
+        const int cell = (int)(d.lo.x & 0xFFFFFFu);
         const int delta[3] = {(int)d.hi.z >> 16, (int)(d.hi.w << 16) >> 16, (int)d.hi.w >> 16}; // SpiralVisit::pair, int16
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            P[p] = __builtin_bit_cast(Pair2, __builtin_amdgcn_raw_buffer_load_b128(rsrc_g, active ? (uint32_t)(cell + delta[p]) * 8u : OOR, 0, 0));
+        for (int p = 0; p < 3; ++p) // unused plan entries (most visits fetch one pair) and idle lanes: out of range, no traffic
+            P[p] = __builtin_bit_cast(Pair2, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rsrc_g, (active && delta[p] != (int)SPIRAL_NO_PAIR) ? (uint32_t)(cell + delta[p]) * 8u : OOR, 0, 0));
     };
 
     // Software pipeline, in units of a set's OWN levels (every second level): descriptors are requested DESC_AHEAD own
@@ -171,23 +171,24 @@ __global__ __launch_bounds__(1024) void k_spiral(const Arena a, const SpiralSche
                 VisitRegs &d0 = D[u % ND];
                 const Pair2 (&p0)[3] = P[u % NP];
                 const bool active = act[u % ND];
-                const uint32_t cell = d0.lo.x;
+                const uint32_t cell = d0.lo.x & 0xFFFFFFu;
                 dst = OOR;
                 if (active) {
-                    // park the six cells of this level's load plan in the thread's private LDS staging: from here on
-                    // every input, fresh or pre-sweep, is "an LDS address" and needs no per-input select logic
+                    const uint32_t flags = d0.lo.x >> 24, wslot = d0.lo.y & 0xFFFFu, stage_slot = d0.lo.y >> 16;
+                    // park the cells of this entry's load plan in its LDS block: this visit reads them from there (every
+                    // input, fresh or pre-sweep, is "an LDS address"), and so do visits of LATER levels that need the
+                    // same pre-sweep cells
+                    if (stage_slot != (uint32_t)SPIRAL_NONE) {
+                        float2 *stage = fresh + stage_slot;
+                        const int used[3] = {(int)d0.hi.z >> 16, (int)(d0.hi.w << 16) >> 16, (int)d0.hi.w >> 16};
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        stage[2 * p] = make_float2(p0[p].x, p0[p].y);
-                        stage[2 * p + 1] = make_float2(p0[p].z, p0[p].w);
+                        for (int p = 0; p < 3; ++p)
+                            if (used[p] != (int)SPIRAL_NO_PAIR) { // the block holds 2 slots per USED pair (pairs are packed from 0)
+                                stage[2 * p] = make_float2(p0[p].x, p0[p].y);
+                                stage[2 * p + 1] = make_float2(p0[p].z, p0[p].w);
+                            }
                     }
-                    const uint32_t flags = d0.lo.y >> 16, wslot = d0.lo.y & 0xFFFFu;
-                    if (flags & SPIRAL_HELPER) {
-                        // a helper only forwards its pair to the slots a later visit will read
-                        const uint32_t s0 = visit_src(d0, 0), s1 = visit_src(d0, 1);
-                        if (s0 != (uint32_t)SPIRAL_NONE) fresh[s0] = stage[0];
-                        if (s1 != (uint32_t)SPIRAL_NONE) fresh[s1] = stage[1];
-                    } else {
+                    if (!(flags & SPIRAL_HELPER)) { // (a helper only fetches)
                         float w[9], g[9], pr[9];
 #pragma unroll
                         for (int q = 0; q < 9; ++q) { // :453,458 block<3,3>(x-1, y-1), column-major linear index
@@ -241,7 +242,7 @@ void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hi
     if (width < 64) width = 64;
     const int threads = 2 * width; // two wave sets (see k_spiral)
     // gg_create guarantees max_level_width <= 1024 (one visit per thread per level)
-    const size_t lds = ((size_t)sc.slots + (size_t)width * 6) * sizeof(float2);
+    const size_t lds = (size_t)sc.slots * sizeof(float2);
     hipLaunchKernelGGL(k_spiral, dim3(n_clouds), dim3(threads), lds, s, a, sc, d_params);
 }
 
