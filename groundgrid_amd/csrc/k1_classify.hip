@@ -52,47 +52,62 @@ GG_DEV bool locate_point(const Arena &a, const CloudParams &cp, const PointIn &p
     return inside && gi0 >= 0 && gi1 >= 0 && gi0 < g.rows && gi1 < g.cols;
 }
 
-// :237-279 -- ignore test, line-of-sight outlier test, key.  `oldgroundheight` = ground(gi) before this cloud.
-GG_DEV uint32_t finish_point(const Arena &a, const CloudParams &cp, const float2 *__restrict__ gp2, const PointIn &pt, int gi0, int gi1,
-                             float oldgroundheight)
+// :237-244 -- ignore test and the entry condition of the line-of-sight test.  `oldgroundheight` = ground(gi) before this cloud.
+GG_DEV int classify_point(const Arena &a, const CloudParams &cp, const PointIn &pt, float oldgroundheight, bool &walk)
+{
+    const float dx = pt.x - cp.ox, dy = pt.y - cp.oy;
+    const float sqdist = (float)((double)dx * (double)dx + (double)dy * (double)dy); // :223
+    walk = false;
+    if (pt.ring > a.cfg.max_ring || sqdist < a.g.min_dist_squared) return GG_CLASS_IGNORED; // :237
+    walk = (double)pt.z < (double)oldgroundheight - 0.2; // :243-244 Outlier detection test
+    return GG_CLASS_KEPT;
+}
+
+// :246-275 -- the line-of-sight walk of ONE point, run by a whole wavefront: lane l evaluates the steps 3 + l, 67 + l, ...
+// The reference walks `step` = 3, 4, ... while |step * v|^2 < len^2 and stops at the first cell whose stored ground lies
+// above the ray.  The steps do not depend on each other and the continuation test is monotonic in `step` (a product with
+// a fixed float factor is monotonic), so "some step before the end of the ray hits" is the same predicate -- evaluated
+// 64 steps at a time instead of one lane idling its 63 neighbours through up to a hundred serial steps.
+GG_DEV bool ray_walk_hits(const Arena &a, const CloudParams &cp, const float2 *__restrict__ gp2, float px, float py, float pz, int lane)
 {
     const Geometry &g = a.g;
     const int rows = g.rows, cols = g.cols;
-    const float dx = pt.x - cp.ox, dy = pt.y - cp.oy;
-    const float sqdist = (float)((double)dx * (double)dx + (double)dy * (double)dy); // :223
-
-    int cls = GG_CLASS_KEPT;
-    if (pt.ring > a.cfg.max_ring || sqdist < g.min_dist_squared) { // :237
-        cls = GG_CLASS_IGNORED;
-    } else if ((double)pt.z < (double)oldgroundheight - 0.2) { // :243-244 Outlier detection test
-        float vx = pt.x - cp.ox, vy = pt.y - cp.oy, vz = pt.z - cp.oz; // :248-250
-        const float len = sqrtf(vx * vx + vy * vy + vz * vz);           // :252
-        vx /= len;                                                        // :253-255
-        vy /= len;
-        vz /= len;
-        const double len2 = (double)len * (double)len;
-        for (int step = 3;; ++step) { // :258
-            const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
-            const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
-            if (!(d2 < len2 && vz < -0.01f)) break;
+    float vx = px - cp.ox, vy = py - cp.oy, vz = pz - cp.oz;        // :248-250
+    const float len = sqrtf(vx * vx + vy * vy + vz * vz);           // :252
+    vx /= len;                                                      // :253-255
+    vy /= len;
+    vz /= len;
+    const double len2 = (double)len * (double)len;
+    for (int base = 3;; base += 64) { // :258
+        const int step = base + lane;
+        const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
+        const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
+        const bool on_ray = d2 < len2 && vz < -0.01f;
+        bool hit = false;
+        if (on_ray) {
             const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
             int I0, I1;
             index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0, I1); // :261
-            if (I0 <= 0 || I1 <= 0 || I0 >= rows - 1 || I1 >= cols - 1) continue;         // :264-265
-            const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                            // :268
-            float e[9];
+            if (!(I0 <= 0 || I1 <= 0 || I0 >= rows - 1 || I1 >= cols - 1)) {              // :264-265
+                const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                       // :268
+                float e[9];
 #pragma unroll
-            for (int s = 0; s < 9; ++s) e[s] = gp2[(r0 + s % 3) + (c0 + s / 3) * rows].y;
-            const float bsum = tree9(e);
-            const float2 gI = gp2[I0 + I1 * rows];
-            if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gI.y > 0.01f &&
-                (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) { // :269
-                cls = GG_CLASS_OUTLIER;
-                break;
+                for (int s = 0; s < 9; ++s) e[s] = gp2[(r0 + s % 3) + (c0 + s / 3) * rows].y;
+                const float bsum = tree9(e);
+                const float2 gI = gp2[I0 + I1 * rows];
+                hit = (double)bsum > a.cfg.min_outlier_detection_ground_confidence && gI.y > 0.01f &&
+                      (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance; // :269
             }
         }
+        if (__ballot(hit) != 0ull) return true;
+        if (__ballot(on_ray) != ~0ull) return false; // the ray ended inside this group of steps
     }
-    const uint32_t emit = (rows <= gi0 + 3 || cols <= gi1 + 3) ? 0u : KEY_EMIT_BIT; // :167-168 (decided by the cell only)
+}
+
+GG_DEV uint32_t make_key(const Arena &a, int gi0, int gi1, int cls)
+{
+    const Geometry &g = a.g;
+    const uint32_t emit = (g.rows <= gi0 + 3 || g.cols <= gi1 + 3) ? 0u : KEY_EMIT_BIT; // :167-168 (decided by the cell only)
     const uint32_t tile = (uint32_t)a.tile_rank[(gi0 / TILE) + (gi1 / TILE) * g.tiles_r];
     return (tile << KEY_TILE_SHIFT) | emit | ((uint32_t)cls << KEY_CLASS_SHIFT) | (uint32_t)(gi0 % TILE) |
            ((uint32_t)(gi1 % TILE) << 4);
@@ -149,12 +164,19 @@ __global__ __launch_bounds__(256, 8) void k_classify(const Arena a, const CloudP
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int p = p0 + j * 64 + lane;
+            int cls = GG_CLASS_KEPT;
+            bool walk = false;
+            if (inmap_[j]) cls = classify_point(a, cp, pt[j], og[j], walk);
+            for (unsigned long long todo = __ballot(walk); todo != 0ull; todo &= todo - 1ull) { // (uniform loop, rarely entered)
+                const int src = __builtin_ctzll(todo);
+                const bool hit = ray_walk_hits(a, cp, gp2, __shfl(pt[j].x, src, 64), __shfl(pt[j].y, src, 64), __shfl(pt[j].z, src, 64), lane);
+                if (lane == src && hit) cls = GG_CLASS_OUTLIER;
+            }
             uint32_t key = KEY_OUTSIDE;
-            if (inmap_[j]) key = finish_point(a, cp, gp2, pt[j], gi0[j], gi1[j], og[j]);
+            if (inmap_[j]) key = make_key(a, gi0[j], gi1[j], cls);
             if (valid[j]) rec[p] = make_uint2(__float_as_uint(pt[j].z), key);
             const bool inmap = key != KEY_OUTSIDE;
             if (inmap) atomicAdd(&hist[key >> KEY_TILE_SHIFT], 1u);
-            const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
             const bool emit = inmap && (key & KEY_EMIT_BIT);
             n_inmap += (uint32_t)__popcll(__ballot(inmap));
             n_kept += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_KEPT));

@@ -86,6 +86,28 @@ def test_hdl64_full_size_three_frames():
     assert (r["cls"] == oracle.OUTLIER).sum() > 0  # warm map: the line-of-sight test fired
 
 
+def test_line_of_sight_walk_many_candidates():
+    """k_classify runs the ray walk of :246-275 cooperatively (64 steps of one point per wavefront pass); it must
+    decide exactly like the serial loop for short and long rays, rays leaving the map, and candidates in every lane."""
+    base = synth.hdl64_cloud(seed=12, n_az=900)
+    rng = np.random.default_rng(12)
+    low = synth.clone_cloud(base)
+    sel = rng.random(len(low)) < 0.2            # one point in five dives 0.3 .. 2.5 m under the surface
+    low["z"][sel] -= rng.uniform(0.3, 2.5, sel.sum()).astype(np.float32)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(base))
+    ref = oracle.OracleMap(120.0, 0.33)
+    n_out = 0
+    for f, (cloud, origin) in enumerate([(base, ORIGIN0), (low, ORIGIN0), (low, (7.5, -3.0, 0.4)), (low, (-80.0, 20.0, 1.0))]):
+        _, labels, index = seg.filter_cloud(cloud, origin, -1.73, return_details=True)
+        r = ref.filter_cloud(cloud, origin, -1.73)
+        cls, _ = seg.point_classes(len(cloud))
+        assert np.array_equal(cls, r["cls"]), f
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), f
+        assert_same_state(seg.map(0), ref)
+        n_out += int((r["cls"] == oracle.OUTLIER).sum())
+    assert n_out > 1000
+
+
 def test_hdl64_firing_order():
     run_pair(synth.hdl64_cloud(seed=5, order="azimuth"), frames=2)  # every consecutive point in another cell/tile
 
