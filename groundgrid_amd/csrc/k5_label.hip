@@ -130,18 +130,21 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                 label = (tolerance + (double)gh[j] < (double)z) ? GG_LABEL_NONGROUND : GG_LABEL_GROUND; // :173
                 idx = is_kept ? (int32_t)(kept_base + (uint32_t)rank_below(mk)) : (int32_t)(ign_base + (uint32_t)rank_below(mi));
             }
-            // :176 points(gi) += 1 per non-ground point.  Neighbouring lanes mostly hit the same cell, and same-address
-            // atomics serialise in L2: one hardware float atomic per distinct cell of the window, adding the lane count
-            // (exact: integer-valued floats < 2^24, order-free).
+            // :176 points(gi) += 1 per non-ground point.  Consecutive points of a scan line mostly fall into the same cell,
+            // and same-address atomics serialise in L2: every RUN of consecutive lanes with the same cell issues one
+            // hardware float atomic carrying the run length (exact: integer-valued floats < 2^24, order-free) -- one
+            // atomic instruction per window, no loop over cells.
             {
                 const bool ng = label == GG_LABEL_NONGROUND;
-                unsigned long long todo = __ballot(ng);
-                while (todo) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cidx[j], leader);
-                    const unsigned long long same = __ballot(ng && (uint32_t)cidx[j] == c0);
-                    if (lane == leader) unsafeAtomicAdd(&points[c0], (float)__popcll(same));
-                    todo &= ~same;
+                const uint32_t c = (uint32_t)cidx[j];
+                const uint32_t c_prev = (uint32_t)__shfl_up((int)c, 1, 64);
+                const unsigned long long ngm = __ballot(ng);
+                const bool joins = ng && lane > 0 && ((ngm >> (lane - 1)) & 1ull) && c == c_prev; // continues the previous lane's run
+                const unsigned long long jm = __ballot(joins);
+                if (ng && !joins) {
+                    const unsigned long long after = lane == 63 ? 0ull : ~(jm >> (lane + 1)); // first 1 bit = first lane that does not join
+                    const int run = 1 + (after ? __builtin_ctzll(after) : 63 - lane);
+                    unsafeAtomicAdd(&points[c], (float)run);
                 }
             }
             if (valid[j]) {
