@@ -109,4 +109,17 @@ GG_DEV void key_to_cell(const Arena &a, uint32_t key, int &row, int &col)
     col = tc * TILE + (int)((key >> 4) & 15u);
 }
 
+
+// XCD-aware work distribution.  The 8 XCDs (each with its own 4 MiB L2) receive work-groups round-robin by dispatch order,
+// so neighbouring blockIdx values land on DIFFERENT L2s: two tiles that share 128-byte lines would each leave half-written
+// lines in two caches.  This remaps the linear dispatch id so that XCD x works through one contiguous range of the
+// (cloud-major, item-minor) work list: consecutive items -- vertically adjacent tiles, the same cloud -- meet in one L2.
+// Returns the item index in [0, n_items).
+GG_DEV uint32_t xcd_contiguous_item(uint32_t lin, uint32_t n_items)
+{
+    const uint32_t xcd = lin & 7u, idx = lin >> 3;
+    const uint32_t q = n_items >> 3, r = n_items & 7u;
+    return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
 } // namespace gg

@@ -46,9 +46,12 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     __shared__ float hst[8][HMAX];               // running state of the delegated heavy cells (step 4); row 7 = count after the pass
     __shared__ uint16_t hseg[2][HMAX];           // their segment start / length in zsorted
 
-    const int cloud = blockIdx.y;
+    // (cloud, tile rank) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD,
+    // in Morton order, so vertically adjacent tiles complete each other's 128-byte layer lines in the same L2
+    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int cloud = (int)(item / gridDim.x);
     const CloudParams cp = params[cloud];
-    const int rank = blockIdx.x;
+    const int rank = (int)(item % gridDim.x);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int tile = a.rank_tile[rank];
