@@ -212,24 +212,25 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
             const uint32_t s0 = (uint32_t)hseg[0][lane], n = (uint32_t)hseg[1][lane];
             float hc = hst[0][lane]; // points before this pass
             float znext = zsorted[s0];
+            // (`hc` is an integer-valued float < 2^24: hc + 1.0f is the reference's (float)((double)hc + 1.0), :309)
             if (role == 0) {
-                float hmean = hst[1][lane], hm2 = hst[2][lane], hmn = hst[3][lane];
+                float hmean = hst[1][lane], hm2 = hst[2][lane], hmn0 = hst[3][lane]; // (min: here only without the other chains)
                 for (uint32_t i = 0; i < n; ++i) {
                     const float z = znext;
                     if (i + 1 < n) znext = zsorted[s0 + i + 1];
                     const float planeDist = z - oz;                   // :295
-                    if ((double)hmean == 0.0) hmean = planeDist;      // :298-299
+                    if (hmean == 0.0f) hmean = planeDist;             // :298-299
                     if (!isnan(planeDist)) {                          // :300
                         const float delta = planeDist - hmean;        // :301
                         hmean += delta / (hc + 1.0f);                 // :302
                         hm2 += delta * (planeDist - hmean);           // :304
                     }
-                    hmn = std_min(hmn, z - 0.0001f);                  // :308
-                    hc = (float)((double)hc + 1.0);                   // :309
+                    if (!FULL) hmn0 = std_min(hmn0, z - 0.0001f);     // :308
+                    hc += 1.0f;                                       // :309
                 }
+                if (!FULL) hst[3][lane] = hmn0;
                 hst[1][lane] = hmean;
                 hst[2][lane] = hm2;
-                hst[3][lane] = hmn;
                 hst[7][lane] = hc; // points after this pass (row 0 is still being read by the other two chains)
             } else if (role == 1) {
                 float hgc = hst[4][lane], hmx = hst[6][lane];
@@ -238,20 +239,22 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
                     if (i + 1 < n) znext = zsorted[s0 + i + 1];
                     hgc = (z + hc * hgc) / (hc + 1.0f);               // :296
                     hmx = std_max(hmx, z);                            // :307
-                    hc = (float)((double)hc + 1.0);
+                    hc += 1.0f;
                 }
                 hst[4][lane] = hgc;
                 hst[6][lane] = hmx;
             } else {
-                float hpdm = hst[5][lane];
+                float hpdm = hst[5][lane], hmn = hst[3][lane];
                 for (uint32_t i = 0; i < n; ++i) {
                     const float z = znext;
                     if (i + 1 < n) znext = zsorted[s0 + i + 1];
                     const float planeDist = z - oz;
                     if (!isnan(planeDist)) hpdm = (planeDist + hc * hpdm) / (hc + 1.0f); // :300, :303
-                    hc = (float)((double)hc + 1.0);
+                    hmn = std_min(hmn, z - 0.0001f);                  // :308
+                    hc += 1.0f;
                 }
                 hst[5][lane] = hpdm;
+                hst[3][lane] = hmn;
             }
         }
         __syncthreads();
