@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="independent (cloud, map) pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="independent (cloud, map) pairs per GPU per step")
     ap.add_argument("--minimal-layers", action="store_true", help="skip the four layers nothing in the path reads")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
@@ -218,14 +218,17 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
+                summary = json.load(open(pmc))
+                traffic = summary.get(dominant, {}).get("hbm_bytes_per_launch")
+                if traffic is not None and summary.get("batch") and summary["batch"] != B:
+                    traffic = int(traffic * B / summary["batch"])  # profile taken at another batch: per-cloud traffic x B
             except Exception:
                 traffic = None
         g = groups[dominant]
         result["roofline"] = {
             "kernel": dominant, "bound": "hbm", "achieved": g["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": g["frac_hbm"], "traffic": traffic,
-            "note": "K4_spiral is a 903-level dependent chain (latency-bound); its bytes/s is reported, not a bandwidth claim"
+            "note": "K4_spiral is a 905-level dependent chain (latency-bound); its bytes/s is reported, not a bandwidth claim"
             if dominant == "K4_spiral" else "",
         }
         result["kernels"] = groups

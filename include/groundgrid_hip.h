@@ -115,7 +115,7 @@ enum {
     GG_FLAG_MINIMAL_LAYERS = 1, /* skip the four layers nothing in the path reads (groundCandidates, planeDist,
                                    maxGroundHeight, meanVariance are still zero/initial-filled); default off */
     GG_FLAG_PROFILE = 2,        /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
-    GG_FLAG_SPIRAL_NARROW = 4   /* terrain sweep: always use the one-wavefront level schedule (default: batches >= 384) */
+    GG_FLAG_SPIRAL_NARROW = 4   /* terrain sweep: use the second exact schedule (levels of one wavefront); default off */
 };
 
 typedef struct gg_context gg_context;
