@@ -58,13 +58,16 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
     for (int t0 = 0; t0 < T; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
         uint32_t s = 0;
-        if (t < T)
+        if (t < T) {
+#pragma unroll 16
             for (int c = 0; c < nch; ++c) s += hist[(size_t)c * T + t];
+        }
         uint32_t total;
         const uint32_t excl = block_exclusive_scan(s, lds, total);
         if (t < T) {
             uint32_t running = carry + excl;
             tile_start[t] = running;
+#pragma unroll 16
             for (int c = 0; c < nch; ++c) {
                 const uint32_t h = hist[(size_t)c * T + t];
                 hist[(size_t)c * T + t] = running;
