@@ -114,11 +114,11 @@ GG_DEV uint32_t make_key(const Arena &a, int gi0, int gi1, int cls)
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256, 8) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
+__global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
 {
     extern __shared__ uint32_t lds_hist[]; // [4][T]
     const int cloud = blockIdx.y;
-    const CloudParams cp = params[cloud];
+    const CloudParams &cp = params[cloud]; // (a reference: the 12 transform doubles stay in memory unless has_tf)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * 4 + wave;
     const int n = cp.n_points;
