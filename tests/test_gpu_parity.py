@@ -108,6 +108,19 @@ def test_line_of_sight_walk_many_candidates():
     assert n_out > 1000
 
 
+@pytest.mark.parametrize("length,resolution", [(4.0, 0.33), (10.0, 0.5), (33.0, 0.33), (61.0, 0.25), (150.0, 0.25), (240.0, 0.33)])
+def test_geometries_from_tiny_to_wider_than_the_level_cap(length, resolution):
+    """Everything derived from the geometry on the host -- sort tiles, R1 table, the sweep's level schedule with its LDS
+    slot allocation (12 x 12 cells up to 727 x 727, whose widest hazard levels exceed the 512-lane cap and get split) --
+    must reproduce the CPU path; the cloud is scaled to cover the map."""
+    base = synth.hdl64_cloud(seed=19, n_az=500)
+    cloud = synth.clone_cloud(base)
+    k = np.float32(length / 120.0)
+    cloud["x"] *= k
+    cloud["y"] *= k
+    run_pair(cloud, length=length, resolution=resolution, frames=3)
+
+
 def test_hdl64_firing_order():
     run_pair(synth.hdl64_cloud(seed=5, order="azimuth"), frames=2)  # every consecutive point in another cell/tile
 
