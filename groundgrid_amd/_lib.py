@@ -38,6 +38,7 @@ SYMBOLS = [
     "gg_set_config", "gg_get_config", "gg_set_flags", "gg_get_size", "gg_get_geometry", "gg_last_error",
     "gg_reset_map", "gg_set_map_position", "gg_move_map", "gg_get_map_position", "gg_set_layer", "gg_get_layer", "gg_get_expected_points",
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
+    "gg_debug_replay_spiral_schedule",
 ]
 
 

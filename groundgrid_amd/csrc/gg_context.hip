@@ -509,6 +509,88 @@ extern "C" {
 
 int gg_abi_version(void) { return GG_ABI_VERSION; }
 
+// Testing hook (no GPU needed): build the terrain sweep's level schedule for an n x n grid and EXECUTE it on the host with
+// the semantics k_spiral relies on -- entries of a level are mutually independent, values travel through the LDS slots the
+// descriptors name, pre-sweep cells are read from the layer as it was BEFORE the sweep -- then store like the kernel.
+// `gp2` is the interleaved (ground, groundpatch) layer [n * n][2], updated in place.  Returns 0, or a negative code when
+// the schedule breaks one of its own rules (-2: a slot read in the level it was written by another entry, -3: a slot read
+// before anything was written to it, -4: slot out of range).  tests/test_spiral_schedule_cpu.py compares the result with
+// the serial sweep of the oracle.
+int gg_debug_replay_spiral_schedule(int n, double resolution, float min_dist_squared, int cap, float *gp2, float base_z, double decrease)
+{
+    if (n < 8 || !gp2 || cap < 1) return GG_ERR_INVALID;
+    std::vector<SpiralVisit> visits;
+    std::vector<uint32_t> level_start;
+    int max_width = 0, n_slots = 0;
+    build_spiral_schedule(n, resolution, min_dist_squared, cap, visits, level_start, max_width, n_slots);
+    const int n_levels = (int)level_start.size() - 1;
+    const int center = n / 2 - 1;
+    gp2[2 * (size_t)(center + center * n)] = base_z; // :405
+    gp2[2 * (size_t)(center + center * n) + 1] = 1.0f;
+    const std::vector<float> before(gp2, gp2 + (size_t)2 * n * n);
+    struct Slot { float g = 0.f, w = 0.f; int level = 0; int64_t writer = -1; };
+    std::vector<Slot> lds((size_t)n_slots);
+    auto tree9h = [](const float *e) { return ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + (e[7] + e[8]))); };
+    struct Out { uint32_t slot; float g, w; bool store; uint32_t cell; };
+    for (int l = 0; l < n_levels; ++l) {
+        const int level = l + 1;
+        std::vector<Out> outs;
+        // phase 1: every entry parks its fetched cells in its own block ...
+        for (uint32_t v = level_start[l]; v < level_start[l + 1]; ++v) {
+            const SpiralVisit &d = visits[v];
+            const int cell = (int)(d.cell_flags & 0xFFFFFFu);
+            if (d.stage != SPIRAL_NONE)
+                for (int p = 0; p < 3; ++p) {
+                    if (d.pair[p] == SPIRAL_NO_PAIR) continue;
+                    for (int el = 0; el < 2; ++el) {
+                        const size_t s_ = (size_t)d.stage + 2 * p + el, c = (size_t)(cell + d.pair[p] + el);
+                        if (s_ >= lds.size() || c >= (size_t)n * n) return -4;
+                        lds[s_] = Slot{before[2 * c], before[2 * c + 1], level, (int64_t)v};
+                    }
+                }
+        }
+        // ... phase 2: every visit reads its nine inputs; results are applied only after the whole level has read
+        for (uint32_t v = level_start[l]; v < level_start[l + 1]; ++v) {
+            const SpiralVisit &d = visits[v];
+            const uint32_t flags = d.cell_flags >> 24, cell = d.cell_flags & 0xFFFFFFu;
+            if (flags & SPIRAL_HELPER) continue;
+            float g[9], w[9], pr[9];
+            for (int q = 0; q < 9; ++q) {
+                if (d.src[q] >= lds.size()) return -4;
+                const Slot &sl = lds[d.src[q]];
+                if (sl.level == 0) return -3;
+                if (sl.level == level && sl.writer != (int64_t)v) return -2;
+                g[q] = sl.g;
+                w[q] = sl.w;
+            }
+            const float height = g[4], occupied = w[4];
+            const float gvlSum = tree9h(w) + FLT_MIN;
+            for (int q = 0; q < 9; ++q) pr[q] = w[q] * g[q];
+            const float avg = tree9h(pr) / gvlSum;
+            const float new_g = (1.0f - occupied) * avg + occupied * height;
+            float new_w = occupied;
+            if (flags & SPIRAL_DECAY) {
+                const double t = (double)occupied - (double)occupied / decrease;
+                new_w = (float)(t < 0.001 ? 0.001 : t);
+            }
+            outs.push_back(Out{d.wslot, new_g, new_w, (flags & SPIRAL_STORE) != 0, cell});
+        }
+        for (size_t k = 0, v = level_start[l]; k < outs.size(); ++v) {
+            if ((visits[v].cell_flags >> 24) & SPIRAL_HELPER) continue;
+            const Out &o = outs[k++];
+            if (o.slot != SPIRAL_NONE) {
+                if (o.slot >= lds.size()) return -4;
+                lds[o.slot] = Slot{o.g, o.w, level, (int64_t)v};
+            }
+            if (o.store) {
+                gp2[2 * (size_t)o.cell] = o.g;
+                gp2[2 * (size_t)o.cell + 1] = o.w;
+            }
+        }
+    }
+    return GG_OK;
+}
+
 const char *gg_kernel_name(int k)
 {
     static const char *names[GG_NUM_KERNELS] = {"k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_spiral", "k_label"};

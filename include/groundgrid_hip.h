@@ -243,6 +243,12 @@ int gg_get_kernel_times(gg_context *ctx, double ms[GG_NUM_KERNELS], int64_t laun
 const char *gg_kernel_name(int k);
 int gg_abi_version(void);
 
+/* Testing hook, runs on the host (no GPU): builds the terrain sweep's level schedule for an n x n grid with `cap` visits
+ * per level and executes it with the hand-over rules the sweep kernel relies on; gp2 = interleaved (ground, groundpatch)
+ * [n*n][2], updated in place like spiral_ground_interpolation (src/GroundSegmentation.cpp:398-465) would.  0 or < 0. */
+int gg_debug_replay_spiral_schedule(int n, double resolution, float min_dist_squared, int cap, float *gp2, float base_z,
+                                    double occupied_cells_decrease_factor);
+
 #ifdef __cplusplus
 }
 #endif
