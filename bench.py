@@ -109,7 +109,9 @@ def main():
     B = args.batch
     clouds = make_clouds(B, rank)
     n_points = [len(c) for c in clouds]
-    stride = max(n_points)
+    from groundgrid_amd.dist import common_stride
+
+    stride = common_stride(max(n_points), device=dev)  # one shape on every rank; multiple of 64 (2-bit masks need 4)
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride, device=local_rank)
     seg.set_flags(minimal_layers=args.minimal_layers, profile=not args.no_profile)
 
@@ -122,7 +124,7 @@ def main():
     # Double-buffered outputs: the all-gather of step i's label masks (RCCL's own stream, async_op) overlaps step i+1's
     # kernels; buffer i % 2 is reused only after its gather completed.
     outs = [None, None]
-    gathered = [torch.empty((world * B, stride), dtype=torch.uint8, device=dev) for _ in range(2)] if dist else None
+    gathered = [torch.empty((world * B, stride // 4), dtype=torch.uint8, device=dev) for _ in range(2)] if dist else None
     pending = [None, None]
     step_no = 0
     out = None
@@ -133,10 +135,10 @@ def main():
         if pending[k] is not None:
             pending[k].wait()  # orders the compute stream after the gather that still reads outs[k].labels
             pending[k] = None
-        outs[k] = seg.filter_batch(points, n_points, origins, base_z, out=outs[k])
+        outs[k] = seg.filter_batch(points, n_points, origins, base_z, out=outs[k], want_masks=dist is not None)
         out = outs[k]
         if dist:
-            pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k].labels, async_op=True)
+            pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k].label_masks, async_op=True)  # 2 bits per point
         step_no += 1
 
     def fence():
@@ -184,7 +186,7 @@ def main():
         "config": {
             "workload": "BASELINE configs[1]: synthetic Velodyne HDL-64E cloud, 364x364 grid @ 0.33 m, "
                         f"{B} independent (cloud, map-state) pairs per GPU per step, warm map state"
-                        + ("; + RCCL all-gather of label masks per step (configs[2])" if world > 1 else ""),
+                        + ("; + RCCL all-gather of the 2-bit label masks per step (configs[2])" if world > 1 else ""),
             "clouds_per_gpu_per_step": B,
             "points_per_cloud_mean": int(np.mean(n_points)),
             "grid": "364x364",

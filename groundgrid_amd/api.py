@@ -138,6 +138,7 @@ class BatchOutputs:
     out_index: "object"   # torch.int32 [B, stride]
     counts: "object"      # torch.int32 [B, 4]: returned size, kept, ignored, outliers
     out_clouds: "object" = None
+    label_masks: "object" = None  # torch.uint8 [B, stride // 4]: 2 bits per point (0 dropped, 1 ground, 2 non-ground)
 
 
 class GroundSegmentation:
@@ -267,7 +268,8 @@ class GroundSegmentation:
 
     # -- batched device-resident form
     def filter_batch(self, points, n_points: Sequence[int], origins, base_z, *, first_slot: int = 0,
-                     out: Optional[BatchOutputs] = None, want_clouds: bool = False, stream=None, transforms=None) -> BatchOutputs:
+                     out: Optional[BatchOutputs] = None, want_clouds: bool = False, want_masks: bool = False, stream=None,
+                     transforms=None) -> BatchOutputs:
         """points: CUDA torch tensor [B, stride, 16] (packed gg_point16) or [B, stride, 32] (PointXYZIR), uint8.
         Enqueues on the current torch stream and returns without synchronising."""
         import torch
@@ -283,6 +285,7 @@ class GroundSegmentation:
                 out_index=torch.empty((B, stride), dtype=torch.int32, device=points.device),
                 counts=torch.empty((B, 4), dtype=torch.int32, device=points.device),
                 out_clouds=torch.empty((B, stride, 32), dtype=torch.uint8, device=points.device) if want_clouds else None,
+                label_masks=torch.zeros((B, stride // 4), dtype=torch.uint8, device=points.device) if want_masks else None,
             )
         npts = (C.c_int32 * B)(*[int(v) for v in n_points])
         org = np.ascontiguousarray(np.asarray(origins, dtype=np.float32).reshape(B, 3))
@@ -300,6 +303,7 @@ class GroundSegmentation:
         b.d_out_index = out.out_index.data_ptr()
         b.d_out_clouds = out.out_clouds.data_ptr() if out.out_clouds is not None else None
         b.d_out_counts = out.counts.data_ptr()
+        b.d_label_masks = out.label_masks.data_ptr() if out.label_masks is not None else None
         s = stream if stream is not None else torch.cuda.current_stream(points.device).cuda_stream
         rc = self._L.gg_filter_batch(self._ctx, C.byref(b), C.c_void_p(s))
         _check(self._L, self._ctx, rc, "gg_filter_batch")

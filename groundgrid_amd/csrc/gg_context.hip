@@ -469,6 +469,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     io.d_out_index = b->d_out_index;
     io.d_out_clouds = b->d_out_clouds;
     io.d_out_counts = b->d_out_counts;
+    io.d_label_masks = b->d_label_masks;
 
     Arena a = ctx->arena;
     a.flags = ctx->flags;
@@ -1118,6 +1119,7 @@ int gg_filter_batch(gg_context *ctx, const gg_batch *b, void *stream)
     if (!b->d_points || !b->n_points || !b->origins || !b->base_z) return fail(ctx, GG_ERR_INVALID, "null batch field");
     if (b->point_format != GG_POINT32 && b->point_format != GG_POINT16) return fail(ctx, GG_ERR_INVALID, "point_format");
     if (b->d_out_clouds && b->point_format != GG_POINT32) return fail(ctx, GG_ERR_INVALID, "d_out_clouds needs GG_POINT32 input");
+    if (b->d_label_masks && (b->cloud_stride & 3u)) return fail(ctx, GG_ERR_INVALID, "d_label_masks needs cloud_stride % 4 == 0");
     for (int i = 0; i < b->n_clouds; ++i)
         if (b->n_points[i] < 0 || (size_t)b->n_points[i] > ctx->max_points || (size_t)b->n_points[i] > b->cloud_stride)
             return fail(ctx, GG_ERR_CAPACITY, "n_points exceeds max_points / cloud_stride");

@@ -142,6 +142,7 @@ struct BatchIO {
     int32_t *d_out_index;
     gg_point32 *d_out_clouds;
     int32_t *d_out_counts;
+    uint8_t *d_label_masks;
 };
 
 // kernel launchers (one per .hip file)

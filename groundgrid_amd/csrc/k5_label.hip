@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
     const uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
     const char *pts = reinterpret_cast<const char *>(io.d_points) + (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
     uint8_t *labels = io.d_labels ? io.d_labels + (size_t)cloud * io.cloud_stride : nullptr;
+    uint8_t *masks = io.d_label_masks ? io.d_label_masks + (size_t)cloud * ((io.cloud_stride + 3) / 4) : nullptr;
     int32_t *out_index = io.d_out_index ? io.d_out_index + (size_t)cloud * io.cloud_stride : nullptr;
     gg_point32 *out_cloud = (FMT == GG_POINT32 && io.d_out_clouds) ? io.d_out_clouds + (size_t)cloud * io.cloud_stride : nullptr;
 
@@ -146,6 +147,12 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                     const int run = 1 + (after ? __builtin_ctzll(after) : 63 - lane);
                     unsafeAtomicAdd(&points[c], (float)run);
                 }
+            }
+            if (masks) { // 2-bit label mask, four points per byte: lanes 4k .. 4k+3 -> lane 4k (windows start at multiples of 64)
+                const uint32_t code = !valid[j] ? 0u : label == GG_LABEL_GROUND ? 1u : label == GG_LABEL_NONGROUND ? 2u : 0u;
+                const uint32_t b4 = code | ((uint32_t)__shfl_down((int)code, 1, 64) << 2) | ((uint32_t)__shfl_down((int)code, 2, 64) << 4) |
+                                    ((uint32_t)__shfl_down((int)code, 3, 64) << 6);
+                if ((lane & 3) == 0 && p < (int)io.cloud_stride) masks[p >> 2] = (uint8_t)b4;
             }
             if (valid[j]) {
                 if (labels) labels[p] = label;

@@ -44,3 +44,38 @@ def all_gather_label_masks(labels, counts=None, group=None):
     cparts = [torch.empty_like(counts) for _ in range(world)]
     dist.all_gather(cparts, counts.contiguous(), group=group)
     return out, torch.cat(cparts, dim=0)
+
+
+def unpack_label_masks(masks, stride=None):
+    """[N, S/4] uint8 2-bit masks (gg_batch.d_label_masks) -> [N, S] uint8 labels 0 / 49 / 99.  Pure torch (any device)."""
+    import torch
+
+    shifts = torch.tensor([0, 2, 4, 6], dtype=torch.uint8, device=masks.device)
+    codes = (masks.unsqueeze(-1) >> shifts) & 3
+    lut = torch.tensor([0, 49, 99, 0], dtype=torch.uint8, device=masks.device)
+    out = lut[codes.long()].reshape(masks.shape[0], -1)
+    return out if stride is None else out[:, :stride]
+
+
+def pack_label_masks(labels):
+    """Inverse of unpack_label_masks, pure torch (CPU tests; on the GPU the masks come straight out of k_label)."""
+    import torch
+
+    n, s = labels.shape
+    assert s % 4 == 0
+    codes = ((labels == 49).to(torch.uint8) + 2 * (labels == 99).to(torch.uint8)).reshape(n, s // 4, 4)
+    return codes[..., 0] | (codes[..., 1] << 2) | (codes[..., 2] << 4) | (codes[..., 3] << 6)
+
+
+def common_stride(local_max_points: int, group=None, device=None, multiple: int = 64) -> int:
+    """Per-cloud buffer length every rank agrees on: the largest cloud anywhere, rounded up (the gathered masks need one
+    shape on all ranks, and the 2-bit masks a multiple of 4).  One tiny all-reduce(MAX)."""
+    import torch
+    import torch.distributed as dist
+
+    stride = (int(local_max_points) + multiple - 1) // multiple * multiple
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.tensor([stride], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        stride = int(t.item())
+    return stride

@@ -202,6 +202,10 @@ typedef struct gg_batch {
     int32_t *d_out_index;    /* [n_clouds][cloud_stride], nullable */
     gg_point32 *d_out_clouds; /* [n_clouds][cloud_stride], nullable; needs point_format == GG_POINT32 */
     int32_t *d_out_counts;   /* [n_clouds][4]: returned-cloud size, kept, ignored, outliers; nullable */
+    uint8_t *d_label_masks;  /* [n_clouds][(cloud_stride + 3) / 4], nullable: the labels as a 2-bit mask, point p in bits
+                                2*(p%4).. of byte p/4: 0 dropped, 1 ground (49), 2 non-ground (99) -- what a multi-GPU
+                                caller all-gathers (a quarter of d_labels).  cloud_stride must be a multiple of 4; only the bytes
+                                covering points < n_points (rounded up to a multiple of 64) are written */
 } gg_batch;
 int gg_filter_batch(gg_context *ctx, const gg_batch *batch, void *stream);
 int gg_synchronize(gg_context *ctx);

@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from groundgrid_amd.dist import all_gather_label_masks, owner_of, shard_range
+from groundgrid_amd.dist import (all_gather_label_masks, common_stride, owner_of, pack_label_masks, shard_range,
+                                 unpack_label_masks)
 
 
 def test_shard_range_covers_every_cloud_once():
@@ -58,6 +59,16 @@ def _worker(rank, world, port, n_clouds, stride, q):
     for b in range(n_clouds):
         lab, n = _expected_labels(b, stride)
         ok &= bool(np.array_equal(g[b].numpy(), lab)) and int(c[b, 0]) == n
+    # what bench.py does at N > 1: every rank has its own largest cloud, the ranks agree on one stride, and the labels travel
+    # as 2-bit masks (a quarter of the bytes)
+    local_max = 250 + 7 * rank
+    cs = common_stride(local_max)
+    ok &= cs == 320 and cs % 4 == 0
+    wide = torch.zeros((cnt, cs), dtype=torch.uint8)
+    wide[:, :stride] = labels
+    gm = all_gather_label_masks(pack_label_masks(wide))
+    ok &= tuple(gm.shape) == (n_clouds, cs // 4)
+    ok &= bool(torch.equal(unpack_label_masks(gm, stride), g))
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok, tuple(g.shape)))
@@ -77,3 +88,12 @@ def test_all_gather_of_label_masks_world2():
         assert p.exitcode == 0
     for rank, ok, shape in res:
         assert ok and shape == (n_clouds, stride), (rank, ok, shape)
+
+
+def test_label_mask_packing_round_trip():
+    rng = np.random.default_rng(3)
+    lab = torch.from_numpy(rng.choice(np.array([0, 49, 99], dtype=np.uint8), size=(5, 64)))
+    m = pack_label_masks(lab)
+    assert m.shape == (5, 16) and m.dtype == torch.uint8
+    assert torch.equal(unpack_label_masks(m), lab)
+    assert int(m[0, 0]) == sum(({0: 0, 49: 1, 99: 2}[int(lab[0, k])]) << (2 * k) for k in range(4))

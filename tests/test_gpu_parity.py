@@ -231,6 +231,32 @@ def test_batched_independent_maps(fmt):
     assert (seg.map(0)["ground"] == 0).all()
 
 
+def test_two_bit_label_masks_from_the_label_kernel():
+    """gg_batch.d_label_masks: what a multi-GPU caller all-gathers (groundgrid_amd/dist.py) -- the labels, 2 bits per point."""
+    import torch
+    from groundgrid_amd.dist import pack_label_masks, unpack_label_masks
+
+    clouds = [synth.hdl64_cloud(seed=200 + k, n_az=250 + 41 * k) for k in range(4)] + [synth.empty_cloud(0)]
+    B, stride = len(clouds), (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride)
+    pts = _batch_inputs(16, clouds, stride)
+    out = None
+    for _ in range(2):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73), out=out, want_masks=True)
+    torch.cuda.synchronize()
+    labels = out.labels.cpu()
+    for b, c in enumerate(clouds):
+        n = len(c)
+        nb = (n + 3) // 4
+        want = torch.zeros(stride, dtype=torch.uint8)
+        want[:n] = labels[b, :n]
+        assert torch.equal(out.label_masks[b, :nb].cpu(), pack_label_masks(want[None, :])[0, :nb]), b
+        assert torch.equal(unpack_label_masks(out.label_masks[b : b + 1].cpu(), stride)[0, :n], labels[b, :n]), b
+    with pytest.raises(api.GroundGridError):  # a stride that is not a multiple of 4 cannot carry masks
+        bad = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=1002)
+        bad.filter_batch(_batch_inputs(16, [synth.empty_cloud(0)], 1002), [0], np.zeros((1, 3), np.float32), np.full(1, -1.73), want_masks=True)
+
+
 def test_minimal_layers_flag_keeps_labels_and_terrain():
     cloud = synth.hdl64_cloud(seed=8, n_az=600)
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
