@@ -337,7 +337,8 @@ void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::v
                     else b_ = n_blk[cls]++;
                     blk_cls[id] = cls;
                     blk_idx[id] = b_;
-                    rel_blk[(size_t)std::max(last_blk[id], (int)l) + 1].push_back({cls, b_});
+                    // (+ 2: k_spiral writes a block one barrier interval BEFORE its level, while the previous level still reads)
+                    rel_blk[std::min((size_t)std::max(last_blk[id], (int)l) + 2, (size_t)n_levels + 1)].push_back({cls, b_});
                 }
             }
         }
@@ -515,7 +516,7 @@ int gg_abi_version(void) { return GG_ABI_VERSION; }
 // descriptors name, pre-sweep cells are read from the layer as it was BEFORE the sweep -- then store like the kernel.
 // `gp2` is the interleaved (ground, groundpatch) layer [n * n][2], updated in place.  Returns 0, or a negative code when
 // the schedule breaks one of its own rules (-2: a slot read in the level it was written by another entry, -3: a slot read
-// before anything was written to it, -4: slot out of range).  tests/test_spiral_schedule_cpu.py compares the result with
+// before anything was written to it, -4: slot out of range, -5: a slot read after the next level's early block write took it).  tests/test_spiral_schedule_cpu.py compares the result with
 // the serial sweep of the oracle.
 int gg_debug_replay_spiral_schedule(int n, double resolution, float min_dist_squared, int cap, float *gp2, float base_z, double decrease)
 {
@@ -536,8 +537,10 @@ int gg_debug_replay_spiral_schedule(int n, double resolution, float min_dist_squ
     for (int l = 0; l < n_levels; ++l) {
         const int level = l + 1;
         std::vector<Out> outs;
-        // phase 1: every entry parks its fetched cells in its own block ...
-        for (uint32_t v = level_start[l]; v < level_start[l + 1]; ++v) {
+        // phase 1: the entries of the NEXT level park their fetched cells in their blocks (the kernel does that one barrier
+        // interval early, concurrently with this level's reads; level 1's own blocks are written before the loop) ...
+        for (uint32_t v = (l == 0 ? level_start[0] : level_start[l + 1]); v < (l + 2 <= n_levels ? level_start[l + 2] : level_start[l + 1]); ++v) {
+            const int level = (v < level_start[l + 1]) ? l + 1 : l + 2;
             const SpiralVisit &d = visits[v];
             const int cell = (int)(d.cell_flags & 0xFFFFFFu);
             if (d.stage != SPIRAL_NONE)
@@ -561,6 +564,7 @@ int gg_debug_replay_spiral_schedule(int n, double resolution, float min_dist_squ
                 const Slot &sl = lds[d.src[q]];
                 if (sl.level == 0) return -3;
                 if (sl.level == level && sl.writer != (int64_t)v) return -2;
+                if (sl.level > level) return -5; // overwritten by a block of the next level, which is parked one interval early
                 g[q] = sl.g;
                 w[q] = sl.w;
             }
@@ -712,28 +716,51 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 
     std::vector<SpiralVisit> visits[2];
     std::vector<uint32_t> level_start[2];
-    int caps[2] = {512, 64}; // k_spiral runs two wave sets of `cap` lanes: 2 * 512 = the largest work-group
+    int caps[2] = {448, 64}; // k_spiral runs two compute sets of `cap` lanes + a loader wave: 2 * 448 + 64 threads at most
     if (const char *e = getenv("GG_SPIRAL_CAPS")) { // tuning knob: "<latency schedule cap>,<throughput schedule cap>"
         int c0 = 0, c1 = 0;
-        if (sscanf(e, "%d,%d", &c0, &c1) == 2 && c0 >= 64 && c0 <= 512 && c1 >= 64 && c1 <= 512) {
+        if (sscanf(e, "%d,%d", &c0, &c1) == 2 && c0 >= 64 && c0 <= 448 && c1 >= 64 && c1 <= 448) {
             caps[0] = c0;
             caps[1] = c1;
         }
     }
     for (int v = 0; v < 2; ++v) {
-        int max_width = 0, spiral_slots = 0;
-        build_spiral_schedule(n, res, geom.min_dist_squared, caps[v], visits[v], level_start[v], max_width, spiral_slots);
-        if (getenv("GG_DEBUG_SCHEDULE"))
-            fprintf(stderr, "groundgrid_hip: spiral schedule %d (cap %d): %zu entries (%zu visits), %zu levels, widest %d, %d LDS slots\n", v, caps[v],
-                    visits[v].size(), (size_t)((size_t)(n / 2 - 2) * ((size_t)(n / 2 - 2) + 1) * 4 + 2 * (size_t)(n / 2 - 2)), level_start[v].size() - 1, max_width, spiral_slots);
-        a.sched[v].n_levels = (int)level_start[v].size() - 1;
-        a.sched[v].max_level_width = max_width;
-        a.sched[v].slots = spiral_slots;
-        a.sched[v].pad_ = 0;
-        if (spiral_slots >= (int)SPIRAL_NONE || n + 1 > 32766 || (size_t)spiral_slots * 8 > 150 * 1024 || (size_t)n * n >= (1u << 24) ||
-            max_width > 512) {
+        // the level cap is lowered until the schedule's LDS demand (value slots + the descriptor ring of k_spiral) and the
+        // work-group (2 x cap + 64 threads) fit: 448 suffices up to ~730 x 730, larger grids get narrower levels
+        static const int fallback[] = {448, 384, 320, 256, 192, 128, 64};
+        bool fits = false;
+        for (int attempt = -1; attempt < (int)(sizeof fallback / sizeof fallback[0]) && !fits; ++attempt) {
+            const int cap = attempt < 0 ? caps[v] : fallback[attempt];
+            if (attempt >= 0 && cap >= caps[v]) continue;
+            int max_width = 0, spiral_slots = 0;
+            build_spiral_schedule(n, res, geom.min_dist_squared, cap, visits[v], level_start[v], max_width, spiral_slots);
+            if (getenv("GG_DEBUG_SCHEDULE"))
+                fprintf(stderr, "groundgrid_hip: spiral schedule %d (cap %d): %zu entries, %zu levels, widest %d, %d LDS slots, %zu B of LDS\n", v, cap,
+                        visits[v].size(), level_start[v].size() - 1, max_width, spiral_slots, spiral_lds_bytes(spiral_slots, max_width));
+            a.sched[v].n_levels = (int)level_start[v].size() - 1;
+            a.sched[v].max_level_width = max_width;
+            a.sched[v].slots = spiral_slots;
+            a.sched[v].pad_ = 0;
+            for (int k = 0; k < 8; ++k) {
+                a.sched[v].first_wide[k] = a.sched[v].n_levels;
+                a.sched[v].last_wide[k] = -1;
+                for (int l = 0; l < a.sched[v].n_levels; ++l)
+                    if ((int)(level_start[v][l + 1] - level_start[v][l]) > 64 * k) {
+                        if (a.sched[v].first_wide[k] == a.sched[v].n_levels) a.sched[v].first_wide[k] = l;
+                        a.sched[v].last_wide[k] = l;
+                    }
+            }
+            if (getenv("GG_DEBUG_SCHEDULE"))
+                for (int k = 0; k < 8; ++k) {
+                    int wide = 0;
+                    for (int l = 0; l < a.sched[v].n_levels; ++l) wide += (int)(level_start[v][l + 1] - level_start[v][l]) > 64 * k;
+                    if (wide) fprintf(stderr, "groundgrid_hip:   wavefront %d of a set: levels %d..%d, %d of them wider than %d\n", k, a.sched[v].first_wide[k], a.sched[v].last_wide[k], wide, 64 * k);
+                }
+            fits = spiral_slots < (int)SPIRAL_NONE && max_width <= 448 && spiral_lds_bytes(spiral_slots, max_width) <= 158 * 1024;
+        }
+        if (!fits || n + 1 > 32766 || (size_t)n * n >= (1u << 24)) {
             gg_destroy(ctx);
-            return GG_ERR_GEOMETRY; // the spiral's fresh-value window no longer fits LDS
+            return GG_ERR_GEOMETRY; // the sweep's LDS window no longer fits
         }
     }
 
@@ -762,7 +789,6 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t Npad = align_up(max_points * 8, A) / 8;
     const size_t o_expected = carve(C * 4);
     size_t o_visits[2], o_lstart[2];
-    std::vector<char> soa[2]; // must outlive the async copies below
     for (int v = 0; v < 2; ++v) {
         o_visits[v] = carve(visits[v].size() * sizeof(SpiralVisit));
         o_lstart[v] = carve(level_start[v].size() * 4);
@@ -825,17 +851,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
     for (int v = 0; v < 2; ++v) {
-        {
-            // device layout: the first 16 bytes of all descriptors, then the second 16 bytes of all descriptors -- a
-            // wavefront's 16-byte loads then cover whole cache lines instead of every other half line
-            const size_t ne = visits[v].size();
-            soa[v].resize(ne * sizeof(SpiralVisit));
-            for (size_t i = 0; i < ne; ++i) {
-                memcpy(soa[v].data() + i * 16, reinterpret_cast<const char *>(&visits[v][i]), 16);
-                memcpy(soa[v].data() + (ne + i) * 16, reinterpret_cast<const char *>(&visits[v][i]) + 16, 16);
-            }
-        }
-        CREATE_CHK(hipMemcpyAsync(base + o_visits[v], soa[v].data(), soa[v].size(), hipMemcpyHostToDevice, ctx->stream));
+        CREATE_CHK(hipMemcpyAsync(base + o_visits[v], visits[v].data(), visits[v].size() * sizeof(SpiralVisit), hipMemcpyHostToDevice, ctx->stream));
         CREATE_CHK(hipMemcpyAsync(base + o_lstart[v], level_start[v].data(), level_start[v].size() * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));

@@ -84,6 +84,8 @@ struct SpiralSched {
     int max_level_width;          // visits per level <= this (the work-group size is its round-up to 64)
     int slots;                    // LDS slots the fresh-value window needs
     int pad_;
+    int first_wide[8], last_wide[8]; // first / last level (0-based) with more than 64 * k entries: wavefront k of a compute set of
+                                     // k_spiral has nothing to do outside [first_wide[k], last_wide[k]]
 };
 
 // per-cloud parameters of one batched call (device array, one entry per cloud of the batch)
@@ -152,6 +154,7 @@ void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, i
 void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
+size_t spiral_lds_bytes(int slots, int max_level_width); // dynamic LDS k_spiral needs for a schedule (k4_spiral.hip)
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
