@@ -44,6 +44,7 @@ struct gg_context {
     size_t arena_bytes = 0;
     std::vector<float> h_expected;
     std::vector<double> pos_x, pos_y; // per slot map position
+    std::vector<char> no_confidence;  // per slot: groundpatch <= 0.01 everywhere for sure (set by gg_reset_map, cleared by any writer)
 
     // per-call parameter ring (pinned host + device)
     CloudParams *h_params = nullptr; // [PARAM_RING][n_slots] pinned
@@ -456,7 +457,8 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
         p.pos_x = ctx->pos_x[slot];
         p.pos_y = ctx->pos_y[slot];
         p.has_tf = b->transforms ? 1 : 0;
-        p.pad_ = 0;
+        p.no_confidence = ctx->no_confidence[slot] ? 1 : 0;
+        ctx->no_confidence[slot] = 0; // the sweep of this call writes confidences
         for (int k = 0; k < 12; ++k) p.tf[k] = b->transforms ? b->transforms[(size_t)i * 12 + k] : 0.0;
         max_n = std::max(max_n, p.n_points);
     }
@@ -667,6 +669,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->max_points = max_points;
     gg_default_config(&ctx->cfg);
     ctx->pos_x.assign(n_slots, 0.0);
+    ctx->no_confidence.assign(n_slots, 0); // layers start as zeros, but only gg_reset_map makes a slot usable
     ctx->pos_y.assign(n_slots, 0.0);
 
 #define CREATE_CHK(call)                                             \
@@ -947,6 +950,7 @@ const char *gg_last_error(const gg_context *ctx) { return ctx ? ctx->last_error.
 int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float odom_z)
 {
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    ctx->no_confidence[slot] = 1; // groundpatch := 1e-7 everywhere (scrolling keeps that: exposed cells get 0)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->pos_x[slot] = pos_x;
     ctx->pos_y[slot] = pos_y;
@@ -1009,6 +1013,7 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if (!src || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (layer == GG_LAYER_GROUNDPATCH) ctx->no_confidence[slot] = 0;
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) { // de-interleave at the host boundary
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
         launch_plane_insert(gp2_ptr(ctx->arena, slot), layer == GG_LAYER_GROUNDPATCH, ctx->d_image, (size_t)ctx->arena.g.C, ctx->stream);

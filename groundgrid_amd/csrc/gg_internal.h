@@ -96,7 +96,8 @@ struct CloudParams {
     float base_z;   // (float)translation.z
     double pos_x, pos_y;
     int has_tf;     // points are in the sensor frame: p_map = (float)(R p + t) first (src/GroundGridNodelet.cpp:166-181)
-    int pad_;
+    int no_confidence; // the slot's groundpatch layer is known to hold nothing above 0.01 (fresh or only scrolled since
+                    // gg_reset_map): the line-of-sight test (:269 needs groundpatch(I) > 0.01f) cannot fire, K1 skips the walks
     double tf[12];  // map <- cloud frame, 3x4 row-major (R | t)
 };
 

@@ -14,6 +14,8 @@
 
 namespace gg {
 
+constexpr int WALK_COOPERATIVE_MAX = 12; // candidates per 64-point window up to which their rays are walked cooperatively
+
 struct PointIn {
     float x, y, z;
     int ring;
@@ -59,7 +61,10 @@ GG_DEV int classify_point(const Arena &a, const CloudParams &cp, const PointIn &
     const float sqdist = (float)((double)dx * (double)dx + (double)dy * (double)dy); // :223
     walk = false;
     if (pt.ring > a.cfg.max_ring || sqdist < a.g.min_dist_squared) return GG_CLASS_IGNORED; // :237
-    walk = (double)pt.z < (double)oldgroundheight - 0.2; // :243-244 Outlier detection test
+    // :243-244 Outlier detection test.  (A map that holds no confidence above 0.01 anywhere -- the first cloud after
+    // gg_reset_map -- cannot produce an outlier, :269: the walk is skipped instead of marching every ground return's ray
+    // to its end.)
+    walk = !cp.no_confidence && (double)pt.z < (double)oldgroundheight - 0.2;
     return GG_CLASS_KEPT;
 }
 
@@ -101,6 +106,39 @@ GG_DEV bool ray_walk_hits(const Arena &a, const CloudParams &cp, const float2 *_
         }
         if (__ballot(hit) != 0ull) return true;
         if (__ballot(on_ray) != ~0ull) return false; // the ray ended inside this group of steps
+    }
+}
+
+// The same walk, one point per lane, serially (the reference's loop as written).  Used when most lanes of a window are
+// candidates -- a freshly initialised map has ground = 0, so every return from the road surface is "below ground" -- where
+// 64 lanes walking their own rays in parallel beat 64 cooperative walks one after the other.
+GG_DEV bool ray_walk_hits_lane(const Arena &a, const CloudParams &cp, const float2 *__restrict__ gp2, float px, float py, float pz)
+{
+    const Geometry &g = a.g;
+    const int rows = g.rows, cols = g.cols;
+    float vx = px - cp.ox, vy = py - cp.oy, vz = pz - cp.oz;        // :248-250
+    const float len = sqrtf(vx * vx + vy * vy + vz * vz);           // :252
+    vx /= len;                                                      // :253-255
+    vy /= len;
+    vz /= len;
+    const double len2 = (double)len * (double)len;
+    for (int step = 3;; ++step) { // :258
+        const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
+        const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
+        if (!(d2 < len2 && vz < -0.01f)) return false;
+        const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
+        int I0, I1;
+        index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0, I1); // :261
+        if (I0 <= 0 || I1 <= 0 || I0 >= rows - 1 || I1 >= cols - 1) continue;         // :264-265
+        const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                            // :268
+        float e[9];
+#pragma unroll
+        for (int s = 0; s < 9; ++s) e[s] = gp2[(r0 + s % 3) + (c0 + s / 3) * rows].y;
+        const float bsum = tree9(e);
+        const float2 gI = gp2[I0 + I1 * rows];
+        if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gI.y > 0.01f &&
+            (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) // :269
+            return true;
     }
 }
 
@@ -167,7 +205,12 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
             int cls = GG_CLASS_KEPT;
             bool walk = false;
             if (inmap_[j]) cls = classify_point(a, cp, pt[j], og[j], walk);
-            for (unsigned long long todo = __ballot(walk); todo != 0ull; todo &= todo - 1ull) { // (uniform loop, rarely entered)
+            unsigned long long todo = __ballot(walk);
+            if (__popcll(todo) > WALK_COOPERATIVE_MAX) { // (uniform) most lanes are candidates: everybody walks its own ray
+                if (walk && ray_walk_hits_lane(a, cp, gp2, pt[j].x, pt[j].y, pt[j].z)) cls = GG_CLASS_OUTLIER;
+                todo = 0ull;
+            }
+            for (; todo != 0ull; todo &= todo - 1ull) { // (uniform loop, rarely entered)
                 const int src = __builtin_ctzll(todo);
                 const bool hit = ray_walk_hits(a, cp, gp2, __shfl(pt[j].x, src, 64), __shfl(pt[j].y, src, 64), __shfl(pt[j].z, src, 64), lane);
                 if (lane == src && hit) cls = GG_CLASS_OUTLIER;
