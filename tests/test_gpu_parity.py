@@ -433,14 +433,17 @@ def test_map_scroll_edge_cases():
 
 # ---------------------------------------------------------------- N3: KITTI-format sequence replay (configs[4] harness)
 
-def test_kitti_format_sequence_replay_matches_cpu_path(tmp_path):
+@pytest.mark.parametrize("n_frames,n_az", [(5, 260), (70, 1200)])
+def test_kitti_format_sequence_replay_matches_cpu_path(tmp_path, n_frames, n_az):
+    """configs[0] / configs[4] plumbing: reader -> poses -> map scroll -> filter -> evaluator.  The long case drives 77 m
+    (more than half a map width of scrolling, 0.1 rad of yaw per frame) with ~75 k points per cloud."""
     from groundgrid_amd import kitti, replay
     from tests.test_kitti_cpu import OracleBackend, _synthetic_sequence
 
-    d, _ = _synthetic_sequence(tmp_path, n_frames=5)
+    d, _ = _synthetic_sequence(tmp_path, n_frames=n_frames, n_az=n_az)
     seq = kitti.KittiSequence(d)
     per_frame = {"gpu": [], "cpu": []}
-    ev_gpu, _ = replay.replay(seq, replay.DeviceBackend(max_points=20000), on_frame=lambda fr, lab, idx: per_frame["gpu"].append((lab.copy(), idx.copy())))
+    ev_gpu, _ = replay.replay(seq, replay.DeviceBackend(max_points=100000), on_frame=lambda fr, lab, idx: per_frame["gpu"].append((lab.copy(), idx.copy())))
     ev_cpu, _ = replay.replay(seq, OracleBackend(), on_frame=lambda fr, lab, idx: per_frame["cpu"].append((lab.copy(), idx.copy())))
     for k, ((lg, ig), (lc, ic)) in enumerate(zip(per_frame["gpu"], per_frame["cpu"])):
         assert np.array_equal(lg, lc) and np.array_equal(ig, ic), k

@@ -45,8 +45,8 @@ def test_evaluator_counts_points_like_the_reference_callback():
         ev.add_cloud(np.array([49]), np.array([7]))    # label id outside the yaml: the reference raises too
 
 
-def _synthetic_sequence(tmp_path, n_frames=4):
-    base = synth.hdl64_cloud(seed=5, n_az=260)
+def _synthetic_sequence(tmp_path, n_frames=4, n_az=260):
+    base = synth.hdl64_cloud(seed=5, n_az=n_az)
     # fake semantic labels: ground-ish points "road", high points "building", a few "vegetation"
     lab = np.where(base["z"] < -1.4, 40, 50).astype(np.uint16)
     lab[::17] = 70
