@@ -155,10 +155,12 @@ template <int FMT>
 __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
 {
     extern __shared__ uint32_t lds_hist[]; // [4][T]
-    const int cloud = blockIdx.y;
+    // XCD-aware (gg_device.h): the chunks of one cloud run on one XCD, so its layers / records are cached in ONE L2
+    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int cloud = (int)(item / gridDim.x), bx = (int)(item % gridDim.x);
     const CloudParams &cp = params[cloud]; // (a reference: the 12 transform doubles stay in memory unless has_tf)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * 4 + wave;
+    const int chunk = bx * 4 + wave;
     const int n = cp.n_points;
     const int nch = (n + a.PW - 1) / a.PW;
     if (chunk >= nch) return;

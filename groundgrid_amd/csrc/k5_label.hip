@@ -16,15 +16,17 @@ namespace gg {
 template <int FMT>
 __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
 {
-    const int cloud = blockIdx.y;
+    // XCD-aware (gg_device.h): the chunks of one cloud run on one XCD, so its layers / records are cached in ONE L2
+    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int cloud = (int)(item / gridDim.x), bx = (int)(item % gridDim.x);
     const CloudParams cp = params[cloud];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * 4 + wave;
+    const int chunk = bx * 4 + wave;
     const int n = cp.n_points;
     const int nch = (n + a.PW - 1) / a.PW;
 
     const uint32_t *totals = a.totals + (size_t)cp.slot * 4;
-    if (io.d_out_counts && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (io.d_out_counts && bx == 0 && threadIdx.x == 0) {
         int32_t *oc = io.d_out_counts + (size_t)cloud * 4;
         oc[0] = (int32_t)(totals[0] + totals[1] + totals[2]);
         oc[1] = (int32_t)totals[0];

@@ -104,10 +104,12 @@ void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipS
 __global__ __launch_bounds__(256) void k_scatter(const Arena a, const CloudParams *__restrict__ params)
 {
     extern __shared__ uint32_t lds_offs[]; // [4][T]
-    const int cloud = blockIdx.y;
+    // XCD-aware (gg_device.h): the chunks of one cloud run on one XCD, so its layers / records are cached in ONE L2
+    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int cloud = (int)(item / gridDim.x), bx = (int)(item % gridDim.x);
     const CloudParams cp = params[cloud];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * 4 + wave;
+    const int chunk = bx * 4 + wave;
     const int n = cp.n_points;
     const int nch = (n + a.PW - 1) / a.PW;
     if (chunk >= nch) return;
