@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="independent (cloud, map) pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="independent (cloud, map) pairs per GPU per step")
     ap.add_argument("--minimal-layers", action="store_true", help="skip the four layers nothing in the path reads")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
