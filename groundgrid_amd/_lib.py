@@ -39,7 +39,15 @@ SYMBOLS = [
     "gg_reset_map", "gg_set_map_position", "gg_move_map", "gg_get_map_position", "gg_set_layer", "gg_get_layer", "gg_get_expected_points",
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_debug_replay_spiral_schedule",
+    "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
+    "gg_filter_cloud_async", "gg_filter_cloud_wait",
 ]
+
+GG_EIGEN_33, GG_EIGEN_34_SSE = 0, 1
+GG_ROT_TF2, GG_ROT_KDL = 0, 1
+ROTATION = {"tf2": GG_ROT_TF2, "kdl": GG_ROT_KDL}
+GG_ASYNC_DEPTH = 2
+HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the legacy default ("null") stream, as torch's default stream handle 0 means it
 
 
 class GGConfig(C.Structure):
@@ -61,6 +69,10 @@ class GGConfig(C.Structure):
         ("min_outlier_detection_ground_confidence", C.c_double),
         ("thread_count", C.c_int),
     ]
+
+
+class GGConventions(C.Structure):
+    _fields_ = [("eigen_reduction", C.c_int), ("reserved", C.c_int * 7)]
 
 
 class GGGeometry(C.Structure):
@@ -144,5 +156,11 @@ def load():
     L.gg_synchronize.argtypes = [vp]
     L.gg_get_point_classes.argtypes = [vp, C.c_int, C.c_size_t, vp, vp]
     L.gg_get_kernel_times.argtypes = [vp, P(C.c_double), P(C.c_int64), C.c_int]
+    L.gg_set_conventions.argtypes = [vp, P(GGConventions)]
+    L.gg_get_conventions.argtypes = [vp, P(GGConventions)]
+    L.gg_rotation_from_quaternion.argtypes = [C.c_int, P(C.c_double), P(C.c_double)]
+    L.gg_transform_from_pose.argtypes = [C.c_int, P(C.c_double), P(C.c_double)]
+    L.gg_filter_cloud_async.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, P(C.c_int)]
+    L.gg_filter_cloud_wait.argtypes = [vp, C.c_int, vp, P(C.c_size_t), vp, vp]
     _lib = L
     return L

@@ -34,6 +34,17 @@ def default_config() -> GGConfig:
     return c
 
 
+def transform_from_pose(pose7, rotation: str = "kdl") -> np.ndarray:
+    """(tx, ty, tz, qx, qy, qz, qw) -> 3x4 (R | t) with the rotation built the way tf2::Matrix3x3::setRotation ("tf2") or
+    KDL::Rotation::Quaternion ("kdl": what doTransform(PointStamped) goes through in ROS Noetic) builds it."""
+    p = (C.c_double * 7)(*[float(v) for v in pose7])
+    out = (C.c_double * 12)()
+    rc = _lib.load().gg_transform_from_pose(_lib.ROTATION[rotation], p, out)
+    if rc != _lib.GG_OK:
+        raise GroundGridError(f"gg_transform_from_pose: {_lib.STATUS.get(rc, rc)}")
+    return np.array(list(out), dtype=np.float64).reshape(3, 4)
+
+
 def pack16(cloud: np.ndarray) -> np.ndarray:
     """PointXYZIR (32 B) -> packed 16-B device records (x, y, z, ring)."""
     out = np.zeros(cloud.shape[0], dtype=POINT16_DTYPE)
@@ -74,14 +85,15 @@ class GridMap:
         _check(L, ctx, L.gg_set_map_position(ctx, self.slot, float(x), float(y)), "gg_set_map_position")
         self._pos = (float(x), float(y))
 
-    def move(self, odom_x: float, odom_y: float, base_to_map=(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0)):
-        """GroundGrid::update (src/GroundGrid.cpp:83-147) on the device.  base_to_map = (tx, ty, tz, qx, qy, qz, qw).
-        Returns the index shift (rows, cols)."""
+    def move(self, odom_x: float, odom_y: float, base_to_map=(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0), rotation: str = "kdl"):
+        """GroundGrid::update (src/GroundGrid.cpp:83-147) on the device.  base_to_map = (tx, ty, tz, qx, qy, qz, qw) of
+        lookupTransform("base_link", "map"); `rotation` picks the quaternion -> matrix convention of doTransform (the ABI
+        itself takes the matrix entries).  Returns the index shift (rows, cols)."""
         L, ctx = self._seg._L, self._seg._ctx
-        self._seg._sync_torch()
-        tf = (C.c_double * 7)(*[float(v) for v in base_to_map])
+        M = transform_from_pose(base_to_map, rotation)
+        plane = (C.c_double * 4)(M[2, 0], M[2, 1], M[2, 2], M[2, 3])
         sh = (C.c_int * 2)()
-        _check(L, ctx, L.gg_move_map(ctx, self.slot, float(odom_x), float(odom_y), tf, sh), "gg_move_map")
+        _check(L, ctx, L.gg_move_map(ctx, self.slot, float(odom_x), float(odom_y), plane, sh), "gg_move_map")
         x, y = C.c_double(), C.c_double()
         L.gg_get_map_position(ctx, self.slot, C.byref(x), C.byref(y))
         self._pos = (x.value, y.value)
@@ -96,7 +108,6 @@ class GridMap:
     def get(self, layer: str) -> np.ndarray:
         """Layer as a (rows, cols) float32 array (element (i, j) == Eigen's matrix(i, j))."""
         L, ctx = self._seg._L, self._seg._ctx
-        self._seg._sync_torch()
         buf = np.empty(self._seg.rows * self._seg.cols, dtype=np.float32)
         _check(L, ctx, L.gg_get_layer(ctx, self.slot, LAYERS.index(layer), buf.ctypes.data), "gg_get_layer")
         return buf.reshape((self._seg.rows, self._seg.cols), order="F")
@@ -105,7 +116,6 @@ class GridMap:
 
     def set(self, layer: str, arr: np.ndarray):
         L, ctx = self._seg._L, self._seg._ctx
-        self._seg._sync_torch()
         a = np.asfortranarray(np.asarray(arr, dtype=np.float32))
         assert a.shape == (self._seg.rows, self._seg.cols)
         flat = np.ascontiguousarray(a.reshape(-1, order="F"))
@@ -117,7 +127,6 @@ class GridMap:
     def image_u8(self, layer: str):
         """GridMapCvConverter::toImage<unsigned char,1> (Nodelet.cpp:239): (rows x cols uint8 image, lower, upper)."""
         L, ctx = self._seg._L, self._seg._ctx
-        self._seg._sync_torch()
         img = np.empty((self._seg.rows, self._seg.cols), dtype=np.uint8)
         lo, hi = C.c_float(), C.c_float()
         _check(L, ctx, L.gg_get_layer_image_u8(ctx, self.slot, LAYERS.index(layer), img.ctypes.data, C.byref(lo), C.byref(hi)), "gg_get_layer_image_u8")
@@ -126,7 +135,6 @@ class GridMap:
     def terrain_image(self) -> np.ndarray:
         """The 32FC3 terrain image of Nodelet.cpp:247-268: rows x cols x (ground, visited flag, pointsRaw)."""
         L, ctx = self._seg._L, self._seg._ctx
-        self._seg._sync_torch()
         img = np.empty((self._seg.rows, self._seg.cols, 3), dtype=np.float32)
         _check(L, ctx, L.gg_get_terrain_image(ctx, self.slot, img.ctypes.data), "gg_get_terrain_image")
         return img
@@ -148,6 +156,7 @@ class GroundSegmentation:
         self._L = _lib.load()
         self._ctx = None
         self._torch_used = False
+        self._async = {}
 
     # -- GroundSegmentation::init(nodeHandle, dimension, resolution) (src/GroundSegmentation.cpp:37-48)
     def init(self, dimension: float = 120.0, resolution: float = 0.33, *, n_slots: int = 1,
@@ -220,7 +229,6 @@ class GroundSegmentation:
         index = np.zeros(max(n, 1), dtype=np.int32)
         out_n = C.c_size_t(0)
         org = (C.c_float * 3)(*[float(v) for v in cloudOrigin])
-        self._sync_torch()
         if map_from_cloud is None:
             rc = self._L.gg_filter_cloud(self._ctx, gm.slot, cloud.ctypes.data, n, org, float(mapToBase_z),
                                          out.ctypes.data, C.byref(out_n), labels.ctypes.data, index.ctypes.data)
@@ -250,7 +258,6 @@ class GroundSegmentation:
         tf = None
         if map_from_cloud is not None:
             tf = (C.c_double * 12)(*[float(v) for v in np.asarray(map_from_cloud, dtype=np.float64).reshape(-1)[:12]])
-        self._sync_torch()
         rc = self._L.gg_filter_cloud_pc2(self._ctx, gm.slot, buf.ctypes.data, n, point_step, offsets[0], offsets[1], offsets[2], offsets[3],
                                          tf, org, float(mapToBase_z), labels.ctypes.data, index.ctypes.data, C.byref(out_n))
         _check(self._L, self._ctx, rc, "gg_filter_cloud_pc2")
@@ -261,7 +268,6 @@ class GroundSegmentation:
         gm = map if map is not None else self._maps[0]
         cls = np.zeros(max(n, 1), dtype=np.uint8)
         cell = np.zeros(max(n, 1), dtype=np.int32)
-        self._sync_torch()
         rc = self._L.gg_get_point_classes(self._ctx, gm.slot, n, cls.ctypes.data, cell.ctypes.data)
         _check(self._L, self._ctx, rc, "gg_get_point_classes")
         return cls[:n], cell[:n]
@@ -305,7 +311,9 @@ class GroundSegmentation:
         b.d_out_counts = out.counts.data_ptr()
         b.d_label_masks = out.label_masks.data_ptr() if out.label_masks is not None else None
         s = stream if stream is not None else torch.cuda.current_stream(points.device).cuda_stream
-        rc = self._L.gg_filter_batch(self._ctx, C.byref(b), C.c_void_p(s))
+        # torch hands out 0 for its default stream = the legacy null stream; NULL would mean "the context's own stream" to
+        # the library, which is not ordered with torch ops / RCCL -- so name the legacy stream explicitly
+        rc = self._L.gg_filter_batch(self._ctx, C.byref(b), C.c_void_p(s if s else _lib.HIP_STREAM_LEGACY))
         _check(self._L, self._ctx, rc, "gg_filter_batch")
         return out
 
@@ -313,18 +321,49 @@ class GroundSegmentation:
         """(ms[7], launches[7]) accumulated under set_flags(profile=True)."""
         ms = (C.c_double * _lib.GG_NUM_KERNELS)()
         ln = (C.c_int64 * _lib.GG_NUM_KERNELS)()
-        self._sync_torch()
         _check(self._L, self._ctx, self._L.gg_get_kernel_times(self._ctx, ms, ln, 1 if reset else 0), "gg_get_kernel_times")
         names = [self._L.gg_kernel_name(k).decode() for k in range(_lib.GG_NUM_KERNELS)]
         return {names[k]: (ms[k], ln[k]) for k in range(_lib.GG_NUM_KERNELS)}
 
     def synchronize(self):
-        self._sync_torch()
+        """Waits for everything the context has enqueued, batches on caller streams included (the library orders its own
+        stream after them, include/groundgrid_hip.h gg_filter_batch)."""
         _check(self._L, self._ctx, self._L.gg_synchronize(self._ctx), "gg_synchronize")
 
-    def _sync_torch(self):
-        # batched calls run on torch's stream; host-path calls and layer copies run on the context's stream
-        if self._torch_used:
-            import torch
+    # -- pipelined reference-shaped call (gg_filter_cloud_async / gg_filter_cloud_wait)
+    def filter_cloud_async(self, cloud: np.ndarray, cloudOrigin: Sequence[float], mapToBase_z: float, map: Optional[GridMap] = None,
+                           map_from_cloud=None) -> int:
+        """Enqueue one cloud and return a ticket; at most GG_ASYNC_DEPTH tickets may be outstanding."""
+        assert cloud.dtype == POINT_DTYPE
+        gm = map if map is not None else self._maps[0]
+        cloud = np.ascontiguousarray(cloud)
+        org = (C.c_float * 3)(*[float(v) for v in cloudOrigin])
+        tf = None
+        if map_from_cloud is not None:
+            tf = (C.c_double * 12)(*[float(v) for v in np.asarray(map_from_cloud, dtype=np.float64).reshape(-1)[:12]])
+        t = C.c_int(-1)
+        rc = self._L.gg_filter_cloud_async(self._ctx, gm.slot, cloud.ctypes.data, cloud.shape[0], tf, org, float(mapToBase_z), C.byref(t))
+        _check(self._L, self._ctx, rc, "gg_filter_cloud_async")
+        self._async[t.value] = cloud  # keeps the input alive until the wait
+        return t.value
 
-            torch.cuda.synchronize(self.device)
+    def filter_cloud_wait(self, ticket: int, return_details: bool = False, want_cloud: bool = True):
+        cloud = self._async.pop(ticket)
+        n = cloud.shape[0]
+        out = np.zeros(max(n, 1) * 32, dtype=np.uint8).view(POINT_DTYPE) if want_cloud else None
+        labels = np.zeros(max(n, 1), dtype=np.uint8)
+        index = np.zeros(max(n, 1), dtype=np.int32)
+        out_n = C.c_size_t(0)
+        rc = self._L.gg_filter_cloud_wait(self._ctx, ticket, out.ctypes.data if want_cloud else None, C.byref(out_n),
+                                          labels.ctypes.data, index.ctypes.data)
+        _check(self._L, self._ctx, rc, "gg_filter_cloud_wait")
+        seg = out[: out_n.value] if want_cloud else None
+        if return_details:
+            return seg, labels[:n], index[:n]
+        return seg
+
+    def set_conventions(self, eigen_reduction: int = 0):
+        """Which Eigen the reference is built against (0 = 3.3.x order of the 5x5 block sums, 1 = 3.4.x SSE2)."""
+        c = _lib.GGConventions()
+        c.eigen_reduction = int(eigen_reduction)
+        _check(self._L, self._ctx, self._L.gg_set_conventions(self._ctx, C.byref(c)), "gg_set_conventions")

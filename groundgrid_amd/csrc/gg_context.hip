@@ -46,6 +46,31 @@ struct gg_context {
     std::vector<double> pos_x, pos_y; // per slot map position
     std::vector<char> no_confidence;  // per slot: groundpatch <= 0.01 everywhere for sure (set by gg_reset_map, cleared by any writer)
 
+    gg_conventions conv{};
+
+    // cross-stream ordering (include/groundgrid_hip.h, gg_filter_batch): `map_event` is recorded on ctx->stream after every
+    // map mutation enqueued there, `batch_event` on the launch stream after every batch
+    hipEvent_t map_event = nullptr, batch_event = nullptr;
+    bool map_event_pending = false;          // a mutation was enqueued on ctx->stream since the last batch waited for it
+    hipStream_t last_batch_stream = nullptr; // stream batch_event was last recorded on
+    bool have_batch_event = false;
+
+    // pipelined host entry point (gg_filter_cloud_async / _wait): GG_ASYNC_DEPTH staging sets + a copy stream each way
+    struct AsyncSlot {
+        gg_point16 *h_pts = nullptr, *d_pts = nullptr;
+        uint8_t *h_labels = nullptr, *d_labels = nullptr;
+        int32_t *h_index = nullptr, *d_index = nullptr;
+        int32_t *h_counts = nullptr, *d_counts = nullptr;
+        hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
+        const gg_point32 *cloud = nullptr;
+        size_t n = 0;
+        bool has_tf = false;
+        double tf[12]{};
+        int ticket = -1;
+    } async_slot[GG_ASYNC_DEPTH];
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    int next_ticket = 0, oldest_ticket = 0;
+
     // per-call parameter ring (pinned host + device)
     CloudParams *h_params = nullptr; // [PARAM_RING][n_slots] pinned
     CloudParams *d_params = nullptr; // [PARAM_RING][n_slots]
@@ -393,6 +418,23 @@ void make_dev_config(const gg_config &c, DevConfig &d)
 
 hipStream_t pick_stream(gg_context *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
+// Entry points that read or write map state on ctx->stream call this first: the context's stream waits for the last batch
+// that ran on another stream (gg_get_layer after a batch on a caller stream read stale layers).
+int own_stream_waits_for_batches(gg_context *ctx)
+{
+    if (ctx->have_batch_event && ctx->last_batch_stream != ctx->stream)
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_event, 0));
+    return GG_OK;
+}
+// ... and this after enqueueing a mutation of map state on ctx->stream (reset, move, set_layer): the next batch on any
+// other stream waits for it.
+int own_stream_mutated_map(gg_context *ctx)
+{
+    HIPCHK(ctx, hipEventRecord(ctx->map_event, ctx->stream));
+    ctx->map_event_pending = true;
+    return GG_OK;
+}
+
 struct Profiler {
     gg_context *ctx;
     hipStream_t s;
@@ -462,6 +504,10 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
         for (int k = 0; k < 12; ++k) p.tf[k] = b->transforms ? b->transforms[(size_t)i * 12 + k] : 0.0;
         max_n = std::max(max_n, p.n_points);
     }
+    // order this batch after everything that touched map state on the context's stream, and after an earlier batch that ran
+    // on another stream
+    if (s != ctx->stream && ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->map_event, 0));
+    if (ctx->have_batch_event && ctx->last_batch_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->batch_event, 0));
     HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * nb, hipMemcpyHostToDevice, s));
 
     BatchIO io;
@@ -476,6 +522,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
 
     Arena a = ctx->arena;
     a.flags = ctx->flags;
+    a.eigen_reduction = ctx->conv.eigen_reduction;
     Profiler prof{ctx, s, (ctx->flags & GG_FLAG_PROFILE) != 0};
 
     prof.begin(GG_K_CLASSIFY);
@@ -502,6 +549,10 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ring_done[g], s));
     ctx->ring_used[g] = true;
+    HIPCHK(ctx, hipEventRecord(ctx->batch_event, s));
+    ctx->last_batch_stream = s;
+    ctx->have_batch_event = true;
+    if (s != ctx->stream) ctx->map_event_pending = false; // (this stream has waited; later batches anywhere follow batch_event)
     return GG_OK;
 }
 
@@ -684,6 +735,10 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 
     CREATE_CHK(hipSetDevice(device));
     CREATE_CHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
+    CREATE_CHK(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->map_event, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->batch_event, hipEventDisableTiming));
     gg::configure_kernels();
 
     Arena &a = ctx->arena;
@@ -815,6 +870,13 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_scnt = carve(64);
     const size_t o_scls = carve(max_points);
     const size_t o_scell = carve(max_points * 4);
+    size_t o_apts[GG_ASYNC_DEPTH], o_alab[GG_ASYNC_DEPTH], o_aidx[GG_ASYNC_DEPTH], o_acnt[GG_ASYNC_DEPTH];
+    for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
+        o_apts[k] = carve(max_points * sizeof(gg_point16));
+        o_alab[k] = carve(max_points);
+        o_aidx[k] = carve(max_points * 4);
+        o_acnt[k] = carve(64);
+    }
     const size_t o_scroll = carve(2 * Cpad * 4);
     const size_t o_image = carve(3 * Cpad * 4);
     const size_t o_bounds = carve(64);
@@ -848,6 +910,13 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_stage_counts = (int32_t *)(base + o_scnt);
     ctx->d_stage_class = (uint8_t *)(base + o_scls);
     ctx->d_stage_cell = (int32_t *)(base + o_scell);
+    for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
+        gg_context::AsyncSlot &as = ctx->async_slot[k];
+        as.d_pts = (gg_point16 *)(base + o_apts[k]);
+        as.d_labels = (uint8_t *)(base + o_alab[k]);
+        as.d_index = (int32_t *)(base + o_aidx[k]);
+        as.d_counts = (int32_t *)(base + o_acnt[k]);
+    }
     ctx->d_scroll_scratch = (float *)(base + o_scroll);
     ctx->d_image = (float *)(base + o_image);
     ctx->d_bounds = (float *)(base + o_bounds);
@@ -867,6 +936,16 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipHostMalloc((void **)&ctx->h_stage_index, max_points * 4, hipHostMallocDefault));
     CREATE_CHK(hipHostMalloc((void **)&ctx->h_stage_counts, 64, hipHostMallocDefault));
     for (int i = 0; i < PARAM_RING; ++i) CREATE_CHK(hipEventCreateWithFlags(&ctx->ring_done[i], hipEventDisableTiming));
+    for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
+        gg_context::AsyncSlot &as = ctx->async_slot[k];
+        CREATE_CHK(hipHostMalloc((void **)&as.h_pts, max_points * sizeof(gg_point16), hipHostMallocDefault));
+        CREATE_CHK(hipHostMalloc((void **)&as.h_labels, max_points, hipHostMallocDefault));
+        CREATE_CHK(hipHostMalloc((void **)&as.h_index, max_points * 4, hipHostMallocDefault));
+        CREATE_CHK(hipHostMalloc((void **)&as.h_counts, 64, hipHostMallocDefault));
+        CREATE_CHK(hipEventCreateWithFlags(&as.uploaded, hipEventDisableTiming));
+        CREATE_CHK(hipEventCreateWithFlags(&as.computed, hipEventDisableTiming));
+        CREATE_CHK(hipEventCreateWithFlags(&as.downloaded, hipEventDisableTiming));
+    }
 
     for (int s = 0; s < n_slots; ++s) {
         const int rc = gg_reset_map(ctx, s, 0.0, 0.0, 0.0f);
@@ -885,7 +964,10 @@ void gg_destroy(gg_context *ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->have_batch_event) hipEventSynchronize(ctx->batch_event);
+    if (ctx->h2d_stream) hipStreamSynchronize(ctx->h2d_stream);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->d2h_stream) hipStreamSynchronize(ctx->d2h_stream);
     for (auto &p : ctx->pending) {
         hipEventDestroy(p.start);
         hipEventDestroy(p.stop);
@@ -896,6 +978,20 @@ void gg_destroy(gg_context *ctx)
     }
     for (int i = 0; i < PARAM_RING; ++i)
         if (ctx->ring_done[i]) hipEventDestroy(ctx->ring_done[i]);
+    for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
+        gg_context::AsyncSlot &as = ctx->async_slot[k];
+        if (as.h_pts) hipHostFree(as.h_pts);
+        if (as.h_labels) hipHostFree(as.h_labels);
+        if (as.h_index) hipHostFree(as.h_index);
+        if (as.h_counts) hipHostFree(as.h_counts);
+        if (as.uploaded) hipEventDestroy(as.uploaded);
+        if (as.computed) hipEventDestroy(as.computed);
+        if (as.downloaded) hipEventDestroy(as.downloaded);
+    }
+    if (ctx->map_event) hipEventDestroy(ctx->map_event);
+    if (ctx->batch_event) hipEventDestroy(ctx->batch_event);
+    if (ctx->h2d_stream) hipStreamDestroy(ctx->h2d_stream);
+    if (ctx->d2h_stream) hipStreamDestroy(ctx->d2h_stream);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_stage_pts) hipHostFree(ctx->h_stage_pts);
     if (ctx->h_stage_labels) hipHostFree(ctx->h_stage_labels);
@@ -928,6 +1024,62 @@ int gg_set_flags(gg_context *ctx, unsigned flags)
     return GG_OK;
 }
 
+int gg_set_conventions(gg_context *ctx, const gg_conventions *conv)
+{
+    if (!ctx || !conv) return GG_ERR_INVALID;
+    if (conv->eigen_reduction != GG_EIGEN_33 && conv->eigen_reduction != GG_EIGEN_34_SSE) return fail(ctx, GG_ERR_INVALID, "eigen_reduction");
+    for (int r : conv->reserved)
+        if (r != 0) return fail(ctx, GG_ERR_INVALID, "gg_conventions.reserved must be 0");
+    ctx->conv = *conv;
+    return GG_OK;
+}
+
+int gg_get_conventions(const gg_context *ctx, gg_conventions *conv)
+{
+    if (!ctx || !conv) return GG_ERR_INVALID;
+    *conv = ctx->conv;
+    return GG_OK;
+}
+
+// host arithmetic only (this file is compiled with -ffp-contract=off: no fused multiply-adds, like the x86-64 reference)
+int gg_rotation_from_quaternion(int convention, const double q[4], double R[9])
+{
+    if (!q || !R) return GG_ERR_INVALID;
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    if (convention == GG_ROT_TF2) { // tf2/LinearMath/Matrix3x3.h setRotation
+        const double d = x * x + y * y + z * z + w * w;
+        const double s = 2.0 / d;
+        const double xs = x * s, ys = y * s, zs = z * s;
+        const double wx = w * xs, wy = w * ys, wz = w * zs;
+        const double xx = x * xs, xy = x * ys, xz = x * zs;
+        const double yy = y * ys, yz = y * zs, zz = z * zs;
+        R[0] = 1.0 - (yy + zz); R[1] = xy - wz;         R[2] = xz + wy;
+        R[3] = xy + wz;         R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+        R[6] = xz - wy;         R[7] = yz + wx;         R[8] = 1.0 - (xx + yy);
+    } else if (convention == GG_ROT_KDL) { // orocos_kdl frames.cpp Rotation::Quaternion
+        const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+        R[0] = w2 + x2 - y2 - z2;     R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
+        R[3] = 2 * x * y + 2 * w * z; R[4] = w2 - x2 + y2 - z2;     R[5] = 2 * y * z - 2 * w * x;
+        R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = w2 - x2 - y2 + z2;
+    } else {
+        return GG_ERR_INVALID;
+    }
+    return GG_OK;
+}
+
+int gg_transform_from_pose(int convention, const double pose7[7], double out12[12])
+{
+    if (!pose7 || !out12) return GG_ERR_INVALID;
+    double R[9];
+    const int rc = gg_rotation_from_quaternion(convention, pose7 + 3, R);
+    if (rc != GG_OK) return rc;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out12[r * 4 + c] = R[r * 3 + c];
+        out12[r * 4 + 3] = pose7[r];
+    }
+    return GG_OK;
+}
+
 int gg_get_size(const gg_context *ctx, int *rows, int *cols)
 {
     if (!ctx) return GG_ERR_INVALID;
@@ -952,6 +1104,7 @@ int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float od
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     ctx->no_confidence[slot] = 1; // groundpatch := 1e-7 everywhere (scrolling keeps that: exposed cells get 0)
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     ctx->pos_x[slot] = pos_x;
     ctx->pos_y[slot] = pos_y;
     const Arena &a = ctx->arena;
@@ -962,7 +1115,7 @@ int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float od
         if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH) launch_fill(layer_ptr(a, slot, l), C, init[l], ctx->stream);
     launch_fill2(gp2_ptr(a, slot), C, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], ctx->stream); // interleaved pair
     HIPCHK(ctx, hipGetLastError());
-    return GG_OK;
+    return own_stream_mutated_map(ctx);
 }
 
 int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y)
@@ -973,10 +1126,10 @@ int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y)
     return GG_OK;
 }
 
-int gg_move_map(gg_context *ctx, int slot, double odom_x, double odom_y, const double base_to_map[7], int shift_out[2])
+int gg_move_map(gg_context *ctx, int slot, double odom_x, double odom_y, const double base_plane[4], int shift_out[2])
 {
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
-    if (!base_to_map) return GG_ERR_INVALID;
+    if (!base_plane) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const double res = ctx->arena.g.resolution;
     // grid_map_core getIndexShiftFromPositionShift: round half away from zero, map frame -> buffer order (sign flip)
@@ -992,12 +1145,13 @@ int gg_move_map(gg_context *ctx, int slot, double odom_x, double odom_y, const d
         shift_out[1] = s[1];
     }
     if (s[0] == 0 && s[1] == 0) return GG_OK; // src/GroundGrid.cpp:135-137
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     // getPositionShiftFromIndexShift: the position advances by whole cells, not to the odometry position
     ctx->pos_x[slot] += (double)(-s[0]) * res;
     ctx->pos_y[slot] += (double)(-s[1]) * res;
-    launch_scroll(ctx->arena, slot, ctx->d_scroll_scratch, s[0], s[1], ctx->pos_x[slot], ctx->pos_y[slot], base_to_map, ctx->stream);
+    launch_scroll(ctx->arena, slot, ctx->d_scroll_scratch, s[0], s[1], ctx->pos_x[slot], ctx->pos_y[slot], base_plane, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
-    return GG_OK;
+    return own_stream_mutated_map(ctx);
 }
 
 int gg_get_map_position(const gg_context *ctx, int slot, double *pos_x, double *pos_y)
@@ -1013,6 +1167,7 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if (!src || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     if (layer == GG_LAYER_GROUNDPATCH) ctx->no_confidence[slot] = 0;
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) { // de-interleave at the host boundary
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1021,6 +1176,7 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
     } else {
         HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
     }
+    if (const int rc = own_stream_mutated_map(ctx)) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
@@ -1030,6 +1186,7 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if (!dst || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const float *plane = layer_ptr(ctx->arena, slot, layer);
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) {
         launch_plane_extract(gp2_ptr(ctx->arena, slot), layer == GG_LAYER_GROUNDPATCH, ctx->d_image, (size_t)ctx->arena.g.C, ctx->stream);
@@ -1046,6 +1203,7 @@ int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, fl
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if (!dst || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const Geometry &g = ctx->arena.g;
     uint8_t *d_img = reinterpret_cast<uint8_t *>(ctx->d_image);
     const float *plane = layer_ptr(ctx->arena, slot, layer);
@@ -1069,6 +1227,7 @@ int gg_get_terrain_image(gg_context *ctx, int slot, float *dst)
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if (!dst) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const Geometry &g = ctx->arena.g;
     launch_terrain_image(gp2_ptr(ctx->arena, slot), layer_ptr(ctx->arena, slot, GG_LAYER_POINTSRAW), g.rows, g.cols,
                          ctx->d_image, ctx->stream);
@@ -1152,62 +1311,96 @@ int gg_synchronize(gg_context *ctx)
 {
     if (!ctx) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc; // batches on caller streams included
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
 
-static int filter_cloud_impl(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *tf, const float origin[3],
-                             double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index)
+// pack PointXYZIR -> 16-B records while copying into pinned staging (halves PCIe and HBM traffic; only x, y, z, ring are
+// ever read, :222-250).  One 16-byte load + the ring per point, one 16-byte store: the loop vectorises to SSE moves.
+static void pack_points(const gg_point32 *__restrict__ cloud, gg_point16 *__restrict__ dst, size_t n)
 {
-    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
-    if ((!cloud && n) || !origin) return fail(ctx, GG_ERR_INVALID, "null cloud / origin");
-    if (n > ctx->max_points) return fail(ctx, GG_ERR_CAPACITY, "cloud larger than max_points");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-
-    // pack PointXYZIR -> 16-B records while copying into pinned staging (halves PCIe and HBM traffic)
     for (size_t i = 0; i < n; ++i) {
-        gg_point16 &d = ctx->h_stage_pts[i];
+        gg_point16 d;
         d.x = cloud[i].x;
         d.y = cloud[i].y;
         d.z = cloud[i].z;
         d.ring = cloud[i].ring;
         d.pad = 0;
+        dst[i] = d;
     }
-    if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage_pts, ctx->h_stage_pts, n * sizeof(gg_point16), hipMemcpyHostToDevice, s));
+}
+
+int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *tf, const float origin[3],
+                          double base_z, int *ticket)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if ((!cloud && n) || !origin || !ticket) return fail(ctx, GG_ERR_INVALID, "null cloud / origin / ticket");
+    if (n > ctx->max_points) return fail(ctx, GG_ERR_CAPACITY, "cloud larger than max_points");
+    if (ctx->next_ticket - ctx->oldest_ticket >= GG_ASYNC_DEPTH) return fail(ctx, GG_ERR_CAPACITY, "GG_ASYNC_DEPTH tickets outstanding: wait for the oldest first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    gg_context::AsyncSlot &as = ctx->async_slot[ctx->next_ticket % GG_ASYNC_DEPTH];
+
+    pack_points(cloud, as.h_pts, n); // overlaps the device work of the previous ticket
+    if (n) HIPCHK(ctx, hipMemcpyAsync(as.d_pts, as.h_pts, n * sizeof(gg_point16), hipMemcpyHostToDevice, ctx->h2d_stream));
+    HIPCHK(ctx, hipEventRecord(as.uploaded, ctx->h2d_stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, as.uploaded, 0));
 
     const int32_t n32 = (int32_t)n;
     gg_batch b{};
     b.n_clouds = 1;
     b.first_slot = slot;
     b.point_format = GG_POINT16;
-    b.d_points = ctx->d_stage_pts;
+    b.d_points = as.d_pts;
     b.cloud_stride = ctx->max_points;
     b.n_points = &n32;
     b.origins = origin;
     b.base_z = &base_z;
     b.transforms = tf;
-    b.d_labels = ctx->d_stage_labels;
-    b.d_out_index = ctx->d_stage_index;
+    b.d_labels = as.d_labels;
+    b.d_out_index = as.d_index;
     b.d_out_clouds = nullptr;
-    b.d_out_counts = ctx->d_stage_counts;
-    const int rc = enqueue_batch(ctx, &b, s);
+    b.d_out_counts = as.d_counts;
+    const int rc = enqueue_batch(ctx, &b, ctx->stream);
     if (rc != GG_OK) return rc;
+    HIPCHK(ctx, hipEventRecord(as.computed, ctx->stream));
 
+    // results come back on their own stream, so that the next ticket's kernels do not queue behind this download
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->d2h_stream, as.computed, 0));
     if (n) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage_labels, ctx->d_stage_labels, n, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage_index, ctx->d_stage_index, n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(as.h_labels, as.d_labels, n, hipMemcpyDeviceToHost, ctx->d2h_stream));
+        HIPCHK(ctx, hipMemcpyAsync(as.h_index, as.d_index, n * 4, hipMemcpyDeviceToHost, ctx->d2h_stream));
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage_counts, ctx->d_stage_counts, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
+    HIPCHK(ctx, hipMemcpyAsync(as.h_counts, as.d_counts, 16, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    HIPCHK(ctx, hipEventRecord(as.downloaded, ctx->d2h_stream));
 
-    if (out_n) *out_n = (size_t)ctx->h_stage_counts[0];
-    if (out_label && n) memcpy(out_label, ctx->h_stage_labels, n);
-    if (out_index && n) memcpy(out_index, ctx->h_stage_index, n * 4);
+    as.cloud = cloud;
+    as.n = n;
+    as.has_tf = tf != nullptr;
+    if (tf) memcpy(as.tf, tf, sizeof as.tf);
+    as.ticket = ctx->next_ticket;
+    *ticket = ctx->next_ticket++;
+    return GG_OK;
+}
+
+int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    if (ticket != ctx->oldest_ticket || ticket >= ctx->next_ticket) return fail(ctx, GG_ERR_INVALID, "tickets are waited for in issue order");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    gg_context::AsyncSlot &as = ctx->async_slot[ticket % GG_ASYNC_DEPTH];
+    ctx->oldest_ticket = ticket + 1; // (also on error below: the slot is reusable either way)
+    HIPCHK(ctx, hipEventSynchronize(as.downloaded));
+    const size_t n = as.n;
+    if (out_n) *out_n = (size_t)as.h_counts[0];
+    if (out_label && n) memcpy(out_label, as.h_labels, n);
+    if (out_index && n) memcpy(out_index, as.h_index, n * 4);
     if (out_cloud) {
         // the returned cloud (:173-189): the host owns the input, so it assembles the output from index + label
+        const gg_point32 *cloud = as.cloud;
+        const double *tf = as.has_tf ? as.tf : nullptr;
         for (size_t i = 0; i < n; ++i) {
-            const int32_t k = ctx->h_stage_index[i];
+            const int32_t k = as.h_index[i];
             if (k < 0) continue;
             out_cloud[k] = cloud[i];
             if (tf) { // map-frame coordinates, same arithmetic as the device (this file is built with -ffp-contract=off)
@@ -1216,10 +1409,22 @@ static int filter_cloud_impl(gg_context *ctx, int slot, const gg_point32 *cloud,
                 out_cloud[k].y = (float)(((tf[4] * dx + tf[5] * dy) + tf[6] * dz) + tf[7]);
                 out_cloud[k].z = (float)(((tf[8] * dx + tf[9] * dy) + tf[10] * dz) + tf[11]);
             }
-            out_cloud[k].intensity = (float)ctx->h_stage_labels[i];
+            out_cloud[k].intensity = (float)as.h_labels[i];
         }
     }
     return GG_OK;
+}
+
+// the synchronous reference-shaped call = one ticket, waited for at once
+static int filter_cloud_impl(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *tf, const float origin[3],
+                             double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    if (ctx->next_ticket != ctx->oldest_ticket) return fail(ctx, GG_ERR_INVALID, "gg_filter_cloud while async tickets are outstanding");
+    int ticket = -1;
+    const int rc = gg_filter_cloud_async(ctx, slot, cloud, n, tf, origin, base_z, &ticket);
+    if (rc != GG_OK) return rc;
+    return gg_filter_cloud_wait(ctx, ticket, out_cloud, out_n, out_label, out_index);
 }
 
 int gg_filter_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const float origin[3], double base_z,
@@ -1242,6 +1447,7 @@ int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class
     if (n > ctx->max_points) return GG_ERR_CAPACITY;
     if (n == 0) return GG_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     launch_decode_classes(ctx->arena, slot, n, ctx->d_stage_class, ctx->d_stage_cell, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     if (out_class) HIPCHK(ctx, hipMemcpyAsync(out_class, ctx->d_stage_class, n, hipMemcpyDeviceToHost, ctx->stream));

@@ -34,6 +34,20 @@ GG_DEV float tree25(const float *e)
     return (a + b) + (c + d);
 }
 
+// Eigen 3.4.x, SSE2 build (Packet4f): Block<MatrixXf,5,5>::sum() takes SliceVectorizedTraversal -- rows 0..3 of the five
+// columns are accumulated lane-wise, column by column, reduced with predux = (a0 + a2) + (a1 + a3), then row 4 of every
+// column is added in column order (Redux.h redux_impl<..., SliceVectorizedTraversal, ...>; oracle/gg_oracle.c tree25_eigen34).
+GG_DEV float tree25_eigen34(const float *e)
+{
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = (((e[r] + e[5 + r]) + e[10 + r]) + e[15 + r]) + e[20 + r];
+    float res = (p[0] + p[2]) + (p[1] + p[3]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) res = res + e[4 + 5 * j];
+    return res;
+}
+
 // x86-64 cvttsd2si: truncation toward zero, INT_MIN for NaN / out of range
 GG_DEV int trunc_to_int(double v)
 {

@@ -120,6 +120,7 @@ struct Arena {
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)
     unsigned flags;
+    int eigen_reduction; // gg_conventions::eigen_reduction (GG_EIGEN_33 / GG_EIGEN_34_SSE): order of the 5x5 block sums in K3
 };
 
 __host__ __device__ inline float *layer_ptr(const Arena &a, int slot, int layer)
@@ -164,7 +165,7 @@ void launch_plane_insert(float2 *dst, int comp, const float *src, size_t n, hipS
 void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds, uint8_t *d_img, hipStream_t s);
 void launch_terrain_image(const float2 *gp2, const float *raw, int rows, int cols, float *d_img, hipStream_t s);
 void configure_kernels(); // one-time function attributes (dynamic LDS above 64 KiB)
-void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double tf[7], hipStream_t s);
+void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double plane[4], hipStream_t s);
 void launch_pack16(const gg_point32 *src, gg_point16 *dst, size_t n, hipStream_t s);
 void launch_decode_classes(const Arena &a, int slot, size_t n, uint8_t *d_class, int32_t *d_cell, hipStream_t s);
 

@@ -17,7 +17,7 @@ struct ScrollParams {
     double pos_x, pos_y; // map position AFTER the move
     double first0, first1; // L/2 - res/2  (getVectorToFirstCell)
     double res;
-    double m20, m21, m22, tz; // third row of the base_link<-map rotation (tf2::Matrix3x3::setRotation) and translation z
+    double m20, m21, m22, tz; // third row of the base_link<-map rotation and translation z (gg_move_map base_plane)
 };
 
 __global__ __launch_bounds__(256) void k_scroll(const float2 *__restrict__ gp2, float2 *__restrict__ out, int rows, int cols,
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_scroll(const float2 *__restrict__ gp2, 
         // grid_map getPositionFromIndex: position = mapPosition + offset + resolution * (-index)
         const double px = (sp.pos_x + sp.first0) + sp.res * (double)(-i);
         const double py = (sp.pos_y + sp.first1) + sp.res * (double)(-j);
-        // tf2: v_out.z = (m20 * x + m21 * y + m22 * 0) + origin.z ; ground = -z (:130), groundpatch = 0 (:131)
+        // doTransform: v_out.z = (m20 * x + m21 * y + m22 * 0) + origin.z ; ground = -z (:130), groundpatch = 0 (:131)
         const double z = ((sp.m20 * px + sp.m21 * py) + sp.m22 * 0.0) + sp.tz;
         g = (float)(-z);
         w = 0.0f;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_scroll(const float2 *__restrict__ gp2, 
     out[(size_t)i + (size_t)j * rows] = make_float2(g, w);
 }
 
-void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double tf[7],
+void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double plane[4],
                    hipStream_t s)
 {
     ScrollParams sp;
@@ -60,17 +60,11 @@ void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, dou
     sp.res = a.g.resolution;
     sp.first0 = a.g.half0 - 0.5 * a.g.resolution;
     sp.first1 = a.g.half1 - 0.5 * a.g.resolution;
-    // tf2::Matrix3x3::setRotation(q), third row
-    const double qx = tf[3], qy = tf[4], qz = tf[5], qw = tf[6];
-    const double d = qx * qx + qy * qy + qz * qz + qw * qw;
-    const double sc = 2.0 / d;
-    const double xs = qx * sc, ys = qy * sc, zs = qz * sc;
-    const double wx = qw * xs, wy = qw * ys;
-    const double xx = qx * xs, xz = qx * zs, yy = qy * ys, yz = qy * zs;
-    sp.m20 = xz - wy;
-    sp.m21 = yz + wx;
-    sp.m22 = 1.0 - (xx + yy);
-    sp.tz = tf[2];
+    // third row of the base_link <- map rotation and translation z, as the binding built them (gg_move_map)
+    sp.m20 = plane[0];
+    sp.m21 = plane[1];
+    sp.m22 = plane[2];
+    sp.tz = plane[3];
     float2 *gp2 = gp2_ptr(a, slot);
     float2 *out = reinterpret_cast<float2 *>(scratch);
     dim3 grid((a.g.rows + 63) / 64, (a.g.cols + 3) / 4);

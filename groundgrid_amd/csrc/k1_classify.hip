@@ -15,6 +15,11 @@
 namespace gg {
 
 constexpr int WALK_COOPERATIVE_MAX = 12; // candidates per 64-point window up to which their rays are walked cooperatively
+// The reference walks a candidate's ray one metre per step until it reaches the point (:258) with no bound of its own: a
+// corrupt z of -1e9 costs it seconds, and past 2^31 steps its int counter overflows (UB).  A library that takes raw
+// sensor buffers must not hang the GPU on such a record, so steps >= WALK_MAX_STEP are not evaluated (documented
+// deviation, mirrored by the oracle): it only matters for points more than 65 km away from the sensor.
+constexpr int WALK_MAX_STEP = 1 << 16;
 
 struct PointIn {
     float x, y, z;
@@ -83,11 +88,11 @@ GG_DEV bool ray_walk_hits(const Arena &a, const CloudParams &cp, const float2 *_
     vy /= len;
     vz /= len;
     const double len2 = (double)len * (double)len;
-    for (int base = 3;; base += 64) { // :258
+    for (int base = 3; base < WALK_MAX_STEP; base += 64) { // :258
         const int step = base + lane;
         const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
         const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
-        const bool on_ray = d2 < len2 && vz < -0.01f;
+        const bool on_ray = d2 < len2 && vz < -0.01f && step < WALK_MAX_STEP;
         bool hit = false;
         if (on_ray) {
             const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
@@ -107,6 +112,7 @@ GG_DEV bool ray_walk_hits(const Arena &a, const CloudParams &cp, const float2 *_
         if (__ballot(hit) != 0ull) return true;
         if (__ballot(on_ray) != ~0ull) return false; // the ray ended inside this group of steps
     }
+    return false;
 }
 
 // The same walk, one point per lane, serially (the reference's loop as written).  Used when most lanes of a window are
@@ -122,7 +128,7 @@ GG_DEV bool ray_walk_hits_lane(const Arena &a, const CloudParams &cp, const floa
     vy /= len;
     vz /= len;
     const double len2 = (double)len * (double)len;
-    for (int step = 3;; ++step) { // :258
+    for (int step = 3; step < WALK_MAX_STEP; ++step) { // :258
         const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
         const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
         if (!(d2 < len2 && vz < -0.01f)) return false;
@@ -140,6 +146,7 @@ GG_DEV bool ray_walk_hits_lane(const Arena &a, const CloudParams &cp, const floa
             (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) // :269
             return true;
     }
+    return false;
 }
 
 GG_DEV uint32_t make_key(const Arena &a, int gi0, int gi1, int cls)
@@ -247,6 +254,13 @@ void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO 
     if (nch == 0 || n_clouds == 0) return;
     dim3 grid((nch + 3) / 4, n_clouds);
     const size_t lds = (size_t)4 * a.g.T * sizeof(uint32_t);
+    // per-wave tile histograms beyond the 64 KiB default (grids above ~1024 cells per side) need the explicit opt-in
+    static bool big_lds_ok = false;
+    if (lds > 64 * 1024 && !big_lds_ok) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds_ok = true;
+    }
     if (io.point_format == GG_POINT16)
         hipLaunchKernelGGL(k_classify<GG_POINT16>, grid, dim3(256), lds, s, a, d_params, io);
     else

@@ -28,7 +28,9 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
     // :355 pointsBlock, column-major linear index s -> (row s % S, col s / S)
 #pragma unroll
     for (int s = 0; s < SS; ++s) e[s] = pts[lc - ci + s / S][lr - ci + s % S];
-    const float pointsblockSum = (S == 3) ? tree9(e) : tree25(e); // :359
+    const bool e34 = a.eigen_reduction == GG_EIGEN_34_SSE; // (uniform) which Eigen the reference was built against
+    auto sum25 = [&](const float *v) { return e34 ? tree25_eigen34(v) : tree25(v); };
+    const float pointsblockSum = (S == 3) ? tree9(e) : sum25(e); // :359
     const size_t idx = (size_t)i + (size_t)j * rows;
     const float expected = a.expected[idx]; // :358
 
@@ -57,13 +59,13 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
         float pr[SS];
 #pragma unroll
         for (int s = 0; s < SS; ++s) pr[s] = e[s] * var[lc - ci + s / S][lr - ci + s % S];
-        maxVar = ((S == 3) ? tree9(pr) : tree25(pr)) / pointsblockSum;
+        maxVar = ((S == 3) ? tree9(pr) : sum25(pr)) / pointsblockSum;
     }
     // :375
     float pm[SS];
 #pragma unroll
     for (int s = 0; s < SS; ++s) pm[s] = e[s] * mnl[lc - ci + s / S][lr - ci + s % S];
-    const float groundlevel = ((S == 3) ? tree9(pm) : tree25(pm)) / pointsblockSum;
+    const float groundlevel = ((S == 3) ? tree9(pm) : sum25(pm)) / pointsblockSum;
     // :376
     const float groundDiff = std_max((groundlevel - oldGroundheight) * (2.0f * oldConfidence), 1.0f);
 
@@ -114,7 +116,9 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
 
     const int tr = threadIdx.x % PR, tcl = threadIdx.x / PR;
     const int i = r0 + tr, j = c0 + tcl;
-    if (i >= rows - 2 || j >= cols - 2) return; // interior [2, n-2) (:325-328)
+    // the four quadrants (:325-328) cover rows [2, 2 * (cols / 2) - 2) -- the FIRST loop variable, bounded by cols / 2, is
+    // used as the row index -- and cols [2, rows - 2): for odd sizes row n - 3 is never visited
+    if (i >= 2 * (cols / 2) - 2 || j >= rows - 2) return;
 
     // :332
     const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;

@@ -94,16 +94,32 @@ def quaternion_from_matrix(M: np.ndarray) -> np.ndarray:
     return q
 
 
-def matrix_from_quaternion(q) -> np.ndarray:
-    """tf2::Matrix3x3::setRotation (what tf2::doTransform builds from the message quaternion)."""
+# Which rotation matrix tf2::doTransform(PointStamped) -- the overload the reference calls for the cloud transform, the
+# cloud origin and GroundGrid::update (src/GroundGridNodelet.cpp:146,176, src/GroundGrid.cpp:129) -- builds from the message
+# quaternion is a third-party convention (tools/pin/ decides it on a ROS box): ROS Melodic / Noetic route that overload
+# through KDL (gmTransformToKDL -> KDL::Rotation::Quaternion), the Point / Vector3 overloads through tf2::Matrix3x3.
+ROTATION_CONVENTION = "kdl"
+
+
+def matrix_from_quaternion(q, rotation: str = None) -> np.ndarray:
+    """Quaternion (x, y, z, w) -> rotation matrix, "tf2" = tf2::Matrix3x3::setRotation, "kdl" = KDL::Rotation::Quaternion
+    (same operation order as the C helpers gg_rotation_from_quaternion / ggo_rotation_from_quaternion; Python floats are
+    IEEE doubles, so the entries are bit-identical to theirs)."""
+    rotation = rotation or ROTATION_CONVENTION
     x, y, z, w = (float(v) for v in q)
-    d = x * x + y * y + z * z + w * w
-    s = 2.0 / d
-    xs, ys, zs = x * s, y * s, z * s
-    wx, wy, wz = w * xs, w * ys, w * zs
-    xx, xy, xz = x * xs, x * ys, x * zs
-    yy, yz, zz = y * ys, y * zs, z * zs
-    return np.array([[1.0 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1.0 - (xx + zz), yz - wx], [xz - wy, yz + wx, 1.0 - (xx + yy)]])
+    if rotation == "tf2":
+        d = x * x + y * y + z * z + w * w
+        s = 2.0 / d
+        xs, ys, zs = x * s, y * s, z * s
+        wx, wy, wz = w * xs, w * ys, w * zs
+        xx, xy, xz = x * xs, x * ys, x * zs
+        yy, yz, zz = y * ys, y * zs, z * zs
+        return np.array([[1.0 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1.0 - (xx + zz), yz - wx], [xz - wy, yz + wx, 1.0 - (xx + yy)]])
+    assert rotation == "kdl", rotation
+    x2, y2, z2, w2 = x * x, y * y, z * z, w * w
+    return np.array([[w2 + x2 - y2 - z2, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y],
+                     [2 * x * y + 2 * w * z, w2 - x2 + y2 - z2, 2 * y * z - 2 * w * x],
+                     [2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, w2 - x2 - y2 + z2]])
 
 
 def transform_cloud(cloud: np.ndarray, R: np.ndarray, t: np.ndarray) -> np.ndarray:
@@ -151,7 +167,7 @@ class KittiSequence:
 
 def make_frame(i: int, cloud_sensor: np.ndarray, pose: np.ndarray) -> Frame:
     q = quaternion_from_matrix(pose)                  # player: quaternion of the pose (:199)
-    R = matrix_from_quaternion(q)                     # nodelet: tf2 rebuilds the rotation from the quaternion
+    R = matrix_from_quaternion(q)                     # nodelet: doTransform rebuilds the rotation from the quaternion
     t = np.array([pose[0, 3], pose[1, 3], pose[2, 3]])
     cloud_map = transform_cloud(cloud_sensor, R, t)
     origin = tuple(np.float32(v) for v in t)          # Nodelet.cpp:139-146,192-195 (velodyne == kitti_base_link)

@@ -25,7 +25,9 @@ class DeviceBackend:
         self.map.reset(odom_z=odom_z, pos=pos)
 
     def move(self, odom, base_to_map):
-        self.map.move(odom[0], odom[1], base_to_map)
+        from . import kitti
+
+        self.map.move(odom[0], odom[1], base_to_map, rotation=kitti.ROTATION_CONVENTION)
 
     def filter(self, cloud_map, origin, base_z):
         _, labels, index = self.seg.filter_cloud(cloud_map, origin, base_z, return_details=True)

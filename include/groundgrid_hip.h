@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 1
+#define GG_ABI_VERSION 2
 
 typedef enum gg_status {
     GG_OK = 0,
@@ -136,6 +136,35 @@ int gg_set_config(gg_context *ctx, const gg_config *cfg);
 int gg_get_config(const gg_context *ctx, gg_config *cfg);
 int gg_set_flags(gg_context *ctx, unsigned flags);
 
+/* Third-party conventions the reference inherits from the libraries it is built against (versions unpinned by the
+ * reference: package.xml:29, CMakeLists.txt:41).  Each is one swappable function on the device and in the oracle;
+ * tools/pin/ holds the probe that decides them on a real ROS box.
+ *   eigen_reduction: order of Block<MatrixXf,5,5>::sum() / cwiseProduct().sum() (src/GroundSegmentation.cpp:359,374-375)
+ *     GG_EIGEN_33       Eigen 3.3.x (Ubuntu 20.04 / ROS Noetic): DefaultTraversal + CompleteUnrolling, redux_novec_unroller
+ *     GG_EIGEN_34_SSE   Eigen 3.4.x built for SSE2 (Packet4f): SliceVectorizedTraversal for the 5x5 blocks -- four row
+ *                       lanes accumulated column by column, predux (a0+a2)+(a1+a3), then row 4 of every column
+ *   The 3x3 blocks (:268, :457-458) take redux_novec_unroller under both versions. */
+enum { GG_EIGEN_33 = 0, GG_EIGEN_34_SSE = 1 };
+typedef struct gg_conventions {
+    int eigen_reduction; /* GG_EIGEN_33 (default) */
+    int reserved[7];     /* must be 0 */
+} gg_conventions;
+int gg_set_conventions(gg_context *ctx, const gg_conventions *conv);
+int gg_get_conventions(const gg_context *ctx, gg_conventions *conv);
+
+/* Quaternion (x, y, z, w) -> row-major 3x3 rotation the way the two candidates behind tf2::doTransform do it (host
+ * arithmetic, no device involved):
+ *   GG_ROT_TF2  tf2::Matrix3x3::setRotation (s = 2 / |q|^2; entries 1 - (yy + zz), xy - wz, ...): what
+ *               doTransform(geometry_msgs::Point / Vector3, ...) and tf2::Transform use
+ *   GG_ROT_KDL  KDL::Rotation::Quaternion (entries w2 + x2 - y2 - z2, 2xy - 2wz, ..., no normalisation): what
+ *               tf2_geometry_msgs' doTransform(PointStamped) goes through (gmTransformToKDL) in ROS Melodic / Noetic --
+ *               the overload the reference calls at src/GroundGrid.cpp:129 and src/GroundGridNodelet.cpp:146,176 */
+enum { GG_ROT_TF2 = 0, GG_ROT_KDL = 1 };
+int gg_rotation_from_quaternion(int convention, const double q_xyzw[4], double rot[9]);
+/* {tx, ty, tz, qx, qy, qz, qw} -> 3x4 row-major (R | t) for gg_filter_cloud_tf / gg_batch.transforms, and the
+ * {r20, r21, r22, tz} plane of gg_move_map */
+int gg_transform_from_pose(int convention, const double pose7[7], double out12[12]);
+
 int gg_get_size(const gg_context *ctx, int *rows, int *cols);          /* grid_map::GridMap::getSize */
 int gg_get_geometry(const gg_context *ctx, double *resolution, double *length_x, double *length_y);
 const char *gg_last_error(const gg_context *ctx);
@@ -149,9 +178,14 @@ int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y);
 /* GroundGrid::update for an initialised map (src/GroundGrid.cpp:83-147): grid_map::GridMap::move to the odometry
  * position (whole cells; the map position is snapped), newly exposed cells get ground = -(z of the cell centre in
  * base_link) and groundpatch = 0 (:121-131), then convertToDefaultStartIndex (:143) -- on the device, so that the two
- * persistent layers never leave HBM between clouds.  base_to_map = {tx, ty, tz, qx, qy, qz, qw} of
- * lookupTransform("base_link", "map") (:103).  shift (nullable) receives the index shift (rows, cols). */
-int gg_move_map(gg_context *ctx, int slot, double odom_x, double odom_y, const double base_to_map[7], int shift[2]);
+ * persistent layers never leave HBM between clouds.
+ * base_plane = {r20, r21, r22, tz}: third row of the rotation and z of the translation of
+ * lookupTransform("base_link", "map") (:103), i.e. z_base(p) = ((r20 * p.x + r21 * p.y) + r22 * p.z) + tz, evaluated in
+ * this order in double (:129).  ABI v2: the caller hands over matrix entries, NOT a quaternion -- which rotation matrix
+ * tf2::doTransform(PointStamped) builds from the quaternion (tf2::Matrix3x3::setRotation or KDL::Rotation::Quaternion)
+ * is the binding's decision (gg_rotation_from_quaternion offers both).  shift (nullable) receives the index shift
+ * (rows, cols). */
+int gg_move_map(gg_context *ctx, int slot, double odom_x, double odom_y, const double base_plane[4], int shift[2]);
 int gg_get_map_position(const gg_context *ctx, int slot, double *pos_x, double *pos_y);
 /* any of the 11 layers, column-major rows x cols float32 (Eigen::MatrixXf), host memory */
 int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src);
@@ -181,10 +215,28 @@ int gg_filter_cloud_tf(gg_context *ctx, int slot, const gg_point32 *cloud, size_
                        const float origin[3], double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label,
                        int32_t *out_index);
 
+/* Pipelined form of gg_filter_cloud / gg_filter_cloud_tf (map_from_cloud nullable): packs the cloud into one of
+ * GG_ASYNC_DEPTH pinned staging buffers, enqueues upload + kernels + download and returns a ticket without waiting;
+ * gg_filter_cloud_wait blocks until that cloud is done and hands out the results.  With two clouds in flight the
+ * host-side packing and the H2D copy of cloud k+1 overlap the kernels of cloud k, and the result download / returned-
+ * cloud assembly of cloud k overlaps the kernels of cloud k+1 (clouds of one slot still execute in call order: cloud k+1
+ * reads the map state cloud k left).  `cloud` must stay valid until the matching wait when out_cloud is requested
+ * there.  Tickets must be waited for in issue order; at most GG_ASYNC_DEPTH may be outstanding (GG_ERR_CAPACITY). */
+#define GG_ASYNC_DEPTH 2
+int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *map_from_cloud,
+                          const float origin[3], double base_z, int *ticket);
+int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label,
+                         int32_t *out_index);
+
 /* Batched, device-resident form of the same call: n_clouds independent (cloud, map-state) pairs in
  * one set of launches, slot first_slot + b for cloud b.  Pointers prefixed d_ are device memory.
- * Enqueues on `stream` (a hipStream_t passed as void*, NULL = the context's own stream) and returns
- * without waiting. */
+ * Enqueues on `stream` (a hipStream_t passed as void*, NULL = the context's own stream; pass hipStreamLegacy,
+ * (void*)1, for the legacy default stream) and returns without waiting.
+ * Ordering across streams is the library's job, not the caller's: a batch waits (hipStreamWaitEvent) for every earlier
+ * map mutation of the context (gg_reset_map, gg_move_map, gg_set_layer, earlier batches on other streams), and every
+ * later entry point that reads or writes map state on the context's own stream (gg_get_layer, gg_set_layer,
+ * gg_move_map, gg_reset_map, the image / class getters, gg_filter_cloud*) waits for the batch.  The caller only has to
+ * keep the buffers named in gg_batch alive and unmodified until the stream has passed the batch. */
 typedef struct gg_batch {
     int n_clouds;
     int first_slot;

@@ -70,7 +70,56 @@ GGO_ALWAYS_INLINE float tree25(const float *e)
     const float d = (e[18] + (e[19] + e[20])) + ((e[21] + e[22]) + (e[23] + e[24]));
     return (a + b) + (c + d);
 }
-GGO_ALWAYS_INLINE float treeSS(const float *e, const int S) { return S == 3 ? tree9(e) : tree25(e); }
+/* Eigen 3.4.x Redux.h, SSE2 build (Packet4f = 4 floats): for a 5x5 block SliceVectorizedWork = (5 / 4) * 5 = 5 >= 3, so
+ * redux_impl<Func, Evaluator, SliceVectorizedTraversal, NoUnrolling> runs:
+ *   packet_res = packet(0,0);  for j in 0..4: for i in (j == 0 ? 4 : 0) .. 4 step 4: packet_res += packet(j, i)
+ *   res = predux(packet_res)            SSE: tmp = a + movehl(a,a); tmp[0] + tmp[1]  ==  (a0 + a2) + (a1 + a3)
+ *   for j in 0..4: for i in 4..5: res = res + coeff(j, i)         (row 4 of every column, in column order)
+ * (3x3 blocks: SliceVectorizedWork = 0, they stay on redux_novec_unroller.)  cwiseProduct().sum() applies the same
+ * traversal to the element-wise products. */
+GGO_ALWAYS_INLINE float tree25_eigen34(const float *e)
+{
+    float p[4];
+    for (int r = 0; r < 4; ++r) p[r] = (((e[r] + e[5 + r]) + e[10 + r]) + e[15 + r]) + e[20 + r];
+    float res = (p[0] + p[2]) + (p[1] + p[3]);
+    for (int j = 0; j < 5; ++j) res = res + e[4 + 5 * j];
+    return res;
+}
+static int g_eigen_reduction = 0;
+void ggo_set_eigen_reduction(int order) { g_eigen_reduction = order ? 1 : 0; }
+int ggo_get_eigen_reduction(void) { return g_eigen_reduction; }
+GGO_ALWAYS_INLINE float treeSS(const float *e, const int S)
+{
+    return S == 3 ? tree9(e) : (g_eigen_reduction ? tree25_eigen34(e) : tree25(e));
+}
+
+float ggo_block_sum(const float *e, int S) { return treeSS(e, S); }
+
+/* Quaternion -> rotation matrix, the two candidates behind tf2::doTransform (see gg_oracle.h):
+ *   0  tf2/LinearMath/Matrix3x3.h setRotation: d = |q|^2, s = 2/d, xs = x*s ..., rows
+ *        (1-(yy+zz), xy-wz, xz+wy), (xy+wz, 1-(xx+zz), yz-wx), (xz-wy, yz+wx, 1-(xx+yy))
+ *   1  orocos_kdl frames.cpp Rotation::Quaternion(x,y,z,w): x2 = x*x ..., rows
+ *        (w2+x2-y2-z2, 2xy-2wz, 2xz+2wy), (2xy+2wz, w2-x2+y2-z2, 2yz-2wx), (2xz-2wy, 2yz+2wx, w2-x2-y2+z2) */
+void ggo_rotation_from_quaternion(int convention, const double q[4], double R[9])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    if (convention == 0) {
+        const double d = x * x + y * y + z * z + w * w; /* length2(): x*x + y*y + z*z + w*w, left to right */
+        const double s = 2.0 / d;
+        const double xs = x * s, ys = y * s, zs = z * s;
+        const double wx = w * xs, wy = w * ys, wz = w * zs;
+        const double xx = x * xs, xy = x * ys, xz = x * zs;
+        const double yy = y * ys, yz = y * zs, zz = z * zs;
+        R[0] = 1.0 - (yy + zz); R[1] = xy - wz;         R[2] = xz + wy;
+        R[3] = xy + wz;         R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+        R[6] = xz - wy;         R[7] = yz + wx;         R[8] = 1.0 - (xx + yy);
+    } else {
+        const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+        R[0] = w2 + x2 - y2 - z2;       R[1] = 2 * x * y - 2 * w * z;   R[2] = 2 * x * z + 2 * w * y;
+        R[3] = 2 * x * y + 2 * w * z;   R[4] = w2 - x2 + y2 - z2;       R[5] = 2 * y * z - 2 * w * x;
+        R[6] = 2 * x * z - 2 * w * y;   R[7] = 2 * y * z + 2 * w * x;   R[8] = w2 - x2 - y2 + z2;
+    }
+}
 
 /* glibc sysdeps/ieee754/flt-32/e_hypotf.c (2.13 .. 2.35): finite, non-zero arguments take
  * (float)sqrt((double)x*x + (double)y*y); inf/NaN/zero special cases as IEEE hypot. */
@@ -201,7 +250,7 @@ void ggo_map_destroy(ggo_map *m)
 /* N1: GroundGrid::update (src/GroundGrid.cpp:83-147) + grid_map::GridMap::move / getPosition /  */
 /*     convertToDefaultStartIndex (grid_map_core 1.6.x) + tf2 doTransform of a point            */
 /* ------------------------------------------------------------------------------------------ */
-int ggo_map_update(ggo_map *m, double odom_x, double odom_y, const double tf[7], int shift[2])
+int ggo_map_update(ggo_map *m, double odom_x, double odom_y, const double plane[4], int shift[2])
 {
     const int n[2] = {m->rows, m->cols};
     const double res = m->resolution;
@@ -223,15 +272,8 @@ int ggo_map_update(ggo_map *m, double odom_x, double odom_y, const double tf[7],
     m->position[0] += (double)(-s[0]) * res;
     m->position[1] += (double)(-s[1]) * res;
 
-    /* tf2::Matrix3x3::setRotation, third row only (Matrix3x3.h) */
-    const double qx = tf[3], qy = tf[4], qz = tf[5], qw = tf[6];
-    const double d = qx * qx + qy * qy + qz * qz + qw * qw;
-    const double sc = 2.0 / d;
-    const double xs = qx * sc, ys = qy * sc, zs = qz * sc;
-    const double wx = qw * xs, wy = qw * ys;
-    const double xx = qx * xs, xz = qx * zs, yy = qy * ys, yz = qy * zs;
-    (void)zs;
-    const double m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+    /* third row of the rotation + translation z of base_link <- map (ggo_rotation_from_quaternion picks the convention) */
+    const double m20 = plane[0], m21 = plane[1], m22 = plane[2], tz = plane[3];
 
     const size_t C = (size_t)n[0] * (size_t)n[1];
     float *tmp = (float *)malloc(C * sizeof(float));
@@ -254,8 +296,8 @@ int ggo_map_update(ggo_map *m, double odom_x, double odom_y, const double tf[7],
                         /* getPositionFromIndex: position = mapPosition + offset + resolution * (-index) */
                         const double px = (m->position[0] + first0) + res * (double)(-i);
                         const double py = (m->position[1] + first1) + res * (double)(-j);
-                        /* tf2: v_out.z = (m20 * x + m21 * y + m22 * 0) + origin.z; ground = -z (:130) */
-                        const double z = ((m20 * px + m21 * py) + m22 * 0.0) + tf[2];
+                        /* doTransform: v_out.z = (m20 * x + m21 * y + m22 * 0) + origin.z; ground = -z (:130) */
+                        const double z = ((m20 * px + m21 * py) + m22 * 0.0) + tz;
                         v = (float)(-z);
                     } else if (l == GGO_GROUNDPATCH) {
                         v = 0.0f; /* :131 */
@@ -337,7 +379,7 @@ void ggo_stage_insert(ggo_map *m, const ggo_config *cfg, const ggo_point *cloud,
             vy /= len;
             vz /= len;
             const double len2 = (double)len * (double)len;
-            for (int step = 3;; ++step) { /* :258 */
+            for (int step = 3; step < GGO_WALK_MAX_STEP; ++step) { /* :258; the bound is the library's (see gg_oracle.h) */
                 const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
                 const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
                 if (!(d2 < len2 && vz < -0.01f)) break;

@@ -88,6 +88,21 @@ typedef struct ggo_map {
     float *expectedPoints;        /* R1 table, column-major                     */
 } ggo_map;
 
+/* Documented deviation shared with the library: the line-of-sight walk (:258) has no bound in the reference (a corrupt
+ * z of -1e9 walks 1e9 steps, past 2^31 its int step overflows); steps >= GGO_WALK_MAX_STEP are not evaluated.  Only
+ * points more than 65 km from the sensor can tell the difference. */
+#define GGO_WALK_MAX_STEP (1 << 16)
+
+/* Third-party conventions (unpinned, see tools/pin/): which Eigen the reference is built against decides the order of
+ * the 5x5 block sums (:359, :374-375).  0 = Eigen 3.3.x redux_novec_unroller (default, ROS Noetic / Ubuntu 20.04),
+ * 1 = Eigen 3.4.x SSE2 slice-vectorised reduction.  Process-wide (test infrastructure). */
+void ggo_set_eigen_reduction(int order);
+int ggo_get_eigen_reduction(void);
+
+/* Quaternion (x,y,z,w) -> row-major rotation: convention 0 = tf2::Matrix3x3::setRotation, 1 = KDL::Rotation::Quaternion
+ * (what tf2_geometry_msgs' doTransform(PointStamped) uses in ROS Noetic). */
+void ggo_rotation_from_quaternion(int convention, const double q_xyzw[4], double rot[9]);
+
 void ggo_default_config(ggo_config *c);
 
 /* grid_map::GridMap::setGeometry + GroundSegmentation::init + GroundGrid::initGroundGrid state.
@@ -120,14 +135,16 @@ void ggo_stage_spiral(ggo_map *m, const ggo_config *cfg, double base_z); /* :398
 /* GroundGrid::update (src/GroundGrid.cpp:83-147) on an already initialised map: grid_map::GridMap::move to the odometry
  * position (snapped to whole cells), newly exposed cells get ground = -(z of (cell centre, 0) in base_link) and
  * groundpatch = 0 (:121-131), every other layer NaN there (grid_map clears dropped rows/cols of all layers),
- * then convertToDefaultStartIndex (:143).  base_to_map = {tx, ty, tz, qx, qy, qz, qw} of the transform
- * lookupTransform("base_link", "map") returns (:103).  shift[2] receives the index shift (rows, cols); returns 1 if
- * the map moved. */
-int ggo_map_update(ggo_map *m, double odom_x, double odom_y, const double base_to_map[7], int shift[2]);
+ * then convertToDefaultStartIndex (:143).  base_plane = {r20, r21, r22, tz}: third row of the rotation and translation z
+ * of the transform lookupTransform("base_link", "map") returns (:103), built from the quaternion by whichever
+ * convention doTransform(PointStamped) follows (ggo_rotation_from_quaternion).  shift[2] receives the index shift
+ * (rows, cols); returns 1 if the map moved. */
+int ggo_map_update(ggo_map *m, double odom_x, double odom_y, const double base_plane[4], int shift[2]);
 
 /* helpers exported for unit tests */
 int ggo_get_index(const ggo_map *m, double px, double py, int *row, int *col); /* returns isInside */
 float ggo_tree_sum(const float *e, int len);   /* Eigen 3.3.7 redux_novec_unroller order */
+float ggo_block_sum(const float *e, int S);    /* Block<MatrixXf,S,S>::sum(), S = 3 or 5, under the selected Eigen order */
 float ggo_hypotf(float x, float y);            /* glibc e_hypotf.c: (float)sqrt((double)x*x+(double)y*y) */
 size_t ggo_spiral_visit_count(int rows);
 

@@ -115,18 +115,52 @@ def lib():
         ]
         L.ggo_stage_detect.argtypes = [C.POINTER(_Map), C.POINTER(Config)]
         L.ggo_stage_spiral.argtypes = [C.POINTER(_Map), C.POINTER(Config), C.c_double]
+        L.ggo_set_eigen_reduction.argtypes = [C.c_int]
+        L.ggo_get_eigen_reduction.restype = C.c_int
+        L.ggo_rotation_from_quaternion.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ggo_rotation_from_quaternion.restype = None
         L.ggo_map_update.restype = C.c_int
         L.ggo_map_update.argtypes = [C.POINTER(_Map), C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.ggo_get_index.restype = C.c_int
         L.ggo_get_index.argtypes = [C.POINTER(_Map), C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ggo_tree_sum.restype = C.c_float
         L.ggo_tree_sum.argtypes = [C.POINTER(C.c_float), C.c_int]
+        L.ggo_block_sum.restype = C.c_float
+        L.ggo_block_sum.argtypes = [C.POINTER(C.c_float), C.c_int]
         L.ggo_hypotf.restype = C.c_float
         L.ggo_hypotf.argtypes = [C.c_float, C.c_float]
         L.ggo_spiral_visit_count.restype = C.c_size_t
         L.ggo_spiral_visit_count.argtypes = [C.c_int]
         _lib = L
     return _lib
+
+
+ROTATION = {"tf2": 0, "kdl": 1}
+
+
+def rotation_from_quaternion(q_xyzw, rotation: str = "kdl") -> np.ndarray:
+    """3x3 rotation the way tf2::Matrix3x3::setRotation ("tf2") or KDL::Rotation::Quaternion ("kdl") builds it."""
+    q = (C.c_double * 4)(*[float(v) for v in q_xyzw])
+    R = (C.c_double * 9)()
+    lib().ggo_rotation_from_quaternion(ROTATION[rotation], q, R)
+    return np.array(list(R), dtype=np.float64).reshape(3, 3)
+
+
+def plane_from_pose(pose7, rotation: str = "kdl"):
+    """(tx, ty, tz, qx, qy, qz, qw) -> (r20, r21, r22, tz): what GroundGrid::update needs of base_link <- map."""
+    R = rotation_from_quaternion(pose7[3:7], rotation)
+    return float(R[2, 0]), float(R[2, 1]), float(R[2, 2]), float(pose7[2])
+
+
+def matrix_from_pose(pose7, rotation: str = "kdl") -> np.ndarray:
+    """(tx, ty, tz, qx, qy, qz, qw) -> 3x4 (R | t)."""
+    R = rotation_from_quaternion(pose7[3:7], rotation)
+    return np.concatenate([R, np.asarray(pose7[:3], dtype=np.float64).reshape(3, 1)], axis=1)
+
+
+def set_eigen_reduction(order: int):
+    """0 = Eigen 3.3.x order of the 5x5 block sums (default), 1 = Eigen 3.4.x SSE2 (process-wide)."""
+    lib().ggo_set_eigen_reduction(int(order))
 
 
 def default_config() -> Config:
@@ -184,11 +218,13 @@ class OracleMap:
     def reset_state(self, pos=(0.0, 0.0), odom_z=0.0):
         self._L.ggo_map_reset_state(self._m, pos[0], pos[1], C.c_float(odom_z))
 
-    def update(self, odom_x: float, odom_y: float, base_to_map):
-        """GroundGrid::update.  base_to_map = (tx, ty, tz, qx, qy, qz, qw).  Returns (moved, (shift_rows, shift_cols))."""
-        tf = (C.c_double * 7)(*[float(v) for v in base_to_map])
+    def update(self, odom_x: float, odom_y: float, base_to_map, rotation: str = "kdl"):
+        """GroundGrid::update.  base_to_map = (tx, ty, tz, qx, qy, qz, qw) of lookupTransform("base_link", "map");
+        `rotation` = which quaternion -> matrix convention doTransform(PointStamped) follows ("kdl" or "tf2").
+        Returns (moved, (shift_rows, shift_cols))."""
+        plane = (C.c_double * 4)(*plane_from_pose(base_to_map, rotation))
         sh = (C.c_int * 2)()
-        moved = self._L.ggo_map_update(self._m, float(odom_x), float(odom_y), tf, sh)
+        moved = self._L.ggo_map_update(self._m, float(odom_x), float(odom_y), plane, sh)
         return bool(moved), (sh[0], sh[1])
 
     def layer(self, name: str) -> np.ndarray:

@@ -27,6 +27,24 @@ def tree_sum(e):
     return f32(tree_sum(e[:h]) + tree_sum(e[h:]))
 
 
+EIGEN_REDUCTION = 0  # 0 = Eigen 3.3.x (every fixed-size block sum takes the unrolled tree), 1 = Eigen 3.4.x SSE2 build
+
+
+def block_sum(e):
+    """Block<MatrixXf,S,S>::sum() of the S*S column-major coefficients e.  Under Eigen 3.4 (Packet4f) the 5x5 blocks take
+    the slice-vectorised reduction: four row lanes accumulated over the columns, predux (a0+a2)+(a1+a3), then row 4 of
+    every column; 3x3 blocks keep the unrolled tree under both versions."""
+    if EIGEN_REDUCTION == 0 or len(e) != 25:
+        return tree_sum(e)
+    lanes = [f32(e[r]) for r in range(4)]
+    for j in range(1, 5):
+        lanes = [f32(lanes[r] + f32(e[5 * j + r])) for r in range(4)]
+    res = f32(f32(lanes[0] + lanes[2]) + f32(lanes[1] + lanes[3]))
+    for j in range(5):
+        res = f32(res + f32(e[5 * j + 4]))
+    return res
+
+
 def std_min(a, b):
     return b if b < a else a
 
@@ -163,7 +181,7 @@ class PyRef:
         resf = f32(self.res)
         sqdist = f32((f64(i - n / 2.0) ** 2 + f64(j - n / 2.0) ** 2) * (f64(resf) * f64(resf)))
         expected = self.expected[i, j]
-        psum = tree_sum(pts)
+        psum = block_sum(pts)
         oldC, oldG = L["groundpatch"][i, j], L["ground"][i, j]
         gp = f64(cfg["ground_patch_detection_minimum_point_count_threshold"])
         if f64(psum) < std_max(np.floor(gp * f64(S) * f64(expected)), f64(3.0)):
@@ -176,8 +194,8 @@ class PyRef:
         if pts[ci + ci * S] >= f32(cfg["point_count_cell_variance_threshold"]):
             max_var = variance
         else:
-            max_var = f32(tree_sum([f32(p * v) for p, v in zip(pts, var)]) / psum)
-        groundlevel = f32(tree_sum([f32(p * m) for p, m in zip(pts, mn)]) / psum)
+            max_var = f32(block_sum([f32(p * v) for p, v in zip(pts, var)]) / psum)
+        groundlevel = f32(block_sum([f32(p * m) for p, m in zip(pts, mn)]) / psum)
         ground_diff = std_max(f32(f32(groundlevel - oldG) * f32(f32(2.0) * oldC)), f32(1.0))
         if f64(oldC) > 0.5 and f64(groundlevel) >= f64(oldG) + f64(cfg["outlier_tolerance"]):
             return

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_kernel_names(lib):
-    assert lib.gg_abi_version() == 1
+    assert lib.gg_abi_version() == 2  # v2: gg_move_map takes matrix entries, conventions, async host call
     names = [lib.gg_kernel_name(k).decode() for k in range(_lib.GG_NUM_KERNELS)]
     assert names == ["k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_spiral", "k_label"]
 
@@ -49,6 +49,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.GGGeometry) == 16
     assert C.sizeof(_lib.GGConfig) == 104          # 2 int, 11 double, 1 int (+pad) as the C compiler lays it out
     assert C.sizeof(_lib.GGBatch) == 104
+    assert C.sizeof(_lib.GGConventions) == 32
     from groundgrid_amd import api, synth
     assert synth.POINT_DTYPE.itemsize == 32 and api.POINT16_DTYPE.itemsize == 16
     # compile a tiny C program against the header and compare sizeof / offsetof
@@ -56,15 +57,17 @@ def test_struct_layouts_match_the_header():
     #include <stdio.h>
     #include <stddef.h>
     #include "groundgrid_hip.h"
-    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(gg_point32), sizeof(gg_point16), sizeof(gg_config),
-        sizeof(gg_geometry), sizeof(gg_batch), offsetof(gg_point32, ring), offsetof(gg_batch, d_out_counts)); return 0; }
+    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\n", sizeof(gg_point32), sizeof(gg_point16), sizeof(gg_config),
+        sizeof(gg_geometry), sizeof(gg_batch), offsetof(gg_point32, ring), offsetof(gg_batch, d_out_counts),
+        sizeof(gg_conventions), GG_ASYNC_DEPTH); return 0; }
     '''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         vals = list(map(int, subprocess.check_output([os.path.join(d, "t")], text=True).split()))
-    assert vals == [32, 16, C.sizeof(_lib.GGConfig), 16, C.sizeof(_lib.GGBatch), 20, _lib.GGBatch.d_out_counts.offset]
+    assert vals == [32, 16, C.sizeof(_lib.GGConfig), 16, C.sizeof(_lib.GGBatch), 20, _lib.GGBatch.d_out_counts.offset,
+                    C.sizeof(_lib.GGConventions), _lib.GG_ASYNC_DEPTH]
 
 
 def test_defaults_are_the_reference_cfg(lib):
@@ -106,6 +109,12 @@ def test_bad_arguments_are_rejected_before_touching_the_device(lib):
     assert lib.gg_set_config(None, None) == -1
     assert lib.gg_filter_batch(None, None, None) == -1
     assert lib.gg_get_layer(None, 0, 0, None) == -5
+    assert lib.gg_set_conventions(None, None) == -1
+    assert lib.gg_move_map(None, 0, 0.0, 0.0, None, None) == -5
+    assert lib.gg_filter_cloud_wait(None, 0, None, None, None, None) == -1
+    q = (C.c_double * 4)(0, 0, 0, 1)
+    R = (C.c_double * 9)()
+    assert lib.gg_rotation_from_quaternion(7, q, R) == -1 and lib.gg_rotation_from_quaternion(0, None, R) == -1
 
 
 def test_product_never_imports_the_oracle():

@@ -27,6 +27,39 @@ def compile_adapter():
     return EXE
 
 
+STREAMS_EXE = os.path.join(ROOT, "tests", "cpp", "test_streams")
+
+
+def compile_streams():
+    build.build()
+    oracle.build()
+    src = os.path.join(ROOT, "tests", "cpp", "test_streams.c")
+    if not os.path.exists(STREAMS_EXE) or os.path.getmtime(STREAMS_EXE) < os.path.getmtime(src):
+        subprocess.check_call([
+            "gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__", src, "-o", STREAMS_EXE,
+            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), "-I", "/opt/rocm/include",
+            "-L", os.path.join(ROOT, "groundgrid_amd"), "-lgroundgrid_hip", "-L", os.path.join(ROOT, "oracle"), "-lgg_oracle",
+            "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+            "-Wl,-rpath," + os.path.join(ROOT, "groundgrid_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+            "-Wl,-rpath,/opt/rocm/lib",
+        ])
+    return STREAMS_EXE
+
+
+def test_plain_c_stream_and_async_program_compiles():
+    assert os.path.exists(compile_streams())
+
+
+@pytest.mark.gpu
+def test_foreign_stream_ordering_and_async_pipeline_in_plain_c():
+    """gg_filter_batch on a caller stream followed at once by gg_get_layer / gg_set_layer / gg_move_map, and the two-deep
+    gg_filter_cloud_async pipeline: a C program with no Python in the loop, bit-compared with the C oracle."""
+    exe = compile_streams()
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+
 def test_adapter_compiles_and_links_against_the_c_abi():
     assert os.path.exists(compile_adapter())
 

@@ -521,3 +521,125 @@ def test_wire_formats_pointcloud2_ingest_and_images():
         for dj in (-1, 0, 1):
             s[1:-1, 1:-1] += raw[1 + di : raw.shape[0] - 1 + di, 1 + dj : raw.shape[1] - 1 + dj]   # integer-valued: order-free
     assert np.array_equal(t[1:-1, 1:-1, 1], (s[1:-1, 1:-1] >= 27).astype(np.float32))
+
+
+# ---------------------------------------------------------------- round 2: conventions, robustness, pipelined host call
+
+def test_odd_grid_dense_points_on_row_n_minus_3():
+    """for odd sizes the reference's quadrant split (:325-328) never runs detect_ground_patch on row n - 3.
+    A 727 x 727 map (240 m / 0.33 m) with enough points on and around that row to pass the 3-point early-out."""
+    n, res = 727, 0.33
+    rng = np.random.default_rng(12)
+    m = 60000
+    # map frame: row index 0 is at +x; row r covers x in (L/2 - (r+1) res, L/2 - r res]
+    L = n * np.float64(np.float32(res))
+    rows = rng.integers(n - 8, n - 1, size=m)
+    x = L / 2 - (rows + rng.random(m)) * np.float64(np.float32(res))
+    y = rng.uniform(-L / 2 + 1, L / 2 - 1, size=m)
+    z = -1.7 + rng.normal(0, 0.01, size=m)
+    cloud = synth.make_cloud(np.column_stack([x, y, z]).astype(np.float32), ring=rng.integers(0, 64, m))
+    r = run_pair(cloud, length=240.0, resolution=res, frames=3)
+    assert (r["cls"] == oracle.KEPT).sum() > 40000
+
+
+def test_eigen34_reduction_order_on_device():
+    """gg_conventions.eigen_reduction = GG_EIGEN_34_SSE: the 5x5 block sums of K3 follow Eigen 3.4's slice-vectorised order;
+    bit-identical to the oracle under the same switch, and different from the Eigen 3.3 terrain somewhere."""
+    cloud = synth.hdl64_cloud(seed=21, n_az=900)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    grounds = {}
+    try:
+        for order in (1, 0):
+            oracle.set_eigen_reduction(order)
+            seg.set_conventions(eigen_reduction=order)
+            ref = oracle.OracleMap(120.0, 0.33)
+            seg.map(0).reset()
+            for f in range(3):
+                _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+                r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+                assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), (order, f)
+                assert_same_state(seg.map(0), ref, f"eigen order {order} frame {f}")
+            grounds[order] = seg.map(0)["ground"]
+    finally:
+        oracle.set_eigen_reduction(0)
+    assert not np.array_equal(grounds[0], grounds[1]) and np.max(np.abs(grounds[0] - grounds[1])) < 1e-3
+
+
+@pytest.mark.parametrize("rotation", ["kdl", "tf2"])
+def test_map_scroll_under_both_rotation_conventions(rotation):
+    """gg_move_map takes matrix entries (ABI v2); whichever quaternion -> matrix convention the binding picks, device and
+    oracle fill the exposed cells with the same plane."""
+    seg = api.GroundSegmentation().init(21.12, 0.33, n_slots=1, max_points=16)
+    ref = oracle.OracleMap(21.12, 0.33)
+    q = np.array([0.013, -0.021, 0.31, 0.95])
+    q /= np.linalg.norm(q)
+    pose = (0.3, 0.2, 1.5) + tuple(q)
+    moved, shift = ref.update(3.1, -2.2, pose, rotation=rotation)
+    assert moved and tuple(seg.map(0).move(3.1, -2.2, pose, rotation=rotation)) == tuple(shift)
+    for name in ("ground", "groundpatch"):
+        assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+
+
+def test_corrupt_z_does_not_hang_the_device():
+    """an in-map point with z = -1e9 walked ~1e9 line-of-sight steps.  The walk is bounded (documented
+    deviation shared with the oracle); the call returns promptly and still matches."""
+    import time
+
+    good = synth.hdl64_cloud(seed=2, n_az=300)
+    bad = synth.make_cloud(np.array([[4.0, 4.0, -1e9], [10.0, -3.0, -3e38], [0.2, 25.0, -1e7], [7.0, 7.0, -70000.0]], dtype=np.float32))
+    cloud = np.concatenate([good, bad])
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    ref = oracle.OracleMap(120.0, 0.33)
+    for f in range(3):
+        t0 = time.perf_counter()
+        _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+        assert time.perf_counter() - t0 < 5.0
+        r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+        cls, _ = seg.point_classes(len(cloud))
+        assert np.array_equal(cls, r["cls"]) and np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), f
+        assert_same_state(seg.map(0), ref, f"frame {f}")
+
+
+def test_pipelined_host_call_matches_the_serial_path():
+    """gg_filter_cloud_async / gg_filter_cloud_wait two clouds deep on one map: same returned clouds, labels and terrain as
+    the serial oracle; a third outstanding ticket is refused."""
+    clouds = [synth.hdl64_cloud(seed=30 + k, n_az=500) for k in range(3)]
+    seq = [clouds[k % 3] for k in range(7)]
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=max(len(c) for c in clouds))
+    ref = oracle.OracleMap(120.0, 0.33)
+    tickets = [seg.filter_cloud_async(seq[0], ORIGIN0, -1.73)]
+    for k in range(len(seq)):
+        if k + 1 < len(seq):
+            tickets.append(seg.filter_cloud_async(seq[k + 1], ORIGIN0, -1.73))
+        if k == 0:
+            with pytest.raises(api.GroundGridError):
+                seg.filter_cloud_async(seq[0], ORIGIN0, -1.73)
+        out, labels, index = seg.filter_cloud_wait(tickets[k], return_details=True)
+        r = ref.filter_cloud(seq[k], ORIGIN0, -1.73)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), k
+        assert out.tobytes() == r["out_points"].tobytes(), k
+    assert_same_state(seg.map(0), ref, "after the pipelined sequence")
+
+
+def test_batch_on_torch_default_stream_is_ordered_with_torch_ops():
+    """torch's default stream handle is 0, which the C ABI reads as "the context's own stream".  The binding
+    now names the legacy stream, so a torch op enqueued right behind filter_batch sees its results without any host
+    synchronisation."""
+    import torch
+
+    cloud = synth.hdl64_cloud(seed=8, n_az=800)
+    n = len(cloud)
+    stride = (n + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=stride)
+    host = np.zeros((1, stride), dtype=api.POINT16_DTYPE)
+    host[0, :n] = api.pack16(cloud)
+    pts = torch.from_numpy(host.view(np.uint8).reshape(1, stride, 16)).cuda()
+    ref = oracle.OracleMap(120.0, 0.33)
+    out = None
+    for f in range(3):
+        out = seg.filter_batch(pts, [n], np.zeros((1, 3), np.float32), np.array([-1.73]), out=out)
+        snapshot = out.labels[0, :n].clone()          # torch op on the same (default) stream, no synchronize in between
+        r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+        assert np.array_equal(snapshot.cpu().numpy(), r["label"]), f
+        # ... and the library orders its own stream behind the batch: no torch.cuda.synchronize() before reading layers
+        assert nan_equal(seg.map(0)["ground"], ref.layer("ground")), f
