@@ -47,7 +47,7 @@ GG_EIGEN_33, GG_EIGEN_34_SSE = 0, 1
 GG_ROT_TF2, GG_ROT_KDL = 0, 1
 ROTATION = {"tf2": GG_ROT_TF2, "kdl": GG_ROT_KDL}
 GG_ASYNC_DEPTH = 2
-HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the legacy default ("null") stream, as torch's default stream handle 0 means it
+GG_STREAM_DEFAULT = C.c_void_p(-1).value  # include/groundgrid_hip.h: the legacy default ("null") stream -- what torch's handle 0 means
 
 
 class GGConfig(C.Structure):

@@ -312,8 +312,8 @@ class GroundSegmentation:
         b.d_label_masks = out.label_masks.data_ptr() if out.label_masks is not None else None
         s = stream if stream is not None else torch.cuda.current_stream(points.device).cuda_stream
         # torch hands out 0 for its default stream = the legacy null stream; NULL would mean "the context's own stream" to
-        # the library, which is not ordered with torch ops / RCCL -- so name the legacy stream explicitly
-        rc = self._L.gg_filter_batch(self._ctx, C.byref(b), C.c_void_p(s if s else _lib.HIP_STREAM_LEGACY))
+        # the library, which is not ordered with torch ops / RCCL -- so name the default stream explicitly
+        rc = self._L.gg_filter_batch(self._ctx, C.byref(b), C.c_void_p(s if s else _lib.GG_STREAM_DEFAULT))
         _check(self._L, self._ctx, rc, "gg_filter_batch")
         return out
 

@@ -416,7 +416,11 @@ void make_dev_config(const gg_config &c, DevConfig &d)
     d.min_point_height_obs_thres = c.minimum_point_height_obstacle_threshold;
 }
 
-hipStream_t pick_stream(gg_context *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+hipStream_t pick_stream(gg_context *ctx, void *stream)
+{
+    if (stream == GG_STREAM_DEFAULT) return (hipStream_t) nullptr; // the legacy default stream
+    return stream ? (hipStream_t)stream : ctx->stream;
+}
 
 // Entry points that read or write map state on ctx->stream call this first: the context's stream waits for the last batch
 // that ran on another stream (gg_get_layer after a batch on a caller stream read stale layers).

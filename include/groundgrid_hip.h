@@ -230,8 +230,8 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
 
 /* Batched, device-resident form of the same call: n_clouds independent (cloud, map-state) pairs in
  * one set of launches, slot first_slot + b for cloud b.  Pointers prefixed d_ are device memory.
- * Enqueues on `stream` (a hipStream_t passed as void*, NULL = the context's own stream; pass hipStreamLegacy,
- * (void*)1, for the legacy default stream) and returns without waiting.
+ * Enqueues on `stream` (a hipStream_t passed as void*; NULL = the context's own stream, GG_STREAM_DEFAULT = the legacy
+ * default ("null") stream, which as a hipStream_t is itself 0) and returns without waiting.
  * Ordering across streams is the library's job, not the caller's: a batch waits (hipStreamWaitEvent) for every earlier
  * map mutation of the context (gg_reset_map, gg_move_map, gg_set_layer, earlier batches on other streams), and every
  * later entry point that reads or writes map state on the context's own stream (gg_get_layer, gg_set_layer,
@@ -259,6 +259,7 @@ typedef struct gg_batch {
                                 caller all-gathers (a quarter of d_labels).  cloud_stride must be a multiple of 4; only the bytes
                                 covering points < n_points (rounded up to a multiple of 64) are written */
 } gg_batch;
+#define GG_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int gg_filter_batch(gg_context *ctx, const gg_batch *batch, void *stream);
 int gg_synchronize(gg_context *ctx);
 

@@ -1,0 +1,3 @@
+#pragma once
+// declaration-only stand-in (see README.md)
+namespace grid_map_msgs { struct GridMap; }

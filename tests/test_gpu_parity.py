@@ -587,7 +587,9 @@ def test_corrupt_z_does_not_hang_the_device():
 
     good = synth.hdl64_cloud(seed=2, n_az=300)
     bad = synth.make_cloud(np.array([[4.0, 4.0, -1e9], [10.0, -3.0, -3e38], [0.2, 25.0, -1e7], [7.0, 7.0, -70000.0]], dtype=np.float32))
-    cloud = np.concatenate([good, bad])
+    cloud = synth.empty_cloud(len(good) + len(bad))
+    cloud[: len(good)] = good
+    cloud[len(good):] = bad
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
     ref = oracle.OracleMap(120.0, 0.33)
     for f in range(3):

@@ -1,0 +1,73 @@
+"""The pinning kit (tools/pin/): what can be checked without a ROS box.
+
+* compare.py's Python mirror of the probe's seeded input generator produces the same bits as the C++ generator
+  (pin_inputs.h, compiled here through inputs_dump.cpp -- no Eigen / grid_map / tf2 needed for that);
+* vectors emitted by the oracle under one variant are reproduced by exactly that variant and flagged against the
+  other one: the comparison is sensitive to both conventions (Eigen 5x5 order, tf2 vs KDL rotation);
+* a corrupted vector makes compare.py fail.
+probe.cpp itself needs the real libraries and is run by a maintainer on a ROS Noetic machine (tools/pin/README.md)."""
+import importlib.util
+import json
+import os
+import struct
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PIN = os.path.join(ROOT, "tools", "pin")
+
+
+def load_compare():
+    spec = importlib.util.spec_from_file_location("pin_compare", os.path.join(PIN, "compare.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_python_mirror_of_the_input_generator_matches_cpp(tmp_path):
+    exe = str(tmp_path / "inputs_dump")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", os.path.join(PIN, "inputs_dump.cpp"), "-o", exe])
+    lines = subprocess.check_output([exe], text=True).split()
+    cmp_ = load_compare()
+    a = cmp_.Lcg(0xE16E0001)
+    mine = [cmp_.hex32(a.wide_float()) for _ in range(200)]
+    b = cmp_.Lcg(0x61D00002)
+    mine += [cmp_.hex64(b.unit()) for _ in range(200)]
+    assert mine == lines
+    vals = [struct.unpack("<f", bytes.fromhex(h)[::-1])[0] for h in lines[:200]]
+    assert min(abs(v) for v in vals if v) < 1e-3 and max(abs(v) for v in vals) > 1e3  # cancellation-heavy range
+
+
+@pytest.mark.parametrize("eigen,rotation", [(0, "kdl"), (1, "tf2")])
+def test_emitted_vectors_select_their_own_variant(tmp_path, eigen, rotation, capsys):
+    cmp_ = load_compare()
+    doc = cmp_.emit(eigen, rotation)
+    path = tmp_path / "v.json"
+    json.dump(doc, open(path, "w"))
+    assert cmp_.compare(json.load(open(path))) == 0
+    out = capsys.readouterr().out
+    assert f"eigen_reduction={eigen}" in out.split("Select:")[1]
+    assert f'rotation="{rotation}"' in out.split("Select:")[1]
+    other_e, other_r = 1 - eigen, ("tf2" if rotation == "kdl" else "kdl")
+    five = [l for l in out.splitlines() if "5x5" in l][0]
+    assert f"eigen_reduction={other_e}" not in five             # the 5x5 order is observable in the vectors
+    upd = [l for l in out.splitlines() if "doTransform" in l][0]
+    assert f'rotation="{other_r}"' not in upd                   # and so is the rotation convention
+
+
+def test_a_wrong_vector_is_reported(tmp_path, capsys):
+    cmp_ = load_compare()
+    doc = cmp_.emit(0, "kdl")
+    doc["gm_index"][5] += 1
+    doc["hypotf"][7] = "3f800000"
+    assert cmp_.compare(doc) == 1
+    out = capsys.readouterr().out
+    assert "FAIL  grid_map getIndex" in out and "FAIL  glibc hypotf" in out
+
+
+def test_probe_source_is_present_and_cites_the_reference():
+    src = open(os.path.join(PIN, "probe.cpp")).read()
+    for needle in ("tf2::doTransform(ps, ps, base_to_map)", "convertToDefaultStartIndex", "block<S, S>", "std::hypot", "GroundSegmentation.cpp:", "GroundGrid.cpp:"):
+        assert needle in src
