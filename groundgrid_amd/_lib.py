@@ -23,7 +23,7 @@ STATUS = {
 }
 
 GG_POINT32, GG_POINT16 = 0, 1
-GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE, GG_FLAG_SPIRAL_NARROW = 1, 2, 4
+GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE, GG_FLAG_SPIRAL_NARROW, GG_FLAG_SPIRAL_LEVELS = 1, 2, 4, 8
 GG_NUM_KERNELS = 7
 GG_NUM_LAYERS = 11
 
@@ -40,7 +40,7 @@ SYMBOLS = [
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_debug_replay_spiral_schedule",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
-    "gg_filter_cloud_async", "gg_filter_cloud_wait",
+    "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep",
 ]
 
 GG_EIGEN_33, GG_EIGEN_34_SSE = 0, 1

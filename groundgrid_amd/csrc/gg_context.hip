@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "gg_internal.h"
+#include "sweep_core.h"
 
 using namespace gg;
 
@@ -47,6 +48,7 @@ struct gg_context {
     std::vector<char> no_confidence;  // per slot: groundpatch <= 0.01 everywhere for sure (set by gg_reset_map, cleared by any writer)
 
     gg_conventions conv{};
+    gg::sweep::Params sweep_params{};
 
     // cross-stream ordering (include/groundgrid_hip.h, gg_filter_batch): `map_event` is recorded on ctx->stream after every
     // map mutation enqueued there, `batch_event` on the launch stream after every batch
@@ -545,7 +547,15 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     launch_patch(a, dp, nb, s);
     prof.end();
     prof.begin(GG_K_SPIRAL);
-    launch_spiral(a, dp, nb, s);
+    if (ctx->flags & GG_FLAG_SPIRAL_LEVELS) {
+        launch_spiral(a, dp, nb, s);
+    } else {
+        sweep::Params sp = ctx->sweep_params;
+        sp.decrease = ctx->cfg.occupied_cells_decrease_factor;
+        sp.inv_decrease = 1.0 / sp.decrease;
+        sp.decay_fast = sp.decrease >= 1.25 && sp.decrease < 1e300;
+        launch_sweep(a, sp, dp, nb, s);
+    }
     prof.end();
     prof.begin(GG_K_LABEL);
     launch_label(a, dp, io, nb, max_n, s);
@@ -776,6 +786,11 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
             ctx->h_expected[i + j * cellCount] = atanf(1 / dist) / geom.vertical_point_ang_dist;
         }
 
+    ctx->sweep_params = gg::sweep::make_params(n, res, geom.min_dist_squared, ctx->cfg.occupied_cells_decrease_factor);
+    if (gg::sweep_lds_bytes(ctx->sweep_params) > 158 * 1024) {
+        gg_destroy(ctx);
+        return GG_ERR_GEOMETRY; // the sweep's hand-over tables no longer fit in LDS (n > ~1030)
+    }
     std::vector<SpiralVisit> visits[2];
     std::vector<uint32_t> level_start[2];
     int caps[2] = {448, 64}; // k_spiral runs two compute sets of `cap` lanes + a loader wave: 2 * 448 + 64 threads at most

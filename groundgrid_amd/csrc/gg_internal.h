@@ -157,6 +157,12 @@ void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hi
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 size_t spiral_lds_bytes(int slots, int max_level_width); // dynamic LDS k_spiral needs for a schedule (k4_spiral.hip)
+namespace sweep {
+struct Params;
+Params make_params(int n, double resolution, float min_dist_squared, double decrease); // sweep_emul.hip (host)
+} // namespace sweep
+void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4_sweep.hip
+size_t sweep_lds_bytes(const sweep::Params &P);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);

@@ -1,0 +1,199 @@
+// K4 -- spiral_ground_interpolation / interpolate_cell (src/GroundSegmentation.cpp:398-465), second generation: the
+// ring-per-lane dataflow of sweep_core.h on gfx950.
+//
+// One work-group per cloud: 4 x W chain wavefronts (sides A, B, C, D of the rings; a wavefront owns groups of 64
+// consecutive rings, lane = ring, ring r + 1 three steps behind ring r) + two corner wavefronts (one active lane each).
+// There is no barrier after start-up and no table: every wavefront free-runs through its steps; what a step needs from
+// other wavefronts arrives through LDS behind monotonic progress counters that the consumer polls (LDS operations of a
+// wavefront are executed in issue order, so "data, then counter" needs no fence), what it needs from the inner ring of the
+// same side arrives by a wave shift (DPP wave_shr:1) of a value computed three steps earlier -- off the critical path.
+// The dependent chain of a step is: product with the predecessor's new height -> 3 adds of the Eigen tree -> IEEE divide
+// -> blend; everything else (all confidence sums, the other 8 products, the decay of the confidence) is independent of it.
+//
+// Memory: per step and lane one 8-byte element of the own line and one of the outer line, requested PF steps ahead with
+// range-checked buffer loads (lanes with nothing to fetch pass an out-of-range offset: no traffic) so that the step stays
+// branch-free; results are written fire-and-forget.  LDS: 24 KB for n = 364 (progress counters, corner values, joins, the
+// chains of the group-boundary rings), so several clouds share a CU and one cloud's waits are another's compute.
+//
+// The same per-lane code runs on the host under a lock-step emulation (sweep_emul.hip, tests/test_sweep_emul_cpu.py).
+#include "gg_device.h"
+#include "sweep_core.h"
+
+namespace gg {
+
+using namespace sweep;
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+
+struct DevMem {
+    __amdgpu_buffer_rsrc_t rsrc; // the interleaved (ground, confidence) layer of this cloud
+    lds_int *lds;
+    static constexpr uint32_t OOR = 0x80000000u; // beyond the buffer: loads return 0, stores are dropped, no traffic
+
+    GG_DEV Cell load_issue(bool valid, int cell) const
+    {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, valid ? (uint32_t)cell * 8u : OOR, 0, 0);
+        return Cell{__uint_as_float(v.x), __uint_as_float(v.y)};
+    }
+    GG_DEV Cell load_value(const Cell &queued, bool, int) const { return queued; }
+    GG_DEV Cell fresh(const Cell &v) const
+    {
+        Cell o;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(o.g), "=&v"(o.w) : "v"(v.g), "v"(v.w));
+        return o;
+    }
+    GG_DEV void store(int cell, Cell v) const
+    {
+        u32x2 d;
+        d.x = __float_as_uint(v.g);
+        d.y = __float_as_uint(v.w);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (uint32_t)cell * 8u, 0, 0);
+    }
+    // LDS.  Other wavefronts write what is read here: every access is an atomic (relaxed, work-group scope) so that the
+    // compiler neither caches nor hoists it; ordering comes from the hardware (in-order DS queue per wavefront).
+    GG_DEV WP get(int word) const
+    {
+        const uint64_t u = __hip_atomic_load((lds_u64 *)(lds + word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return WP{__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32))};
+    }
+    GG_DEV void put(int word, WP v) const
+    {
+        const uint64_t u = (uint64_t)__float_as_uint(v.w) | ((uint64_t)__float_as_uint(v.p) << 32);
+        __hip_atomic_store((lds_u64 *)(lds + word), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    GG_DEV void publish(int data_word, WP v, int counter_word, int value) const
+    {
+        // data, then counter, as two DS writes of one instruction group: the DS queue keeps them in this order
+        const uint32_t da = (uint32_t)(data_word * 4) + lds_base(), ca = (uint32_t)(counter_word * 4) + lds_base();
+        u32x2 d;
+        d.x = __float_as_uint(v.w);
+        d.y = __float_as_uint(v.p);
+        asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(da), "v"(d), "v"(ca), "v"(value) : "memory");
+    }
+    GG_DEV int counter(int word) const
+    {
+        int v;
+        const uint32_t ca = (uint32_t)(word * 4) + lds_base();
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ca) : "memory");
+        return __builtin_amdgcn_readfirstlane(v);
+    }
+    GG_DEV uint32_t lds_base() const { return (uint32_t)(uintptr_t)lds; } // LDS byte address of word 0 (an address-space-3 pointer IS the offset)
+};
+
+GG_DEV float wave_shr1(float v)
+{
+    // DPP wave_shr:1 -- lane l reads lane l - 1 (lane 0 keeps its own value)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+
+template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMem &mem, int wave_of_side, int lane)
+{
+    ChainLane<SIDE> st;
+    for (int group = wave_of_side; group < P.groups; group += P.waves_per_side) {
+        const int r0 = LANES * group + 1;
+        const int nl = min(P.rings - (r0 - 1), (int)LANES);
+        st.init(lane, r0, nl, group, P, L);
+        const int t_first = group_first_step(), t_last = group_last_step<SIDE>(r0, nl);
+        const bool has_next = group + 1 < P.groups;
+        // PF steps per trip, no per-step condition: a step past t_last finds every lane idle (no loads, no stores, nothing
+        // to wait for), and without a conditional around it the queue registers of a slot never meet a control-flow join --
+        // a join makes the compiler copy freshly loaded registers, i.e. wait for the loads it has just issued
+        PlanIter<SIDE> plan;
+        plan.init(r0, nl, group > 0);
+        for (int tb = t_first; tb <= t_last; tb += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = tb + u;
+                const StepPlan<SIDE> pl = plan.at(t);
+                if (pl.start_lane >= 0 || pl.join_lane >= 0 || pl.need_bnd > 0)
+                    while (!chain_ready<SIDE>(pl, P, L, group, mem)) __builtin_amdgcn_s_sleep(1);
+                const WP x_in{wave_shr1(st.h3.w), wave_shr1(st.h3.p)};
+                st.step(t, u, x_in, P, L, pl, has_next, group, mem);
+                plan.advance(t);
+            }
+        }
+    }
+}
+
+template <int CD> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMem &mem, int lane)
+{
+    if (lane != 0) return;
+    // the old cells of a ring are requested one ring ahead; two rings per trip so that the two register sets swap roles by
+    // name instead of being copied (a copy of a register that is being loaded is a wait for that load)
+    typename CornerLane<CD>::Old a = CornerLane<CD>::load(1, P, mem);
+    for (int r = 1; r <= P.rings; r += 2) {
+        const typename CornerLane<CD>::Old b = CornerLane<CD>::load(r + 1, P, mem);
+        while (!CornerLane<CD>::ready(r, L, mem)) __builtin_amdgcn_s_sleep(1);
+        CornerLane<CD>::ring(r, a, P, L, mem);
+        a = CornerLane<CD>::load(r + 2, P, mem);
+        if (r + 1 <= P.rings) CornerLane<CD>::ring(r + 1, b, P, L, mem);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sweep(const Arena a, const Params P, const LdsMap L, const CloudParams *__restrict__ params)
+{
+    extern __shared__ int lds[];
+    const int cloud = blockIdx.x;
+    const CloudParams &cp = params[cloud];
+    float2 *gp2 = gp2_ptr(a, cp.slot);
+    float *points = a.layers + (size_t)cp.slot * a.slot_layer_stride + GG_LAYER_POINTS * a.layer_stride;
+    const int nthreads = blockDim.x;
+
+    // hand-over tables start empty: counters 0 = "ring 0 done", and ring 0 of every table is the centre cell
+    for (int k = threadIdx.x; k < L.corner; k += nthreads) lds[k] = 0;
+    const WP centre{1.0f, 1.0f * cp.base_z}; // :405 groundpatch(centre) = 1, :406-411 ground(centre) = translation.z
+    if (threadIdx.x == 0) {
+        gp2[P.c + P.c * P.n] = make_float2(cp.base_z, 1.0f);
+        float *f = reinterpret_cast<float *>(lds);
+        for (int side = 0; side < 2; ++side) {
+            f[L.corner + 2 * ((side * P.c + 0) * 2) + 2] = centre.w;
+            f[L.corner + 2 * ((side * P.c + 0) * 2) + 3] = centre.p;
+        }
+        for (int side = SIDE_C; side <= SIDE_D; ++side) {
+            f[L.join + 2 * (side * P.c + 0)] = centre.w;
+            f[L.join + 2 * (side * P.c + 0) + 1] = centre.p;
+        }
+    }
+    // :147 map["points"].setConstant(0.0) -- K3 was the last reader of the KEPT counts; K5 re-counts non-ground points
+    for (int k = threadIdx.x; k < a.g.C; k += nthreads) points[k] = 0.0f;
+    __syncthreads(); // the only barrier of the sweep
+
+    DevMem mem;
+    mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, a.g.C * 8, 0x00020000);
+    mem.lds = (lds_int *)lds;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
+    const int W = P.waves_per_side;
+    if (wave < W)
+        run_chain<SIDE_A>(P, L, mem, wave, lane);
+    else if (wave < 2 * W)
+        run_chain<SIDE_B>(P, L, mem, wave - W, lane);
+    else if (wave < 3 * W)
+        run_chain<SIDE_C>(P, L, mem, wave - 2 * W, lane);
+    else if (wave < 4 * W)
+        run_chain<SIDE_D>(P, L, mem, wave - 3 * W, lane);
+    else if (wave == 4 * W)
+        run_corner<0>(P, L, mem, lane);
+    else
+        run_corner<1>(P, L, mem, lane);
+}
+
+size_t sweep_lds_bytes(const Params &P) { return (size_t)lds_layout(P.c, P.groups).words * 4; }
+
+void launch_sweep(const Arena &a, const Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s)
+{
+    if (n_clouds == 0 || P.rings <= 0) return;
+    const LdsMap L = lds_layout(P.c, P.groups);
+    const size_t lds = (size_t)L.words * 4;
+    static bool big_lds_ok = false;
+    if (lds > 64 * 1024 && !big_lds_ok) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds_ok = true;
+    }
+    const int threads = (4 * P.waves_per_side + 2) * 64;
+    hipLaunchKernelGGL(k_sweep, dim3(n_clouds), dim3(threads), lds, s, a, P, L, d_params);
+}
+
+} // namespace gg

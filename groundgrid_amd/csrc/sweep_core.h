@@ -1,0 +1,542 @@
+// sweep_core.h -- the terrain sweep (spiral_ground_interpolation / interpolate_cell, src/GroundSegmentation.cpp:398-465)
+// as a ring-per-lane dataflow.  Written once, in per-lane scalar form, and compiled twice: for gfx950 (k4_sweep.hip, one
+// lane = one thread of a wavefront) and for the host (sweep_emul.hip: a lock-step emulation of the same wavefronts with
+// randomised wave scheduling, compared with the oracle's serial sweep by tests/test_sweep_emul_cpu.py -- no GPU needed).
+//
+// The serial sweep.  c = n/2 - 1.  For ring r = 1 .. c-1 (rp = c - r, R = c + r) the reference visits, in this order,
+//     A_k = (rp, rp+k)  k = 0..2r-1      B_k = (rp+k, rp)  k = 0..2r-1      (B_0 revisits the corner (rp, rp))
+//     C_k = (R, R-k)    k = 0..2r        D_k = (R-k, R)    k = 0..2r        (D_0 revisits the corner (R, R))
+// and every visit rewrites its cell from the 3x3 block around it, in place: neighbours visited earlier are read NEW, the
+// others OLD (= their value before the sweep: every cell is rewritten by its own visit only).
+//
+// Dependences (Appendix F of SURVEY.md, re-derived here).  Along a side every visit needs its predecessor (a first-order
+// chain); from the ring inside it needs three NEW cells; the two doubly visited corners chain three visits per ring
+// (A_0 -> A_1 -> B_0, C_0 -> C_1 -> D_0) and read nothing new from anybody else.  The critical path is 5 visits per ring:
+// no schedule is shorter than ~5 (c - 1) steps (904 for n = 364), and one exists that is exactly that long:
+//   * two CORNER lanes walk the corner chains ring by ring (3 visits per ring) and publish A_1, B_0 / C_1, D_0;
+//   * every (side, ring) is a CHAIN owned by one lane: A_2..A_{2r-1}, B_1..B_{2r-1}, C_2..C_{2r}, D_1..D_{2r};
+//     lanes of one wavefront = 64 consecutive rings of one side, ring r+1 running 3 steps behind ring r.
+// With k0 = first chain index (2, 1, 2, 1) and len = chain length (2r-2, 2r-1, 2r-1, 2r), step s of a chain needs the
+// stream S[s], S[s+1], S[s+2] from the inner side, where -- for all four sides alike --
+//     S[0], S[1]            corner values (A: B_0(r-1), A_1(r-1)   B: A_1(r), B_0(r-1)   C: D_0(r-1), C_1(r-1)   D: C_1(r), D_0(r-1))
+//     S[m], 2 <= m < len    result of step m-2 of the SAME side's chain of ring r-1   (lane l-1, three steps ago)
+//     S[len]                the JOIN: last value of another side (A: D_last(r-1)  B: C_last(r-1)  C: B_last(r)  D: A_last(r))
+//     S[len+1]              an OLD cell (it belongs to a chain of ring r that has not got there yet)
+// Everything else in a window is OLD and streams from the layer, prefetched: one cell of the own line and one of the outer
+// line per step.  NEW values never travel through memory: lane to lane inside a wavefront (a 3-deep history read with a
+// wave shift), through LDS between wavefronts (corner values, joins, the chain of the last ring of a 64-ring group), each
+// LDS hand-over guarded by a monotonic progress counter that the consumer polls.  No barriers, no descriptors, no
+// per-visit tables: the schedule is arithmetic on (side, ring, step).
+//
+// Exactness: per visit the float operations are the reference's, in its order (Eigen's unrolled tree over the 3x3 block
+// in column-major order).  A neighbour's product w * g is formed once, where the neighbour is produced or loaded -- the
+// same two floats the reference multiplies.
+#pragma once
+
+#include <float.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SW_HD __host__ __device__ __forceinline__
+#else
+#define SW_HD inline
+#endif
+
+namespace gg {
+namespace sweep {
+
+enum { SIDE_A = 0, SIDE_B = 1, SIDE_C = 2, SIDE_D = 3 };
+enum { LANES = 64, SKEW = 3, PF = 6 }; // rings per group, steps between neighbouring rings, prefetch distance of the layer streams
+// (PF = 6 = lcm of the periods of everything that rotates per step -- the load queue, the 3-deep window lines and history, the
+//  2-deep own line: a loop body of PF steps carries every value in a fixed register, no copies at the back edge)
+
+struct WP {
+    float w, p; // confidence, confidence * ground
+};
+struct Cell {
+    float g, w; // ground, confidence (the interleaved layer's element)
+};
+
+// uniform parameters of one sweep
+struct Params {
+    int n;      // rows = cols
+    int c;      // centre index n/2 - 1
+    int rings;  // c - 1
+    int groups; // ceil(rings / LANES)
+    int waves_per_side;
+    int r2min;  // the confidence decay (:463-464) applies to cell (x, y) iff (x-c)^2 + (y-c)^2 >= r2min (host-computed, exact)
+    double decrease, inv_decrease;
+    int decay_fast;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// geometry of a side (compile-time SIDE)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int SIDE> SW_HD int chain_len(int r) { return SIDE == SIDE_A ? 2 * r - 2 : SIDE == SIDE_D ? 2 * r : 2 * r - 1; }
+template <int SIDE> SW_HD int chain_k0() { return (SIDE == SIDE_A || SIDE == SIDE_C) ? 2 : 1; }
+
+// cell of `line` (-1 inner, 0 own, +1 outer) at along-position j of ring r; returns the linear index x + y * n
+template <int SIDE> SW_HD int side_cell(int n, int c, int r, int line, int j)
+{
+    const int rp = c - r, R = c + r;
+    int x, y;
+    if (SIDE == SIDE_A) {
+        x = rp - line;
+        y = rp + j;
+    } else if (SIDE == SIDE_B) {
+        x = rp + j;
+        y = rp - line;
+    } else if (SIDE == SIDE_C) {
+        x = R + line;
+        y = R - j;
+    } else {
+        x = R - j;
+        y = R + line;
+    }
+    return x + y * n;
+}
+
+// (x - c)^2 + (y - c)^2 of the own-line cell at along-position j
+template <int SIDE> SW_HD int side_r2(int r, int j)
+{
+    const int a = (SIDE == SIDE_A || SIDE == SIDE_B) ? j - r : r - j; // offset along the side from the centre column / row
+    return r * r + a * a;
+}
+
+// position of window element (line, pos) in the 3x3 block's column-major linear order q = drow + 3 * dcol
+//   line: 0 inner, 1 own, 2 outer        pos: 0 predecessor side, 1 self, 2 successor side
+template <int SIDE> SW_HD constexpr int tree_pos(int line, int pos)
+{
+    return SIDE == SIDE_A   ? (2 - line) + 3 * pos        // rows: outer, own, inner    cols: pred, self, succ
+           : SIDE == SIDE_B ? pos + 3 * (2 - line)        // rows: pred, self, succ     cols: outer, own, inner
+           : SIDE == SIDE_C ? line + 3 * (2 - pos)        // rows: inner, own, outer    cols: succ, self, pred
+                            : (2 - pos) + 3 * line;       // rows: succ, self, pred     cols: inner, own, outer
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// one visit: interpolate_cell (:445-465) on a prepared window
+// ---------------------------------------------------------------------------------------------------------------------
+SW_HD float sw_tree9(const float *e) { return ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + (e[7] + e[8]))); }
+SW_HD double sw_max(double a, double b) { return (a < b) ? b : a; } // libstdc++ std::max
+
+SW_HD Cell visit(const float (&w)[9], const float (&p)[9], float height, float occupied, bool decay, const Params &P)
+{
+    const float gvlSum = sw_tree9(w) + FLT_MIN;                      // :457
+    const float avg = sw_tree9(p) / gvlSum;                          // :458
+    Cell out;
+    out.g = (1.0f - occupied) * avg + occupied * height;             // :460
+    out.w = occupied;
+    if (decay) { // :463-464  (float)max(x - x / decrease, 0.001) in double; multiply form when it provably rounds alike
+        const double x = (double)occupied;
+        const double t = x - x * P.inv_decrease;
+        const float lo = (float)sw_max(t * (1.0 - 0x1p-48), 0.001);
+        const float hi = (float)sw_max(t * (1.0 + 0x1p-48), 0.001);
+        out.w = lo;
+        if (!(P.decay_fast && lo == hi)) out.w = (float)sw_max(x - x / P.decrease, 0.001);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS image of one sweep: progress counters + the values that cross wavefronts.  Offsets in 4-byte words.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LdsMap {
+    int corner_done; // [2]   rings finished by the AB / CD corner lane
+    int join_done;   // [4]   highest ring whose chain of that side has published its last value
+    int bnd_done;    // [4][groups]   steps published by the last lane of a group (consumed by lane 0 of the next group)
+    int corner;      // WP[2][c][2]   AB: (A_1, B_0), CD: (C_1, D_0) per ring; ring 0 = the centre cell
+    int join;        // WP[4][c]      last chain value per side and ring
+    int bnd;         // WP[4][bnd_words / 2]   full chains of the group-boundary rings
+    int bnd_stride;  // WP entries per side
+    int words;       // total size
+};
+
+SW_HD int bnd_offset(int b) { return 64 * b * (b + 1) + 2 * b; } // boundary b = ring 64 (b + 1): chains of <= 128 (b + 1) + 2 steps before it
+
+SW_HD LdsMap lds_layout(int c, int groups)
+{
+    LdsMap m;
+    int o = 0;
+    m.corner_done = o;
+    o += 2;
+    m.join_done = o;
+    o += 4;
+    m.bnd_done = o;
+    o += 4 * groups;
+    o = (o + 1) & ~1;
+    m.corner = o;
+    o += 2 * c * 2 * 2;
+    m.join = o;
+    o += 4 * c * 2;
+    m.bnd_stride = bnd_offset(groups > 0 ? groups - 1 : 0);
+    m.bnd = o;
+    o += 4 * m.bnd_stride * 2;
+    m.words = o;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Memory back end.  The device one (k4_sweep.hip) issues real loads / LDS operations; the host one can resolve a queued
+// layer load as late as its use (worst case for write-after-read hazards) and counts what it is asked to do.
+//   Cell  load_issue(bool valid, int cell)    start a load of the interleaved layer element (invalid: no traffic, value 0)
+//   Cell  load_value(const Cell &queued, bool valid, int cell)   the value at use time (device: `queued` itself)
+//   Cell  fresh(Cell v)                   v in registers of its own (host: identity)
+//   void  store(int cell, Cell v)
+//   int   counter(int word)               read a progress counter (LDS)
+//   void  publish(int data_word, WP v, int counter_word, int value)    LDS data, then counter -- in this order
+//   void  put(int data_word, WP v)  /  WP get(int data_word)
+// ---------------------------------------------------------------------------------------------------------------------
+
+// What a chain wavefront needs from LDS at wave-step t, as wave-uniform integers: which lane starts, which lane reads its
+// join, how far the previous group's boundary chain must have been published.  -1 = nobody.
+template <int SIDE> struct StepPlan {
+    int start_lane, start_ring;  // lane whose step 0 is t
+    int join_lane, join_ring;    // lane whose stream element S[len] arrives at t, and the ring whose join value that is
+    int need_bnd;                // > 0: lane 0 takes S[t+2] from the previous group's boundary chain: bnd_done must be >= need_bnd
+    int last_lane;               // lane whose last step (s == len - 1) is t: takes the old cell S[len + 1], publishes its join value
+    int warm_lane;               // lane whose step -2 is t: its own-line slot delivers that old cell
+};
+
+template <int SIDE> SW_HD StepPlan<SIDE> plan_step(int t, int r0, int nl, bool has_prev_group)
+{
+    StepPlan<SIDE> pl;
+    pl.start_lane = -1;
+    pl.start_ring = 0;
+    if (t >= 0 && t % SKEW == 0 && t / SKEW < nl && chain_len<SIDE>(r0 + t / SKEW) > 0) {
+        pl.start_lane = t / SKEW;
+        pl.start_ring = r0 + pl.start_lane;
+    }
+    // join: lane l with s + 2 == len(r0 + l), s = t - 3 l >= 0:  3 l + 2 (r0 + l) + b - 2 == t,  len(r) = 2 r + b
+    const int b = SIDE == SIDE_A ? -2 : SIDE == SIDE_D ? 0 : -1;
+    pl.join_lane = -1;
+    pl.join_ring = 0;
+    const int num = t + 2 - b - 2 * r0;
+    if (num >= 0 && num % (SKEW + 2) == 0) {
+        const int l = num / (SKEW + 2);
+        if (l < nl && t - SKEW * l >= 0) {
+            pl.join_lane = l;
+            pl.join_ring = (SIDE == SIDE_A || SIDE == SIDE_B) ? r0 + l - 1 : r0 + l;
+        }
+    }
+    // lane 0 of a later group: S[m], 2 <= m < len, m = t + 2, is step t of the previous group's last ring
+    pl.need_bnd = 0;
+    if (has_prev_group && t >= 0 && t + 2 < chain_len<SIDE>(r0)) pl.need_bnd = t + 1;
+    // last step: s == len - 1:  3 l + 2 (r0 + l) + b - 1 == t
+    pl.last_lane = -1;
+    const int num1 = t + 1 - b - 2 * r0;
+    if (num1 >= 0 && num1 % (SKEW + 2) == 0) {
+        const int l = num1 / (SKEW + 2);
+        if (l < nl && t - SKEW * l >= 0) pl.last_lane = l;
+    }
+    pl.warm_lane = -1;
+    if (t + 2 >= 0 && (t + 2) % SKEW == 0 && (t + 2) / SKEW < nl) pl.warm_lane = (t + 2) / SKEW;
+    return pl;
+}
+
+// The same plan, stepped: the events of a group come at fixed strides (starts every SKEW steps, joins and last steps every
+// SKEW + 2), so a wavefront keeps "time and lane of the next event" in scalar registers instead of dividing every step.
+// (The emulation checks at() against the closed form plan_step() at every step.)
+template <int SIDE> struct PlanIter {
+    enum { NEVER = 0x7fffffff };
+    int r0, nl;
+    int start_t, start_l, warm_t, warm_l, join_t, join_l, last_t, last_l, bnd_end;
+
+    SW_HD void init(int r0_, int nl_, bool has_prev_group)
+    {
+        r0 = r0_;
+        nl = nl_;
+        const int b = SIDE == SIDE_A ? -2 : SIDE == SIDE_D ? 0 : -1; // len(r) = 2 r + b
+        auto first_lane_with_len = [&](int need) { // smallest l >= 0 with 2 (r0 + l) + b >= need
+            int l = (need - b + 1) / 2 - r0;       // ceil((need - b) / 2) - r0
+            return l < 0 ? 0 : l;
+        };
+        start_l = first_lane_with_len(1);
+        start_t = start_l < nl ? SKEW * start_l : (int)NEVER;
+        warm_l = 0;
+        warm_t = nl > 0 ? -2 : (int)NEVER;
+        join_l = first_lane_with_len(2);
+        join_t = join_l < nl ? (SKEW + 2) * join_l + 2 * r0 + b - 2 : (int)NEVER;
+        last_l = first_lane_with_len(1);
+        last_t = last_l < nl ? (SKEW + 2) * last_l + 2 * r0 + b - 1 : (int)NEVER;
+        bnd_end = has_prev_group ? chain_len<SIDE>(r0) - 2 : 0;
+    }
+    SW_HD StepPlan<SIDE> at(int t) const
+    {
+        StepPlan<SIDE> pl;
+        pl.start_lane = t == start_t ? start_l : -1;
+        pl.start_ring = t == start_t ? r0 + start_l : 0;
+        pl.join_lane = t == join_t ? join_l : -1;
+        pl.join_ring = t == join_t ? ((SIDE == SIDE_A || SIDE == SIDE_B) ? r0 + join_l - 1 : r0 + join_l) : 0;
+        pl.need_bnd = (t >= 0 && t < bnd_end) ? t + 1 : 0;
+        pl.last_lane = t == last_t ? last_l : -1;
+        pl.warm_lane = t == warm_t ? warm_l : -1;
+        return pl;
+    }
+    SW_HD void advance(int t)
+    {
+        if (t == start_t) {
+            ++start_l;
+            start_t = start_l < nl ? start_t + SKEW : (int)NEVER;
+        }
+        if (t == warm_t) {
+            ++warm_l;
+            warm_t = warm_l < nl ? warm_t + SKEW : (int)NEVER;
+        }
+        if (t == join_t) {
+            ++join_l;
+            join_t = join_l < nl ? join_t + SKEW + 2 : (int)NEVER;
+        }
+        if (t == last_t) {
+            ++last_l;
+            last_t = last_l < nl ? last_t + SKEW + 2 : (int)NEVER;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// one lane of a chain wavefront
+// ---------------------------------------------------------------------------------------------------------------------
+// The step is written branch-free on purpose: every lane issues the same memory and LDS operations every step (addresses
+// of lanes that have nothing to fetch are clamped or out of range: no traffic), and the rare events -- first step, join,
+// boundary hand-over, last step -- are selects on values that were fetched anyway.  On the device a conditional load makes
+// the compiler drain the whole prefetch queue (s_waitcnt vmcnt(0)); here the queue stays PF steps deep.
+template <int SIDE> struct ChainLane {
+    int l, r, len;     // lane in the group, ring, chain length (0: idle lane)
+    int a_s0, a_s1, a_pred, a_join, a_bnd; // LDS words of S[0], S[1], the predecessor, the join, the previous group's boundary chain
+    int xold_cell;     // layer cell of S[len + 1]
+    // window: inner and outer lines as (w, p); own line: predecessor (w, p) new, self and successor old (g, w, p)
+    WP I[3], U[3], OP;
+    float Sg, Sw, Sp, Ng, Nw, Np;
+    WP xold;           // S[len + 1]
+    WP h1, h2, h3;     // results of the last three steps (what lane l + 1 reads three steps later)
+    Cell q_own[PF], q_out[PF]; // layer loads in flight, one slot per wave-step mod PF
+
+    SW_HD void init(int lane, int r0, int nl, int group, const Params &P, const LdsMap &L)
+    {
+        l = lane;
+        const bool live = lane < nl;
+        r = live ? r0 + lane : r0; // (idle lanes keep a valid ring for their never-used addresses)
+        len = live ? chain_len<SIDE>(r) : 0;
+        const int side = (SIDE == SIDE_A || SIDE == SIDE_B) ? 0 : 1;
+        const int own_first = L.corner + 2 * ((side * P.c + r) * 2), own_second = own_first + 2;
+        const int in_first = L.corner + 2 * ((side * P.c + r - 1) * 2), in_second = in_first + 2;
+        const int side_from = SIDE == SIDE_A ? SIDE_D : SIDE == SIDE_B ? SIDE_C : SIDE == SIDE_C ? SIDE_B : SIDE_A;
+        a_join = L.join + 2 * (side_from * P.c + ((SIDE == SIDE_A || SIDE == SIDE_B) ? r - 1 : r));
+        if (SIDE == SIDE_A) { // S[0] = B_0(r-1), S[1] = A_1(r-1), predecessor A_1(r)
+            a_s0 = in_second;
+            a_s1 = in_first;
+            a_pred = own_first;
+        } else if (SIDE == SIDE_B) { // A_1(r), B_0(r-1), predecessor B_0(r)
+            a_s0 = own_first;
+            a_s1 = in_second;
+            a_pred = own_second;
+        } else if (SIDE == SIDE_C) { // D_0(r-1), C_1(r-1) -- for ring 1 that cell is B_last(1), i.e. the join --, predecessor C_1(r)
+            a_s0 = in_second;
+            a_s1 = r == 1 ? a_join : in_first;
+            a_pred = own_first;
+        } else { // C_1(r), D_0(r-1), predecessor D_0(r)
+            a_s0 = own_first;
+            a_s1 = in_second;
+            a_pred = own_second;
+        }
+        a_bnd = group > 0 ? L.bnd + 2 * (SIDE * L.bnd_stride + bnd_offset(group - 1)) : L.bnd;
+        xold_cell = side_cell<SIDE>(P.n, P.c, r, -1, chain_k0<SIDE>() + len);
+        I[0] = I[1] = I[2] = U[0] = U[1] = U[2] = OP = xold = h1 = h2 = h3 = WP{0.f, 0.f};
+        Sg = Sw = Sp = Ng = Nw = Np = 0.f;
+        for (int k = 0; k < PF; ++k) q_own[k] = q_out[k] = Cell{0.f, 0.f};
+    }
+
+    // One wave-step.  `slot` = a compile-time-friendly wave-step index mod PF; x_in = (lane l - 1).h3 as it was BEFORE this
+    // step (lane 0: anything).
+    template <class Mem>
+    SW_HD void step(int t, int slot, WP x_in, const Params &P, const LdsMap &L, const StepPlan<SIDE> &pl, bool has_next_group, int group,
+                    Mem &mem)
+    {
+        const int s = t - SKEW * l;
+        const int k0 = chain_k0<SIDE>();
+        // ---- LDS: everything this lane could need, every step (garbage until published; selected only when it is)
+        const WP c_s0 = mem.get(a_s0), c_s1 = mem.get(a_s1), c_pred = mem.get(a_pred), c_join = mem.get(a_join);
+        const int sb = s < 0 ? 0 : s > 2 * LANES * P.groups ? 0 : s;
+        const WP c_bnd = mem.get(a_bnd + 2 * ((pl.need_bnd > 0 && l == 0) ? sb : 0));
+        // ---- the column that arrives now (along-position k0 + s + 1), requested PF steps ago into this slot; the own-line
+        //      request of step -2 (the predecessor's cell, which is never read from the layer) carries the old cell S[len + 1]
+        const bool col = len > 0 && s >= -2 && s <= len - 1;
+        const int own_cell = s == -2 ? xold_cell : side_cell<SIDE>(P.n, P.c, r, 0, k0 + s + 1);
+        // (mem.fresh: on the device a real register copy.  The arriving values stay live for two or three more steps as
+        //  window elements; copied out here, the slot's registers are free for the request below, and the compiler does not
+        //  have to copy freshly requested registers at the loop's back edge -- which would be a wait for loads just issued)
+        const Cell own = mem.fresh(mem.load_value(q_own[slot], col, own_cell));
+        const Cell out = mem.fresh(mem.load_value(q_out[slot], col, side_cell<SIDE>(P.n, P.c, r, 1, k0 + s + 1)));
+        // ---- and the one to request for step s + PF
+        const int sq = s + PF;
+        const bool colq = len > 0 && sq >= -2 && sq <= len - 1;
+        q_own[slot] = mem.load_issue(colq, sq == -2 ? xold_cell : side_cell<SIDE>(P.n, P.c, r, 0, k0 + sq + 1));
+        q_out[slot] = mem.load_issue(colq, side_cell<SIDE>(P.n, P.c, r, 1, k0 + sq + 1));
+        // ---- advance the window
+        Sg = Ng;
+        Sw = Nw;
+        Sp = Np;
+        Ng = own.g;
+        Nw = own.w;
+        Np = own.w * own.g;
+        if (pl.warm_lane >= 0 && l == pl.warm_lane) xold = WP{own.w, Np}; // (step -2)
+        U[0] = U[1];
+        U[1] = U[2];
+        U[2] = WP{out.w, out.w * out.g};
+        // stream element S[s + 2]: the inner lane's step s (three wave-steps ago), or -- at the ends -- the previous group's
+        // boundary chain, the join, the old cell.  The rare cases sit behind wave-uniform guards (pl is uniform).
+        WP x = x_in;
+        if (pl.need_bnd > 0 && l == 0) x = c_bnd;
+        if (pl.join_lane >= 0 && l == pl.join_lane) x = c_join;   // s + 2 == len
+        if (pl.last_lane >= 0 && l == pl.last_lane) x = xold;     // s + 2 == len + 1
+        I[0] = I[1];
+        I[1] = I[2];
+        I[2] = x;
+        if (pl.start_lane >= 0 && l == pl.start_lane) { // first step: the corner values
+            I[0] = c_s0;
+            I[1] = c_s1;
+            OP = c_pred;
+        }
+        // ---- the visit
+        const bool active = s >= 0 && s < len;
+        float w[9], p[9];
+#define SW_PUT(line, pos, W_, P_)                 \
+    w[tree_pos<SIDE>(line, pos)] = (W_);          \
+    p[tree_pos<SIDE>(line, pos)] = (P_);
+        SW_PUT(0, 0, I[0].w, I[0].p)
+        SW_PUT(0, 1, I[1].w, I[1].p)
+        SW_PUT(0, 2, I[2].w, I[2].p)
+        SW_PUT(1, 0, OP.w, OP.p)
+        SW_PUT(1, 1, Sw, Sp)
+        SW_PUT(1, 2, Nw, Np)
+        SW_PUT(2, 0, U[0].w, U[0].p)
+        SW_PUT(2, 1, U[1].w, U[1].p)
+        SW_PUT(2, 2, U[2].w, U[2].p)
+#undef SW_PUT
+        WP res = WP{0.f, 0.f};
+        if (active) {
+            const Cell v = visit(w, p, Sg, Sw, side_r2<SIDE>(r, k0 + s) >= P.r2min, P);
+            mem.store(side_cell<SIDE>(P.n, P.c, r, 0, k0 + s), v);
+            res = WP{v.w, v.w * v.g};
+            OP = res;
+        }
+        h3 = h2;
+        h2 = h1;
+        h1 = res;
+        // ---- publish what other wavefronts wait for (data first, then the counter)
+        if (pl.last_lane >= 0 && l == pl.last_lane && len > 0) mem.publish(L.join + 2 * (SIDE * P.c + r), res, L.join_done + SIDE, r);
+        if (has_next_group && l == LANES - 1 && active)
+            mem.publish(L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) + s), res, L.bnd_done + SIDE * P.groups + group, s + 1);
+    }
+};
+
+// Is everything this wave-step needs from other wavefronts published?  (wave-uniform; the device spins on it)
+template <int SIDE, class Mem> SW_HD bool chain_ready(const StepPlan<SIDE> &pl, const Params &P, const LdsMap &L, int group, Mem &mem)
+{
+    const int side = (SIDE == SIDE_A || SIDE == SIDE_B) ? 0 : 1;
+    if (pl.start_lane >= 0) {
+        if (mem.counter(L.corner_done + side) < pl.start_ring) return false;
+        if (SIDE == SIDE_C && pl.start_ring == 1 && mem.counter(L.join_done + SIDE_B) < 1) return false;
+    }
+    if (pl.join_lane >= 0) {
+        const int side_from = SIDE == SIDE_A ? SIDE_D : SIDE == SIDE_B ? SIDE_C : SIDE == SIDE_C ? SIDE_B : SIDE_A;
+        if (mem.counter(L.join_done + side_from) < pl.join_ring) return false;
+    }
+    if (pl.need_bnd > 0 && mem.counter(L.bnd_done + SIDE * P.groups + group - 1) < pl.need_bnd) return false;
+    return true;
+}
+
+// first / last wave-step of a group (lane 0 starts its warm-up columns at step -2, loads are requested PF steps earlier)
+SW_HD int group_first_step() { return -2 - PF; }
+template <int SIDE> SW_HD int group_last_step(int r0, int nl) { return SKEW * (nl - 1) + chain_len<SIDE>(r0 + nl - 1) - 1; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the corner lanes: AB walks (rp, rp), CD walks (R, R); three visits per ring (see the header comment)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CD> struct CornerLane {
+    // CD = 0: corner z = c - r, "outward" o = -1;  CD = 1: z = c + r, o = +1.  Cell (z + o a, z + o b): a, b = -1 inner, 0, +1 outer.
+    // Old cells of ring r: rows a = -1..1, columns b = -2..1 without (-1, -1) [Y_0 of ring r-1] and (-1, -2) [X_1 of ring r-1].
+    struct Old {
+        Cell v[3][4]; // [a + 1][b + 2]
+    };
+    SW_HD static int cell_at(const Params &P, int r, int a, int b)
+    {
+        const int o = CD ? 1 : -1, z = P.c + o * r;
+        return (z + o * a) + (z + o * b) * P.n;
+    }
+    SW_HD static bool is_old(int r, int a, int b)
+    {
+        // ring 1 of AB: (-1, -2) is D_1(1), still old (ring 0 has no X_1)
+        return !(a == -1 && b == -1) && !(a == -1 && b == -2 && !(r == 1 && !CD));
+    }
+    template <class Mem> SW_HD static Old load(int r, const Params &P, Mem &mem)
+    {
+        Old o_;
+        const bool ring_ok = r <= P.rings;
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -2; b <= 1; ++b) o_.v[a + 1][b + 2] = mem.load_issue(ring_ok && is_old(r, a, b), cell_at(P, ring_ok ? r : P.rings, a, b));
+        return o_;
+    }
+    // block index of cell (z + o a, z + o b) in the 3x3 block centred at (z + o ca, z + o cb)
+    SW_HD static int q(int a, int b, int ca, int cb)
+    {
+        const int o = CD ? 1 : -1;
+        return (o * (a - ca) + 1) + 3 * (o * (b - cb) + 1);
+    }
+    SW_HD static WP wp(const Cell &v) { return WP{v.w, v.w * v.g}; }
+
+    // ring r: first-side visits X_0 = (z, z), X_1 = (z, z - o) (A_1 / C_1), then the revisit Y_0 = (z, z) (B_0 / D_0)
+    template <class Mem> SW_HD static void ring(int r, const Old &queued, const Params &P, const LdsMap &L, Mem &mem)
+    {
+        const int o = CD ? 1 : -1, z = P.c + o * r, n = P.n;
+        const int base = L.corner + 2 * ((CD * P.c + r) * 2), prev = L.corner + 2 * ((CD * P.c + r - 1) * 2);
+        Old o_;
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -2; b <= 1; ++b) o_.v[a + 1][b + 2] = mem.load_value(queued.v[a + 1][b + 2], is_old(r, a, b), cell_at(P, r, a, b));
+        auto old = [&](int a, int b) -> const Cell & { return o_.v[a + 1][b + 2]; };
+        const WP in_corner = mem.get(prev + 2); // (z - o, z - o): Y_0 of ring r - 1 (ring 0: the centre)
+        // (z - o, z - 2o): X_1 of ring r - 1.  Ring 1 has no such predecessor ring: for AB that cell is D_1(1), still OLD;
+        // for CD it is B_1(1) = B_last(1), already NEW (sides A and B of a ring come before C and D).
+        const WP in_x1 = r > 1 ? mem.get(prev) : !CD ? wp(old(-1, -2)) : mem.get(L.join + 2 * (SIDE_B * P.c + 1));
+        float w[9], p[9];
+        // ---- X_0 at (0, 0): everything old except the inner corner (-1, -1)
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -1; b <= 1; ++b) {
+                const WP v = (a == -1 && b == -1) ? in_corner : wp(old(a, b));
+                w[q(a, b, 0, 0)] = v.w;
+                p[q(a, b, 0, 0)] = v.p;
+            }
+        const bool decay0 = 2 * r * r >= P.r2min;
+        const Cell x0 = visit(w, p, old(0, 0).g, old(0, 0).w, decay0, P);
+        // ---- X_1 at (0, -1): new = X_0 at (0, 0), inner corner (-1, -1), X_1(r-1) at (-1, -2)
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -2; b <= 0; ++b) {
+                const WP v = (a == 0 && b == 0) ? wp(x0) : (a == -1 && b == -1) ? in_corner : (a == -1 && b == -2) ? in_x1 : wp(old(a, b));
+                w[q(a, b, 0, -1)] = v.w;
+                p[q(a, b, 0, -1)] = v.p;
+            }
+        const bool decay1 = r * r + (r - 1) * (r - 1) >= P.r2min;
+        const Cell x1 = visit(w, p, old(0, -1).g, old(0, -1).w, decay1, P);
+        // ---- Y_0 at (0, 0) again: new = itself (X_0), X_1 at (0, -1), inner corner
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -1; b <= 1; ++b) {
+                const WP v = (a == 0 && b == 0) ? wp(x0) : (a == 0 && b == -1) ? wp(x1) : (a == -1 && b == -1) ? in_corner : wp(old(a, b));
+                w[q(a, b, 0, 0)] = v.w;
+                p[q(a, b, 0, 0)] = v.p;
+            }
+        const Cell y0 = visit(w, p, x0.g, x0.w, decay0, P);
+        mem.store(z + z * n, y0);
+        mem.store(z + (z - o) * n, x1);
+        mem.put(base, wp(x1));
+        mem.publish(base + 2, wp(y0), L.corner_done + CD, r);
+        if (!CD && r == 1) mem.publish(L.join + 2 * (SIDE_A * P.c + 1), wp(x1), L.join_done + SIDE_A, 1); // A_last(1) = A_1(1): side A of ring 1 has no chain
+    }
+    template <class Mem> SW_HD static bool ready(int r, const LdsMap &L, Mem &mem)
+    {
+        return !(CD && r == 1) || mem.counter(L.join_done + SIDE_B) >= 1;
+    }
+};
+
+} // namespace sweep
+} // namespace gg

@@ -1,0 +1,236 @@
+// sweep_emul.hip -- host-side lock-step emulation of the ring sweep (sweep_core.h): the SAME per-lane code the gfx950
+// kernel runs, executed wavefront by wavefront on the CPU with an arbitrary (seeded, adversarial) interleaving of the
+// wavefronts and, optionally, every layer load resolved as late as its use.  tests/test_sweep_emul_cpu.py compares the
+// result with the oracle's serial sweep: the dataflow (who hands what to whom, when it is ready) is proven without a GPU.
+// Host code only; compiled with the library's flags (-ffp-contract=off), so the floats are the device's.
+#include <string.h>
+
+#include <vector>
+
+#include "groundgrid_hip.h"
+#include "sweep_core.h"
+
+namespace {
+
+using namespace gg::sweep;
+
+struct HostMem {
+    Cell *gp2;
+    std::vector<int32_t> lds;
+    bool late;
+    long loads = 0, stores = 0, lds_ops = 0;
+    Cell load_issue(bool valid, int cell)
+    {
+        if (!valid) return Cell{0.f, 0.f};
+        ++loads;
+        return gp2[cell];
+    }
+    Cell load_value(const Cell &queued, bool valid, int cell) { return (late && valid) ? gp2[cell] : queued; }
+    Cell fresh(const Cell &v) { return v; }
+    void store(int cell, Cell v)
+    {
+        ++stores;
+        gp2[cell] = v;
+    }
+    int counter(int word) { return lds[(size_t)word]; }
+    void put(int word, WP v)
+    {
+        ++lds_ops;
+        memcpy(&lds[(size_t)word], &v, sizeof v);
+    }
+    WP get(int word)
+    {
+        ++lds_ops;
+        WP v;
+        memcpy(&v, &lds[(size_t)word], sizeof v);
+        return v;
+    }
+    void publish(int data_word, WP v, int counter_word, int value)
+    {
+        put(data_word, v);
+        lds[(size_t)counter_word] = value;
+    }
+};
+
+struct WaveBase {
+    virtual ~WaveBase() {}
+    virtual bool bad() const { return false; }
+    virtual bool done() const = 0;
+    virtual bool try_step(HostMem &mem) = 0; // false: stalled on another wavefront (or done)
+};
+
+template <int SIDE> struct ChainWave : WaveBase {
+    const Params &P;
+    const LdsMap &L;
+    int wave, group, t, t_last, r0, nl;
+    ChainLane<SIDE> lane[LANES];
+    PlanIter<SIDE> plan;
+    long steps = 0;
+    bool plan_mismatch = false;
+    ChainWave(const Params &p, const LdsMap &l, int w) : P(p), L(l), wave(w), group(w - p.waves_per_side) { next_group(); }
+    void next_group()
+    {
+        group += P.waves_per_side;
+        if (group >= P.groups) return;
+        r0 = LANES * group + 1;
+        nl = P.rings - (r0 - 1) < LANES ? P.rings - (r0 - 1) : LANES;
+        for (int l = 0; l < LANES; ++l) lane[l].init(l, r0, nl, group, P, L);
+        t = group_first_step();
+        t_last = group_last_step<SIDE>(r0, nl);
+        t_last += (PF - (t_last - t + 1) % PF) % PF; // the device runs whole trips of PF steps
+        plan.init(r0, nl, group > 0);
+    }
+    bool done() const override { return group >= P.groups; }
+    bool bad() const override { return plan_mismatch; }
+    bool try_step(HostMem &mem) override
+    {
+        if (done()) return false;
+        const StepPlan<SIDE> pl = plan.at(t), ref = plan_step<SIDE>(t, r0, nl, group > 0);
+        if (pl.start_lane != ref.start_lane || pl.start_ring != ref.start_ring || pl.join_lane != ref.join_lane || pl.join_ring != ref.join_ring ||
+            pl.need_bnd != ref.need_bnd || pl.last_lane != ref.last_lane || pl.warm_lane != ref.warm_lane)
+            plan_mismatch = true;
+        if (!chain_ready<SIDE>(pl, P, L, group, mem)) return false;
+        WP x_in[LANES];
+        for (int l = 0; l < LANES; ++l) x_in[l] = l ? lane[l - 1].h3 : WP{0.f, 0.f}; // wave shift right by one, before anybody moves
+        const int slot = ((t % PF) + PF) % PF;
+        for (int l = 0; l < LANES; ++l) lane[l].step(t, slot, x_in[l], P, L, pl, group + 1 < P.groups, group, mem);
+        ++steps;
+        plan.advance(t);
+        if (++t > t_last) next_group();
+        return true;
+    }
+};
+
+template <int CD> struct CornerWave : WaveBase {
+    const Params &P;
+    const LdsMap &L;
+    int r = 1;
+    bool primed = false;
+    typename CornerLane<CD>::Old cur;
+    CornerWave(const Params &p, const LdsMap &l) : P(p), L(l) {}
+    bool done() const override { return r > P.rings; }
+    bool try_step(HostMem &mem) override
+    {
+        if (done() || !CornerLane<CD>::ready(r, L, mem)) return false;
+        if (!primed) {
+            cur = CornerLane<CD>::load(r, P, mem);
+            primed = true;
+        }
+        const typename CornerLane<CD>::Old next = CornerLane<CD>::load(r + 1, P, mem); // one ring ahead, like the device
+        CornerLane<CD>::ring(r, cur, P, L, mem);
+        cur = next;
+        ++r;
+        return true;
+    }
+};
+
+} // namespace
+
+namespace gg {
+namespace sweep {
+
+Params make_params(int n, double resolution, float min_dist_squared, double decrease)
+{
+    Params P;
+    P.n = n;
+    P.c = n / 2 - 1;
+    P.rings = P.c - 1 > 0 ? P.c - 1 : 0;
+    P.groups = (P.rings + LANES - 1) / LANES;
+    P.waves_per_side = P.groups <= 1 ? 1 : P.groups <= 3 ? 2 : 3; // groups g and g + 2 do not overlap in time up to 3 groups
+    // :463 (pow((float)x - center, 2.0) + pow((float)y - center, 2.0)) * pow(resolution, 2.0f) > minDistSquared: the left side is a
+    // non-decreasing function of the integer (x-c)^2 + (y-c)^2, so the test is an integer threshold
+    int r2 = 0;
+    while (r2 < 2 * n * n && !((double)r2 * (resolution * resolution) > (double)min_dist_squared)) ++r2;
+    P.r2min = r2;
+    P.decrease = decrease;
+    P.inv_decrease = 1.0 / decrease;
+    P.decay_fast = decrease >= 1.25 && decrease < 1e300;
+    return P;
+}
+
+} // namespace sweep
+} // namespace gg
+
+extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z, double decrease,
+                                           unsigned seed, int late_loads, long *stats)
+{
+    if (n < 8 || !gp2) return GG_ERR_INVALID;
+    const Params P = gg::sweep::make_params(n, resolution, min_dist_squared, decrease);
+    const LdsMap L = lds_layout(P.c, P.groups);
+    HostMem mem;
+    mem.gp2 = reinterpret_cast<Cell *>(gp2);
+    mem.lds.assign((size_t)L.words, 0);
+    mem.late = late_loads != 0;
+    // :405-411 centre cell; ring 0 of every hand-over table is the centre
+    const int cc = P.c + P.c * n;
+    mem.gp2[cc] = Cell{base_z, 1.0f};
+    const WP centre{1.0f, 1.0f * base_z};
+    for (int side = 0; side < 2; ++side) mem.put(L.corner + 2 * ((side * P.c + 0) * 2) + 2, centre);
+    mem.put(L.join + 2 * (SIDE_C * P.c + 0), centre);
+    mem.put(L.join + 2 * (SIDE_D * P.c + 0), centre);
+
+    std::vector<WaveBase *> waves;
+    for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_A>(P, L, w));
+    for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_B>(P, L, w));
+    for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_C>(P, L, w));
+    for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_D>(P, L, w));
+    waves.push_back(new CornerWave<0>(P, L));
+    waves.push_back(new CornerWave<1>(P, L));
+
+    // wave scheduling: seed 0 = round robin; otherwise a seeded random walk in which a chosen wavefront runs a random burst
+    // (up to "as far as it can") before the next one is chosen: wavefronts drift apart as far as the dataflow allows
+    uint32_t rng = seed * 2654435761u + 12345u;
+    auto rnd = [&]() { return rng = rng * 1664525u + 1013904223u; };
+    long total_steps = 0, stalls = 0;
+    int rc = GG_OK;
+    for (;;) {
+        bool all_done = true, progress = false;
+        for (auto *w : waves) all_done &= w->done();
+        if (all_done) break;
+        if (seed == 0) {
+            for (auto *w : waves)
+                if (w->try_step(mem)) {
+                    progress = true;
+                    ++total_steps;
+                } else if (!w->done())
+                    ++stalls;
+        } else {
+            for (int tries = 0; tries < 4 * (int)waves.size() && !progress; ++tries) {
+                WaveBase *w = waves[(rnd() >> 8) % waves.size()];
+                const uint32_t mode = (rnd() >> 8) % 8;
+                int burst = mode == 0 ? 1 << 30 : mode < 4 ? 1 + (int)((rnd() >> 8) % 64) : 1;
+                while (burst-- > 0 && w->try_step(mem)) {
+                    progress = true;
+                    ++total_steps;
+                }
+                if (!progress && !w->done()) ++stalls;
+            }
+            if (!progress) // the random picks were all stalled: look at everybody before calling it a deadlock
+                for (auto *w : waves)
+                    if (w->try_step(mem)) {
+                        progress = true;
+                        ++total_steps;
+                        break;
+                    }
+        }
+        if (!progress) {
+            rc = -10; // deadlock: every unfinished wavefront waits for another one
+            break;
+        }
+    }
+    if (stats) {
+        stats[0] = total_steps;
+        stats[1] = stalls;
+        stats[2] = mem.loads;
+        stats[3] = mem.stores;
+        stats[4] = mem.lds_ops;
+        stats[5] = L.words * 4;
+        stats[6] = P.waves_per_side * 4 + 2;
+        stats[7] = P.r2min;
+    }
+    for (auto *w : waves) {
+        if (w->bad() && rc == GG_OK) rc = -11; // the stepped plan disagrees with the closed form
+        delete w;
+    }
+    return rc;
+}

@@ -115,7 +115,10 @@ enum {
     GG_FLAG_MINIMAL_LAYERS = 1, /* skip the four layers nothing in the path reads (groundCandidates, planeDist,
                                    maxGroundHeight, meanVariance are still zero/initial-filled); default off */
     GG_FLAG_PROFILE = 2,        /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
-    GG_FLAG_SPIRAL_NARROW = 4   /* terrain sweep: use the second exact schedule (levels of one wavefront); default off */
+    GG_FLAG_SPIRAL_NARROW = 4,  /* level-scheduled sweep only: use its second exact schedule (levels of one wavefront) */
+    GG_FLAG_SPIRAL_LEVELS = 8   /* terrain sweep: run the round-1 level-scheduled kernel (k_spiral: host-built hazard levels,
+                                   one barrier interval per level) instead of the ring-per-lane dataflow (k_sweep); both are
+                                   exact, kept for A/B measurements; default off */
 };
 
 typedef struct gg_context gg_context;
@@ -305,6 +308,14 @@ int gg_abi_version(void);
  * [n*n][2], updated in place like spiral_ground_interpolation (src/GroundSegmentation.cpp:398-465) would.  0 or < 0. */
 int gg_debug_replay_spiral_schedule(int n, double resolution, float min_dist_squared, int cap, float *gp2, float base_z,
                                     double occupied_cells_decrease_factor);
+
+/* Testing hook, runs on the host (no GPU): the terrain sweep the device runs (ring-per-lane dataflow, csrc/sweep_core.h) --
+ * the same per-lane code -- emulated wavefront by wavefront with a seeded interleaving of the wavefronts (seed 0 = round
+ * robin) and, if late_loads, every layer load resolved only when it is used.  gp2 as in gg_debug_replay_spiral_schedule.
+ * stats (nullable, 8 longs): wave-steps, stalls, layer loads, stores, LDS operations, LDS bytes, wavefronts, decay radius^2.
+ * Returns 0, or -10 if the wavefronts deadlock. */
+int gg_debug_emulate_ring_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z,
+                                double occupied_cells_decrease_factor, unsigned seed, int late_loads, long *stats);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,97 @@
+"""The terrain sweep as the device runs it (ring-per-lane dataflow, groundgrid_amd/csrc/sweep_core.h), checked without a GPU.
+
+The per-lane code of the gfx950 kernel is compiled for the host as well and executed by a lock-step emulation of its
+wavefronts (gg_debug_emulate_ring_sweep): chains of 64 rings per wavefront, corner lanes, LDS hand-overs guarded by
+progress counters.  The wavefronts are interleaved adversarially (seeded bursts: one wavefront runs as far as the
+dataflow lets it while the others stand still) and layer loads can be resolved as late as their use (worst case for
+write-after-read hazards on the in-place layer).  Whatever the interleaving, the result must equal the oracle's serial
+sweep (src/GroundSegmentation.cpp:398-465) bit for bit, and the wavefronts must never deadlock."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from groundgrid_amd import _lib, build
+from oracle import oracle
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    L = C.CDLL(_lib.LIB_PATH)
+    L.gg_debug_emulate_ring_sweep.restype = C.c_int
+    L.gg_debug_emulate_ring_sweep.argtypes = [C.c_int, C.c_double, C.c_float, C.c_void_p, C.c_float, C.c_double, C.c_uint, C.c_int, C.POINTER(C.c_long)]
+    return L
+
+
+def emulate(L, n, resolution, ground, conf, base_z, decrease, seed, late, min_dist_sq=12.0):
+    gp2 = np.empty((n * n, 2), dtype=np.float32)
+    gp2[:, 0] = ground.ravel(order="F")  # Eigen layers are column-major
+    gp2[:, 1] = conf.ravel(order="F")
+    stats = (C.c_long * 8)()
+    rc = L.gg_debug_emulate_ring_sweep(n, resolution, min_dist_sq, gp2.ctypes.data, base_z, decrease, seed, int(late), stats)
+    assert rc == 0, f"the wavefronts deadlocked ({rc})"
+    return gp2[:, 0].reshape((n, n), order="F"), gp2[:, 1].reshape((n, n), order="F"), list(stats)
+
+
+def random_state(n, seed):
+    rng = np.random.default_rng(seed)
+    ground = rng.normal(-1.7, 0.4, (n, n)).astype(np.float32)
+    conf = rng.random((n, n)).astype(np.float32)
+    conf[rng.random((n, n)) < 0.3] = 0.0          # cells without any estimate yet
+    conf[rng.random((n, n)) < 0.05] = 1.0
+    ground[rng.random((n, n)) < 0.01] = np.float32(37.5)
+    return ground, conf
+
+
+@pytest.mark.parametrize("length,resolution", [(4.0, 0.33), (5.0, 0.5), (10.0, 0.5), (33.0, 0.33), (43.0, 0.33), (61.0, 0.25), (120.0, 0.33),
+                                               (150.0, 0.25), (240.0, 0.33)])
+def test_ring_sweep_reproduces_the_serial_sweep(lib, length, resolution):
+    ref = oracle.OracleMap(length, resolution)
+    n = ref.layer("ground").shape[0]
+    ground, conf = random_state(n, n)
+    decrease = float(ref.cfg.occupied_cells_decrease_factor)
+    ref.set_layer("ground", ground)
+    ref.set_layer("groundpatch", conf)
+    ref.stage_spiral(-1.73)
+    seeds = (0, 1, 2, 3) if n <= 400 else (0, 5)
+    for seed in seeds:
+        for late in (False, True):
+            g, w, stats = emulate(lib, n, ref.resolution, ground, conf, -1.73, decrease, seed, late)
+            assert np.array_equal(g, ref.layer("ground")), (seed, late, np.argwhere(g != ref.layer("ground"))[:5].tolist())
+            assert np.array_equal(w, ref.layer("groundpatch")), (seed, late)
+    # cost model of the schedule: every visited cell is stored once (corners: the revisit only), loaded twice (own + outer line)
+    visits = oracle.lib().ggo_spiral_visit_count(n)
+    rings = n // 2 - 2
+    assert stats[3] == visits - 2 * rings
+
+
+@pytest.mark.parametrize("decrease", [1.1, 1.25, 5.0, 0.5, 7.3])
+def test_decay_factors_and_decay_radius(lib, decrease):
+    ref = oracle.OracleMap(33.0, 0.33)
+    n = ref.layer("ground").shape[0]
+    ground, conf = random_state(n, 77)
+    ref.cfg.occupied_cells_decrease_factor = decrease
+    ref.set_layer("ground", ground)
+    ref.set_layer("groundpatch", conf)
+    ref.stage_spiral(0.4)
+    g, w, stats = emulate(lib, n, ref.resolution, ground, conf, 0.4, decrease, 9, True)
+    assert np.array_equal(g, ref.layer("ground")) and np.array_equal(w, ref.layer("groundpatch"))
+    # the decay radius as an integer threshold: 12 m^2 / (0.33 m)^2 = 110.19... -> cells with dx^2 + dy^2 >= 111 decay
+    assert stats[7] == 111
+
+
+def test_special_values_travel_unchanged(lib):
+    """NaN / inf grounds and zero confidences through every hand-over path (lane to lane, LDS, memory)."""
+    ref = oracle.OracleMap(61.0, 0.25)
+    n = ref.layer("ground").shape[0]
+    ground, conf = random_state(n, 5)
+    rng = np.random.default_rng(6)
+    ground[rng.random((n, n)) < 0.02] = np.nan
+    ground[rng.random((n, n)) < 0.01] = np.inf
+    conf[rng.random((n, n)) < 0.01] = np.float32(1e-30)
+    ref.set_layer("ground", ground)
+    ref.set_layer("groundpatch", conf)
+    ref.stage_spiral(-1.0)
+    g, w, _ = emulate(lib, n, ref.resolution, ground, conf, -1.0, 5.0, 4, True)
+    assert np.array_equal(g, ref.layer("ground"), equal_nan=True) and np.array_equal(w, ref.layer("groundpatch"), equal_nan=True)
