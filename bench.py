@@ -56,7 +56,7 @@ def algorithmic_bytes(n_pts, n_in, n_kept, C, full_layers=True):
         "K1_classify": 16 * n_pts + 4 * n_in + 4 * n_pts + 1 * n_pts,
         "K2_sort_reduce": 16 * n_kept + 4 * n_kept + (8 if full_layers else 3) * 4 * C,
         "K3_patch": 6 * 4 * C + 3 * 4 * C,
-        "K4_spiral": 2 * 2 * 4 * C,
+        "K4_sweep": 2 * 2 * 4 * C,
         "K5_label": 16 * n_pts + 4 * n_pts + 8 * n_pts + 1 * n_pts,
     }
 
@@ -65,7 +65,7 @@ GROUPS = {
     "K1_classify": ["k_classify"],
     "K2_sort_reduce": ["k_scan", "k_scatter", "k_reduce"],
     "K3_patch": ["k_patch"],
-    "K4_spiral": ["k_spiral"],
+    "K4_sweep": ["k_sweep"],
     "K5_label": ["k_label"],
 }
 
@@ -230,8 +230,8 @@ def main():
         result["roofline"] = {
             "kernel": dominant, "bound": "hbm", "achieved": g["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": g["frac_hbm"], "traffic": traffic,
-            "note": "K4_spiral is a 905-level dependent chain (latency-bound); its bytes/s is reported, not a bandwidth claim"
-            if dominant == "K4_spiral" else "",
+            "note": "K4_sweep is a 905-level dependent chain (latency-bound); its bytes/s is reported, not a bandwidth claim"
+            if dominant == "K4_sweep" else "",
         }
         result["kernels"] = groups
         result["kernel_ms_raw"] = {k: round(v[0] / max(1, v[1]), 4) for k, v in ktimes.items()}

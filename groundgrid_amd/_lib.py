@@ -23,7 +23,7 @@ STATUS = {
 }
 
 GG_POINT32, GG_POINT16 = 0, 1
-GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE, GG_FLAG_SPIRAL_NARROW, GG_FLAG_SPIRAL_LEVELS = 1, 2, 4, 8
+GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE = 1, 2
 GG_NUM_KERNELS = 7
 GG_NUM_LAYERS = 11
 
@@ -38,7 +38,6 @@ SYMBOLS = [
     "gg_set_config", "gg_get_config", "gg_set_flags", "gg_get_size", "gg_get_geometry", "gg_last_error",
     "gg_reset_map", "gg_set_map_position", "gg_move_map", "gg_get_map_position", "gg_set_layer", "gg_get_layer", "gg_get_expected_points",
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
-    "gg_debug_replay_spiral_schedule",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
     "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep",
 ]

@@ -205,9 +205,8 @@ class GroundSegmentation:
         _check(self._L, self._ctx, self._L.gg_get_config(self._ctx, C.byref(c)), "gg_get_config")
         return c
 
-    def set_flags(self, minimal_layers: bool = False, profile: bool = False, spiral_narrow: bool = False, spiral_levels: bool = False):
-        f = ((_lib.GG_FLAG_MINIMAL_LAYERS if minimal_layers else 0) | (_lib.GG_FLAG_PROFILE if profile else 0)
-             | (_lib.GG_FLAG_SPIRAL_NARROW if spiral_narrow else 0) | (_lib.GG_FLAG_SPIRAL_LEVELS if spiral_levels else 0))
+    def set_flags(self, minimal_layers: bool = False, profile: bool = False):
+        f = (_lib.GG_FLAG_MINIMAL_LAYERS if minimal_layers else 0) | (_lib.GG_FLAG_PROFILE if profile else 0)
         _check(self._L, self._ctx, self._L.gg_set_flags(self._ctx, f), "gg_set_flags")
 
     def expected_points(self) -> np.ndarray:

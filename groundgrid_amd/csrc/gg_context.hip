@@ -138,266 +138,6 @@ uint32_t morton2(uint32_t x, uint32_t y)
     return spread(x) | (spread(y) << 1);
 }
 
-// Replay spiral_ground_interpolation's visit order (src/GroundSegmentation.cpp:413-440) once and turn the serial,
-// in-place sweep into an exact level schedule:
-//   * every visit gets the earliest level compatible with the in-place data hazards on its 3x3 neighbourhood
-//       RAW  level > level of the last earlier visit that wrote any of the 9 cells it reads
-//       WAR  level > level of every earlier visit that read the cell it writes
-//       WAW  level > level of the earlier visit of the same cell (the two doubly-visited corners per ring)
-//     so visits sharing a level are independent and a barrier between levels reproduces the serial sweep;
-//   * for each of the 9 cells a visit reads, the replay knows whether an EARLIER visit rewrote it (fresh value) or
-//     not (pre-sweep value).  Fresh values are handed over through LDS: each written value gets a slot that stays
-//     allocated until the level of its last reader.  Pre-sweep values come from the interleaved (ground, confidence)
-//     layer with a LOAD PLAN of at most three 16-byte requests per visit: the not-yet-visited cells of a block column
-//     are vertically adjacent, and a request covers two consecutive rows.  98.6 % of the visits need exactly three
-//     pairs; the few that need more (ring corners) get "helper" entries one level earlier that fetch the extra pair
-//     and park it in LDS slots, so that the kernel's instruction stream is identical for every visit.
-//     All of this is decided here, from the serial order -- never from timing on the device;
-//   * `cap` bounds the visits per level (a full level spills into the next one; visits of one level are independent,
-//     so any split is legal).  cap = 1024: shortest chain (lowest latency for one cloud); cap = 64: levels of one
-//     wavefront (no idle waves, no work-group barrier).
-void build_spiral_schedule(int n, double res, float min_dist_sq, int cap, std::vector<SpiralVisit> &out_visits,
-                           std::vector<uint32_t> &level_start, int &max_width, int &n_slots)
-{
-    int n_result_slots = 0;
-    const int center = n / 2 - 1;
-    std::vector<uint32_t> cells;
-    for (int i = center - 1; i >= 1; --i) {
-        int rp = i;
-        const int sl = (center - rp) * 2;
-        for (int side = 0; side < 2; ++side)
-            for (int pos = rp; pos < rp + sl; ++pos) {
-                const int x = side % 2 ? pos : rp, y = side % 2 ? rp : pos;
-                cells.push_back((uint32_t)(x + y * n));
-            }
-        rp += sl;
-        for (int side = 0; side < 2; ++side)
-            for (int pos = rp; pos >= rp - sl; --pos) {
-                const int x = side % 2 ? pos : rp, y = side % 2 ? rp : pos;
-                cells.push_back((uint32_t)(x + y * n));
-            }
-    }
-    const size_t V = cells.size();
-    const size_t C = (size_t)n * n;
-
-    // ---- 1. hazard levels (uncapped), sources --------------------------------------------------------------
-    struct Entry {
-        uint32_t cell;
-        int level;          // uncapped level, >= 2 for real visits (level 1 is left for helpers of level-2 visits)
-        int64_t src[9];     // entry index producing the value (>= 0), or -1: pre-sweep value
-        int plan[3];        // load plan: pair p = column c (0..2) * 2 + row offset r (0..1), -1 = unused
-        int64_t rd_entry[9]; // pre-sweep inputs: the loader (entry index; may be the visit itself) whose block holds the value
-        int rd_elem[9];     //                    and the element 0..5 inside that block
-        bool helper;
-        uint16_t flags;
-    };
-    std::vector<Entry> E(V);
-    std::vector<int> last_write(C, 0), last_read(C, 0);
-    std::vector<int64_t> last_writer(C, -1);
-    for (size_t k = 0; k < V; ++k) {
-        Entry &e = E[k];
-        e.cell = cells[k];
-        e.helper = false;
-        const int x = (int)(cells[k] % (uint32_t)n), y = (int)(cells[k] / (uint32_t)n);
-        int lv = last_read[cells[k]];
-        for (int q = 0; q < 9; ++q) lv = std::max(lv, last_write[(x - 1 + q % 3) + (y - 1 + q / 3) * n]);
-        lv = std::max(lv + 1, 2);
-        e.level = lv;
-        for (int q = 0; q < 9; ++q) {
-            const size_t nb = (size_t)((x - 1 + q % 3) + (y - 1 + q / 3) * n);
-            e.src[q] = last_writer[nb];
-            last_read[nb] = std::max(last_read[nb], lv);
-        }
-        last_write[cells[k]] = lv;
-        last_writer[cells[k]] = (int64_t)k;
-        // :463 (pow((float)x - center_idx, 2.0) + pow((float)y - center_idx, 2.0)) * pow(resolution, 2.0f) > minDistSquared
-        const float fx = (float)x - (float)center, fy = (float)y - (float)center;
-        const double d2 = ((double)fx * (double)fx + (double)fy * (double)fy) * (res * res);
-        e.flags = (uint16_t)(d2 > (double)min_dist_sq ? SPIRAL_DECAY : 0);
-    }
-    for (size_t k = 0; k < V; ++k)
-        if (last_writer[E[k].cell] == (int64_t)k) E[k].flags |= SPIRAL_STORE; // only the last visit of a cell stores
-
-    // ---- 2. pre-sweep inputs: read them from LDS if an EARLIER level already fetched the cell, else fetch them --------
-    // An entry that fetches cells ("loader": a visit, or a helper = fetch-only entry one level before the visit that
-    // needs it) parks them in a block of 6 LDS slots (3 pairs x 2 cells); `staged` remembers, per cell, the latest block
-    // element holding its pre-sweep value.  Entries are handled in level order, so "earlier level" is decided on the
-    // uncapped hazard levels and stays true under any split of a level.
-    struct Staged { int64_t entry = -1; int elem = 0; int level = 0; };
-    std::vector<Staged> staged(C);
-    std::vector<Entry> H;
-    std::vector<size_t> by_lvl(V);
-    for (size_t k = 0; k < V; ++k) by_lvl[k] = k;
-    std::stable_sort(by_lvl.begin(), by_lvl.end(), [&](size_t a_, size_t b_) { return E[a_].level < E[b_].level; });
-    for (size_t kk = 0; kk < V; ++kk) {
-        const size_t k = by_lvl[kk];
-        Entry &e = E[k];
-        const int x = (int)(e.cell % (uint32_t)n), y = (int)(e.cell / (uint32_t)n);
-        auto cell_of = [&](int q) { return (size_t)((x - 1 + q % 3) + (y - 1 + q / 3) * n); };
-        bool need[9];
-        for (int q = 0; q < 9; ++q) {
-            e.rd_entry[q] = -1;
-            e.rd_elem[q] = 0;
-            need[q] = false;
-            if (e.src[q] >= 0) continue; // fresh value: comes from the producing visit's slot
-            const Staged &sb = staged[cell_of(q)];
-            if (sb.entry >= 0 && sb.level < e.level) {
-                e.rd_entry[q] = sb.entry;
-                e.rd_elem[q] = sb.elem;
-            } else {
-                need[q] = true;
-            }
-        }
-        std::vector<int> pairs; // pair code = block column * 2 + row offset (rows ro, ro + 1 of that column)
-        for (int c = 0; c < 3; ++c) {
-            const bool n0 = need[c * 3 + 0], n1 = need[c * 3 + 1], n2 = need[c * 3 + 2];
-            if (!n0 && !n1 && !n2) continue;
-            if (!n2) pairs.push_back(c * 2 + 0);
-            else if (!n0) pairs.push_back(c * 2 + 1);
-            else { pairs.push_back(c * 2 + 0); pairs.push_back(c * 2 + 1); }
-        }
-        // a pair element may be handed on to later readers only if it is a pre-sweep value for the loader itself (a cell an
-        // earlier visit already rewrote may or may not have reached memory when the prefetch executes)
-        auto publish = [&](int64_t entry_id, int elem, int q, int level) {
-            if (e.src[q] < 0) staged[cell_of(q)] = Staged{entry_id, elem, level};
-        };
-        for (int p = 0; p < 3; ++p) e.plan[p] = p < (int)pairs.size() ? pairs[p] : -1;
-        for (int p = 0; p < 3 && p < (int)pairs.size(); ++p) {
-            const int c = pairs[p] / 2, r = pairs[p] % 2;
-            for (int el = 0; el < 2; ++el) {
-                const int q = c * 3 + r + el;
-                if (need[q]) {
-                    e.rd_entry[q] = (int64_t)k;
-                    e.rd_elem[q] = p * 2 + el;
-                    need[q] = false;
-                }
-                publish((int64_t)k, p * 2 + el, q, e.level);
-            }
-        }
-        for (size_t p = 3; p < pairs.size(); ++p) { // the rest: one fetch-only helper per extra pair, one level earlier
-            Entry h{};
-            h.cell = e.cell;
-            h.level = e.level - 1;
-            h.helper = true;
-            h.flags = SPIRAL_HELPER;
-            for (int q = 0; q < 9; ++q) { h.src[q] = -1; h.rd_entry[q] = -1; h.rd_elem[q] = 0; }
-            h.plan[0] = pairs[p];
-            h.plan[1] = h.plan[2] = -1;
-            const int64_t hid = (int64_t)(V + H.size());
-            const int c = pairs[p] / 2, r = pairs[p] % 2;
-            for (int el = 0; el < 2; ++el) {
-                const int q = c * 3 + r + el;
-                if (need[q]) {
-                    e.rd_entry[q] = hid;
-                    e.rd_elem[q] = el;
-                    need[q] = false;
-                }
-                publish(hid, el, q, h.level);
-            }
-            H.push_back(h);
-        }
-    }
-
-    // ---- 3. final levels: uncapped levels split into chunks of at most `cap` entries (helpers included) ------
-    const size_t NE = V + H.size();
-    auto entry = [&](size_t i) -> Entry & { return i < V ? E[i] : H[i - V]; };
-    int max_level = 0;
-    for (size_t i = 0; i < NE; ++i) max_level = std::max(max_level, entry(i).level);
-    std::vector<std::vector<uint32_t>> by_level((size_t)max_level + 1);
-    for (size_t i = V; i < NE; ++i) by_level[entry(i).level].push_back((uint32_t)i); // helpers first (any order is legal)
-    for (size_t i = 0; i < V; ++i) by_level[entry(i).level].push_back((uint32_t)i);
-    std::vector<uint32_t> order;       // entries in final order
-    std::vector<int> final_level(NE);  // 1-based final level of each entry
-    level_start.assign(1, 0);
-    max_width = 0;
-    for (int l = 1; l <= max_level; ++l) {
-        const auto &v = by_level[l];
-        for (size_t b = 0; b < v.size(); b += (size_t)cap) {
-            const size_t cnt = std::min((size_t)cap, v.size() - b);
-            for (size_t j = 0; j < cnt; ++j) {
-                final_level[v[b + j]] = (int)level_start.size();
-                order.push_back(v[b + j]);
-            }
-            max_width = std::max(max_width, (int)cnt);
-            level_start.push_back((uint32_t)order.size());
-        }
-    }
-    const int n_levels = (int)level_start.size() - 1;
-
-    // ---- 4. LDS slots ------------------------------------------------------------------------------------------
-    // two kinds of values live in LDS until the level of their last reader: a visit's result (one slot) and a
-    // loader's block of fetched cells (6 slots).  Both are recycled through free lists, in final level order.
-    std::vector<int> last_res(NE, 0), last_blk(NE, 0);
-    for (size_t k = 0; k < V; ++k)
-        for (int q = 0; q < 9; ++q) {
-            if (E[k].src[q] >= 0) last_res[(size_t)E[k].src[q]] = std::max(last_res[(size_t)E[k].src[q]], final_level[k]);
-            else last_blk[(size_t)E[k].rd_entry[q]] = std::max(last_blk[(size_t)E[k].rd_entry[q]], final_level[k]);
-        }
-    std::vector<uint16_t> res_slot(NE, SPIRAL_NONE);
-    std::vector<int> blk_base_of(NE, -1); // first slot of the entry's block, relative to the block region
-    {
-        // blocks come in three sizes (2 slots per pair of the load plan); block region = [size-2 | size-4 | size-6] arenas,
-        // each arena recycles its own blocks
-        std::vector<std::vector<uint16_t>> rel_res((size_t)n_levels + 2);
-        std::vector<std::vector<std::pair<int, int>>> rel_blk((size_t)n_levels + 2); // (size class, index)
-        std::vector<uint16_t> free_res;
-        std::vector<int> free_blk[3];
-        int n_res = 0, n_blk[3] = {0, 0, 0};
-        std::vector<int> blk_cls(NE, -1), blk_idx(NE, -1);
-        for (size_t oi = 0, l = 1; l <= (size_t)n_levels; ++l) {
-            for (uint16_t s_ : rel_res[l]) free_res.push_back(s_);
-            for (const auto &b_ : rel_blk[l]) free_blk[b_.first].push_back(b_.second);
-            for (; oi < order.size() && final_level[order[oi]] == (int)l; ++oi) {
-                const size_t id = order[oi];
-                if (last_res[id] > 0) {
-                    uint16_t s_;
-                    if (!free_res.empty()) { s_ = free_res.back(); free_res.pop_back(); }
-                    else s_ = (uint16_t)n_res++;
-                    res_slot[id] = s_;
-                    rel_res[(size_t)last_res[id] + 1].push_back(s_);
-                }
-                if (last_blk[id] > 0) { // (a loader nobody reads -- not even itself -- needs no block)
-                    int npairs = 0;
-                    for (int p = 0; p < 3; ++p) npairs += entry(id).plan[p] >= 0;
-                    const int cls = std::max(npairs, 1) - 1;
-                    int b_;
-                    if (!free_blk[cls].empty()) { b_ = free_blk[cls].back(); free_blk[cls].pop_back(); }
-                    else b_ = n_blk[cls]++;
-                    blk_cls[id] = cls;
-                    blk_idx[id] = b_;
-                    // (+ 2: k_spiral writes a block one barrier interval BEFORE its level, while the previous level still reads)
-                    rel_blk[std::min((size_t)std::max(last_blk[id], (int)l) + 2, (size_t)n_levels + 1)].push_back({cls, b_});
-                }
-            }
-        }
-        const int arena0 = 0, arena1 = 2 * n_blk[0], arena2 = arena1 + 4 * n_blk[1];
-        for (size_t id = 0; id < NE; ++id)
-            if (blk_idx[id] >= 0) blk_base_of[id] = (blk_cls[id] == 0 ? arena0 : blk_cls[id] == 1 ? arena1 : arena2) + 2 * (blk_cls[id] + 1) * blk_idx[id];
-        n_slots = n_res + arena2 + 6 * n_blk[2];
-        n_result_slots = n_res;
-    }
-
-    // ---- 5. descriptors ---------------------------------------------------------------------------------------
-    auto blk_base = [&](size_t id) { return (uint32_t)n_result_slots + (uint32_t)blk_base_of[id]; };
-    out_visits.resize(NE);
-    for (size_t oi = 0; oi < order.size(); ++oi) {
-        const size_t i = order[oi];
-        const Entry &e = entry(i);
-        SpiralVisit d{};
-        d.cell_flags = e.cell | ((uint32_t)e.flags << 24);
-        d.wslot = e.helper ? SPIRAL_NONE : res_slot[i];
-        d.stage = blk_base_of[i] >= 0 ? (uint16_t)blk_base(i) : SPIRAL_NONE;
-        for (int p = 0; p < 3; ++p) // pair code = block column * 2 + row offset  ->  index delta from the centre cell
-            d.pair[p] = e.plan[p] < 0 ? SPIRAL_NO_PAIR : (int16_t)(-1 + (e.plan[p] & 1) + ((e.plan[p] >> 1) - 1) * n);
-        for (int q = 0; q < 9; ++q) {
-            if (e.helper) d.src[q] = SPIRAL_NONE;
-            else if (e.src[q] >= 0) d.src[q] = res_slot[(size_t)e.src[q]];
-            else d.src[q] = (uint16_t)(blk_base((size_t)e.rd_entry[q]) + (uint32_t)e.rd_elem[q]);
-        }
-        out_visits[oi] = d;
-    }
-}
-
 void make_dev_config(const gg_config &c, DevConfig &d)
 {
     d.point_count_cell_variance_threshold = c.point_count_cell_variance_threshold;
@@ -547,9 +287,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     launch_patch(a, dp, nb, s);
     prof.end();
     prof.begin(GG_K_SPIRAL);
-    if (ctx->flags & GG_FLAG_SPIRAL_LEVELS) {
-        launch_spiral(a, dp, nb, s);
-    } else {
+    {
         sweep::Params sp = ctx->sweep_params;
         sp.decrease = ctx->cfg.occupied_cells_decrease_factor;
         sp.inv_decrease = 1.0 / sp.decrease;
@@ -578,94 +316,9 @@ extern "C" {
 
 int gg_abi_version(void) { return GG_ABI_VERSION; }
 
-// Testing hook (no GPU needed): build the terrain sweep's level schedule for an n x n grid and EXECUTE it on the host with
-// the semantics k_spiral relies on -- entries of a level are mutually independent, values travel through the LDS slots the
-// descriptors name, pre-sweep cells are read from the layer as it was BEFORE the sweep -- then store like the kernel.
-// `gp2` is the interleaved (ground, groundpatch) layer [n * n][2], updated in place.  Returns 0, or a negative code when
-// the schedule breaks one of its own rules (-2: a slot read in the level it was written by another entry, -3: a slot read
-// before anything was written to it, -4: slot out of range, -5: a slot read after the next level's early block write took it).  tests/test_spiral_schedule_cpu.py compares the result with
-// the serial sweep of the oracle.
-int gg_debug_replay_spiral_schedule(int n, double resolution, float min_dist_squared, int cap, float *gp2, float base_z, double decrease)
-{
-    if (n < 8 || !gp2 || cap < 1) return GG_ERR_INVALID;
-    std::vector<SpiralVisit> visits;
-    std::vector<uint32_t> level_start;
-    int max_width = 0, n_slots = 0;
-    build_spiral_schedule(n, resolution, min_dist_squared, cap, visits, level_start, max_width, n_slots);
-    const int n_levels = (int)level_start.size() - 1;
-    const int center = n / 2 - 1;
-    gp2[2 * (size_t)(center + center * n)] = base_z; // :405
-    gp2[2 * (size_t)(center + center * n) + 1] = 1.0f;
-    const std::vector<float> before(gp2, gp2 + (size_t)2 * n * n);
-    struct Slot { float g = 0.f, w = 0.f; int level = 0; int64_t writer = -1; };
-    std::vector<Slot> lds((size_t)n_slots);
-    auto tree9h = [](const float *e) { return ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + (e[7] + e[8]))); };
-    struct Out { uint32_t slot; float g, w; bool store; uint32_t cell; };
-    for (int l = 0; l < n_levels; ++l) {
-        const int level = l + 1;
-        std::vector<Out> outs;
-        // phase 1: the entries of the NEXT level park their fetched cells in their blocks (the kernel does that one barrier
-        // interval early, concurrently with this level's reads; level 1's own blocks are written before the loop) ...
-        for (uint32_t v = (l == 0 ? level_start[0] : level_start[l + 1]); v < (l + 2 <= n_levels ? level_start[l + 2] : level_start[l + 1]); ++v) {
-            const int level = (v < level_start[l + 1]) ? l + 1 : l + 2;
-            const SpiralVisit &d = visits[v];
-            const int cell = (int)(d.cell_flags & 0xFFFFFFu);
-            if (d.stage != SPIRAL_NONE)
-                for (int p = 0; p < 3; ++p) {
-                    if (d.pair[p] == SPIRAL_NO_PAIR) continue;
-                    for (int el = 0; el < 2; ++el) {
-                        const size_t s_ = (size_t)d.stage + 2 * p + el, c = (size_t)(cell + d.pair[p] + el);
-                        if (s_ >= lds.size() || c >= (size_t)n * n) return -4;
-                        lds[s_] = Slot{before[2 * c], before[2 * c + 1], level, (int64_t)v};
-                    }
-                }
-        }
-        // ... phase 2: every visit reads its nine inputs; results are applied only after the whole level has read
-        for (uint32_t v = level_start[l]; v < level_start[l + 1]; ++v) {
-            const SpiralVisit &d = visits[v];
-            const uint32_t flags = d.cell_flags >> 24, cell = d.cell_flags & 0xFFFFFFu;
-            if (flags & SPIRAL_HELPER) continue;
-            float g[9], w[9], pr[9];
-            for (int q = 0; q < 9; ++q) {
-                if (d.src[q] >= lds.size()) return -4;
-                const Slot &sl = lds[d.src[q]];
-                if (sl.level == 0) return -3;
-                if (sl.level == level && sl.writer != (int64_t)v) return -2;
-                if (sl.level > level) return -5; // overwritten by a block of the next level, which is parked one interval early
-                g[q] = sl.g;
-                w[q] = sl.w;
-            }
-            const float height = g[4], occupied = w[4];
-            const float gvlSum = tree9h(w) + FLT_MIN;
-            for (int q = 0; q < 9; ++q) pr[q] = w[q] * g[q];
-            const float avg = tree9h(pr) / gvlSum;
-            const float new_g = (1.0f - occupied) * avg + occupied * height;
-            float new_w = occupied;
-            if (flags & SPIRAL_DECAY) {
-                const double t = (double)occupied - (double)occupied / decrease;
-                new_w = (float)(t < 0.001 ? 0.001 : t);
-            }
-            outs.push_back(Out{d.wslot, new_g, new_w, (flags & SPIRAL_STORE) != 0, cell});
-        }
-        for (size_t k = 0, v = level_start[l]; k < outs.size(); ++v) {
-            if ((visits[v].cell_flags >> 24) & SPIRAL_HELPER) continue;
-            const Out &o = outs[k++];
-            if (o.slot != SPIRAL_NONE) {
-                if (o.slot >= lds.size()) return -4;
-                lds[o.slot] = Slot{o.g, o.w, level, (int64_t)v};
-            }
-            if (o.store) {
-                gp2[2 * (size_t)o.cell] = o.g;
-                gp2[2 * (size_t)o.cell + 1] = o.w;
-            }
-        }
-    }
-    return GG_OK;
-}
-
 const char *gg_kernel_name(int k)
 {
-    static const char *names[GG_NUM_KERNELS] = {"k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_spiral", "k_label"};
+    static const char *names[GG_NUM_KERNELS] = {"k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_sweep", "k_label"};
     return (k >= 0 && k < GG_NUM_KERNELS) ? names[k] : "?";
 }
 
@@ -753,7 +406,6 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->map_event, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->batch_event, hipEventDisableTiming));
-    gg::configure_kernels();
 
     Arena &a = ctx->arena;
     Geometry &g = a.g;
@@ -791,56 +443,6 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         gg_destroy(ctx);
         return GG_ERR_GEOMETRY; // the sweep's hand-over tables no longer fit in LDS (n > ~1030)
     }
-    std::vector<SpiralVisit> visits[2];
-    std::vector<uint32_t> level_start[2];
-    int caps[2] = {448, 64}; // k_spiral runs two compute sets of `cap` lanes + a loader wave: 2 * 448 + 64 threads at most
-    if (const char *e = getenv("GG_SPIRAL_CAPS")) { // tuning knob: "<latency schedule cap>,<throughput schedule cap>"
-        int c0 = 0, c1 = 0;
-        if (sscanf(e, "%d,%d", &c0, &c1) == 2 && c0 >= 64 && c0 <= 448 && c1 >= 64 && c1 <= 448) {
-            caps[0] = c0;
-            caps[1] = c1;
-        }
-    }
-    for (int v = 0; v < 2; ++v) {
-        // the level cap is lowered until the schedule's LDS demand (value slots + the descriptor ring of k_spiral) and the
-        // work-group (2 x cap + 64 threads) fit: 448 suffices up to ~730 x 730, larger grids get narrower levels
-        static const int fallback[] = {448, 384, 320, 256, 192, 128, 64};
-        bool fits = false;
-        for (int attempt = -1; attempt < (int)(sizeof fallback / sizeof fallback[0]) && !fits; ++attempt) {
-            const int cap = attempt < 0 ? caps[v] : fallback[attempt];
-            if (attempt >= 0 && cap >= caps[v]) continue;
-            int max_width = 0, spiral_slots = 0;
-            build_spiral_schedule(n, res, geom.min_dist_squared, cap, visits[v], level_start[v], max_width, spiral_slots);
-            if (getenv("GG_DEBUG_SCHEDULE"))
-                fprintf(stderr, "groundgrid_hip: spiral schedule %d (cap %d): %zu entries, %zu levels, widest %d, %d LDS slots, %zu B of LDS\n", v, cap,
-                        visits[v].size(), level_start[v].size() - 1, max_width, spiral_slots, spiral_lds_bytes(spiral_slots, max_width));
-            a.sched[v].n_levels = (int)level_start[v].size() - 1;
-            a.sched[v].max_level_width = max_width;
-            a.sched[v].slots = spiral_slots;
-            a.sched[v].pad_ = 0;
-            for (int k = 0; k < 8; ++k) {
-                a.sched[v].first_wide[k] = a.sched[v].n_levels;
-                a.sched[v].last_wide[k] = -1;
-                for (int l = 0; l < a.sched[v].n_levels; ++l)
-                    if ((int)(level_start[v][l + 1] - level_start[v][l]) > 64 * k) {
-                        if (a.sched[v].first_wide[k] == a.sched[v].n_levels) a.sched[v].first_wide[k] = l;
-                        a.sched[v].last_wide[k] = l;
-                    }
-            }
-            if (getenv("GG_DEBUG_SCHEDULE"))
-                for (int k = 0; k < 8; ++k) {
-                    int wide = 0;
-                    for (int l = 0; l < a.sched[v].n_levels; ++l) wide += (int)(level_start[v][l + 1] - level_start[v][l]) > 64 * k;
-                    if (wide) fprintf(stderr, "groundgrid_hip:   wavefront %d of a set: levels %d..%d, %d of them wider than %d\n", k, a.sched[v].first_wide[k], a.sched[v].last_wide[k], wide, 64 * k);
-                }
-            fits = spiral_slots < (int)SPIRAL_NONE && max_width <= 448 && spiral_lds_bytes(spiral_slots, max_width) <= 158 * 1024;
-        }
-        if (!fits || n + 1 > 32766 || (size_t)n * n >= (1u << 24)) {
-            gg_destroy(ctx);
-            return GG_ERR_GEOMETRY; // the sweep's LDS window no longer fits
-        }
-    }
-
     std::vector<uint16_t> tile_rank(g.T), rank_tile(g.T);
     {
         std::vector<std::pair<uint32_t, int>> order(g.T);
@@ -865,14 +467,12 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t Cpad = align_up(C * 4, A) / 4;
     const size_t Npad = align_up(max_points * 8, A) / 8;
     const size_t o_expected = carve(C * 4);
-    size_t o_visits[2], o_lstart[2];
-    for (int v = 0; v < 2; ++v) {
-        o_visits[v] = carve(visits[v].size() * sizeof(SpiralVisit));
-        o_lstart[v] = carve(level_start[v].size() * 4);
-    }
     const size_t o_trank = carve((size_t)g.T * 2);
     const size_t o_rtile = carve((size_t)g.T * 2);
     const size_t o_layers = carve((size_t)n_slots * GG_NUM_LAYERS * Cpad * 4);
+    a.gpl = make_gp_layout(n);
+    a.gp2_stride = align_up((size_t)a.gpl.elems * 8, A) / 8;
+    const size_t o_gp2 = carve((size_t)n_slots * a.gp2_stride * 8);
     const size_t o_rec = carve((size_t)n_slots * Npad * 8);
     const size_t o_sorted = carve((size_t)n_slots * Npad * 8);
     a.hist_stride = align_up((size_t)a.NCH * g.T * 4, A) / 4;
@@ -896,7 +496,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         o_aidx[k] = carve(max_points * 4);
         o_acnt[k] = carve(64);
     }
-    const size_t o_scroll = carve(2 * Cpad * 4);
+    const size_t o_scroll = carve(a.gp2_stride * 8); // one layer in its device element order (map scroll) / two planes (images)
     const size_t o_image = carve(3 * Cpad * 4);
     const size_t o_bounds = carve(64);
     ctx->arena_bytes = off;
@@ -905,13 +505,10 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipMemsetAsync(base, 0, ctx->arena_bytes, ctx->stream));
 
     a.expected = (const float *)(base + o_expected);
-    for (int v = 0; v < 2; ++v) {
-        a.sched[v].visits = (const SpiralVisit *)(base + o_visits[v]);
-        a.sched[v].level_start = (const uint32_t *)(base + o_lstart[v]);
-    }
     a.tile_rank = (const uint16_t *)(base + o_trank);
     a.rank_tile = (const uint16_t *)(base + o_rtile);
     a.layers = (float *)(base + o_layers);
+    a.gp2 = (float2 *)(base + o_gp2);
     a.layer_stride = Cpad;
     a.slot_layer_stride = Cpad * GG_NUM_LAYERS;
     a.rec = (uint2 *)(base + o_rec);
@@ -941,10 +538,6 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_bounds = (float *)(base + o_bounds);
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
-    for (int v = 0; v < 2; ++v) {
-        CREATE_CHK(hipMemcpyAsync(base + o_visits[v], visits[v].data(), visits[v].size() * sizeof(SpiralVisit), hipMemcpyHostToDevice, ctx->stream));
-        CREATE_CHK(hipMemcpyAsync(base + o_lstart[v], level_start[v].data(), level_start[v].size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_rtile, rank_tile.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipStreamSynchronize(ctx->stream)); // the host vectors above go out of scope
@@ -1132,7 +725,7 @@ int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float od
     const float init[GG_NUM_LAYERS] = {0.0f, odom_z, (float)0.0000001, (float)100.0, (float)-100.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int l = 0; l < GG_NUM_LAYERS; ++l)
         if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH) launch_fill(layer_ptr(a, slot, l), C, init[l], ctx->stream);
-    launch_fill2(gp2_ptr(a, slot), C, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], ctx->stream); // interleaved pair
+    launch_fill2(gp2_ptr(a, slot), (size_t)a.gpl.elems, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], ctx->stream); // interleaved pair
     HIPCHK(ctx, hipGetLastError());
     return own_stream_mutated_map(ctx);
 }
@@ -1168,7 +761,7 @@ int gg_move_map(gg_context *ctx, int slot, double odom_x, double odom_y, const d
     // getPositionShiftFromIndexShift: the position advances by whole cells, not to the odometry position
     ctx->pos_x[slot] += (double)(-s[0]) * res;
     ctx->pos_y[slot] += (double)(-s[1]) * res;
-    launch_scroll(ctx->arena, slot, ctx->d_scroll_scratch, s[0], s[1], ctx->pos_x[slot], ctx->pos_y[slot], base_plane, ctx->stream);
+    launch_scroll(ctx->arena, slot, reinterpret_cast<float2 *>(ctx->d_scroll_scratch), s[0], s[1], ctx->pos_x[slot], ctx->pos_y[slot], base_plane, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return own_stream_mutated_map(ctx);
 }
@@ -1190,7 +783,7 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
     if (layer == GG_LAYER_GROUNDPATCH) ctx->no_confidence[slot] = 0;
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) { // de-interleave at the host boundary
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
-        launch_plane_insert(gp2_ptr(ctx->arena, slot), layer == GG_LAYER_GROUNDPATCH, ctx->d_image, (size_t)ctx->arena.g.C, ctx->stream);
+        launch_plane_insert(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_image, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
     } else {
         HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1208,7 +801,7 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const float *plane = layer_ptr(ctx->arena, slot, layer);
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) {
-        launch_plane_extract(gp2_ptr(ctx->arena, slot), layer == GG_LAYER_GROUNDPATCH, ctx->d_image, (size_t)ctx->arena.g.C, ctx->stream);
+        launch_plane_extract(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_image, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
         plane = ctx->d_image;
     }
@@ -1227,7 +820,7 @@ int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, fl
     uint8_t *d_img = reinterpret_cast<uint8_t *>(ctx->d_image);
     const float *plane = layer_ptr(ctx->arena, slot, layer);
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) {
-        launch_plane_extract(gp2_ptr(ctx->arena, slot), layer == GG_LAYER_GROUNDPATCH, ctx->d_scroll_scratch, (size_t)g.C, ctx->stream);
+        launch_plane_extract(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_scroll_scratch, ctx->stream);
         plane = ctx->d_scroll_scratch;
     }
     launch_layer_to_u8(plane, g.rows, g.cols, ctx->d_bounds, d_img, ctx->stream);
@@ -1248,8 +841,7 @@ int gg_get_terrain_image(gg_context *ctx, int slot, float *dst)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const Geometry &g = ctx->arena.g;
-    launch_terrain_image(gp2_ptr(ctx->arena, slot), layer_ptr(ctx->arena, slot, GG_LAYER_POINTSRAW), g.rows, g.cols,
-                         ctx->d_image, ctx->stream);
+    launch_terrain_image(ctx->arena, slot, ctx->d_image, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(dst, ctx->d_image, (size_t)g.C * 3 * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "groundgrid_hip.h"
+#include "gp_layout.h"
 
 namespace gg {
 
@@ -57,37 +58,6 @@ struct Geometry {
     int center;              // rows/2 - 1
 };
 
-// One visit of spiral_ground_interpolation (src/GroundSegmentation.cpp:413-440), 32 bytes.  Built on the host by
-// replaying the serial sweep once (gg_context.hip build_spiral_schedule): which of the 9 cells it reads were
-// already rewritten earlier in the serial order ("fresh": taken from an LDS slot) and which still hold their
-// pre-sweep value (read from the layer).
-struct SpiralVisit {
-    uint32_t cell_flags; // bits 0..23: row + col * rows; bit 24 STORE (last visit of the cell), 25 DECAY (:463), 26 HELPER
-    uint16_t wslot;      // LDS slot receiving this visit's (ground, confidence); SPIRAL_NONE: nobody reads it during the sweep
-    uint16_t stage;      // first LDS slot of the block (2 slots per used pair) that receives the cells of this entry's load plan;
-                         // SPIRAL_NONE: none
-    uint16_t src[9];     // 3x3 block, column-major: LDS slot holding the value -- a visit's result slot, or an element of a
-                         // loader's block (this entry's own, or one an earlier level fetched: each pre-sweep cell is fetched
-                         // about once per sweep, not once per reader)
-    int16_t pair[3];     // load plan: three 16-byte loads of two vertically adjacent interleaved cells, as cell-index deltas;
-                         // SPIRAL_NO_PAIR: unused
-};
-constexpr uint16_t SPIRAL_NONE = 0xFFFFu;
-constexpr int16_t SPIRAL_NO_PAIR = -32768;
-constexpr uint16_t SPIRAL_STORE = 1u, SPIRAL_DECAY = 2u, SPIRAL_HELPER = 4u;
-
-// One level schedule of the terrain sweep (built by gg_context.hip build_spiral_schedule)
-struct SpiralSched {
-    const SpiralVisit *visits;    // visit descriptors, grouped by level
-    const uint32_t *level_start;  // [n_levels + 1]
-    int n_levels;
-    int max_level_width;          // visits per level <= this (the work-group size is its round-up to 64)
-    int slots;                    // LDS slots the fresh-value window needs
-    int pad_;
-    int first_wide[8], last_wide[8]; // first / last level (0-based) with more than 64 * k entries: wavefront k of a compute set of
-                                     // k_spiral has nothing to do outside [first_wide[k], last_wide[k]]
-};
-
 // per-cloud parameters of one batched call (device array, one entry per cloud of the batch)
 struct CloudParams {
     int slot;
@@ -107,11 +77,11 @@ struct Arena {
     DevConfig cfg;
     // shared
     const float *expected;        // [C]
-    SpiralSched sched[2];         // [0] widest levels (lowest latency), [1] levels capped at one wavefront (throughput)
     const uint16_t *tile_rank;    // [T] tile (tr + tc*tiles_r) -> Morton rank
     const uint16_t *rank_tile;    // [T] Morton rank -> tile
     // per slot (slot s at base + s * stride)
     float *layers;  size_t layer_stride;  size_t slot_layer_stride;  // layer l of slot s: layers + s*slot_layer_stride + l*layer_stride
+    float2 *gp2;    size_t gp2_stride;    GpLayout gpl;              // (ground, confidence) of slot s: gp2 + s*gp2_stride, element order gp_layout.h
     uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
     uint32_t *hist;        size_t hist_stride;   // NCH * T
     uint32_t *chunk_emit;  size_t emit_stride;   // NCH * 4
@@ -129,13 +99,12 @@ __host__ __device__ inline float *layer_ptr(const Arena &a, int slot, int layer)
 }
 
 // `ground` and `groundpatch` (confidence) are always used together -- confidence-weighted height -- and are the only
-// state that persists from cloud to cloud.  They are stored INTERLEAVED as float2 (x = ground, y = confidence) in the two
-// adjacent plane slots GG_LAYER_GROUND / GG_LAYER_GROUNDPATCH: one 8-byte request instead of two 4-byte ones everywhere
-// (the terrain sweep is bound by request count).  gg_get_layer / gg_set_layer de-interleave at the host boundary.
-__host__ __device__ inline float2 *gp2_ptr(const Arena &a, int slot)
-{
-    return reinterpret_cast<float2 *>(layer_ptr(a, slot, GG_LAYER_GROUND));
-}
+// state that persists from cloud to cloud.  They are stored INTERLEAVED as float2 (x = ground, y = confidence), one 8-byte
+// request instead of two 4-byte ones everywhere, in the sheared element order of gp_layout.h (the terrain sweep's
+// wavefronts then read and write 512 contiguous bytes per access); the plane slots GG_LAYER_GROUND / GG_LAYER_GROUNDPATCH
+// of `layers` are unused.  gg_get_layer / gg_set_layer convert at the host boundary.
+__host__ __device__ inline float2 *gp2_ptr(const Arena &a, int slot) { return a.gp2 + (size_t)slot * a.gp2_stride; }
+__host__ __device__ inline int gp_idx(const Arena &a, int row, int col) { return gp_index(a.gpl, row, col); }
 
 // I/O pointers of one batched call
 struct BatchIO {
@@ -155,8 +124,6 @@ void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipS
 void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, int max_n, hipStream_t s);
 void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
-void launch_spiral(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
-size_t spiral_lds_bytes(int slots, int max_level_width); // dynamic LDS k_spiral needs for a schedule (k4_spiral.hip)
 namespace sweep {
 struct Params;
 Params make_params(int n, double resolution, float min_dist_squared, double decrease); // sweep_emul.hip (host)
@@ -166,12 +133,11 @@ size_t sweep_lds_bytes(const sweep::Params &P);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
-void launch_plane_extract(const float2 *src, int comp, float *dst, size_t n, hipStream_t s);
-void launch_plane_insert(float2 *dst, int comp, const float *src, size_t n, hipStream_t s);
+void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s); // sheared layer -> column-major plane
+void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, hipStream_t s);
 void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds, uint8_t *d_img, hipStream_t s);
-void launch_terrain_image(const float2 *gp2, const float *raw, int rows, int cols, float *d_img, hipStream_t s);
-void configure_kernels(); // one-time function attributes (dynamic LDS above 64 KiB)
-void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double plane[4], hipStream_t s);
+void launch_terrain_image(const Arena &a, int slot, float *d_img, hipStream_t s);
+void launch_scroll(const Arena &a, int slot, float2 *scratch, int s0, int s1, double pos_x, double pos_y, const double plane[4], hipStream_t s);
 void launch_pack16(const gg_point32 *src, gg_point16 *dst, size_t n, hipStream_t s);
 void launch_decode_classes(const Arena &a, int slot, size_t n, uint8_t *d_class, int32_t *d_cell, hipStream_t s);
 

@@ -20,9 +20,10 @@ struct ScrollParams {
     double m20, m21, m22, tz; // third row of the base_link<-map rotation and translation z (gg_move_map base_plane)
 };
 
-__global__ __launch_bounds__(256) void k_scroll(const float2 *__restrict__ gp2, float2 *__restrict__ out, int rows, int cols,
-                                                const ScrollParams sp)
+__global__ __launch_bounds__(256) void k_scroll(const Arena a, int slot, float2 *__restrict__ out, const ScrollParams sp)
 {
+    const float2 *gp2 = gp2_ptr(a, slot);
+    const int rows = a.g.rows, cols = a.g.cols;
     const int i = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= rows || j >= cols) return;
@@ -42,14 +43,14 @@ __global__ __launch_bounds__(256) void k_scroll(const float2 *__restrict__ gp2, 
         g = (float)(-z);
         w = 0.0f;
     } else {
-        const float2 v = gp2[(size_t)bi + (size_t)bj * rows];
+        const float2 v = gp2[gp_idx(a, bi, bj)];
         g = v.x;
         w = v.y;
     }
-    out[(size_t)i + (size_t)j * rows] = make_float2(g, w);
+    out[gp_idx(a, i, j)] = make_float2(g, w); // same element order as the layer: copied back whole
 }
 
-void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, double pos_x, double pos_y, const double plane[4],
+void launch_scroll(const Arena &a, int slot, float2 *scratch, int s0, int s1, double pos_x, double pos_y, const double plane[4],
                    hipStream_t s)
 {
     ScrollParams sp;
@@ -65,11 +66,9 @@ void launch_scroll(const Arena &a, int slot, float *scratch, int s0, int s1, dou
     sp.m21 = plane[1];
     sp.m22 = plane[2];
     sp.tz = plane[3];
-    float2 *gp2 = gp2_ptr(a, slot);
-    float2 *out = reinterpret_cast<float2 *>(scratch);
     dim3 grid((a.g.rows + 63) / 64, (a.g.cols + 3) / 4);
-    hipLaunchKernelGGL(k_scroll, grid, dim3(256), 0, s, gp2, out, a.g.rows, a.g.cols, sp);
-    hipMemcpyAsync(gp2, out, (size_t)a.g.C * 8, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_scroll, grid, dim3(256), 0, s, a, slot, scratch, sp);
+    hipMemcpyAsync(gp2_ptr(a, slot), scratch, (size_t)a.gpl.elems * 8, hipMemcpyDeviceToDevice, s); // (elements no cell maps to are never read)
 }
 
 } // namespace gg

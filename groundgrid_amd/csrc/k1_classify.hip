@@ -102,9 +102,9 @@ GG_DEV bool ray_walk_hits(const Arena &a, const CloudParams &cp, const float2 *_
                 const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                       // :268
                 float e[9];
 #pragma unroll
-                for (int s = 0; s < 9; ++s) e[s] = gp2[(r0 + s % 3) + (c0 + s / 3) * rows].y;
+                for (int s = 0; s < 9; ++s) e[s] = gp2[gp_idx(a, r0 + s % 3, c0 + s / 3)].y;
                 const float bsum = tree9(e);
-                const float2 gI = gp2[I0 + I1 * rows];
+                const float2 gI = gp2[gp_idx(a, I0, I1)];
                 hit = (double)bsum > a.cfg.min_outlier_detection_ground_confidence && gI.y > 0.01f &&
                       (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance; // :269
             }
@@ -139,9 +139,9 @@ GG_DEV bool ray_walk_hits_lane(const Arena &a, const CloudParams &cp, const floa
         const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                            // :268
         float e[9];
 #pragma unroll
-        for (int s = 0; s < 9; ++s) e[s] = gp2[(r0 + s % 3) + (c0 + s / 3) * rows].y;
+        for (int s = 0; s < 9; ++s) e[s] = gp2[gp_idx(a, r0 + s % 3, c0 + s / 3)].y;
         const float bsum = tree9(e);
-        const float2 gI = gp2[I0 + I1 * rows];
+        const float2 gI = gp2[gp_idx(a, I0, I1)];
         if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gI.y > 0.01f &&
             (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) // :269
             return true;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { // index math for all windows, then all old-ground gathers in flight together
             inmap_[j] = locate_point(a, cp, pt[j], gi0[j], gi1[j]) && valid[j];
-            og[j] = gp2[inmap_[j] ? gi0[j] + gi1[j] * a.g.rows : 0].x; // :243
+            og[j] = gp2[inmap_[j] ? gp_idx(a, gi0[j], gi1[j]) : 0].x; // :243
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -285,30 +285,36 @@ void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s)
     hipLaunchKernelGGL(k_fill2, dim3(blocks), dim3(256), 0, s, dst, n, x, y);
 }
 
-// one plane of the interleaved (ground, confidence) pair <-> a plain float layer (host boundary, K6)
-__global__ void k_plane_extract(const float2 *__restrict__ src, int comp, float *__restrict__ dst, size_t n)
+// one plane of the interleaved (ground, confidence) pair, device element order (gp_layout.h) <-> a plain column-major
+// float layer (host boundary, K6)
+__global__ void k_plane_extract(const Arena a, int slot, int comp, float *__restrict__ dst)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float2 v = src[i];
+    const float2 *src = gp2_ptr(a, slot);
+    const int rows = a.g.rows;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.g.C; i += gridDim.x * blockDim.x) {
+        const float2 v = src[gp_idx(a, i % rows, i / rows)];
         dst[i] = comp ? v.y : v.x;
     }
 }
-__global__ void k_plane_insert(float2 *__restrict__ dst, int comp, const float *__restrict__ src, size_t n)
+__global__ void k_plane_insert(const Arena a, int slot, int comp, const float *__restrict__ src)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        if (comp) dst[i].y = src[i];
-        else dst[i].x = src[i];
+    float2 *dst = gp2_ptr(a, slot);
+    const int rows = a.g.rows;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.g.C; i += gridDim.x * blockDim.x) {
+        const int k = gp_idx(a, i % rows, i / rows);
+        if (comp) dst[k].y = src[i];
+        else dst[k].x = src[i];
     }
 }
-void launch_plane_extract(const float2 *src, int comp, float *dst, size_t n, hipStream_t s)
+void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s)
 {
-    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)2048);
-    hipLaunchKernelGGL(k_plane_extract, dim3(blocks), dim3(256), 0, s, src, comp, dst, n);
+    const int blocks = std::min((a.g.C + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_plane_extract, dim3(blocks), dim3(256), 0, s, a, slot, comp, dst);
 }
-void launch_plane_insert(float2 *dst, int comp, const float *src, size_t n, hipStream_t s)
+void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, hipStream_t s)
 {
-    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)2048);
-    hipLaunchKernelGGL(k_plane_insert, dim3(blocks), dim3(256), 0, s, dst, comp, src, n);
+    const int blocks = std::min((a.g.C + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_plane_insert, dim3(blocks), dim3(256), 0, s, a, slot, comp, src);
 }
 
 void launch_fill(float *dst, size_t n, float v, hipStream_t s)

@@ -37,7 +37,8 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
     // :364-365
     if ((double)pointsblockSum < std_max(floor(cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) return;
 
-    const float2 old = gp2[idx];
+    const int gidx = gp_idx(a, i, j); // the (ground, confidence) layer has its own element order (gp_layout.h)
+    const float2 old = gp2[gidx];
     const float oldConfidence = old.y;   // :360
     const float oldGroundheight = old.x; // :361
 
@@ -79,9 +80,9 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
         const float G = (groundlevel * newConfidence + (oldConfidence * oldGroundheight) * 2.0f) / (newConfidence + oldConfidence * 2.0f); // :385
         const float Cf =
             (float)std_min(((double)pointsblockSum / cfg.occupied_cells_point_count_factor_x2 + (double)oldConfidence) / 2.0, 1.0); // :387
-        gp2[idx] = make_float2(G, Cf);
+        gp2[gidx] = make_float2(G, Cf);
     } else if (localmin < oldGroundheight) { // :389
-        gp2[idx] = make_float2(localmin, std_min(oldConfidence + 0.1f, 0.5f)); // :391, :393
+        gp2[gidx] = make_float2(localmin, std_min(oldConfidence + 0.1f, 0.5f)); // :391, :393
     }
 }
 

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(1024) void k_sweep(const Arena a, const Params P, c
     for (int k = threadIdx.x; k < L.corner; k += nthreads) lds[k] = 0;
     const WP centre{1.0f, 1.0f * cp.base_z}; // :405 groundpatch(centre) = 1, :406-411 ground(centre) = translation.z
     if (threadIdx.x == 0) {
-        gp2[P.c + P.c * P.n] = make_float2(cp.base_z, 1.0f);
+        gp2[gp_index(P.gl, P.c, P.c)] = make_float2(cp.base_z, 1.0f);
         float *f = reinterpret_cast<float *>(lds);
         for (int side = 0; side < 2; ++side) {
             f[L.corner + 2 * ((side * P.c + 0) * 2) + 2] = centre.w;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024) void k_sweep(const Arena a, const Params P, c
     __syncthreads(); // the only barrier of the sweep
 
     DevMem mem;
-    mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, a.g.C * 8, 0x00020000);
+    mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, P.gl.elems * 8, 0x00020000);
     mem.lds = (lds_int *)lds;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const int W = P.waves_per_side;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             int row = 0, col = 0;
             if (lab[j]) key_to_cell(a, key, row, col);
             cidx[j] = (size_t)row + (size_t)col * rows;
-            gh[j] = gp2[cidx[j]].x;    // :162
+            gh[j] = gp2[gp_idx(a, row, col)].x; // :162
             var[j] = variance[cidx[j]]; // :165
             const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)(valid[j] ? p : base) * (FMT == GG_POINT16 ? 2 : 4)];
             x[j] = __uint_as_float(xy.x);

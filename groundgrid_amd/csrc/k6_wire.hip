@@ -61,9 +61,11 @@ __global__ __launch_bounds__(256) void k_layer_to_u8(const float *__restrict__ l
 }
 
 // Nodelet.cpp:258-268; the reference reads block<3,3>(i-1, j-1) also on the border (UB): border cells get 0 for the flag.
-__global__ __launch_bounds__(256) void k_terrain_image(const float2 *__restrict__ gp2, const float *__restrict__ raw, int rows, int cols,
-                                                       float *__restrict__ img)
+__global__ __launch_bounds__(256) void k_terrain_image(const Arena a, int slot, float *__restrict__ img)
 {
+    const float2 *gp2 = gp2_ptr(a, slot);
+    const float *raw = layer_ptr(a, slot, GG_LAYER_POINTSRAW);
+    const int rows = a.g.rows, cols = a.g.cols;
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= rows || j >= cols) return;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void k_terrain_image(const float2 *__restrict_
         flag = tree9(e) >= 27.0f ? 1.0f : 0.0f;
     }
     float *px = img + ((size_t)i * cols + j) * 3;
-    px[0] = gp2[(size_t)i + (size_t)j * rows].x;
+    px[0] = gp2[gp_idx(a, i, j)].x;
     px[1] = flag;
     px[2] = raw[(size_t)i + (size_t)j * rows];
 }
@@ -87,10 +89,10 @@ void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds,
     hipLaunchKernelGGL(k_layer_to_u8, grid, dim3(256), 0, s, layer, rows, cols, d_bounds, d_img);
 }
 
-void launch_terrain_image(const float2 *gp2, const float *raw, int rows, int cols, float *d_img, hipStream_t s)
+void launch_terrain_image(const Arena &a, int slot, float *d_img, hipStream_t s)
 {
-    dim3 grid((cols + 63) / 64, (rows + 3) / 4);
-    hipLaunchKernelGGL(k_terrain_image, grid, dim3(256), 0, s, gp2, raw, rows, cols, d_img);
+    dim3 grid((a.g.cols + 63) / 64, (a.g.rows + 3) / 4);
+    hipLaunchKernelGGL(k_terrain_image, grid, dim3(256), 0, s, a, slot, d_img);
 }
 
 } // namespace gg

@@ -36,6 +36,8 @@
 #include <float.h>
 #include <stdint.h>
 
+#include "gp_layout.h"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SW_HD __host__ __device__ __forceinline__
@@ -68,6 +70,7 @@ struct Params {
     int r2min;  // the confidence decay (:463-464) applies to cell (x, y) iff (x-c)^2 + (y-c)^2 >= r2min (host-computed, exact)
     double decrease, inv_decrease;
     int decay_fast;
+    GpLayout gl; // where cell (row, col) of the layer lives (gp_layout.h): a wavefront's 64 cells of a step are contiguous
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -76,10 +79,10 @@ struct Params {
 template <int SIDE> SW_HD int chain_len(int r) { return SIDE == SIDE_A ? 2 * r - 2 : SIDE == SIDE_D ? 2 * r : 2 * r - 1; }
 template <int SIDE> SW_HD int chain_k0() { return (SIDE == SIDE_A || SIDE == SIDE_C) ? 2 : 1; }
 
-// cell of `line` (-1 inner, 0 own, +1 outer) at along-position j of ring r; returns the linear index x + y * n
-template <int SIDE> SW_HD int side_cell(int n, int c, int r, int line, int j)
+// cell of `line` (-1 inner, 0 own, +1 outer) at along-position j of ring r, as its element index in the layer
+template <int SIDE> SW_HD int side_cell(const Params &P, int r, int line, int j)
 {
-    const int rp = c - r, R = c + r;
+    const int rp = P.c - r, R = P.c + r;
     int x, y;
     if (SIDE == SIDE_A) {
         x = rp - line;
@@ -94,7 +97,7 @@ template <int SIDE> SW_HD int side_cell(int n, int c, int r, int line, int j)
         x = R - j;
         y = R + line;
     }
-    return x + y * n;
+    return gp_index(P.gl, x, y);
 }
 
 // (x - c)^2 + (y - c)^2 of the own-line cell at along-position j
@@ -304,7 +307,9 @@ template <int SIDE> struct PlanIter {
 template <int SIDE> struct ChainLane {
     int l, r, len;     // lane in the group, ring, chain length (0: idle lane)
     int a_s0, a_s1, a_pred, a_join, a_bnd; // LDS words of S[0], S[1], the predecessor, the join, the previous group's boundary chain
-    int xold_cell;     // layer cell of S[len + 1]
+    int xold_cell;     // layer element of S[len + 1]
+    int own1, out1, own_end; // layer elements of the own / outer line at along-position 1 (stride 64 per position, gp_layout.h)
+                             // and of the own line's far end k0 + len, which belongs to another side
     // window: inner and outer lines as (w, p); own line: predecessor (w, p) new, self and successor old (g, w, p)
     WP I[3], U[3], OP;
     float Sg, Sw, Sp, Ng, Nw, Np;
@@ -341,7 +346,10 @@ template <int SIDE> struct ChainLane {
             a_pred = own_second;
         }
         a_bnd = group > 0 ? L.bnd + 2 * (SIDE * L.bnd_stride + bnd_offset(group - 1)) : L.bnd;
-        xold_cell = side_cell<SIDE>(P.n, P.c, r, -1, chain_k0<SIDE>() + len);
+        xold_cell = side_cell<SIDE>(P, r, -1, chain_k0<SIDE>() + len);
+        own1 = side_cell<SIDE>(P, r, 0, 1);
+        out1 = side_cell<SIDE>(P, r, 1, 1);
+        own_end = side_cell<SIDE>(P, r, 0, chain_k0<SIDE>() + len);
         I[0] = I[1] = I[2] = U[0] = U[1] = U[2] = OP = xold = h1 = h2 = h3 = WP{0.f, 0.f};
         Sg = Sw = Sp = Ng = Nw = Np = 0.f;
         for (int k = 0; k < PF; ++k) q_own[k] = q_out[k] = Cell{0.f, 0.f};
@@ -362,17 +370,17 @@ template <int SIDE> struct ChainLane {
         // ---- the column that arrives now (along-position k0 + s + 1), requested PF steps ago into this slot; the own-line
         //      request of step -2 (the predecessor's cell, which is never read from the layer) carries the old cell S[len + 1]
         const bool col = len > 0 && s >= -2 && s <= len - 1;
-        const int own_cell = s == -2 ? xold_cell : side_cell<SIDE>(P.n, P.c, r, 0, k0 + s + 1);
+        const int own_cell = s == -2 ? xold_cell : s == len - 1 ? own_end : own1 + 64 * (k0 + s);
         // (mem.fresh: on the device a real register copy.  The arriving values stay live for two or three more steps as
         //  window elements; copied out here, the slot's registers are free for the request below, and the compiler does not
         //  have to copy freshly requested registers at the loop's back edge -- which would be a wait for loads just issued)
         const Cell own = mem.fresh(mem.load_value(q_own[slot], col, own_cell));
-        const Cell out = mem.fresh(mem.load_value(q_out[slot], col, side_cell<SIDE>(P.n, P.c, r, 1, k0 + s + 1)));
+        const Cell out = mem.fresh(mem.load_value(q_out[slot], col, out1 + 64 * (k0 + s)));
         // ---- and the one to request for step s + PF
         const int sq = s + PF;
         const bool colq = len > 0 && sq >= -2 && sq <= len - 1;
-        q_own[slot] = mem.load_issue(colq, sq == -2 ? xold_cell : side_cell<SIDE>(P.n, P.c, r, 0, k0 + sq + 1));
-        q_out[slot] = mem.load_issue(colq, side_cell<SIDE>(P.n, P.c, r, 1, k0 + sq + 1));
+        q_own[slot] = mem.load_issue(colq, sq == -2 ? xold_cell : sq == len - 1 ? own_end : own1 + 64 * (k0 + sq));
+        q_out[slot] = mem.load_issue(colq, out1 + 64 * (k0 + sq));
         // ---- advance the window
         Sg = Ng;
         Sw = Nw;
@@ -417,7 +425,7 @@ template <int SIDE> struct ChainLane {
         WP res = WP{0.f, 0.f};
         if (active) {
             const Cell v = visit(w, p, Sg, Sw, side_r2<SIDE>(r, k0 + s) >= P.r2min, P);
-            mem.store(side_cell<SIDE>(P.n, P.c, r, 0, k0 + s), v);
+            mem.store(own1 + 64 * (k0 + s - 1), v);
             res = WP{v.w, v.w * v.g};
             OP = res;
         }
@@ -463,7 +471,7 @@ template <int CD> struct CornerLane {
     SW_HD static int cell_at(const Params &P, int r, int a, int b)
     {
         const int o = CD ? 1 : -1, z = P.c + o * r;
-        return (z + o * a) + (z + o * b) * P.n;
+        return gp_index(P.gl, z + o * a, z + o * b);
     }
     SW_HD static bool is_old(int r, int a, int b)
     {
@@ -489,7 +497,7 @@ template <int CD> struct CornerLane {
     // ring r: first-side visits X_0 = (z, z), X_1 = (z, z - o) (A_1 / C_1), then the revisit Y_0 = (z, z) (B_0 / D_0)
     template <class Mem> SW_HD static void ring(int r, const Old &queued, const Params &P, const LdsMap &L, Mem &mem)
     {
-        const int o = CD ? 1 : -1, z = P.c + o * r, n = P.n;
+        const int o = CD ? 1 : -1, z = P.c + o * r;
         const int base = L.corner + 2 * ((CD * P.c + r) * 2), prev = L.corner + 2 * ((CD * P.c + r - 1) * 2);
         Old o_;
         for (int a = -1; a <= 1; ++a)
@@ -526,8 +534,8 @@ template <int CD> struct CornerLane {
                 p[q(a, b, 0, 0)] = v.p;
             }
         const Cell y0 = visit(w, p, x0.g, x0.w, decay0, P);
-        mem.store(z + z * n, y0);
-        mem.store(z + (z - o) * n, x1);
+        mem.store(gp_index(P.gl, z, z), y0);
+        mem.store(gp_index(P.gl, z, z - o), x1);
         mem.put(base, wp(x1));
         mem.publish(base + 2, wp(y0), L.corner_done + CD, r);
         if (!CD && r == 1) mem.publish(L.join + 2 * (SIDE_A * P.c + 1), wp(x1), L.join_done + SIDE_A, 1); // A_last(1) = A_1(1): side A of ring 1 has no chain

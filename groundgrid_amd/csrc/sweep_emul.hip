@@ -74,7 +74,17 @@ template <int SIDE> struct ChainWave : WaveBase {
         if (group >= P.groups) return;
         r0 = LANES * group + 1;
         nl = P.rings - (r0 - 1) < LANES ? P.rings - (r0 - 1) : LANES;
-        for (int l = 0; l < LANES; ++l) lane[l].init(l, r0, nl, group, P, L);
+        for (int l = 0; l < LANES; ++l) {
+            lane[l].init(l, r0, nl, group, P, L);
+            // the stride-64 addressing of a lane's two lines is the layout's promise: hold it to gp_index() cell by cell
+            const ChainLane<SIDE> &c = lane[l];
+            const int k0 = chain_k0<SIDE>();
+            for (int j = k0; j <= k0 + c.len - 1; ++j)
+                if (c.own1 + 64 * (j - 1) != side_cell<SIDE>(P, c.r, 0, j)) plan_mismatch = true;
+            for (int j = k0 - 1; c.len > 0 && j <= k0 + c.len; ++j)
+                if (c.out1 + 64 * (j - 1) != side_cell<SIDE>(P, c.r, 1, j)) plan_mismatch = true;
+            if (l > 0 && l < nl && c.len > 0 && lane[l - 1].len > 0 && c.own1 != lane[l - 1].own1 + 3 * 64 + 1) plan_mismatch = true; // coalescing: + 3 steps, + 1 lane
+        }
         t = group_first_step();
         t_last = group_last_step<SIDE>(r0, nl);
         t_last += (PF - (t_last - t + 1) % PF) % PF; // the device runs whole trips of PF steps
@@ -145,6 +155,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
     P.decrease = decrease;
     P.inv_decrease = 1.0 / decrease;
     P.decay_fast = decrease >= 1.25 && decrease < 1e300;
+    P.gl = make_gp_layout(n);
     return P;
 }
 
@@ -158,12 +169,15 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
     const Params P = gg::sweep::make_params(n, resolution, min_dist_squared, decrease);
     const LdsMap L = lds_layout(P.c, P.groups);
     HostMem mem;
-    mem.gp2 = reinterpret_cast<Cell *>(gp2);
+    // the layer in the device's sheared element order (gp_layout.h); gp2 is Eigen-style column-major on both ends
+    std::vector<Cell> sheared((size_t)P.gl.elems, Cell{0.f, 0.f});
+    for (int col = 0; col < n; ++col)
+        for (int row = 0; row < n; ++row) sheared[(size_t)gp_index(P.gl, row, col)] = Cell{gp2[2 * ((size_t)row + (size_t)col * n)], gp2[2 * ((size_t)row + (size_t)col * n) + 1]};
+    mem.gp2 = sheared.data();
     mem.lds.assign((size_t)L.words, 0);
     mem.late = late_loads != 0;
     // :405-411 centre cell; ring 0 of every hand-over table is the centre
-    const int cc = P.c + P.c * n;
-    mem.gp2[cc] = Cell{base_z, 1.0f};
+    mem.gp2[gp_index(P.gl, P.c, P.c)] = Cell{base_z, 1.0f};
     const WP centre{1.0f, 1.0f * base_z};
     for (int side = 0; side < 2; ++side) mem.put(L.corner + 2 * ((side * P.c + 0) * 2) + 2, centre);
     mem.put(L.join + 2 * (SIDE_C * P.c + 0), centre);
@@ -232,5 +246,11 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
         if (w->bad() && rc == GG_OK) rc = -11; // the stepped plan disagrees with the closed form
         delete w;
     }
+    for (int col = 0; col < n; ++col)
+        for (int row = 0; row < n; ++row) {
+            const Cell v = sheared[(size_t)gp_index(P.gl, row, col)];
+            gp2[2 * ((size_t)row + (size_t)col * n)] = v.g;
+            gp2[2 * ((size_t)row + (size_t)col * n) + 1] = v.w;
+        }
     return rc;
 }

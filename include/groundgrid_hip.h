@@ -114,11 +114,7 @@ enum { GG_CLASS_OUTSIDE = 0, GG_CLASS_IGNORED = 1, GG_CLASS_OUTLIER = 2, GG_CLAS
 enum {
     GG_FLAG_MINIMAL_LAYERS = 1, /* skip the four layers nothing in the path reads (groundCandidates, planeDist,
                                    maxGroundHeight, meanVariance are still zero/initial-filled); default off */
-    GG_FLAG_PROFILE = 2,        /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
-    GG_FLAG_SPIRAL_NARROW = 4,  /* level-scheduled sweep only: use its second exact schedule (levels of one wavefront) */
-    GG_FLAG_SPIRAL_LEVELS = 8   /* terrain sweep: run the round-1 level-scheduled kernel (k_spiral: host-built hazard levels,
-                                   one barrier interval per level) instead of the ring-per-lane dataflow (k_sweep); both are
-                                   exact, kept for A/B measurements; default off */
+    GG_FLAG_PROFILE = 2         /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
 };
 
 typedef struct gg_context gg_context;
@@ -303,15 +299,11 @@ int gg_get_kernel_times(gg_context *ctx, double ms[GG_NUM_KERNELS], int64_t laun
 const char *gg_kernel_name(int k);
 int gg_abi_version(void);
 
-/* Testing hook, runs on the host (no GPU): builds the terrain sweep's level schedule for an n x n grid with `cap` visits
- * per level and executes it with the hand-over rules the sweep kernel relies on; gp2 = interleaved (ground, groundpatch)
- * [n*n][2], updated in place like spiral_ground_interpolation (src/GroundSegmentation.cpp:398-465) would.  0 or < 0. */
-int gg_debug_replay_spiral_schedule(int n, double resolution, float min_dist_squared, int cap, float *gp2, float base_z,
-                                    double occupied_cells_decrease_factor);
-
 /* Testing hook, runs on the host (no GPU): the terrain sweep the device runs (ring-per-lane dataflow, csrc/sweep_core.h) --
  * the same per-lane code -- emulated wavefront by wavefront with a seeded interleaving of the wavefronts (seed 0 = round
- * robin) and, if late_loads, every layer load resolved only when it is used.  gp2 as in gg_debug_replay_spiral_schedule.
+ * robin) and, if late_loads, every layer load resolved only when it is used.  gp2 = interleaved (ground, groundpatch)
+ * [n*n][2] in Eigen's column-major cell order, updated in place like spiral_ground_interpolation
+ * (src/GroundSegmentation.cpp:398-465) would.
  * stats (nullable, 8 longs): wave-steps, stalls, layer loads, stores, LDS operations, LDS bytes, wavefronts, decay radius^2.
  * Returns 0, or -10 if the wavefronts deadlock. */
 int gg_debug_emulate_ring_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z,

@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_abi_version_and_kernel_names(lib):
     assert lib.gg_abi_version() == 2  # v2: gg_move_map takes matrix entries, conventions, async host call
     names = [lib.gg_kernel_name(k).decode() for k in range(_lib.GG_NUM_KERNELS)]
-    assert names == ["k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_spiral", "k_label"]
+    assert names == ["k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_sweep", "k_label"]
 
 
 def test_struct_layouts_match_the_header():

@@ -110,8 +110,8 @@ def test_line_of_sight_walk_many_candidates():
 
 @pytest.mark.parametrize("length,resolution", [(4.0, 0.33), (10.0, 0.5), (33.0, 0.33), (61.0, 0.25), (150.0, 0.25), (240.0, 0.33)])
 def test_geometries_from_tiny_to_wider_than_the_level_cap(length, resolution):
-    """Everything derived from the geometry on the host -- sort tiles, R1 table, the sweep's level schedule with its LDS
-    slot allocation (12 x 12 cells up to 727 x 727, whose widest hazard levels exceed the 512-lane cap and get split) --
+    """Everything derived from the geometry on the host -- sort tiles, R1 table, the layer's sheared element order, the
+    sweep's ring groups and LDS hand-over tables (12 x 12 cells up to 727 x 727: 6 ring groups on 3 wavefronts per side) --
     must reproduce the CPU path; the cloud is scaled to cover the map."""
     base = synth.hdl64_cloud(seed=19, n_az=500)
     cloud = synth.clone_cloud(base)
@@ -152,7 +152,7 @@ def test_config_variations():
 
 @pytest.mark.parametrize("factor", [1.1, 1.25, 0.5, 7.3, 1e6])
 def test_confidence_decay_factor_fast_and_exact_branches(factor):
-    """k_spiral replaces the f64 divide of :463-464 by a guarded multiply for factors >= 1.25 (tests/test_oracle_cpu.py
+    """k_sweep replaces the f64 divide of :463-464 by a guarded multiply for factors >= 1.25 (tests/test_oracle_cpu.py
     proves the guard); smaller factors take the divide.  Both must reproduce the CPU path over several frames."""
     def edit(c):
         c.occupied_cells_decrease_factor = factor
@@ -270,24 +270,17 @@ def test_minimal_layers_flag_keeps_labels_and_terrain():
             assert nan_equal(seg.map(0)[name], ref.layer(name)), name
 
 
-def test_one_wavefront_spiral_schedule_is_exact_too():
-    """The terrain sweep has two exact level schedules (gg_context.hip build_spiral_schedule, cap 1024 / 64)."""
-    cloud = synth.hdl64_cloud(seed=41, n_az=900)
-    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
-    seg.set_flags(spiral_narrow=True)
-    ref = oracle.OracleMap(120.0, 0.33)
-    for _ in range(3):
-        _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
-        r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
-        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"])
-        assert_same_state(seg.map(0), ref)
-    big = api.GroundSegmentation().init(200.0, 0.2, n_slots=1, max_points=1000)  # 1000 x 1000: 2493 / ~7000 levels
-    big.set_flags(spiral_narrow=True)
-    refb = oracle.OracleMap(200.0, 0.2)
-    c = synth.random_cloud(1000, seed=2, extent=90.0)
-    big.filter_cloud(c, ORIGIN0, -1.7)
-    refb.filter_cloud(c, ORIGIN0, -1.7)
-    assert_same_state(big.map(0), refb)
+def test_largest_supported_grid_and_ring_group_counts():
+    """The sweep's wavefronts own groups of 64 rings: 1000 x 1000 (498 rings, 8 groups on 3 wavefronts per side, 147 KB of LDS
+    hand-over tables) down to grids with fewer rings than lanes; a sparse cloud keeps the oracle fast."""
+    for length, res in ((200.0, 0.2), (43.0, 0.33), (22.0, 0.33)):
+        seg = api.GroundSegmentation().init(length, res, n_slots=1, max_points=1000)
+        ref = oracle.OracleMap(length, res)
+        c = synth.random_cloud(1000, seed=2, extent=0.45 * length)
+        for _ in range(2):
+            seg.filter_cloud(c, ORIGIN0, -1.7)
+            ref.filter_cloud(c, ORIGIN0, -1.7)
+            assert_same_state(seg.map(0), ref, f"{length} m / {res} m")
 
 
 def test_run_to_run_determinism_and_reset():

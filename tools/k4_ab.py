@@ -1,14 +1,14 @@
-"""A/B of the two terrain-sweep kernels on the GPU box: per-launch k_spiral time at several batch sizes (HIP events inside the library)."""
+"""Per-launch kernel times at several batch sizes (HIP events inside the library), on the GPU box."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from groundgrid_amd import api, synth
 
 def run(batch, levels, steps=8):
     clouds = [synth.hdl64_cloud(seed=20240113 + k) for k in range(min(batch, 4))]
     stride = (max(len(c) for c in clouds) + 63) // 64 * 64
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=batch, max_points=stride)
-    seg.set_flags(profile=True, spiral_levels=levels)
+    seg.set_flags(profile=True)
     host = np.zeros((batch, stride), dtype=api.POINT16_DTYPE)
     n = []
     for b in range(batch):
@@ -30,7 +30,5 @@ def run(batch, levels, steps=8):
     return dt * 1e3, {k: v[0] / max(1, v[1]) for k, v in kt.items()}
 
 for batch in (1, 8, 64, 256, 1024):
-    for levels in (True, False):
-        ms, kt = run(batch, levels)
-        print(f"batch {batch:5d} {'levels(r1)' if levels else 'rings (r2)'}: step {ms:8.3f} ms  k_spiral {kt['k_spiral']:8.4f} ms   "
-              + " ".join(f"{k[2:]}={v:.3f}" for k, v in kt.items() if k != 'k_spiral'), flush=True)
+    ms, kt = run(batch, False)
+    print(f"batch {batch:5d}: step {ms:8.3f} ms  k_sweep {kt['k_sweep']:8.4f} ms   " + " ".join(f"{k[2:]}={v:.3f}" for k, v in kt.items() if k != 'k_sweep'), flush=True)

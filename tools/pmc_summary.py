@@ -13,7 +13,7 @@ import os
 import sys
 
 GROUPS = {"K1_classify": ["gg::k_classify"], "K2_sort_reduce": ["gg::k_scan", "gg::k_scatter", "gg::k_reduce"],
-          "K3_patch": ["gg::k_patch"], "K4_spiral": ["gg::k_spiral"], "K5_label": ["gg::k_label"]}
+          "K3_patch": ["gg::k_patch"], "K4_sweep": ["gg::k_sweep"], "K5_label": ["gg::k_label"]}
 
 
 def per_kernel(path):

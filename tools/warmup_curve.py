@@ -19,4 +19,4 @@ for rep in range(2):
         seg.kernel_times(reset=True)
         t0 = time.perf_counter(); out = seg.filter_batch(points, n_points, org, bz, out=out); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         kt = seg.kernel_times(reset=True)
-        if rep: print(f"frame {f}: {dt*1e3:7.2f} ms  classify {kt['k_classify'][0]:.2f} reduce {kt['k_reduce'][0]:.2f} spiral {kt['k_spiral'][0]:.2f} label {kt['k_label'][0]:.2f}")
+        if rep: print(f"frame {f}: {dt*1e3:7.2f} ms  classify {kt['k_classify'][0]:.2f} reduce {kt['k_reduce'][0]:.2f} spiral {kt['k_sweep'][0]:.2f} label {kt['k_label'][0]:.2f}")
