@@ -94,6 +94,7 @@ struct gg_context {
     float *d_scroll_scratch = nullptr; // 2 layers
     float *d_image = nullptr;          // 3 * C floats (wire-format images)
     float *d_bounds = nullptr;         // 2 floats
+    unsigned long long *d_sweep_dbg = nullptr; // GG_SWEEP_TIMING=1: cycle counters of the sweep's wavefronts (cloud 0 of a batch)
 
     // profiling
     std::vector<EventPair> pending;
@@ -292,7 +293,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
         sp.decrease = ctx->cfg.occupied_cells_decrease_factor;
         sp.inv_decrease = 1.0 / sp.decrease;
         sp.decay_fast = sp.decrease >= 1.25 && sp.decrease < 1e300;
-        launch_sweep(a, sp, dp, nb, s);
+        launch_sweep(a, sp, dp, nb, s, ctx->d_sweep_dbg);
     }
     prof.end();
     prof.begin(GG_K_LABEL);
@@ -499,6 +500,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_scroll = carve(a.gp2_stride * 8); // one layer in its device element order (map scroll) / two planes (images)
     const size_t o_image = carve(3 * Cpad * 4);
     const size_t o_bounds = carve(64);
+    const size_t o_dbg = carve(16 * 4 * 8);
     ctx->arena_bytes = off;
     CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
     char *base = (char *)ctx->d_arena;
@@ -536,6 +538,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_scroll_scratch = (float *)(base + o_scroll);
     ctx->d_image = (float *)(base + o_image);
     ctx->d_bounds = (float *)(base + o_bounds);
+    if (getenv("GG_SWEEP_TIMING")) ctx->d_sweep_dbg = (unsigned long long *)(base + o_dbg);
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
@@ -1064,6 +1067,14 @@ int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class
     if (out_class) HIPCHK(ctx, hipMemcpyAsync(out_class, ctx->d_stage_class, n, hipMemcpyDeviceToHost, ctx->stream));
     if (out_cell) HIPCHK(ctx, hipMemcpyAsync(out_cell, ctx->d_stage_cell, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+// tools only (not in the header): cycle counters written by the last sweep when GG_SWEEP_TIMING=1 was set at gg_create
+extern "C" int gg_debug_sweep_timing(gg_context *ctx, unsigned long long out[64])
+{
+    if (!ctx || !out || !ctx->d_sweep_dbg) return GG_ERR_INVALID;
+    if (hipMemcpy(out, ctx->d_sweep_dbg, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
     return GG_OK;
 }
 

@@ -128,7 +128,8 @@ namespace sweep {
 struct Params;
 Params make_params(int n, double resolution, float min_dist_squared, double decrease); // sweep_emul.hip (host)
 } // namespace sweep
-void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4_sweep.hip
+void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s,
+                  unsigned long long *dbg = nullptr); // k4_sweep.hip; dbg: 16 x 4 cycle counters of cloud 0's wavefronts (tools)
 size_t sweep_lds_bytes(const sweep::Params &P);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);

@@ -89,7 +89,23 @@ GG_DEV float wave_shr1(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
 }
 
-template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMem &mem, int wave_of_side, int lane)
+// optional instrumentation (gg_debug_sweep_timing): per wavefront {start, end, cycles spent polling, polls that had to wait}
+struct WaveClock {
+    unsigned long long *out; // nullptr: off
+    unsigned long long t0 = 0, polling = 0, waits = 0;
+    GG_DEV void begin() { t0 = out ? __builtin_readcyclecounter() : 0ull; }
+    GG_DEV void end(int wave, int lane)
+    {
+        if (out && lane == 0) {
+            out[wave * 4 + 0] = t0;
+            out[wave * 4 + 1] = __builtin_readcyclecounter();
+            out[wave * 4 + 2] = polling;
+            out[wave * 4 + 3] = waits;
+        }
+    }
+};
+
+template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMem &mem, int wave_of_side, int lane, WaveClock &clk)
 {
     ChainLane<SIDE> st;
     for (int group = wave_of_side; group < P.groups; group += P.waves_per_side) {
@@ -108,8 +124,17 @@ template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevM
             for (int u = 0; u < PF; ++u) {
                 const int t = tb + u;
                 const StepPlan<SIDE> pl = plan.at(t);
-                if (pl.start_lane >= 0 || pl.join_lane >= 0 || pl.need_bnd > 0)
-                    while (!chain_ready<SIDE>(pl, P, L, group, mem)) __builtin_amdgcn_s_sleep(1);
+                if (pl.start_lane >= 0 || pl.join_lane >= 0 || pl.need_bnd > 0) {
+                    if (!chain_ready<SIDE>(pl, P, L, group, mem)) {
+                        const unsigned long long w0 = clk.out ? __builtin_readcyclecounter() : 0ull;
+                        do __builtin_amdgcn_s_sleep(1);
+                        while (!chain_ready<SIDE>(pl, P, L, group, mem));
+                        if (clk.out) {
+                            clk.polling += __builtin_readcyclecounter() - w0;
+                            clk.waits += 1;
+                        }
+                    }
+                }
                 const WP x_in{wave_shr1(st.h3.w), wave_shr1(st.h3.p)};
                 st.step(t, u, x_in, P, L, pl, has_next, group, mem);
                 plan.advance(t);
@@ -118,8 +143,9 @@ template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevM
     }
 }
 
-template <int CD> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMem &mem, int lane)
+template <int CD> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMem &mem, int lane, WaveClock &clk)
 {
+    (void)clk;
     if (lane != 0) return;
     // the old cells of a ring are requested one ring ahead; two rings per trip so that the two register sets swap roles by
     // name instead of being copied (a copy of a register that is being loaded is a wait for that load)
@@ -133,7 +159,8 @@ template <int CD> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMe
     }
 }
 
-__global__ __launch_bounds__(1024) void k_sweep(const Arena a, const Params P, const LdsMap L, const CloudParams *__restrict__ params)
+__global__ __launch_bounds__(1024) void k_sweep(const Arena a, const Params P, const LdsMap L, const CloudParams *__restrict__ params,
+                                                unsigned long long *dbg)
 {
     extern __shared__ int lds[];
     const int cloud = blockIdx.x;
@@ -166,23 +193,27 @@ __global__ __launch_bounds__(1024) void k_sweep(const Arena a, const Params P, c
     mem.lds = (lds_int *)lds;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const int W = P.waves_per_side;
+    WaveClock clk;
+    clk.out = (dbg && blockIdx.x == 0) ? dbg : nullptr;
+    clk.begin();
     if (wave < W)
-        run_chain<SIDE_A>(P, L, mem, wave, lane);
+        run_chain<SIDE_A>(P, L, mem, wave, lane, clk);
     else if (wave < 2 * W)
-        run_chain<SIDE_B>(P, L, mem, wave - W, lane);
+        run_chain<SIDE_B>(P, L, mem, wave - W, lane, clk);
     else if (wave < 3 * W)
-        run_chain<SIDE_C>(P, L, mem, wave - 2 * W, lane);
+        run_chain<SIDE_C>(P, L, mem, wave - 2 * W, lane, clk);
     else if (wave < 4 * W)
-        run_chain<SIDE_D>(P, L, mem, wave - 3 * W, lane);
+        run_chain<SIDE_D>(P, L, mem, wave - 3 * W, lane, clk);
     else if (wave == 4 * W)
-        run_corner<0>(P, L, mem, lane);
+        run_corner<0>(P, L, mem, lane, clk);
     else
-        run_corner<1>(P, L, mem, lane);
+        run_corner<1>(P, L, mem, lane, clk);
+    clk.end(wave, lane);
 }
 
 size_t sweep_lds_bytes(const Params &P) { return (size_t)lds_layout(P.c, P.groups).words * 4; }
 
-void launch_sweep(const Arena &a, const Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s)
+void launch_sweep(const Arena &a, const Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s, unsigned long long *dbg)
 {
     if (n_clouds == 0 || P.rings <= 0) return;
     const LdsMap L = lds_layout(P.c, P.groups);
@@ -193,7 +224,7 @@ void launch_sweep(const Arena &a, const Params &P, const CloudParams *d_params, 
         big_lds_ok = true;
     }
     const int threads = (4 * P.waves_per_side + 2) * 64;
-    hipLaunchKernelGGL(k_sweep, dim3(n_clouds), dim3(threads), lds, s, a, P, L, d_params);
+    hipLaunchKernelGGL(k_sweep, dim3(n_clouds), dim3(threads), lds, s, a, P, L, d_params, dbg);
 }
 
 } // namespace gg

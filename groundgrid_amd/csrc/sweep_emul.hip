@@ -3,6 +3,8 @@
 // wavefronts and, optionally, every layer load resolved as late as its use.  tests/test_sweep_emul_cpu.py compares the
 // result with the oracle's serial sweep: the dataflow (who hands what to whom, when it is ready) is proven without a GPU.
 // Host code only; compiled with the library's flags (-ffp-contract=off), so the floats are the device's.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -195,12 +197,13 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
     // (up to "as far as it can") before the next one is chosen: wavefronts drift apart as far as the dataflow allows
     uint32_t rng = seed * 2654435761u + 12345u;
     auto rnd = [&]() { return rng = rng * 1664525u + 1013904223u; };
-    long total_steps = 0, stalls = 0;
+    long total_steps = 0, stalls = 0, rounds = 0;
     int rc = GG_OK;
     for (;;) {
         bool all_done = true, progress = false;
         for (auto *w : waves) all_done &= w->done();
         if (all_done) break;
+        ++rounds;
         if (seed == 0) {
             for (auto *w : waves)
                 if (w->try_step(mem)) {
@@ -232,6 +235,7 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
             break;
         }
     }
+    if (getenv("GG_EMUL_VERBOSE")) fprintf(stderr, "ring sweep emulation: n %d, %ld scheduler rounds, %ld wave-steps, %ld stalls\n", n, rounds, total_steps, stalls);
     if (stats) {
         stats[0] = total_steps;
         stats[1] = stalls;

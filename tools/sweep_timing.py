@@ -1,0 +1,19 @@
+"""Cycle counters of the sweep's wavefronts for one cloud (GG_SWEEP_TIMING=1): where does the single-cloud latency go?"""
+import os, sys, ctypes as C
+os.environ["GG_SWEEP_TIMING"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from groundgrid_amd import api, synth, _lib
+cloud = synth.hdl64_cloud(seed=20240113)
+seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+for _ in range(3):
+    seg.filter_cloud(cloud, (0, 0, 0), -1.73)
+L = _lib.load()
+out = (C.c_ulonglong * 64)()
+L.gg_debug_sweep_timing.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+assert L.gg_debug_sweep_timing(seg._ctx, out) == 0
+v = np.array(list(out), dtype=np.int64).reshape(16, 4)
+t0 = v[:10, 0].min()
+names = ["A0", "A1", "B0", "B1", "C0", "C1", "D0", "D1", "cornerAB", "cornerCD"]
+for k, nm in enumerate(names):
+    print(f"{nm:9s} start {v[k,0]-t0:9d} end {v[k,1]-t0:9d} cycles  polling {v[k,2]:9d}  waits {v[k,3]:6d}")
