@@ -538,7 +538,12 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_scroll_scratch = (float *)(base + o_scroll);
     ctx->d_image = (float *)(base + o_image);
     ctx->d_bounds = (float *)(base + o_bounds);
-    if (getenv("GG_SWEEP_TIMING")) ctx->d_sweep_dbg = (unsigned long long *)(base + o_dbg);
+    if (getenv("GG_SWEEP_TIMING")) {
+        ctx->d_sweep_dbg = (unsigned long long *)(base + o_dbg);
+        const unsigned long long mode = getenv("GG_SWEEP_DEBUG") ? strtoull(getenv("GG_SWEEP_DEBUG"), nullptr, 0) : 0ull;
+        hipStreamSynchronize(ctx->stream); // (the arena memset above)
+        hipMemcpy(ctx->d_sweep_dbg + 63, &mode, 8, hipMemcpyHostToDevice);
+    }
 
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));

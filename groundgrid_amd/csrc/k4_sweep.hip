@@ -31,11 +31,12 @@ typedef __attribute__((address_space(3))) uint64_t lds_u64;
 struct DevMem {
     __amdgpu_buffer_rsrc_t rsrc; // the interleaved (ground, confidence) layer of this cloud
     lds_int *lds;
+    int dbg_mode = 0; // timing experiments only (GG_SWEEP_DEBUG): 1 = drop the result stores, 2 = drop the layer loads
     static constexpr uint32_t OOR = 0x80000000u; // beyond the buffer: loads return 0, stores are dropped, no traffic
 
     GG_DEV Cell load_issue(bool valid, int cell) const
     {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, valid ? (uint32_t)cell * 8u : OOR, 0, 0);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (valid && !(dbg_mode & 2)) ? (uint32_t)cell * 8u : OOR, 0, 0);
         return Cell{__uint_as_float(v.x), __uint_as_float(v.y)};
     }
     GG_DEV Cell load_value(const Cell &queued, bool, int) const { return queued; }
@@ -45,12 +46,12 @@ struct DevMem {
         asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(o.g), "=&v"(o.w) : "v"(v.g), "v"(v.w));
         return o;
     }
-    GG_DEV void store(int cell, Cell v) const
+    GG_DEV void store(bool valid, int cell, Cell v) const
     {
         u32x2 d;
         d.x = __float_as_uint(v.g);
         d.y = __float_as_uint(v.w);
-        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (uint32_t)cell * 8u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (valid && !(dbg_mode & 1)) ? (uint32_t)cell * 8u : OOR, 0, 0);
     }
     // LDS.  Other wavefronts write what is read here: every access is an atomic (relaxed, work-group scope) so that the
     // compiler neither caches nor hoists it; ordering comes from the hardware (in-order DS queue per wavefront).
@@ -117,27 +118,30 @@ template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevM
         // PF steps per trip, no per-step condition: a step past t_last finds every lane idle (no loads, no stores, nothing
         // to wait for), and without a conditional around it the queue registers of a slot never meet a control-flow join --
         // a join makes the compiler copy freshly loaded registers, i.e. wait for the loads it has just issued
-        PlanIter<SIDE> plan;
-        plan.init(r0, nl, group > 0);
+        ChainSync<SIDE> sync;
+        sync.init(r0, nl, group, P, L);
         for (int tb = t_first; tb <= t_last; tb += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int t = tb + u;
-                const StepPlan<SIDE> pl = plan.at(t);
-                if (pl.start_lane >= 0 || pl.join_lane >= 0 || pl.need_bnd > 0) {
-                    if (!chain_ready<SIDE>(pl, P, L, group, mem)) {
-                        const unsigned long long w0 = clk.out ? __builtin_readcyclecounter() : 0ull;
-                        do __builtin_amdgcn_s_sleep(1);
-                        while (!chain_ready<SIDE>(pl, P, L, group, mem));
-                        if (clk.out) {
-                            clk.polling += __builtin_readcyclecounter() - w0;
-                            clk.waits += 1;
-                        }
+                sync.advance(t);
+                if (!sync.ok()) { // (rare) something this step reads has not been published yet as far as the cached counters know
+                    const unsigned long long w0 = clk.out ? __builtin_readcyclecounter() : 0ull;
+                    sync.refresh(mem);
+                    int spins = 0;
+                    while (!sync.ok()) {
+                        __builtin_amdgcn_s_sleep(1);
+                        sync.refresh(mem);
+                        ++spins;
+                    }
+                    if (clk.out) {
+                        clk.polling += __builtin_readcyclecounter() - w0;
+                        clk.waits += spins ? 1 : 0;
                     }
                 }
                 const WP x_in{wave_shr1(st.h3.w), wave_shr1(st.h3.p)};
-                st.step(t, u, x_in, P, L, pl, has_next, group, mem);
-                plan.advance(t);
+                constexpr int t_first_mod = ((-2 - (int)PF) % (int)SKEW + (int)SKEW) % (int)SKEW; // tb = t_first (mod PF), PF = 0 (mod SKEW)
+                st.step(t, u, (t_first_mod + u) % (int)SKEW, x_in, P, L, group > 0, has_next, group, mem);
             }
         }
     }
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(1024) void k_sweep(const Arena a, const Params P, c
     const int W = P.waves_per_side;
     WaveClock clk;
     clk.out = (dbg && blockIdx.x == 0) ? dbg : nullptr;
+    mem.dbg_mode = dbg ? (int)dbg[63] : 0;
     clk.begin();
     if (wave < W)
         run_chain<SIDE_A>(P, L, mem, wave, lane, clk);

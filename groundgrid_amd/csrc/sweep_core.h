@@ -49,7 +49,8 @@ namespace gg {
 namespace sweep {
 
 enum { SIDE_A = 0, SIDE_B = 1, SIDE_C = 2, SIDE_D = 3 };
-enum { LANES = 64, SKEW = 3, PF = 6 }; // rings per group, steps between neighbouring rings, prefetch distance of the layer streams
+enum { LANES = 64, SKEW = 3, PF = 6 };
+static_assert(SKEW == 3 && PF % SKEW == 0, "the step code names t mod SKEW residues"); // rings per group, steps between neighbouring rings, prefetch distance of the layer streams
 // (PF = 6 = lcm of the periods of everything that rotates per step -- the load queue, the 3-deep window lines and history, the
 //  2-deep own line: a loop body of PF steps carries every value in a fixed register, no copies at the back edge)
 
@@ -185,136 +186,97 @@ SW_HD LdsMap lds_layout(int c, int groups)
 //   Cell  load_issue(bool valid, int cell)    start a load of the interleaved layer element (invalid: no traffic, value 0)
 //   Cell  load_value(const Cell &queued, bool valid, int cell)   the value at use time (device: `queued` itself)
 //   Cell  fresh(Cell v)                   v in registers of its own (host: identity)
-//   void  store(int cell, Cell v)
+//   void  store(bool valid, int cell, Cell v)
 //   int   counter(int word)               read a progress counter (LDS)
 //   void  publish(int data_word, WP v, int counter_word, int value)    LDS data, then counter -- in this order
 //   void  put(int data_word, WP v)  /  WP get(int data_word)
 // ---------------------------------------------------------------------------------------------------------------------
 
-// What a chain wavefront needs from LDS at wave-step t, as wave-uniform integers: which lane starts, which lane reads its
-// join, how far the previous group's boundary chain must have been published.  -1 = nobody.
-template <int SIDE> struct StepPlan {
-    int start_lane, start_ring;  // lane whose step 0 is t
-    int join_lane, join_ring;    // lane whose stream element S[len] arrives at t, and the ring whose join value that is
-    int need_bnd;                // > 0: lane 0 takes S[t+2] from the previous group's boundary chain: bnd_done must be >= need_bnd
-    int last_lane;               // lane whose last step (s == len - 1) is t: takes the old cell S[len + 1], publishes its join value
-    int warm_lane;               // lane whose step -2 is t: its own-line slot delivers that old cell
-};
-
-template <int SIDE> SW_HD StepPlan<SIDE> plan_step(int t, int r0, int nl, bool has_prev_group)
-{
-    StepPlan<SIDE> pl;
-    pl.start_lane = -1;
-    pl.start_ring = 0;
-    if (t >= 0 && t % SKEW == 0 && t / SKEW < nl && chain_len<SIDE>(r0 + t / SKEW) > 0) {
-        pl.start_lane = t / SKEW;
-        pl.start_ring = r0 + pl.start_lane;
-    }
-    // join: lane l with s + 2 == len(r0 + l), s = t - 3 l >= 0:  3 l + 2 (r0 + l) + b - 2 == t,  len(r) = 2 r + b
-    const int b = SIDE == SIDE_A ? -2 : SIDE == SIDE_D ? 0 : -1;
-    pl.join_lane = -1;
-    pl.join_ring = 0;
-    const int num = t + 2 - b - 2 * r0;
-    if (num >= 0 && num % (SKEW + 2) == 0) {
-        const int l = num / (SKEW + 2);
-        if (l < nl && t - SKEW * l >= 0) {
-            pl.join_lane = l;
-            pl.join_ring = (SIDE == SIDE_A || SIDE == SIDE_B) ? r0 + l - 1 : r0 + l;
-        }
-    }
-    // lane 0 of a later group: S[m], 2 <= m < len, m = t + 2, is step t of the previous group's last ring
-    pl.need_bnd = 0;
-    if (has_prev_group && t >= 0 && t + 2 < chain_len<SIDE>(r0)) pl.need_bnd = t + 1;
-    // last step: s == len - 1:  3 l + 2 (r0 + l) + b - 1 == t
-    pl.last_lane = -1;
-    const int num1 = t + 1 - b - 2 * r0;
-    if (num1 >= 0 && num1 % (SKEW + 2) == 0) {
-        const int l = num1 / (SKEW + 2);
-        if (l < nl && t - SKEW * l >= 0) pl.last_lane = l;
-    }
-    pl.warm_lane = -1;
-    if (t + 2 >= 0 && (t + 2) % SKEW == 0 && (t + 2) / SKEW < nl) pl.warm_lane = (t + 2) / SKEW;
-    return pl;
-}
-
-// The same plan, stepped: the events of a group come at fixed strides (starts every SKEW steps, joins and last steps every
-// SKEW + 2), so a wavefront keeps "time and lane of the next event" in scalar registers instead of dividing every step.
-// (The emulation checks at() against the closed form plan_step() at every step.)
-template <int SIDE> struct PlanIter {
+// ---------------------------------------------------------------------------------------------------------------------
+// What a chain wavefront waits for.  Everything that crosses wavefronts sits behind three monotonic counters: the corner
+// lane's ring count, the partner side's "last value published up to ring", the previous group's boundary chain length.
+// What a group needs of each is a non-decreasing step function of the wave-step t, kept in scalar registers and
+// advanced with a few scalar instructions per step (a lone wavefront issues ~1 instruction per 4 cycles of ANY kind:
+// measured, the first version of this kernel spent more time on its scalar bookkeeping than on the float arithmetic):
+//   corner  ring of the latest lane whose first step is <= t                  (lanes start every SKEW steps)
+//   join    join ring of the latest lane whose join step (s = len - 2) is <= t  (every SKEW + 2 steps)
+//   bnd     t + 1 while lane 0 still reads the previous group's chain
+// The counters are cached; LDS is polled only when a cached value is too small.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int SIDE> struct ChainSync {
     enum { NEVER = 0x7fffffff };
-    int r0, nl;
-    int start_t, start_l, warm_t, warm_l, join_t, join_l, last_t, last_l, bnd_end;
+    int need_corner, need_join, need_bnd;       // what step t requires
+    int have_corner, have_join, have_bnd;       // cached counter values (lower bounds)
+    int start_t, start_r, r_last;               // next lane start: time, ring
+    int join_t, join_r, join_r_last;            // next join: time, join ring
+    int bnd_end;                                // lane 0 reads the previous group's chain for 0 <= t < bnd_end
+    int w_corner, w_join, w_bnd;                // LDS words of the three counters
 
-    SW_HD void init(int r0_, int nl_, bool has_prev_group)
+    SW_HD void init(int r0, int nl, int group, const Params &P, const LdsMap &L)
     {
-        r0 = r0_;
-        nl = nl_;
         const int b = SIDE == SIDE_A ? -2 : SIDE == SIDE_D ? 0 : -1; // len(r) = 2 r + b
-        auto first_lane_with_len = [&](int need) { // smallest l >= 0 with 2 (r0 + l) + b >= need
-            int l = (need - b + 1) / 2 - r0;       // ceil((need - b) / 2) - r0
-            return l < 0 ? 0 : l;
-        };
-        start_l = first_lane_with_len(1);
-        start_t = start_l < nl ? SKEW * start_l : (int)NEVER;
-        warm_l = 0;
-        warm_t = nl > 0 ? -2 : (int)NEVER;
-        join_l = first_lane_with_len(2);
-        join_t = join_l < nl ? (SKEW + 2) * join_l + 2 * r0 + b - 2 : (int)NEVER;
-        last_l = first_lane_with_len(1);
-        last_t = last_l < nl ? (SKEW + 2) * last_l + 2 * r0 + b - 1 : (int)NEVER;
-        bnd_end = has_prev_group ? chain_len<SIDE>(r0) - 2 : 0;
+        const int side_from = SIDE == SIDE_A ? SIDE_D : SIDE == SIDE_B ? SIDE_C : SIDE == SIDE_C ? SIDE_B : SIDE_A;
+        w_corner = L.corner_done + ((SIDE == SIDE_A || SIDE == SIDE_B) ? 0 : 1);
+        w_join = L.join_done + side_from;
+        w_bnd = L.bnd_done + SIDE * P.groups + (group > 0 ? group - 1 : 0);
+        need_corner = need_join = need_bnd = 0;
+        have_corner = have_join = have_bnd = 0;
+        // lanes with a chain (len >= 1) start at t = SKEW * l and join (s = len - 2) at t = (SKEW + 2) l + 2 r0 + b - 2
+        int l1 = (1 - b + 1) / 2 - r0; // smallest l with 2 (r0 + l) + b >= 1
+        if (l1 < 0) l1 = 0;
+        start_t = l1 < nl ? SKEW * l1 : (int)NEVER;
+        start_r = r0 + l1;
+        r_last = r0 + nl - 1;
+        join_t = l1 < nl ? (SKEW + 2) * l1 + 2 * r0 + b - 2 : (int)NEVER;
+        join_r = (SIDE == SIDE_A || SIDE == SIDE_B) ? r0 + l1 - 1 : r0 + l1;
+        join_r_last = (SIDE == SIDE_A || SIDE == SIDE_B) ? r_last - 1 : r_last;
+        bnd_end = group > 0 ? chain_len<SIDE>(r0) - 2 : 0;
     }
-    SW_HD StepPlan<SIDE> at(int t) const
-    {
-        StepPlan<SIDE> pl;
-        pl.start_lane = t == start_t ? start_l : -1;
-        pl.start_ring = t == start_t ? r0 + start_l : 0;
-        pl.join_lane = t == join_t ? join_l : -1;
-        pl.join_ring = t == join_t ? ((SIDE == SIDE_A || SIDE == SIDE_B) ? r0 + join_l - 1 : r0 + join_l) : 0;
-        pl.need_bnd = (t >= 0 && t < bnd_end) ? t + 1 : 0;
-        pl.last_lane = t == last_t ? last_l : -1;
-        pl.warm_lane = t == warm_t ? warm_l : -1;
-        return pl;
-    }
+    // requirements of wave-step t (call with t increasing by one)
     SW_HD void advance(int t)
     {
         if (t == start_t) {
-            ++start_l;
-            start_t = start_l < nl ? start_t + SKEW : (int)NEVER;
-        }
-        if (t == warm_t) {
-            ++warm_l;
-            warm_t = warm_l < nl ? warm_t + SKEW : (int)NEVER;
+            need_corner = start_r;
+            start_r += 1;
+            start_t = start_r <= r_last ? start_t + SKEW : (int)NEVER;
         }
         if (t == join_t) {
-            ++join_l;
-            join_t = join_l < nl ? join_t + SKEW + 2 : (int)NEVER;
+            need_join = join_r;
+            join_r += 1;
+            join_t = join_r <= join_r_last ? join_t + SKEW + 2 : (int)NEVER;
         }
-        if (t == last_t) {
-            ++last_l;
-            last_t = last_l < nl ? last_t + SKEW + 2 : (int)NEVER;
-        }
+        need_bnd = (t >= 0 && t < bnd_end) ? t + 1 : need_bnd;
+    }
+    SW_HD bool ok() const { return have_corner >= need_corner && have_join >= need_join && have_bnd >= need_bnd; }
+    template <class Mem> SW_HD void refresh(Mem &mem)
+    {
+        have_corner = mem.counter(w_corner);
+        have_join = mem.counter(w_join);
+        have_bnd = mem.counter(w_bnd);
     }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // one lane of a chain wavefront
 // ---------------------------------------------------------------------------------------------------------------------
-// The step is written branch-free on purpose: every lane issues the same memory and LDS operations every step (addresses
-// of lanes that have nothing to fetch are clamped or out of range: no traffic), and the rare events -- first step, join,
-// boundary hand-over, last step -- are selects on values that were fetched anyway.  On the device a conditional load makes
-// the compiler drain the whole prefetch queue (s_waitcnt vmcnt(0)); here the queue stays PF steps deep.
+// The step is branch-free on purpose: every lane issues the same memory and LDS operations every step (addresses of lanes
+// that have nothing to fetch are out of range: no traffic) and the rare events -- first step, join, last step -- are
+// selects on per-lane compares of precomputed constants with the (scalar) step number.  A conditional load would make the
+// compiler drain the whole prefetch queue (s_waitcnt vmcnt(0)).
 template <int SIDE> struct ChainLane {
-    int l, r, len;     // lane in the group, ring, chain length (0: idle lane)
-    int a_s0, a_s1, a_pred, a_join, a_bnd; // LDS words of S[0], S[1], the predecessor, the join, the previous group's boundary chain
-    int xold_cell;     // layer element of S[len + 1]
-    int own1, out1, own_end; // layer elements of the own / outer line at along-position 1 (stride 64 per position, gp_layout.h)
-                             // and of the own line's far end k0 + len, which belongs to another side
+    // per-lane constants
+    int l, r, len;      // lane in the group, ring, chain length (0: idle lane)
+    int l3, lend;       // SKEW * l (step s = t - l3),  l3 + len
+    int lim;            // len > 0 ? len + 2 : 0: a column (along-position k0 + s + 1) exists iff (unsigned)(s + 2) < lim
+    int ownA, outA;     // layer element of the own / outer line at step s = ownA / outA + 64 * (t + 1)  [own: column; - 64: the visited cell]
+    int xold_cell, own_end; // layer elements of S[len + 1] and of the own line's far end k0 + len (it belongs to another side)
+    int a_s0, a_s1, a_pred, a_join, a_bnd, a_pub; // LDS words: S[0], S[1], predecessor, join, previous group's chain, own join slot
+    int r2c, r2r;       // (x-c)^2 + (y-c)^2 of the visited cell = r2r + (t + r2c)^2
     // window: inner and outer lines as (w, p); own line: predecessor (w, p) new, self and successor old (g, w, p)
     WP I[3], U[3], OP;
     float Sg, Sw, Sp, Ng, Nw, Np;
-    WP xold;           // S[len + 1]
-    WP h1, h2, h3;     // results of the last three steps (what lane l + 1 reads three steps later)
+    WP xold;            // S[len + 1]
+    WP h1, h2, h3;      // results of the last three steps (what lane l + 1 reads three steps later)
     Cell q_own[PF], q_out[PF]; // layer loads in flight, one slot per wave-step mod PF
 
     SW_HD void init(int lane, int r0, int nl, int group, const Params &P, const LdsMap &L)
@@ -323,11 +285,22 @@ template <int SIDE> struct ChainLane {
         const bool live = lane < nl;
         r = live ? r0 + lane : r0; // (idle lanes keep a valid ring for their never-used addresses)
         len = live ? chain_len<SIDE>(r) : 0;
+        const int k0 = chain_k0<SIDE>();
+        l3 = SKEW * l;
+        lend = l3 + len;
+        lim = len > 0 ? len + 2 : 0;
+        const int own1 = side_cell<SIDE>(P, r, 0, 1), out1 = side_cell<SIDE>(P, r, 1, 1); // along-position 1; stride 64 per position
+        // column of step s = position k0 + s + 1 = element own1 + 64 (k0 + s) = own1 + 64 (k0 - 1 - l3) + 64 (t + 1)
+        ownA = own1 + 64 * (k0 - 1 - l3);
+        outA = out1 + 64 * (k0 - 1 - l3);
+        xold_cell = side_cell<SIDE>(P, r, -1, k0 + len);
+        own_end = side_cell<SIDE>(P, r, 0, k0 + len);
         const int side = (SIDE == SIDE_A || SIDE == SIDE_B) ? 0 : 1;
         const int own_first = L.corner + 2 * ((side * P.c + r) * 2), own_second = own_first + 2;
         const int in_first = L.corner + 2 * ((side * P.c + r - 1) * 2), in_second = in_first + 2;
         const int side_from = SIDE == SIDE_A ? SIDE_D : SIDE == SIDE_B ? SIDE_C : SIDE == SIDE_C ? SIDE_B : SIDE_A;
         a_join = L.join + 2 * (side_from * P.c + ((SIDE == SIDE_A || SIDE == SIDE_B) ? r - 1 : r));
+        a_pub = L.join + 2 * (SIDE * P.c + r);
         if (SIDE == SIDE_A) { // S[0] = B_0(r-1), S[1] = A_1(r-1), predecessor A_1(r)
             a_s0 = in_second;
             a_s1 = in_first;
@@ -346,41 +319,38 @@ template <int SIDE> struct ChainLane {
             a_pred = own_second;
         }
         a_bnd = group > 0 ? L.bnd + 2 * (SIDE * L.bnd_stride + bnd_offset(group - 1)) : L.bnd;
-        xold_cell = side_cell<SIDE>(P, r, -1, chain_k0<SIDE>() + len);
-        own1 = side_cell<SIDE>(P, r, 0, 1);
-        out1 = side_cell<SIDE>(P, r, 1, 1);
-        own_end = side_cell<SIDE>(P, r, 0, chain_k0<SIDE>() + len);
+        // decay test of the visited cell (along-position k0 + s, s = t - l3): offset from the centre line = (k0 + s) - r (sides
+        // A, B) or r - (k0 + s) (C, D); its square is the same
+        r2c = k0 - r - l3;
+        r2r = r * r;
         I[0] = I[1] = I[2] = U[0] = U[1] = U[2] = OP = xold = h1 = h2 = h3 = WP{0.f, 0.f};
         Sg = Sw = Sp = Ng = Nw = Np = 0.f;
         for (int k = 0; k < PF; ++k) q_own[k] = q_out[k] = Cell{0.f, 0.f};
     }
 
-    // One wave-step.  `slot` = a compile-time-friendly wave-step index mod PF; x_in = (lane l - 1).h3 as it was BEFORE this
-    // step (lane 0: anything).
+    // One wave-step.  `slot` = wave-step mod PF and tmod = ((t mod SKEW) + SKEW) mod SKEW, both compile-time constants in the
+    // device's unrolled loop; x_in = (lane l - 1).h3 as it was BEFORE this step (lane 0: anything); lane0 = (l == 0).
     template <class Mem>
-    SW_HD void step(int t, int slot, WP x_in, const Params &P, const LdsMap &L, const StepPlan<SIDE> &pl, bool has_next_group, int group,
-                    Mem &mem)
+    SW_HD void step(int t, int slot, int tmod, WP x_in, const Params &P, const LdsMap &L, bool has_prev_group, bool has_next_group, int group, Mem &mem)
     {
-        const int s = t - SKEW * l;
-        const int k0 = chain_k0<SIDE>();
         // ---- LDS: everything this lane could need, every step (garbage until published; selected only when it is)
-        const WP c_s0 = mem.get(a_s0), c_s1 = mem.get(a_s1), c_pred = mem.get(a_pred), c_join = mem.get(a_join);
-        const int sb = s < 0 ? 0 : s > 2 * LANES * P.groups ? 0 : s;
-        const WP c_bnd = mem.get(a_bnd + 2 * ((pl.need_bnd > 0 && l == 0) ? sb : 0));
+        const WP c_join = mem.get(a_join);
+        const int sb = t < 0 ? 0 : t; // (lane 0: s = t)
+        const WP c_bnd = mem.get(a_bnd + ((has_prev_group && l == 0 && t < len) ? 2 * sb : 0));
         // ---- the column that arrives now (along-position k0 + s + 1), requested PF steps ago into this slot; the own-line
-        //      request of step -2 (the predecessor's cell, which is never read from the layer) carries the old cell S[len + 1]
-        const bool col = len > 0 && s >= -2 && s <= len - 1;
-        const int own_cell = s == -2 ? xold_cell : s == len - 1 ? own_end : own1 + 64 * (k0 + s);
-        // (mem.fresh: on the device a real register copy.  The arriving values stay live for two or three more steps as
-        //  window elements; copied out here, the slot's registers are free for the request below, and the compiler does not
-        //  have to copy freshly requested registers at the loop's back edge -- which would be a wait for loads just issued)
-        const Cell own = mem.fresh(mem.load_value(q_own[slot], col, own_cell));
-        const Cell out = mem.fresh(mem.load_value(q_out[slot], col, out1 + 64 * (k0 + s)));
+        //      request of step -2 (the predecessor's cell, which is never read from the layer) carries the old cell S[len + 1].
+        //      (mem.fresh: on the device a real register copy -- the arriving values stay live for two or three more steps
+        //      as window elements; copied out, the slot's registers are free for the request below and the compiler need not
+        //      copy freshly requested registers at the loop's back edge, which would be a wait for loads just issued)
+        const unsigned ua = (unsigned)(t + 2 - l3); // s + 2
+        const bool col = ua < (unsigned)lim;
+        const Cell own = mem.fresh(mem.load_value(q_own[slot], col, ua == 0u ? xold_cell : (int)ua == len + 1 ? own_end : ownA + 64 * (t + 1)));
+        const Cell out = mem.fresh(mem.load_value(q_out[slot], col, outA + 64 * (t + 1)));
         // ---- and the one to request for step s + PF
-        const int sq = s + PF;
-        const bool colq = len > 0 && sq >= -2 && sq <= len - 1;
-        q_own[slot] = mem.load_issue(colq, sq == -2 ? xold_cell : sq == len - 1 ? own_end : own1 + 64 * (k0 + sq));
-        q_out[slot] = mem.load_issue(colq, out1 + 64 * (k0 + sq));
+        const unsigned uq = ua + (unsigned)PF;
+        const bool colq = uq < (unsigned)lim;
+        q_own[slot] = mem.load_issue(colq, uq == 0u ? xold_cell : (int)uq == len + 1 ? own_end : ownA + 64 * (t + 1 + PF));
+        q_out[slot] = mem.load_issue(colq, outA + 64 * (t + 1 + PF));
         // ---- advance the window
         Sg = Ng;
         Sw = Nw;
@@ -388,26 +358,28 @@ template <int SIDE> struct ChainLane {
         Ng = own.g;
         Nw = own.w;
         Np = own.w * own.g;
-        if (pl.warm_lane >= 0 && l == pl.warm_lane) xold = WP{own.w, Np}; // (step -2)
+        if (tmod == 1 && ua == 0u) xold = WP{own.w, Np}; // step -2: t + 2 = 3 l, i.e. only when t = 1 (mod SKEW = 3)
         U[0] = U[1];
         U[1] = U[2];
         U[2] = WP{out.w, out.w * out.g};
-        // stream element S[s + 2]: the inner lane's step s (three wave-steps ago), or -- at the ends -- the previous group's
-        // boundary chain, the join, the old cell.  The rare cases sit behind wave-uniform guards (pl is uniform).
-        WP x = x_in;
-        if (pl.need_bnd > 0 && l == 0) x = c_bnd;
-        if (pl.join_lane >= 0 && l == pl.join_lane) x = c_join;   // s + 2 == len
-        if (pl.last_lane >= 0 && l == pl.last_lane) x = xold;     // s + 2 == len + 1
+        // stream element S[s + 2]: the inner lane's step s (three wave-steps ago; lane 0: the previous group's boundary chain),
+        // at the ends the join and the old cell
+        WP x = l == 0 ? c_bnd : x_in;
+        if (t + 2 == lend) x = c_join; // s + 2 == len
+        if (t + 1 == lend) x = xold;   // s + 2 == len + 1
         I[0] = I[1];
         I[1] = I[2];
         I[2] = x;
-        if (pl.start_lane >= 0 && l == pl.start_lane) { // first step: the corner values
-            I[0] = c_s0;
-            I[1] = c_s1;
-            OP = c_pred;
+        if (tmod == 0) { // a lane's first step (t = 3 l): the corner values
+            const WP c_s0 = mem.get(a_s0), c_s1 = mem.get(a_s1), c_pred = mem.get(a_pred);
+            if (t == l3) {
+                I[0] = c_s0;
+                I[1] = c_s1;
+                OP = c_pred;
+            }
         }
         // ---- the visit
-        const bool active = s >= 0 && s < len;
+        const bool active = (unsigned)(t - l3) < (unsigned)len;
         float w[9], p[9];
 #define SW_PUT(line, pos, W_, P_)                 \
     w[tree_pos<SIDE>(line, pos)] = (W_);          \
@@ -422,38 +394,20 @@ template <int SIDE> struct ChainLane {
         SW_PUT(2, 1, U[1].w, U[1].p)
         SW_PUT(2, 2, U[2].w, U[2].p)
 #undef SW_PUT
-        WP res = WP{0.f, 0.f};
-        if (active) {
-            const Cell v = visit(w, p, Sg, Sw, side_r2<SIDE>(r, k0 + s) >= P.r2min, P);
-            mem.store(own1 + 64 * (k0 + s - 1), v);
-            res = WP{v.w, v.w * v.g};
-            OP = res;
-        }
+        const int ao = t + r2c;
+        const Cell v = visit(w, p, Sg, Sw, r2r + ao * ao >= P.r2min, P);
+        mem.store(active, ownA + 64 * t, v);
+        const WP res = WP{v.w, v.w * v.g};
+        if (active) OP = res;
         h3 = h2;
         h2 = h1;
         h1 = res;
         // ---- publish what other wavefronts wait for (data first, then the counter)
-        if (pl.last_lane >= 0 && l == pl.last_lane && len > 0) mem.publish(L.join + 2 * (SIDE * P.c + r), res, L.join_done + SIDE, r);
+        if (t + 1 == lend && len > 0) mem.publish(a_pub, res, L.join_done + SIDE, r);
         if (has_next_group && l == LANES - 1 && active)
-            mem.publish(L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) + s), res, L.bnd_done + SIDE * P.groups + group, s + 1);
+            mem.publish(L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) + (t - l3)), res, L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
     }
 };
-
-// Is everything this wave-step needs from other wavefronts published?  (wave-uniform; the device spins on it)
-template <int SIDE, class Mem> SW_HD bool chain_ready(const StepPlan<SIDE> &pl, const Params &P, const LdsMap &L, int group, Mem &mem)
-{
-    const int side = (SIDE == SIDE_A || SIDE == SIDE_B) ? 0 : 1;
-    if (pl.start_lane >= 0) {
-        if (mem.counter(L.corner_done + side) < pl.start_ring) return false;
-        if (SIDE == SIDE_C && pl.start_ring == 1 && mem.counter(L.join_done + SIDE_B) < 1) return false;
-    }
-    if (pl.join_lane >= 0) {
-        const int side_from = SIDE == SIDE_A ? SIDE_D : SIDE == SIDE_B ? SIDE_C : SIDE == SIDE_C ? SIDE_B : SIDE_A;
-        if (mem.counter(L.join_done + side_from) < pl.join_ring) return false;
-    }
-    if (pl.need_bnd > 0 && mem.counter(L.bnd_done + SIDE * P.groups + group - 1) < pl.need_bnd) return false;
-    return true;
-}
 
 // first / last wave-step of a group (lane 0 starts its warm-up columns at step -2, loads are requested PF steps earlier)
 SW_HD int group_first_step() { return -2 - PF; }
@@ -471,7 +425,15 @@ template <int CD> struct CornerLane {
     SW_HD static int cell_at(const Params &P, int r, int a, int b)
     {
         const int o = CD ? 1 : -1, z = P.c + o * r;
-        return gp_index(P.gl, z + o * a, z + o * b);
+        if (r < 3) return gp_index(P.gl, z + o * a, z + o * b);
+        // gp_index specialised (gp_layout.h): from ring 3 on these cells stay in the corner's quadrant, where the side follows
+        // from (a, b) alone -- the first side (A / C) if a >= b, else the second (B / D) -- and the ring is r + max(a, b)
+        const int ring = r + (a >= b ? a : b);
+        const int g = (ring - 1) >> 6, l = (ring - 1) & 63;
+        const int side = CD ? (a >= b ? 2 : 3) : (a >= b ? 0 : 1);
+        const int along = a >= b ? b : a; // the coordinate that runs along the side, in outward units
+        const int v = CD ? P.n - 1 - (z + along) : z - along;
+        return 1 + ((side * P.gl.G + g) * P.gl.VS + v + 4 * l) * 64 + l;
     }
     SW_HD static bool is_old(int r, int a, int b)
     {
@@ -497,7 +459,6 @@ template <int CD> struct CornerLane {
     // ring r: first-side visits X_0 = (z, z), X_1 = (z, z - o) (A_1 / C_1), then the revisit Y_0 = (z, z) (B_0 / D_0)
     template <class Mem> SW_HD static void ring(int r, const Old &queued, const Params &P, const LdsMap &L, Mem &mem)
     {
-        const int o = CD ? 1 : -1, z = P.c + o * r;
         const int base = L.corner + 2 * ((CD * P.c + r) * 2), prev = L.corner + 2 * ((CD * P.c + r - 1) * 2);
         Old o_;
         for (int a = -1; a <= 1; ++a)
@@ -534,8 +495,8 @@ template <int CD> struct CornerLane {
                 p[q(a, b, 0, 0)] = v.p;
             }
         const Cell y0 = visit(w, p, x0.g, x0.w, decay0, P);
-        mem.store(gp_index(P.gl, z, z), y0);
-        mem.store(gp_index(P.gl, z, z - o), x1);
+        mem.store(true, cell_at(P, r, 0, 0), y0);
+        mem.store(true, cell_at(P, r, 0, -1), x1);
         mem.put(base, wp(x1));
         mem.publish(base + 2, wp(y0), L.corner_done + CD, r);
         if (!CD && r == 1) mem.publish(L.join + 2 * (SIDE_A * P.c + 1), wp(x1), L.join_done + SIDE_A, 1); // A_last(1) = A_1(1): side A of ring 1 has no chain

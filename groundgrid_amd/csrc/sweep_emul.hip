@@ -29,8 +29,9 @@ struct HostMem {
     }
     Cell load_value(const Cell &queued, bool valid, int cell) { return (late && valid) ? gp2[cell] : queued; }
     Cell fresh(const Cell &v) { return v; }
-    void store(int cell, Cell v)
+    void store(bool valid, int cell, Cell v)
     {
+        if (!valid) return;
         ++stores;
         gp2[cell] = v;
     }
@@ -66,7 +67,8 @@ template <int SIDE> struct ChainWave : WaveBase {
     const LdsMap &L;
     int wave, group, t, t_last, r0, nl;
     ChainLane<SIDE> lane[LANES];
-    PlanIter<SIDE> plan;
+    ChainSync<SIDE> sync;
+    bool advanced = false;
     long steps = 0;
     bool plan_mismatch = false;
     ChainWave(const Params &p, const LdsMap &l, int w) : P(p), L(l), wave(w), group(w - p.waves_per_side) { next_group(); }
@@ -81,33 +83,45 @@ template <int SIDE> struct ChainWave : WaveBase {
             // the stride-64 addressing of a lane's two lines is the layout's promise: hold it to gp_index() cell by cell
             const ChainLane<SIDE> &c = lane[l];
             const int k0 = chain_k0<SIDE>();
-            for (int j = k0; j <= k0 + c.len - 1; ++j)
-                if (c.own1 + 64 * (j - 1) != side_cell<SIDE>(P, c.r, 0, j)) plan_mismatch = true;
-            for (int j = k0 - 1; c.len > 0 && j <= k0 + c.len; ++j)
-                if (c.out1 + 64 * (j - 1) != side_cell<SIDE>(P, c.r, 1, j)) plan_mismatch = true;
-            if (l > 0 && l < nl && c.len > 0 && lane[l - 1].len > 0 && c.own1 != lane[l - 1].own1 + 3 * 64 + 1) plan_mismatch = true; // coalescing: + 3 steps, + 1 lane
+            for (int j = k0; j <= k0 + c.len - 1; ++j) // visited cell of step s = j - k0 is element ownA + 64 t, t = l3 + s
+                if (c.ownA + 64 * (c.l3 + j - k0) != side_cell<SIDE>(P, c.r, 0, j)) plan_mismatch = true;
+            for (int j = k0 - 1; c.len > 0 && j <= k0 + c.len; ++j) // column of step s = j - k0 - 1 is element outA + 64 (t + 1)
+                if (c.outA + 64 * (c.l3 + j - k0) != side_cell<SIDE>(P, c.r, 1, j)) plan_mismatch = true;
+            if (l > 0 && l < nl && c.len > 0 && lane[l - 1].len > 0 && c.ownA != lane[l - 1].ownA + 1) plan_mismatch = true; // one wave-step = 64 consecutive elements
         }
         t = group_first_step();
         t_last = group_last_step<SIDE>(r0, nl);
         t_last += (PF - (t_last - t + 1) % PF) % PF; // the device runs whole trips of PF steps
-        plan.init(r0, nl, group > 0);
+        sync.init(r0, nl, group, P, L);
+        advanced = false;
     }
     bool done() const override { return group >= P.groups; }
     bool bad() const override { return plan_mismatch; }
     bool try_step(HostMem &mem) override
     {
         if (done()) return false;
-        const StepPlan<SIDE> pl = plan.at(t), ref = plan_step<SIDE>(t, r0, nl, group > 0);
-        if (pl.start_lane != ref.start_lane || pl.start_ring != ref.start_ring || pl.join_lane != ref.join_lane || pl.join_ring != ref.join_ring ||
-            pl.need_bnd != ref.need_bnd || pl.last_lane != ref.last_lane || pl.warm_lane != ref.warm_lane)
-            plan_mismatch = true;
-        if (!chain_ready<SIDE>(pl, P, L, group, mem)) return false;
+        if (!advanced) { // requirements of step t, once
+            sync.advance(t);
+            advanced = true;
+        }
+        if (!sync.ok()) {
+            sync.refresh(mem);
+            if (!sync.ok()) return false;
+        }
+        // the cached counters are lower bounds of what the step reads: hold the lazily polled protocol to the exact needs
+        for (int l = 0; l < nl; ++l) {
+            const ChainLane<SIDE> &c = lane[l];
+            const int s_ = t - c.l3;
+            if (c.len > 0 && s_ == 0 && mem.counter(sync.w_corner) < c.r) plan_mismatch = true;
+            if (c.len > 0 && s_ == c.len - 2 && s_ >= -1 && mem.counter(sync.w_join) < ((SIDE == SIDE_A || SIDE == SIDE_B) ? c.r - 1 : c.r)) plan_mismatch = true;
+        }
+        if (group > 0 && t >= 0 && t + 2 < lane[0].len && mem.counter(sync.w_bnd) < t + 1) plan_mismatch = true;
         WP x_in[LANES];
         for (int l = 0; l < LANES; ++l) x_in[l] = l ? lane[l - 1].h3 : WP{0.f, 0.f}; // wave shift right by one, before anybody moves
-        const int slot = ((t % PF) + PF) % PF;
-        for (int l = 0; l < LANES; ++l) lane[l].step(t, slot, x_in[l], P, L, pl, group + 1 < P.groups, group, mem);
+        const int slot = ((t % PF) + PF) % PF, tmod = ((t % SKEW) + SKEW) % SKEW;
+        for (int l = 0; l < LANES; ++l) lane[l].step(t, slot, tmod, x_in[l], P, L, group > 0, group + 1 < P.groups, group, mem);
         ++steps;
-        plan.advance(t);
+        advanced = false;
         if (++t > t_last) next_group();
         return true;
     }
