@@ -120,9 +120,9 @@ template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevM
         // a join makes the compiler copy freshly loaded registers, i.e. wait for the loads it has just issued
         ChainSync<SIDE> sync;
         sync.init(r0, nl, group, P, L);
-        for (int tb = t_first; tb <= t_last; tb += PF) {
+        for (int tb = t_first; tb <= t_last; tb += TRIP) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
+            for (int u = 0; u < TRIP; ++u) {
                 const int t = tb + u;
                 sync.advance(t);
                 if (!sync.ok()) { // (rare) something this step reads has not been published yet as far as the cached counters know
@@ -140,8 +140,8 @@ template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevM
                     }
                 }
                 const WP x_in{wave_shr1(st.h3.w), wave_shr1(st.h3.p)};
-                constexpr int t_first_mod = ((-2 - (int)PF) % (int)SKEW + (int)SKEW) % (int)SKEW; // tb = t_first (mod PF), PF = 0 (mod SKEW)
-                st.step(t, u, (t_first_mod + u) % (int)SKEW, x_in, P, L, group > 0, has_next, group, mem);
+                constexpr int t_first_mod = ((-2 - (int)PF) % (int)SKEW + (int)SKEW) % (int)SKEW; // tb = t_first (mod TRIP), TRIP = 0 (mod SKEW)
+                st.step(t, u % (int)PF, (t_first_mod + u) % (int)SKEW, x_in, P, L, group > 0, has_next, group, mem);
             }
         }
     }
@@ -163,7 +163,7 @@ template <int CD> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMe
     }
 }
 
-__global__ __launch_bounds__(1024) void k_sweep(const Arena a, const Params P, const LdsMap L, const CloudParams *__restrict__ params,
+__global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const LdsMap L, const CloudParams *__restrict__ params,
                                                 unsigned long long *dbg)
 {
     extern __shared__ int lds[];

@@ -49,10 +49,13 @@ namespace gg {
 namespace sweep {
 
 enum { SIDE_A = 0, SIDE_B = 1, SIDE_C = 2, SIDE_D = 3 };
-enum { LANES = 64, SKEW = 3, PF = 6 };
-static_assert(SKEW == 3 && PF % SKEW == 0, "the step code names t mod SKEW residues"); // rings per group, steps between neighbouring rings, prefetch distance of the layer streams
-// (PF = 6 = lcm of the periods of everything that rotates per step -- the load queue, the 3-deep window lines and history, the
-//  2-deep own line: a loop body of PF steps carries every value in a fixed register, no copies at the back edge)
+// rings per group, steps between neighbouring rings, prefetch distance of the layer streams, steps per trip of the device loop.
+// TRIP = 6 = lcm of the periods of everything that rotates per step -- the load queue, the 3-deep window lines and history, the
+// 2-deep own line: a loop body of TRIP steps can carry every value in a fixed register.  The sweep is bound by instruction
+// issue, not by memory (dropping every load and store changes nothing): PF = 3 steps (~4000 cycles) is ample and keeps the
+// queue at 12 registers.
+enum { LANES = 64, SKEW = 3, PF = 3, TRIP = 6 };
+static_assert(SKEW == 3 && PF % SKEW == 0 && TRIP % PF == 0 && TRIP % 2 == 0, "the step code names t mod SKEW residues");
 
 struct WP {
     float w, p; // confidence, confidence * ground
@@ -124,21 +127,35 @@ template <int SIDE> SW_HD constexpr int tree_pos(int line, int pos)
 SW_HD float sw_tree9(const float *e) { return ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + (e[7] + e[8]))); }
 SW_HD double sw_max(double a, double b) { return (a < b) ? b : a; } // libstdc++ std::max
 
+// :463-464  occupied = (float)max(x - x / decrease, 0.001) in double, for cells outside the decay radius.  It depends on the
+// cell's OLD confidence only, so it is computed ahead of the height chain.  Multiply form when it provably rounds alike:
+// for decrease >= 1.25 the product form differs from the quotient form by < 2^-49 relative, the max and the float conversion
+// are monotonic, so if the two ends of the +-2^-48 interval convert to the same float the exact value does too; otherwise
+// (about 1 visit in 10^7, NaN, or an unusual config) the divide decides.
+SW_HD float decayed_confidence(float occupied, bool decay, const Params &P)
+{
+    const double x = (double)occupied;
+    const double t = x - x * P.inv_decrease;
+    const float lo = (float)sw_max(t * (1.0 - 0x1p-48), 0.001);
+    const float hi = (float)sw_max(t * (1.0 + 0x1p-48), 0.001);
+    float d = lo;
+    if (!(P.decay_fast && lo == hi) && decay) d = (float)sw_max(x - x / P.decrease, 0.001);
+    return decay ? d : occupied;
+}
+
+// :457-460 the new height from the prepared window (w = confidences, p = confidence * height, column-major block order)
+SW_HD float interpolated_height(const float (&w)[9], const float (&p)[9], float height, float occupied)
+{
+    const float gvlSum = sw_tree9(w) + FLT_MIN;          // :457
+    const float avg = sw_tree9(p) / gvlSum;              // :458
+    return (1.0f - occupied) * avg + occupied * height;  // :460
+}
+
 SW_HD Cell visit(const float (&w)[9], const float (&p)[9], float height, float occupied, bool decay, const Params &P)
 {
-    const float gvlSum = sw_tree9(w) + FLT_MIN;                      // :457
-    const float avg = sw_tree9(p) / gvlSum;                          // :458
     Cell out;
-    out.g = (1.0f - occupied) * avg + occupied * height;             // :460
-    out.w = occupied;
-    if (decay) { // :463-464  (float)max(x - x / decrease, 0.001) in double; multiply form when it provably rounds alike
-        const double x = (double)occupied;
-        const double t = x - x * P.inv_decrease;
-        const float lo = (float)sw_max(t * (1.0 - 0x1p-48), 0.001);
-        const float hi = (float)sw_max(t * (1.0 + 0x1p-48), 0.001);
-        out.w = lo;
-        if (!(P.decay_fast && lo == hi)) out.w = (float)sw_max(x - x / P.decrease, 0.001);
-    }
+    out.w = decayed_confidence(occupied, decay, P);
+    out.g = interpolated_height(w, p, height, occupied);
     return out;
 }
 
@@ -333,6 +350,10 @@ template <int SIDE> struct ChainLane {
     template <class Mem>
     SW_HD void step(int t, int slot, int tmod, WP x_in, const Params &P, const LdsMap &L, bool has_prev_group, bool has_next_group, int group, Mem &mem)
     {
+        // ---- the visited cell's new confidence depends on its old one only (its rare exact path is the step's only branch
+        //      besides the publishes at the end: what follows is one basic block for the instruction scheduler)
+        const int ao = t + r2c;
+        const float w_new = decayed_confidence(Nw, r2r + ao * ao >= P.r2min, P); // (the successor of the last step becomes "self" now)
         // ---- LDS: everything this lane could need, every step (garbage until published; selected only when it is)
         const WP c_join = mem.get(a_join);
         const int sb = t < 0 ? 0 : t; // (lane 0: s = t)
@@ -358,25 +379,24 @@ template <int SIDE> struct ChainLane {
         Ng = own.g;
         Nw = own.w;
         Np = own.w * own.g;
-        if (tmod == 1 && ua == 0u) xold = WP{own.w, Np}; // step -2: t + 2 = 3 l, i.e. only when t = 1 (mod SKEW = 3)
+        xold = (tmod == 1 && ua == 0u) ? WP{own.w, Np} : xold; // step -2: t + 2 = 3 l, i.e. only when t = 1 (mod SKEW = 3)
         U[0] = U[1];
         U[1] = U[2];
         U[2] = WP{out.w, out.w * out.g};
         // stream element S[s + 2]: the inner lane's step s (three wave-steps ago; lane 0: the previous group's boundary chain),
         // at the ends the join and the old cell
         WP x = l == 0 ? c_bnd : x_in;
-        if (t + 2 == lend) x = c_join; // s + 2 == len
-        if (t + 1 == lend) x = xold;   // s + 2 == len + 1
+        x = t + 2 == lend ? c_join : x; // s + 2 == len
+        x = t + 1 == lend ? xold : x;   // s + 2 == len + 1
         I[0] = I[1];
         I[1] = I[2];
         I[2] = x;
         if (tmod == 0) { // a lane's first step (t = 3 l): the corner values
             const WP c_s0 = mem.get(a_s0), c_s1 = mem.get(a_s1), c_pred = mem.get(a_pred);
-            if (t == l3) {
-                I[0] = c_s0;
-                I[1] = c_s1;
-                OP = c_pred;
-            }
+            const bool first = t == l3;
+            I[0] = first ? c_s0 : I[0];
+            I[1] = first ? c_s1 : I[1];
+            OP = first ? c_pred : OP;
         }
         // ---- the visit
         const bool active = (unsigned)(t - l3) < (unsigned)len;
@@ -394,11 +414,12 @@ template <int SIDE> struct ChainLane {
         SW_PUT(2, 1, U[1].w, U[1].p)
         SW_PUT(2, 2, U[2].w, U[2].p)
 #undef SW_PUT
-        const int ao = t + r2c;
-        const Cell v = visit(w, p, Sg, Sw, r2r + ao * ao >= P.r2min, P);
+        Cell v;
+        v.w = w_new;
+        v.g = interpolated_height(w, p, Sg, Sw);
         mem.store(active, ownA + 64 * t, v);
         const WP res = WP{v.w, v.w * v.g};
-        if (active) OP = res;
+        OP = active ? res : OP;
         h3 = h2;
         h2 = h1;
         h1 = res;

@@ -91,7 +91,7 @@ template <int SIDE> struct ChainWave : WaveBase {
         }
         t = group_first_step();
         t_last = group_last_step<SIDE>(r0, nl);
-        t_last += (PF - (t_last - t + 1) % PF) % PF; // the device runs whole trips of PF steps
+        t_last += (TRIP - (t_last - t + 1) % TRIP) % TRIP; // the device runs whole trips of TRIP steps
         sync.init(r0, nl, group, P, L);
         advanced = false;
     }
