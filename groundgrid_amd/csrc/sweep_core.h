@@ -475,52 +475,63 @@ template <int CD> struct CornerLane {
         const int o = CD ? 1 : -1;
         return (o * (a - ca) + 1) + 3 * (o * (b - cb) + 1);
     }
-    SW_HD static WP wp(const Cell &v) { return WP{v.w, v.w * v.g}; }
-
-    // ring r: first-side visits X_0 = (z, z), X_1 = (z, z - o) (A_1 / C_1), then the revisit Y_0 = (z, z) (B_0 / D_0)
+    // ring r: first-side visits X_0 = (z, z), X_1 = (z, z - o) (A_1 / C_1), then the revisit Y_0 = (z, z) (B_0 / D_0).
+    // Written for a lone lane, which is bound by instruction issue and by the length of its dependent chain: every product
+    // w * g of an old cell is formed once, the three new confidences (they depend on old confidences only; Y_0 decays X_0's)
+    // come first -- their rare exact-divide path is the only branch --, and what is left is one basic block whose critical
+    // path is height(X_0) -> height(X_1) -> height(Y_0).
     template <class Mem> SW_HD static void ring(int r, const Old &queued, const Params &P, const LdsMap &L, Mem &mem)
     {
         const int base = L.corner + 2 * ((CD * P.c + r) * 2), prev = L.corner + 2 * ((CD * P.c + r - 1) * 2);
-        Old o_;
+        float og[3][4], ow[3][4], op[3][4]; // old cells [a + 1][b + 2]: height, confidence, product
         for (int a = -1; a <= 1; ++a)
-            for (int b = -2; b <= 1; ++b) o_.v[a + 1][b + 2] = mem.load_value(queued.v[a + 1][b + 2], is_old(r, a, b), cell_at(P, r, a, b));
-        auto old = [&](int a, int b) -> const Cell & { return o_.v[a + 1][b + 2]; };
+            for (int b = -2; b <= 1; ++b) {
+                const Cell v = mem.load_value(queued.v[a + 1][b + 2], is_old(r, a, b), cell_at(P, r, a, b));
+                og[a + 1][b + 2] = v.g;
+                ow[a + 1][b + 2] = v.w;
+                op[a + 1][b + 2] = v.w * v.g;
+            }
+        const bool decay0 = 2 * r * r >= P.r2min, decay1 = r * r + (r - 1) * (r - 1) >= P.r2min;
+        const float x0w = decayed_confidence(ow[1][2], decay0, P); // X_0: (0, 0)
+        const float x1w = decayed_confidence(ow[1][1], decay1, P); // X_1: (0, -1)
+        const float y0w = decayed_confidence(x0w, decay0, P);      // Y_0: (0, 0) again
         const WP in_corner = mem.get(prev + 2); // (z - o, z - o): Y_0 of ring r - 1 (ring 0: the centre)
         // (z - o, z - 2o): X_1 of ring r - 1.  Ring 1 has no such predecessor ring: for AB that cell is D_1(1), still OLD;
         // for CD it is B_1(1) = B_last(1), already NEW (sides A and B of a ring come before C and D).
-        const WP in_x1 = r > 1 ? mem.get(prev) : !CD ? wp(old(-1, -2)) : mem.get(L.join + 2 * (SIDE_B * P.c + 1));
+        const WP in_x1 = r > 1 ? mem.get(prev) : !CD ? WP{ow[0][0], op[0][0]} : mem.get(L.join + 2 * (SIDE_B * P.c + 1));
         float w[9], p[9];
         // ---- X_0 at (0, 0): everything old except the inner corner (-1, -1)
         for (int a = -1; a <= 1; ++a)
             for (int b = -1; b <= 1; ++b) {
-                const WP v = (a == -1 && b == -1) ? in_corner : wp(old(a, b));
-                w[q(a, b, 0, 0)] = v.w;
-                p[q(a, b, 0, 0)] = v.p;
+                const bool nc = a == -1 && b == -1;
+                w[q(a, b, 0, 0)] = nc ? in_corner.w : ow[a + 1][b + 2];
+                p[q(a, b, 0, 0)] = nc ? in_corner.p : op[a + 1][b + 2];
             }
-        const bool decay0 = 2 * r * r >= P.r2min;
-        const Cell x0 = visit(w, p, old(0, 0).g, old(0, 0).w, decay0, P);
+        const float x0g = interpolated_height(w, p, og[1][2], ow[1][2]);
+        const WP x0{x0w, x0w * x0g};
         // ---- X_1 at (0, -1): new = X_0 at (0, 0), inner corner (-1, -1), X_1(r-1) at (-1, -2)
         for (int a = -1; a <= 1; ++a)
             for (int b = -2; b <= 0; ++b) {
-                const WP v = (a == 0 && b == 0) ? wp(x0) : (a == -1 && b == -1) ? in_corner : (a == -1 && b == -2) ? in_x1 : wp(old(a, b));
+                const WP v = (a == 0 && b == 0) ? x0 : (a == -1 && b == -1) ? in_corner : (a == -1 && b == -2) ? in_x1 : WP{ow[a + 1][b + 2], op[a + 1][b + 2]};
                 w[q(a, b, 0, -1)] = v.w;
                 p[q(a, b, 0, -1)] = v.p;
             }
-        const bool decay1 = r * r + (r - 1) * (r - 1) >= P.r2min;
-        const Cell x1 = visit(w, p, old(0, -1).g, old(0, -1).w, decay1, P);
+        const float x1g = interpolated_height(w, p, og[1][1], ow[1][1]);
+        const WP x1{x1w, x1w * x1g};
         // ---- Y_0 at (0, 0) again: new = itself (X_0), X_1 at (0, -1), inner corner
         for (int a = -1; a <= 1; ++a)
             for (int b = -1; b <= 1; ++b) {
-                const WP v = (a == 0 && b == 0) ? wp(x0) : (a == 0 && b == -1) ? wp(x1) : (a == -1 && b == -1) ? in_corner : wp(old(a, b));
+                const WP v = (a == 0 && b == 0) ? x0 : (a == 0 && b == -1) ? x1 : (a == -1 && b == -1) ? in_corner : WP{ow[a + 1][b + 2], op[a + 1][b + 2]};
                 w[q(a, b, 0, 0)] = v.w;
                 p[q(a, b, 0, 0)] = v.p;
             }
-        const Cell y0 = visit(w, p, x0.g, x0.w, decay0, P);
-        mem.store(true, cell_at(P, r, 0, 0), y0);
-        mem.store(true, cell_at(P, r, 0, -1), x1);
-        mem.put(base, wp(x1));
-        mem.publish(base + 2, wp(y0), L.corner_done + CD, r);
-        if (!CD && r == 1) mem.publish(L.join + 2 * (SIDE_A * P.c + 1), wp(x1), L.join_done + SIDE_A, 1); // A_last(1) = A_1(1): side A of ring 1 has no chain
+        const float y0g = interpolated_height(w, p, x0g, x0w);
+        const WP y0{y0w, y0w * y0g};
+        mem.store(true, cell_at(P, r, 0, 0), Cell{y0g, y0w});
+        mem.store(true, cell_at(P, r, 0, -1), Cell{x1g, x1w});
+        mem.put(base, x1);
+        mem.publish(base + 2, y0, L.corner_done + CD, r);
+        if (!CD && r == 1) mem.publish(L.join + 2 * (SIDE_A * P.c + 1), x1, L.join_done + SIDE_A, 1); // A_last(1) = A_1(1): side A of ring 1 has no chain
     }
     template <class Mem> SW_HD static bool ready(int r, const LdsMap &L, Mem &mem)
     {
