@@ -31,7 +31,20 @@ typedef __attribute__((address_space(3))) uint64_t lds_u64;
 struct DevMem {
     __amdgpu_buffer_rsrc_t rsrc; // the interleaved (ground, confidence) layer of this cloud
     lds_int *lds;
-    int dbg_mode = 0; // timing experiments only (GG_SWEEP_DEBUG): 1 = drop the result stores, 2 = drop the layer loads
+    int dbg_mode = 0; // timing experiments only (GG_SWEEP_DEBUG): 1 = drop the result stores, 2 = drop the layer loads, 4 = phase marks
+    unsigned long long *marks = nullptr, last_mark = 0, acc[6] = {0, 0, 0, 0, 0, 0};
+    GG_DEV void mark(int k)
+    {
+        if (!(dbg_mode & 4)) return;
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (k > 0) acc[k] += now - last_mark;
+        last_mark = now;
+    }
+    GG_DEV void flush_marks()
+    {
+        if (dbg_mode & 4)
+            for (int k = 0; k < 6; ++k) marks[k] = acc[k];
+    }
     static constexpr uint32_t OOR = 0x80000000u; // beyond the buffer: loads return 0, stores are dropped, no traffic
 
     GG_DEV Cell load_issue(bool valid, int cell) const
@@ -153,14 +166,19 @@ template <int CD> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMe
     if (lane != 0) return;
     // the old cells of a ring are requested one ring ahead; two rings per trip so that the two register sets swap roles by
     // name instead of being copied (a copy of a register that is being loaded is a wait for that load)
-    typename CornerLane<CD>::Old a = CornerLane<CD>::load(1, P, mem);
+    typename CornerLane<CD>::Addr ad;
+    CornerLane<CD>::advance(ad, 1, P);
+    typename CornerLane<CD>::Old a = CornerLane<CD>::load(1, ad, P, mem);
     for (int r = 1; r <= P.rings; r += 2) {
-        const typename CornerLane<CD>::Old b = CornerLane<CD>::load(r + 1, P, mem);
+        CornerLane<CD>::advance(ad, r + 1, P);
+        const typename CornerLane<CD>::Old b = CornerLane<CD>::load(r + 1, ad, P, mem);
         while (!CornerLane<CD>::ready(r, L, mem)) __builtin_amdgcn_s_sleep(1);
         CornerLane<CD>::ring(r, a, P, L, mem);
-        a = CornerLane<CD>::load(r + 2, P, mem);
+        CornerLane<CD>::advance(ad, r + 2, P);
+        a = CornerLane<CD>::load(r + 2, ad, P, mem);
         if (r + 1 <= P.rings) CornerLane<CD>::ring(r + 1, b, P, L, mem);
     }
+    mem.flush_marks();
 }
 
 __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const LdsMap L, const CloudParams *__restrict__ params,
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     WaveClock clk;
     clk.out = (dbg && blockIdx.x == 0) ? dbg : nullptr;
     mem.dbg_mode = dbg ? (int)dbg[63] : 0;
+    mem.marks = dbg ? dbg + 48 + ((threadIdx.x >> 6) & 1) * 6 : nullptr; // (the two corner wavefronts have consecutive wave ids)
     clk.begin();
     if (wave < W)
         run_chain<SIDE_A>(P, L, mem, wave, lane, clk);

@@ -132,12 +132,15 @@ SW_HD double sw_max(double a, double b) { return (a < b) ? b : a; } // libstdc++
 // for decrease >= 1.25 the product form differs from the quotient form by < 2^-49 relative, the max and the float conversion
 // are monotonic, so if the two ends of the +-2^-48 interval convert to the same float the exact value does too; otherwise
 // (about 1 visit in 10^7, NaN, or an unusual config) the divide decides.
+SW_HD float sw_maxf(float a, float b) { return (a < b) ? b : a; }
 SW_HD float decayed_confidence(float occupied, bool decay, const Params &P)
 {
+    // (float)std::max(v, 0.001) == max((float)v, (float)0.001) with the same NaN behaviour: the conversion is monotonic
+    const float floor_f = (float)0.001;
     const double x = (double)occupied;
     const double t = x - x * P.inv_decrease;
-    const float lo = (float)sw_max(t * (1.0 - 0x1p-48), 0.001);
-    const float hi = (float)sw_max(t * (1.0 + 0x1p-48), 0.001);
+    const float lo = sw_maxf((float)(t * (1.0 - 0x1p-48)), floor_f);
+    const float hi = sw_maxf((float)(t * (1.0 + 0x1p-48)), floor_f);
     float d = lo;
     if (!(P.decay_fast && lo == hi) && decay) d = (float)sw_max(x - x / P.decrease, 0.001);
     return decay ? d : occupied;
@@ -203,6 +206,7 @@ SW_HD LdsMap lds_layout(int c, int groups)
 //   Cell  load_issue(bool valid, int cell)    start a load of the interleaved layer element (invalid: no traffic, value 0)
 //   Cell  load_value(const Cell &queued, bool valid, int cell)   the value at use time (device: `queued` itself)
 //   Cell  fresh(Cell v)                   v in registers of its own (host: identity)
+//   void  mark(int k)                     timing instrumentation point (no-op unless a tool asks for it)
 //   void  store(bool valid, int cell, Cell v)
 //   int   counter(int word)               read a progress counter (LDS)
 //   void  publish(int data_word, WP v, int counter_word, int value)    LDS data, then counter -- in this order
@@ -440,8 +444,12 @@ template <int SIDE> SW_HD int group_last_step(int r0, int nl) { return SKEW * (n
 template <int CD> struct CornerLane {
     // CD = 0: corner z = c - r, "outward" o = -1;  CD = 1: z = c + r, o = +1.  Cell (z + o a, z + o b): a, b = -1 inner, 0, +1 outer.
     // Old cells of ring r: rows a = -1..1, columns b = -2..1 without (-1, -1) [Y_0 of ring r-1] and (-1, -2) [X_1 of ring r-1].
+    struct Addr {
+        int e[3][4]; // layer element of cell [a + 1][b + 2] of some ring
+    };
     struct Old {
         Cell v[3][4]; // [a + 1][b + 2]
+        int e00, e0m1; // elements of (0, 0) and (0, -1): where this ring's results go
     };
     SW_HD static int cell_at(const Params &P, int r, int a, int b)
     {
@@ -456,17 +464,28 @@ template <int CD> struct CornerLane {
         const int v = CD ? P.n - 1 - (z + along) : z - along;
         return 1 + ((side * P.gl.G + g) * P.gl.VS + v + 4 * l) * 64 + l;
     }
+    // Elements of ring r's cells given ring r - 1's: one ring out, every cell moves one lane up and three sheared positions on
+    // (+ 3 * 64 + 1) as long as its own ring stays in the same 64-ring storage group; near group boundaries, recompute.
+    SW_HD static void advance(Addr &ad, int r, const Params &P)
+    {
+        const int rr = r <= P.rings ? r : P.rings;
+        const bool recompute = r > P.rings || r <= 3 || (r & 63) <= 2;
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -2; b <= 1; ++b) ad.e[a + 1][b + 2] = recompute ? cell_at(P, rr, a, b) : ad.e[a + 1][b + 2] + 3 * 64 + 1;
+    }
     SW_HD static bool is_old(int r, int a, int b)
     {
         // ring 1 of AB: (-1, -2) is D_1(1), still old (ring 0 has no X_1)
         return !(a == -1 && b == -1) && !(a == -1 && b == -2 && !(r == 1 && !CD));
     }
-    template <class Mem> SW_HD static Old load(int r, const Params &P, Mem &mem)
+    template <class Mem> SW_HD static Old load(int r, const Addr &ad, const Params &P, Mem &mem)
     {
         Old o_;
         const bool ring_ok = r <= P.rings;
         for (int a = -1; a <= 1; ++a)
-            for (int b = -2; b <= 1; ++b) o_.v[a + 1][b + 2] = mem.load_issue(ring_ok && is_old(r, a, b), cell_at(P, ring_ok ? r : P.rings, a, b));
+            for (int b = -2; b <= 1; ++b) o_.v[a + 1][b + 2] = mem.load_issue(ring_ok && is_old(r, a, b), ad.e[a + 1][b + 2]);
+        o_.e00 = ad.e[1][2];
+        o_.e0m1 = ad.e[1][1];
         return o_;
     }
     // block index of cell (z + o a, z + o b) in the 3x3 block centred at (z + o ca, z + o cb)
@@ -484,9 +503,10 @@ template <int CD> struct CornerLane {
     {
         const int base = L.corner + 2 * ((CD * P.c + r) * 2), prev = L.corner + 2 * ((CD * P.c + r - 1) * 2);
         float og[3][4], ow[3][4], op[3][4]; // old cells [a + 1][b + 2]: height, confidence, product
+        mem.mark(0);
         for (int a = -1; a <= 1; ++a)
             for (int b = -2; b <= 1; ++b) {
-                const Cell v = mem.load_value(queued.v[a + 1][b + 2], is_old(r, a, b), cell_at(P, r, a, b));
+                const Cell v = mem.load_value(queued.v[a + 1][b + 2], is_old(r, a, b), cell_at(P, r, a, b)); // (the element only matters to the host's late loads)
                 og[a + 1][b + 2] = v.g;
                 ow[a + 1][b + 2] = v.w;
                 op[a + 1][b + 2] = v.w * v.g;
@@ -495,6 +515,7 @@ template <int CD> struct CornerLane {
         const float x0w = decayed_confidence(ow[1][2], decay0, P); // X_0: (0, 0)
         const float x1w = decayed_confidence(ow[1][1], decay1, P); // X_1: (0, -1)
         const float y0w = decayed_confidence(x0w, decay0, P);      // Y_0: (0, 0) again
+        mem.mark(1);
         const WP in_corner = mem.get(prev + 2); // (z - o, z - o): Y_0 of ring r - 1 (ring 0: the centre)
         // (z - o, z - 2o): X_1 of ring r - 1.  Ring 1 has no such predecessor ring: for AB that cell is D_1(1), still OLD;
         // for CD it is B_1(1) = B_last(1), already NEW (sides A and B of a ring come before C and D).
@@ -509,6 +530,7 @@ template <int CD> struct CornerLane {
             }
         const float x0g = interpolated_height(w, p, og[1][2], ow[1][2]);
         const WP x0{x0w, x0w * x0g};
+        mem.mark(2);
         // ---- X_1 at (0, -1): new = X_0 at (0, 0), inner corner (-1, -1), X_1(r-1) at (-1, -2)
         for (int a = -1; a <= 1; ++a)
             for (int b = -2; b <= 0; ++b) {
@@ -518,6 +540,7 @@ template <int CD> struct CornerLane {
             }
         const float x1g = interpolated_height(w, p, og[1][1], ow[1][1]);
         const WP x1{x1w, x1w * x1g};
+        mem.mark(3);
         // ---- Y_0 at (0, 0) again: new = itself (X_0), X_1 at (0, -1), inner corner
         for (int a = -1; a <= 1; ++a)
             for (int b = -1; b <= 1; ++b) {
@@ -527,11 +550,13 @@ template <int CD> struct CornerLane {
             }
         const float y0g = interpolated_height(w, p, x0g, x0w);
         const WP y0{y0w, y0w * y0g};
-        mem.store(true, cell_at(P, r, 0, 0), Cell{y0g, y0w});
-        mem.store(true, cell_at(P, r, 0, -1), Cell{x1g, x1w});
+        mem.mark(4);
+        mem.store(true, queued.e00, Cell{y0g, y0w});
+        mem.store(true, queued.e0m1, Cell{x1g, x1w});
         mem.put(base, x1);
         mem.publish(base + 2, y0, L.corner_done + CD, r);
         if (!CD && r == 1) mem.publish(L.join + 2 * (SIDE_A * P.c + 1), x1, L.join_done + SIDE_A, 1); // A_last(1) = A_1(1): side A of ring 1 has no chain
+        mem.mark(5);
     }
     template <class Mem> SW_HD static bool ready(int r, const LdsMap &L, Mem &mem)
     {

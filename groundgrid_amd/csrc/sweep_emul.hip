@@ -29,6 +29,7 @@ struct HostMem {
     }
     Cell load_value(const Cell &queued, bool valid, int cell) { return (late && valid) ? gp2[cell] : queued; }
     Cell fresh(const Cell &v) { return v; }
+    void mark(int) {}
     void store(bool valid, int cell, Cell v)
     {
         if (!valid) return;
@@ -131,18 +132,25 @@ template <int CD> struct CornerWave : WaveBase {
     const Params &P;
     const LdsMap &L;
     int r = 1;
-    bool primed = false;
+    bool primed = false, bad_addr = false;
+    bool bad() const override { return bad_addr; }
     typename CornerLane<CD>::Old cur;
+    typename CornerLane<CD>::Addr ad;
     CornerWave(const Params &p, const LdsMap &l) : P(p), L(l) {}
     bool done() const override { return r > P.rings; }
     bool try_step(HostMem &mem) override
     {
         if (done() || !CornerLane<CD>::ready(r, L, mem)) return false;
         if (!primed) {
-            cur = CornerLane<CD>::load(r, P, mem);
+            CornerLane<CD>::advance(ad, r, P);
+            cur = CornerLane<CD>::load(r, ad, P, mem);
             primed = true;
         }
-        const typename CornerLane<CD>::Old next = CornerLane<CD>::load(r + 1, P, mem); // one ring ahead, like the device
+        CornerLane<CD>::advance(ad, r + 1, P);
+        for (int a = -1; a <= 1 && r + 1 <= P.rings; ++a) // the incremental addressing against the generic index
+            for (int b = -2; b <= 1; ++b)
+                if (ad.e[a + 1][b + 2] != gp_index(P.gl, P.c + (CD ? 1 : -1) * (r + 1 + a), P.c + (CD ? 1 : -1) * (r + 1 + b))) bad_addr = true;
+        const typename CornerLane<CD>::Old next = CornerLane<CD>::load(r + 1, ad, P, mem); // one ring ahead, like the device
         CornerLane<CD>::ring(r, cur, P, L, mem);
         cur = next;
         ++r;

@@ -17,3 +17,5 @@ t0 = v[:10, 0].min()
 names = ["A0", "A1", "B0", "B1", "C0", "C1", "D0", "D1", "cornerAB", "cornerCD"]
 for k, nm in enumerate(names):
     print(f"{nm:9s} start {v[k,0]-t0:9d} end {v[k,1]-t0:9d} cycles  polling {v[k,2]:9d}  waits {v[k,3]:6d}")
+m = np.array(list(out), dtype=np.int64)[48:60].reshape(2, 6)
+print("corner phase cycles per ring (wave parity 0 / 1): load-consume+decays, gets+X0, X1, Y0, publish", (m[:, 1:] / 180.0).round(0).tolist())
