@@ -483,6 +483,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_totals = carve((size_t)n_slots * 4 * 4);
     a.tile_start_stride = align_up((size_t)(g.T + 1) * 4, A) / 4;
     const size_t o_tstart = carve((size_t)n_slots * a.tile_start_stride * 4);
+    a.tile_live_stride = align_up((size_t)g.T, A);
+    const size_t o_tlive = carve((size_t)n_slots * a.tile_live_stride);
     const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
     const size_t o_spts = carve(max_points * sizeof(gg_point16));
     const size_t o_slab = carve(max_points);
@@ -520,6 +522,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.chunk_emit = (uint32_t *)(base + o_emit);
     a.totals = (uint32_t *)(base + o_totals);
     a.tile_start = (uint32_t *)(base + o_tstart);
+    a.tile_live = (uint8_t *)(base + o_tlive);
     a.flags = 0;
     ctx->d_params = (CloudParams *)(base + o_params);
     ctx->d_stage_pts = (gg_point16 *)(base + o_spts);
@@ -734,6 +737,8 @@ int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float od
     for (int l = 0; l < GG_NUM_LAYERS; ++l)
         if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH) launch_fill(layer_ptr(a, slot, l), C, init[l], ctx->stream);
     launch_fill2(gp2_ptr(a, slot), (size_t)a.gpl.elems, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], ctx->stream); // interleaved pair
+    // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
+    launch_fill_bytes(a.tile_live + (size_t)slot * a.tile_live_stride, (size_t)a.g.T, 1, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return own_stream_mutated_map(ctx);
 }
@@ -795,6 +800,8 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
         HIPCHK(ctx, hipGetLastError());
     } else {
         HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
+        // the host wrote a per-call layer: it may hold anything now, the next cloud rewrites every tile
+        launch_fill_bytes(ctx->arena.tile_live + (size_t)slot * ctx->arena.tile_live_stride, (size_t)ctx->arena.g.T, 1, ctx->stream);
     }
     if (const int rc = own_stream_mutated_map(ctx)) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

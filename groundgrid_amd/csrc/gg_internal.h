@@ -87,6 +87,9 @@ struct Arena {
     uint32_t *chunk_emit;  size_t emit_stride;   // NCH * 4
     uint32_t *totals;      // [slot][4]  (emitted kept, emitted ignored, outliers, in-map)
     uint32_t *tile_start;  size_t tile_start_stride; // T + 1
+    uint8_t *tile_live;    size_t tile_live_stride;  // [slot][T] by Morton rank: 1 = the tile's nine per-call layers may hold
+                                                     // something else than the per-call reset values (:61-75), i.e. K2 has to
+                                                     // rewrite the tile even if this cloud leaves it empty
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)
     unsigned flags;
@@ -133,6 +136,7 @@ void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_p
 size_t sweep_lds_bytes(const sweep::Params &P);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
+void launch_fill_bytes(uint8_t *dst, size_t n, uint8_t v, hipStream_t s);
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
 void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s); // sheared layer -> column-major plane
 void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, hipStream_t s);

@@ -317,6 +317,17 @@ void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, h
     hipLaunchKernelGGL(k_plane_insert, dim3(blocks), dim3(256), 0, s, a, slot, comp, src);
 }
 
+__global__ void k_fill_bytes(uint8_t *dst, size_t n, uint8_t v)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+void launch_fill_bytes(uint8_t *dst, size_t n, uint8_t v, hipStream_t s)
+{
+    if (n == 0) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)256);
+    hipLaunchKernelGGL(k_fill_bytes, dim3(blocks), dim3(256), 0, s, dst, n, v);
+}
+
 void launch_fill(float *dst, size_t n, float v, hipStream_t s)
 {
     if (n == 0) return;

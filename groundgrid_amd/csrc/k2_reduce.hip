@@ -59,6 +59,12 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
 
     const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
     const uint32_t start = tile_start[rank], end = tile_start[rank + 1];
+    // More than half of the tiles of a sensor cloud receive no point at all, and a tile that received none in the previous
+    // cloud either already holds the per-call reset values (:61-75: they were written when it last went empty): nothing to
+    // do.  tile_live[rank] = "the tile's per-call layers may hold something else" (set by the cloud that put points there, by
+    // gg_reset_map and by host writes).  Exact: every layer in HBM holds at all times what the reference's would.
+    uint8_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    if (start == end && !tile_live[rank]) return; // (uniform)
     const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
     const float oz = cp.oz;
 
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
         }
     }
 
+    if (tid == 0) tile_live[rank] = start != end;
     const int row = tr * TILE + (tid & 15), col = tc * TILE + (tid >> 4);
     if (row < a.g.rows && col < a.g.cols) {
         const size_t idx = (size_t)row + (size_t)col * a.g.rows;
