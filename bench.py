@@ -1,12 +1,22 @@
 #!/usr/bin/env python
 """bench.py -- point clouds/s through the GroundGrid hot path on N x MI355X (one process per GPU).
 
-A "step" = one pass of filter_cloud semantics (src/GroundSegmentation.cpp:50-197) over one batch of
-independent (cloud, map-state) pairs per GPU: BASELINE.json configs[1] (synthetic Velodyne HDL-64E,
-~120 k points, 120 m / 0.33 m grid -> 364 x 364 cells), `--batch` clouds per GPU per step.  Inputs are
-resident in HBM (packed 16-B records) before the timed region.  For N > 1 the clouds shard across
-ranks (no data-path collective) and each step ends with one RCCL all-gather of the label masks
-(BASELINE.json configs[2]).  Rank 0 prints ONE JSON line.
+A "step" = one pass of filter_cloud semantics (src/GroundSegmentation.cpp:50-197) over one batch of independent
+(cloud, map-state) pairs per GPU: BASELINE.json configs[1] (synthetic Velodyne HDL-64E, ~120 k points, 120 m / 0.33 m grid
+-> 364 x 364 cells), `--batch` clouds per GPU per step, every cloud meeting a FRESHLY INITIALISED map (the "cold" contract
+case of SURVEY.md 8(d): ground := 0, groundpatch := 1e-7, GroundGrid.cpp:71-75; the re-initialisation of the persistent state
+is part of the timed step).  Inputs are resident in HBM (packed 16-B records) before the timed region.  For N > 1 the clouds
+shard across ranks (no data-path collective) and each step ends with one RCCL all-gather of the 2-bit label masks
+(BASELINE.json configs[2]).  Rank 0 prints ONE JSON line; besides the headline it carries
+
+  roofline        dominant KERNEL of the timed steps: algorithmic GB/s vs the 8 TB/s HBM peak (+ PMC traffic from profiles/)
+  kernels         every kernel: avg ms per launch, algorithmic bytes, fraction of peak;  scatter_read_frac (north star)
+  warm_map        the steady state (same clouds re-applied to their warm maps), as in round 1
+  config3         BASELINE configs[2]: 64 clouds in total, sharded 64 / N per GPU, fresh maps, all-gather of the masks
+  config4         BASELINE configs[3]: dense 2.1 M-point clouds on a 1000 x 1000 grid (rank 0, N = 1 only)
+  host_api        the drop-in call gg_filter_cloud (host buffers in and out over PCIe), synchronous and pipelined
+  cpu_baseline    the oracle (1 thread) on the same clouds on this box's host cores;  cpu_baseline_8p4: the reference's
+                  default 8 + 4 thread shape (timing only)
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -29,11 +39,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def make_clouds(batch: int, rank: int, n_scenes: int = 8):
+def make_clouds(batch: int, rank: int, n_scenes: int = 8, seed0: int = 20240113):
     """`batch` distinct synthetic HDL-64E clouds: n_scenes ray-cast scenes (seeds 20240113 + ...) x yaw rotations."""
     from groundgrid_amd import synth
 
-    scenes = [synth.hdl64_cloud(seed=20240113 + rank * n_scenes + k) for k in range(min(n_scenes, batch))]
+    scenes = [synth.hdl64_cloud(seed=seed0 + rank * n_scenes + k) for k in range(min(n_scenes, batch))]
     clouds = []
     for b in range(batch):
         base = scenes[b % len(scenes)]
@@ -50,24 +60,42 @@ def make_clouds(batch: int, rank: int, n_scenes: int = 8):
     return clouds
 
 
-def algorithmic_bytes(n_pts, n_in, n_kept, C, full_layers=True):
-    """minimal compulsory traffic per cloud for each kernel group (bytes)."""
+def algorithmic_bytes(n_pts, n_in, n_kept, C, T, nch, full_layers=True):
+    """minimal compulsory traffic per cloud, per kernel (bytes).  The sort kernels have no row of their own
+    in 8(d) (their bytes are part of K2's 20 N): scan = the chunk histograms read and written once, scatter = one (z, key)
+    record read and written per in-map point."""
     return {
-        "K1_classify": 16 * n_pts + 4 * n_in + 4 * n_pts + 1 * n_pts,
-        "K2_sort_reduce": 16 * n_kept + 4 * n_kept + (8 if full_layers else 3) * 4 * C,
-        "K3_patch": 6 * 4 * C + 3 * 4 * C,
-        "K4_sweep": 2 * 2 * 4 * C,
-        "K5_label": 16 * n_pts + 4 * n_pts + 8 * n_pts + 1 * n_pts,
+        "k_classify": 16 * n_pts + 4 * n_in + 4 * n_pts + 1 * n_pts,
+        "k_scan": 2 * 4 * nch * T,
+        "k_scatter": 8 * n_in + 8 * n_in,
+        "k_reduce": 8 * n_in + (9 if full_layers else 5) * 4 * C,
+        "k_patch": 6 * 4 * C + 3 * 4 * C,
+        "k_sweep": 2 * 2 * 4 * C,
+        "k_label": 16 * n_pts + 4 * n_pts + 8 * n_pts + 1 * n_pts,
     }
 
 
-GROUPS = {
-    "K1_classify": ["k_classify"],
-    "K2_sort_reduce": ["k_scan", "k_scatter", "k_reduce"],
-    "K3_patch": ["k_patch"],
-    "K4_sweep": ["k_sweep"],
-    "K5_label": ["k_label"],
-}
+def kernel_table(ktimes, alg, clouds_per_launch):
+    rows = {}
+    for k, (ms, launches) in ktimes.items():
+        avg = ms / max(1, launches)
+        bytes_per_launch = alg[k] * clouds_per_launch
+        gbs = bytes_per_launch / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        rows[k] = {"avg_ms": round(avg, 4), "alg_MB_per_launch": round(bytes_per_launch / 1e6, 2), "GBps": round(gbs, 1),
+                   "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+    return rows
+
+
+def pmc_traffic(kernel, clouds_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_summary.json), scaled to this
+    launch size; None when no profile of this kernel is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        summary = json.load(open(path))
+        per_cloud = summary["kernels"][kernel]["hbm_bytes_per_cloud"]
+        return int(per_cloud * clouds_per_launch)
+    except Exception:
+        return None
 
 
 def main():
@@ -79,6 +107,7 @@ def main():
     ap.add_argument("--minimal-layers", action="store_true", help="skip the four layers nothing in the path reads")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (no warm / config3 / config4 / host_api / CPU legs)")
     args = ap.parse_args()
 
     import torch
@@ -105,12 +134,11 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from groundgrid_amd import api
+    from groundgrid_amd.dist import common_stride, shard_range, unpack_label_masks
 
     B = args.batch
     clouds = make_clouds(B, rank)
     n_points = [len(c) for c in clouds]
-    from groundgrid_amd.dist import common_stride
-
     stride = common_stride(max(n_points), device=dev)  # one shape on every rank; multiple of 64 (2-bit masks need 4)
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride, device=local_rank)
     seg.set_flags(minimal_layers=args.minimal_layers, profile=not args.no_profile)
@@ -121,52 +149,62 @@ def main():
     points = torch.from_numpy(host.view(np.uint8).reshape(B, stride, 16)).to(dev)
     origins = np.zeros((B, 3), dtype=np.float32)
     base_z = np.full(B, -1.73)
-    # Double-buffered outputs: the all-gather of step i's label masks (RCCL's own stream, async_op) overlaps step i+1's
-    # kernels; buffer i % 2 is reused only after its gather completed.
-    outs = [None, None]
-    gathered = [torch.empty((world * B, stride // 4), dtype=torch.uint8, device=dev) for _ in range(2)] if dist else None
-    pending = [None, None]
-    step_no = 0
-    out = None
 
-    def step():
-        nonlocal step_no, out
-        k = step_no % 2
-        if pending[k] is not None:
-            pending[k].wait()  # orders the compute stream after the gather that still reads outs[k].labels
-            pending[k] = None
-        outs[k] = seg.filter_batch(points, n_points, origins, base_z, out=outs[k], want_masks=dist is not None)
-        out = outs[k]
-        if dist:
-            pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k].label_masks, async_op=True)  # 2 bits per point
-        step_no += 1
+    class Pipeline:
+        """Double-buffered outputs: the all-gather of step i's label masks (RCCL's own stream, async_op) overlaps step i+1's
+        kernels; buffer i % 2 is reused only after its gather completed."""
 
-    def fence():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-        torch.cuda.synchronize(dev)
-        if dist:
-            dist.barrier()
+        def __init__(self, seg_, pts, npts, org, bz, cold):
+            self.seg, self.pts, self.npts, self.org, self.bz, self.cold = seg_, pts, npts, org, bz, cold
+            self.outs, self.pending, self.step_no, self.out = [None, None], [None, None], 0, None
+            nb = pts.shape[0]
+            self.gathered = [torch.empty((world * nb, pts.shape[1] // 4), dtype=torch.uint8, device=dev) for _ in range(2)] if dist else None
+
+        def step(self):
+            k = self.step_no % 2
+            if self.pending[k] is not None:
+                self.pending[k].wait()  # orders the compute stream after the gather that still reads outs[k].label_masks
+                self.pending[k] = None
+            if self.cold:  # every cloud meets a freshly initialised map: ground := 0, groundpatch := 1e-7 (one launch, timed)
+                self.seg.reset_maps(0, self.pts.shape[0], odom_z=0.0, persistent_only=True)
+            self.outs[k] = self.seg.filter_batch(self.pts, self.npts, self.org, self.bz, out=self.outs[k], want_masks=dist is not None)
+            self.out = self.outs[k]
+            if dist:
+                self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.outs[k].label_masks, async_op=True)
+            self.step_no += 1
+
+        def fence(self):
+            for k in range(2):
+                if self.pending[k] is not None:
+                    self.pending[k].wait()
+                    self.pending[k] = None
+            self.seg.synchronize()
             torch.cuda.synchronize(dev)
+            if dist:
+                dist.barrier()
+                torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    if not args.no_profile:
-        seg.kernel_times(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def timed(self, steps, warmup):
+            for _ in range(warmup):
+                self.step()
+            self.fence()
+            if not args.no_profile:
+                self.seg.kernel_times(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.fence()
+            elapsed = time.perf_counter() - t0
+            if dist:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            kt = self.seg.kernel_times(reset=True) if not args.no_profile else {}
+            return elapsed, kt
 
-    ktimes = seg.kernel_times(reset=True) if not args.no_profile else {}
+    # ---------------------------------------------------------------- headline: cold maps, K timed steps
+    pipe = Pipeline(seg, points, n_points, origins, base_z, cold=True)
+    elapsed, ktimes = pipe.timed(args.steps, args.warmup)
     total_clouds = world * B * args.steps
     value = total_clouds / elapsed
 
@@ -185,11 +223,13 @@ def main():
         "data": "synthetic (seeded HDL-64E ray caster, 8 scenes x yaw rotations per GPU; no dataset on the box)",
         "config": {
             "workload": "BASELINE configs[1]: synthetic Velodyne HDL-64E cloud, 364x364 grid @ 0.33 m, "
-                        f"{B} independent (cloud, map-state) pairs per GPU per step, warm map state"
+                        f"{B} independent (cloud, map-state) pairs per GPU per step, COLD maps (each step re-initialises the persistent "
+                        "state of its maps -- ground 0, groundpatch 1e-7 -- inside the timed region, then filters)"
                         + ("; + RCCL all-gather of the 2-bit label masks per step (configs[2])" if world > 1 else ""),
             "clouds_per_gpu_per_step": B,
             "points_per_cloud_mean": int(np.mean(n_points)),
             "grid": "364x364",
+            "map_state": "cold",
             "point_format": "packed 16 B (x,y,z,ring) resident in HBM",
             "layers": "minimal" if args.minimal_layers else "all 11",
             "parallelism": f"clouds sharded {B}/GPU x {world} GPU, no data-path collective"
@@ -197,69 +237,108 @@ def main():
         },
     }
 
+    rows, C = seg.rows, seg.rows * seg.rows
+    T = ((rows + 15) // 16) ** 2
     if rank == 0 and ktimes:
-        rows = seg.rows
-        C = rows * rows
         torch.cuda.synchronize(dev)
-        counts = out.counts.cpu().numpy()
+        counts = pipe.out.counts.cpu().numpy()
         n_mean = float(np.mean(n_points))
-        n_in = float(np.mean(counts[:, 1] + counts[:, 2] + counts[:, 3]))  # emitted kept+ignored+outliers ~ in-map
+        n_in = float(np.mean(counts[:, 1] + counts[:, 2] + counts[:, 3]))  # emitted kept + ignored + outliers ~ in-map
         n_kept = float(np.mean(counts[:, 1]))
-        alg = algorithmic_bytes(n_mean, n_in, n_kept, C, full_layers=not args.minimal_layers)
-        groups = {}
-        for gname, ks in GROUPS.items():
-            ms = sum(ktimes[k][0] for k in ks)
-            launches = max(1, ktimes[ks[0]][1])
-            avg_ms = ms / launches  # one launch set == one step of B clouds
-            bytes_per_launch = alg[gname] * B
-            gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            groups[gname] = {"avg_ms": round(avg_ms, 4), "alg_MB_per_launch": round(bytes_per_launch / 1e6, 2),
-                             "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
-        dominant = max(groups, key=lambda g: groups[g]["avg_ms"])
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                summary = json.load(open(pmc))
-                traffic = summary.get(dominant, {}).get("hbm_bytes_per_launch")
-                if traffic is not None and summary.get("batch") and summary["batch"] != B:
-                    traffic = int(traffic * B / summary["batch"])  # profile taken at another batch: per-cloud traffic x B
-            except Exception:
-                traffic = None
-        g = groups[dominant]
+        alg = algorithmic_bytes(n_mean, n_in, n_kept, C, T, (stride + 1023) // 1024, full_layers=not args.minimal_layers)
+        table = kernel_table(ktimes, alg, B)
+        dominant = max(table, key=lambda k: table[k]["avg_ms"])
+        g = table[dominant]
         result["roofline"] = {
-            "kernel": dominant, "bound": "hbm", "achieved": g["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": g["frac_hbm"], "traffic": traffic,
-            "note": "K4_sweep is a 905-level dependent chain (latency-bound); its bytes/s is reported, not a bandwidth claim"
-            if dominant == "K4_sweep" else "",
+            "kernel": dominant, "bound": "hbm", "achieved": g["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g["frac_hbm"],
+            "traffic": pmc_traffic(dominant, B),
+            "note": "dominant single kernel of the timed (cold) steps; achieved = SURVEY 8(d) algorithmic bytes x clouds per launch / its "
+                    "average launch duration (HIP events on the launch stream inside the timed region)",
         }
-        result["kernels"] = groups
-        result["kernel_ms_raw"] = {k: round(v[0] / max(1, v[1]), 4) for k, v in ktimes.items()}
+        result["kernels"] = table
+        insert_ms = sum(table[k]["avg_ms"] for k in ("k_classify", "k_scan", "k_scatter", "k_reduce"))
+        read_gbs = 20.0 * n_mean * B / (insert_ms * 1e-3) / 1e9
+        result["scatter_read_frac"] = {
+            "frac": round(read_gbs / HBM_PEAK_GBS, 4), "GBps": round(read_gbs, 1), "insert_ms": round(insert_ms, 4),
+            "note": "north star: SURVEY 8(d) scatter read figure 20 N bytes per cloud over the whole insert (classify + scan + scatter + reduce)",
+        }
+        whole = sum(alg.values()) * B / (1e-3 * sum(r["avg_ms"] for r in table.values())) / 1e9
+        result["all_kernels_frac_hbm"] = round(whole / HBM_PEAK_GBS, 4)
 
-    # ---- CPU baseline: the oracle (C restatement, 1 thread) on the same clouds, rank 0 at N = 1 only ----
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    extras = not args.no_extras
+    # ---------------------------------------------------------------- warm steady state (round 1's headline), all ranks
+    if extras:
+        warm = Pipeline(seg, points, n_points, origins, base_z, cold=False)
+        w_steps = max(4, args.steps // 2)
+        w_elapsed, w_kt = warm.timed(w_steps, 2)
+        if rank == 0:
+            result["warm_map"] = {"clouds_per_s": round(world * B * w_steps / w_elapsed, 1), "ms_per_step": round(1e3 * w_elapsed / w_steps, 4),
+                                  "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in w_kt.items()},
+                                  "note": "same clouds re-applied to their warm maps (no re-initialisation in the step)"}
+
+    # ---------------------------------------------------------------- configs[2]: 64 clouds in total, 64 / N per GPU
+    if extras:
+        first, cnt = shard_range(64, rank, world)
+        c3_clouds = make_clouds(64, 0, seed0=20240113)[first:first + cnt]  # cloud b = seed 20240113 + b % 8 (+ yaw): same set at every N
+        c3_np = [len(c) for c in c3_clouds]
+        c3_stride = common_stride(max(c3_np) if c3_np else 64, device=dev)
+        seg3 = api.GroundSegmentation().init(120.0, 0.33, n_slots=max(cnt, 1), max_points=c3_stride, device=local_rank)
+        h3 = np.zeros((max(cnt, 1), c3_stride), dtype=api.POINT16_DTYPE)
+        for b, c in enumerate(c3_clouds):
+            h3[b, : len(c)] = api.pack16(c)
+        p3 = torch.from_numpy(h3.view(np.uint8).reshape(max(cnt, 1), c3_stride, 16)).to(dev)[:cnt].contiguous() if cnt else None
+        pipe3 = Pipeline(seg3, p3, c3_np, np.zeros((cnt, 3), np.float32), np.full(cnt, -1.73), cold=True)
+        c3_steps = max(10, args.steps)
+        e3, _ = pipe3.timed(c3_steps, 3)
+        ok3 = None
+        if dist:  # every rank now holds all 64 masks: hold the gathered copy of this rank's clouds to its own labels
+            g = unpack_label_masks(pipe3.gathered[(pipe3.step_no - 1) % 2][first:first + cnt], c3_stride)
+            ok3 = all(bool(torch.equal(g[b, : c3_np[b]], pipe3.out.labels[b, : c3_np[b]])) for b in range(cnt))
+            t = torch.tensor([1 if ok3 else 0], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok3 = bool(t.item())
+        if rank == 0:
+            result["config3"] = {"clouds_total": 64, "clouds_per_gpu": cnt, "clouds_per_s": round(64 * c3_steps / e3, 1),
+                                 "ms_per_step": round(1e3 * e3 / c3_steps, 4), "scaling": "strong", "map_state": "cold",
+                                 "gathered_masks_match_labels": ok3,
+                                 "note": "BASELINE configs[2]: 64 independent clouds sharded 64/N per GPU + one all-gather of the 2-bit "
+                                         "label masks per step (N = 1: no collective)"}
+        seg3.close()
+
+    # ---------------------------------------------------------------- rank 0, N = 1: CPU legs, host API, config 4, latency
+    if rank == 0 and world == 1 and extras and args.cpu_seconds > 0:
         from oracle import oracle
 
         n_cpu = min(B, 8)
         maps = [oracle.OracleMap(120.0, 0.33) for _ in range(n_cpu)]
-        for b in range(n_cpu):  # warm the map state like the GPU run (untimed)
-            maps[b].filter_cloud(clouds[b], (0.0, 0.0, 0.0), -1.73)
         done, t_cpu0 = 0, time.perf_counter()
         while time.perf_counter() - t_cpu0 < args.cpu_seconds:
             for b in range(n_cpu):
+                maps[b].reset_state()
                 maps[b].filter_cloud(clouds[b], (0.0, 0.0, 0.0), -1.73)
             done += n_cpu
         t_cpu = time.perf_counter() - t_cpu0
         result["cpu_baseline"] = {
             "value": round(done / t_cpu, 2), "unit": "clouds/s", "cores": 1, "kind": "port",
-            "sample": f"{done} filter_cloud calls over {n_cpu} of the batch's clouds (warm maps), {t_cpu:.1f} s, "
-                      "oracle/gg_oracle.c gcc -O2 single thread (the reference's deterministic thread_count=1)",
+            "sample": f"{done} filter_cloud calls over {n_cpu} of the batch's clouds, each on a freshly initialised map (cold, as the GPU "
+                      f"steps), {t_cpu:.1f} s, oracle/gg_oracle.c gcc -O2 single thread (the reference's deterministic thread_count=1)",
             "host_cores_available": os.cpu_count(),
         }
         result["speedup_vs_cpu_1thread"] = round(value / (done / t_cpu), 1)
+        done8, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < max(3.0, args.cpu_seconds / 3):
+            for b in range(n_cpu):
+                maps[b].reset_state()
+                maps[b].filter_cloud_threads(clouds[b], (0.0, 0.0, 0.0), -1.73, 8)
+            done8 += n_cpu
+        t8 = time.perf_counter() - t0
+        result["cpu_baseline_8p4"] = {
+            "value": round(done8 / t8, 2), "unit": "clouds/s", "cores": 8, "kind": "port",
+            "sample": f"{done8} calls, {t8:.1f} s: the reference's default threading shape (8 racing insertion threads + 4 detection "
+                      "threads, cfg/GroundGrid.cfg:21, src/GroundSegmentation.cpp:98-134) -- timing only, not deterministic",
+        }
 
         # parity gate in the same run: fresh maps, 2 frames, first clouds of the batch
-        seg.synchronize()
         chk = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=stride, device=local_rank)
         ok = True
         for b in range(min(2, B)):
@@ -272,33 +351,94 @@ def main():
                 ok &= bool(np.max(np.abs(chk.map(0)["ground"] - ref.layer("ground"))) <= 1e-4)
         result["parity_checked_in_run"] = ok
 
-        # the cold-map case of SURVEY.md 8(d): every cloud meets a freshly initialised map (GroundGrid.cpp:71-75).  Maps are
-        # re-initialised (untimed) before each of three timed steps; the headline value above is the warm steady state.
-        cold = []
-        for _ in range(3):
-            for b in range(B):
-                seg.map(b).reset()
-            seg.synchronize()
-            torch.cuda.synchronize(dev)
-            tc0 = time.perf_counter()
-            out = seg.filter_batch(points, n_points, origins, base_z, out=out)
-            torch.cuda.synchronize(dev)
-            cold.append(time.perf_counter() - tc0)
-        result["cold_map"] = {"clouds_per_s": round(B / min(cold), 1), "ms_per_step": round(1e3 * min(cold), 4),
-                              "note": "fresh map state per cloud (ground 0, groundpatch 1e-7), best of 3 single steps"}
+        # the drop-in call: gg_filter_cloud with host buffers in and out (PCIe both ways), one map, a stream of clouds
+        seq = [clouds[b % min(B, 8)] for b in range(64)]
+        for c in seq[:4]:
+            chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
+        t0 = time.perf_counter()
+        for c in seq:
+            chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
+        t_sync = (time.perf_counter() - t0) / len(seq)
+        t0 = time.perf_counter()
+        tick = chk.filter_cloud_async(seq[0], (0.0, 0.0, 0.0), -1.73)
+        for k in range(len(seq)):
+            nxt = chk.filter_cloud_async(seq[k + 1], (0.0, 0.0, 0.0), -1.73) if k + 1 < len(seq) else None
+            chk.filter_cloud_wait(tick)
+            tick = nxt
+        t_pipe = (time.perf_counter() - t0) / len(seq)
+        result["host_api"] = {
+            "sync_clouds_per_s": round(1.0 / t_sync, 1), "pipelined_clouds_per_s": round(1.0 / t_pipe, 1),
+            "sync_ms": round(1e3 * t_sync, 4), "pipelined_ms": round(1e3 * t_pipe, 4),
+            "vs_cpu_1thread": round((1.0 / t_pipe) / (done / t_cpu), 1),
+            "note": "gg_filter_cloud: 32-byte PointXYZIR cloud in host memory -> returned cloud in host memory, one map, consecutive clouds; "
+                    "pipelined = gg_filter_cloud_async two clouds deep (pack + upload of cloud k+1 overlap the kernels of cloud k)",
+        }
 
         # single-cloud latency through the same kernels (one cloud per launch, device-resident input)
-        lat = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=stride, device=local_rank)
         p1 = points[:1].contiguous()
         o1 = None
         for _ in range(5):
-            o1 = lat.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
-        torch.cuda.synchronize(dev)
+            o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
+        chk.synchronize()
         t1 = time.perf_counter()
         for _ in range(20):
-            o1 = lat.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
-        torch.cuda.synchronize(dev)
+            o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
+        chk.synchronize()
         result["single_cloud_latency_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+        chk.close()
+
+        # BASELINE configs[3]: dense OS-128-style clouds, 200 m / 0.2 m -> 1000 x 1000 cells
+        try:
+            from groundgrid_amd import synth
+
+            seg.close()
+            del points
+            B4 = 8
+            base4 = synth.os128_cloud_fast(seed=20240113)  # ~2.1 M returns; the other clouds of the batch are yaw rotations of it
+            c4 = []
+            for b in range(B4):
+                ang = np.float32(2.0 * np.pi * b / B4)
+                cc, ss = np.cos(ang), np.sin(ang)
+                o = synth.clone_cloud(base4)
+                o["x"] = (cc * base4["x"] - ss * base4["y"]).astype(np.float32)
+                o["y"] = (ss * base4["x"] + cc * base4["y"]).astype(np.float32)
+                c4.append(o)
+            n4 = [len(c) for c in c4]
+            s4 = (max(n4) + 63) // 64 * 64
+            seg4 = api.GroundSegmentation().init(200.0, 0.2, n_slots=B4, max_points=s4, device=local_rank)
+            seg4.set_flags(profile=True)
+            h4 = np.zeros((B4, s4), dtype=api.POINT16_DTYPE)
+            for b, c in enumerate(c4):
+                h4[b, : len(c)] = api.pack16(c)
+            p4 = torch.from_numpy(h4.view(np.uint8).reshape(B4, s4, 16)).to(dev)
+            pipe4 = Pipeline(seg4, p4, n4, np.zeros((B4, 3), np.float32), np.full(B4, -1.73), cold=True)
+            e4, kt4 = pipe4.timed(6, 2)
+            cnt4 = pipe4.out.counts.cpu().numpy()
+            C4, T4 = seg4.rows * seg4.rows, ((seg4.rows + 15) // 16) ** 2
+            alg4 = algorithmic_bytes(float(np.mean(n4)), float(np.mean(cnt4[:, 1] + cnt4[:, 2] + cnt4[:, 3])), float(np.mean(cnt4[:, 1])), C4, T4,
+                                     (s4 + 8191) // 8192)
+            tab4 = kernel_table(kt4, alg4, B4)
+            dom4 = max(tab4, key=lambda k: tab4[k]["avg_ms"])
+            m4 = oracle.OracleMap(200.0, 0.2)
+            t0 = time.perf_counter()
+            r4 = m4.filter_cloud(c4[0], (0.0, 0.0, 0.0), -1.73)
+            t4 = time.perf_counter() - t0
+            lab4 = pipe4.out.labels[0, : n4[0]].cpu().numpy()
+            ins4 = sum(tab4[k]["avg_ms"] for k in ("k_classify", "k_scan", "k_scatter", "k_reduce"))
+            result["config4"] = {
+                "workload": f"BASELINE configs[3]: {int(np.mean(n4))} points per cloud (128 rings x 16384 azimuths), 1000x1000 grid @ 0.2 m, "
+                            f"{B4} clouds per launch, cold maps",
+                "clouds_per_s": round(B4 * 6 / e4, 2), "ms_per_step": round(1e3 * e4 / 6, 4),
+                "roofline": {"kernel": dom4, "bound": "hbm", "achieved": tab4[dom4]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": tab4[dom4]["frac_hbm"], "traffic": None},
+                "kernels": tab4,
+                "scatter_read_frac": round(20.0 * float(np.mean(n4)) * B4 / (ins4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "cpu_baseline": {"value": round(1.0 / t4, 3), "unit": "clouds/s", "cores": 1, "kind": "port", "sample": f"1 call, {t4:.2f} s"},
+                "labels_match_oracle": bool(np.array_equal(lab4, r4["label"])),
+            }
+            seg4.close()
+        except Exception as e:  # the headline must not depend on the stress configuration
+            result["config4"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(result))

@@ -196,6 +196,15 @@ class GroundSegmentation:
     def map(self, slot: int = 0) -> GridMap:
         return self._maps[slot]
 
+    def reset_maps(self, first_slot: int = 0, n_slots: Optional[int] = None, odom_z: float = 0.0, pos=(0.0, 0.0), persistent_only: bool = False):
+        """GroundGrid::initGroundGrid values (src/GroundGrid.cpp:71-75) for a range of map states in one launch; with
+        persistent_only just ground / groundpatch, the state that outlives a cloud (a "cold" start)."""
+        n = self.n_slots - first_slot if n_slots is None else n_slots
+        _check(self._L, self._ctx, self._L.gg_reset_maps(self._ctx, first_slot, n, float(pos[0]), float(pos[1]), C.c_float(odom_z),
+                                                          1 if persistent_only else 0), "gg_reset_maps")
+        for s in range(first_slot, first_slot + n):
+            self._maps[s]._pos = (float(pos[0]), float(pos[1]))
+
     # -- GroundSegmentation::setConfig (src/GroundSegmentation.cpp:468-471)
     def setConfig(self, config: GGConfig):
         _check(self._L, self._ctx, self._L.gg_set_config(self._ctx, C.byref(config)), "gg_set_config")

@@ -722,25 +722,39 @@ int gg_get_geometry(const gg_context *ctx, double *resolution, double *length_x,
 
 const char *gg_last_error(const gg_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
+int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double pos_y, float odom_z, int persistent_only)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    if (n < 0 || first_slot < 0 || first_slot + n > ctx->n_slots) return GG_ERR_CAPACITY;
+    if (n == 0) return GG_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
+    const Arena &a = ctx->arena;
+    const size_t C = (size_t)a.g.C;
+    for (int s = first_slot; s < first_slot + n; ++s) {
+        ctx->no_confidence[s] = 1; // groundpatch := 1e-7 everywhere (scrolling keeps that: exposed cells get 0)
+        ctx->pos_x[s] = pos_x;
+        ctx->pos_y[s] = pos_y;
+    }
+    // src/GroundGrid.cpp:71-75; the layers filter_cloud adds later (:61-75) start at 0.  The slots' regions are equally
+    // spaced, so one strided fill per layer covers all n slots.
+    const float init[GG_NUM_LAYERS] = {0.0f, odom_z, (float)0.0000001, (float)100.0, (float)-100.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!persistent_only) {
+        for (int l = 0; l < GG_NUM_LAYERS; ++l)
+            if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH)
+                launch_fill_strided(layer_ptr(a, first_slot, l), C, a.slot_layer_stride, n, init[l], ctx->stream);
+        // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
+        launch_fill_bytes(a.tile_live + (size_t)first_slot * a.tile_live_stride, (size_t)n * a.tile_live_stride, 1, ctx->stream);
+    }
+    launch_fill2_strided(gp2_ptr(a, first_slot), (size_t)a.gpl.elems, a.gp2_stride, n, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return own_stream_mutated_map(ctx);
+}
+
 int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float odom_z)
 {
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
-    ctx->no_confidence[slot] = 1; // groundpatch := 1e-7 everywhere (scrolling keeps that: exposed cells get 0)
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
-    ctx->pos_x[slot] = pos_x;
-    ctx->pos_y[slot] = pos_y;
-    const Arena &a = ctx->arena;
-    const size_t C = (size_t)a.g.C;
-    // src/GroundGrid.cpp:71-75; the layers filter_cloud adds later (:61-75) start at 0
-    const float init[GG_NUM_LAYERS] = {0.0f, odom_z, (float)0.0000001, (float)100.0, (float)-100.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < GG_NUM_LAYERS; ++l)
-        if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH) launch_fill(layer_ptr(a, slot, l), C, init[l], ctx->stream);
-    launch_fill2(gp2_ptr(a, slot), (size_t)a.gpl.elems, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], ctx->stream); // interleaved pair
-    // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
-    launch_fill_bytes(a.tile_live + (size_t)slot * a.tile_live_stride, (size_t)a.g.T, 1, ctx->stream);
-    HIPCHK(ctx, hipGetLastError());
-    return own_stream_mutated_map(ctx);
+    return gg_reset_maps(ctx, slot, 1, pos_x, pos_y, odom_z, 0);
 }
 
 int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y)

@@ -137,6 +137,8 @@ size_t sweep_lds_bytes(const sweep::Params &P);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
 void launch_fill_bytes(uint8_t *dst, size_t n, uint8_t v, hipStream_t s);
+void launch_fill_strided(float *dst, size_t n, size_t stride, int count, float v, hipStream_t s);   // count regions of n floats, `stride` apart
+void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float x, float y, hipStream_t s);
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
 void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s); // sheared layer -> column-major plane
 void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, hipStream_t s);

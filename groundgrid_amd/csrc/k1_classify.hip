@@ -317,6 +317,29 @@ void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, h
     hipLaunchKernelGGL(k_plane_insert, dim3(blocks), dim3(256), 0, s, a, slot, comp, src);
 }
 
+__global__ void k_fill_strided(float *dst, size_t n, size_t stride, float v)
+{
+    float *d = dst + (size_t)blockIdx.y * stride;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = v;
+}
+void launch_fill_strided(float *dst, size_t n, size_t stride, int count, float v, hipStream_t s)
+{
+    if (n == 0 || count <= 0) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)256);
+    hipLaunchKernelGGL(k_fill_strided, dim3(blocks, count), dim3(256), 0, s, dst, n, stride, v);
+}
+__global__ void k_fill2_strided(float2 *dst, size_t n, size_t stride, float x, float y)
+{
+    float2 *d = dst + (size_t)blockIdx.y * stride;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = make_float2(x, y);
+}
+void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float x, float y, hipStream_t s)
+{
+    if (n == 0 || count <= 0) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)256);
+    hipLaunchKernelGGL(k_fill2_strided, dim3(blocks, count), dim3(256), 0, s, dst, n, stride, x, y);
+}
+
 __global__ void k_fill_bytes(uint8_t *dst, size_t n, uint8_t v)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;

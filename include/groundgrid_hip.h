@@ -172,6 +172,10 @@ const char *gg_last_error(const gg_context *ctx);
 
 /* GroundGrid::initGroundGrid layer values (src/GroundGrid.cpp:71-75) + map position */
 int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float odom_z);
+/* The same for n_slots consecutive map states in one launch (position (pos_x, pos_y) and height odom_z for all).  With
+ * persistent_only != 0 only the state that outlives a cloud is re-initialised -- ground := odom_z, groundpatch := 1e-7 -- which
+ * is all a "cold" start needs: the nine per-call layers are rewritten by the next filter call anyway (:61-75). */
+int gg_reset_maps(gg_context *ctx, int first_slot, int n_slots, double pos_x, double pos_y, float odom_z, int persistent_only);
 /* map position after grid_map::move (src/GroundGrid.cpp:97); layers unchanged */
 int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y);
 /* GroundGrid::update for an initialised map (src/GroundGrid.cpp:83-147): grid_map::GridMap::move to the odometry

@@ -18,6 +18,7 @@
 #include <float.h>
 #include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -680,5 +681,131 @@ size_t ggo_filter_cloud(ggo_map *m, const ggo_config *cfg, const ggo_point *clou
 
     if (!out_class) free(cls);
     if (!out_cell) free(cell);
+    return out_n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* TIMING ONLY: the reference's default threading shape (see gg_oracle.h)                     */
+/* ------------------------------------------------------------------------------------------ */
+struct insert_job {
+    ggo_map *m;
+    const ggo_config *cfg;
+    const ggo_point *cloud;
+    size_t start, end;
+    const float *origin;
+    uint8_t *cls;
+    int32_t *cell;
+};
+static void *insert_thread(void *p)
+{
+    struct insert_job *j = (struct insert_job *)p;
+    /* :101-106 insert_cloud(cloud, start, end, ...) on the shared map: same statements as ggo_stage_insert on a sub-range */
+    ggo_stage_insert(j->m, j->cfg, j->cloud + j->start, j->end - j->start, j->origin, j->cls + j->start, j->cell + j->start);
+    return NULL;
+}
+struct detect_job {
+    ggo_map *m;
+    const ggo_config *cfg;
+    int section;
+};
+static void detect_section(ggo_map *m, const ggo_config *cfg, int section)
+{
+    const int size0 = m->rows, size1 = m->cols;
+    const float resolution = (float)m->resolution;
+    const int gcols = m->cols, grows = m->rows;
+    const int cols_start = 2 + section % 2 * (gcols / 2 - 2);             /* :325 */
+    const int rows_start = section >= 2 ? grows / 2 : 2;                   /* :326 */
+    const int cols_end = (gcols) / 2 + section % 2 * (gcols / 2 - 2);      /* :327 */
+    const int rows_end = section >= 2 ? grows - 2 : (grows) / 2;           /* :328 */
+    for (int i = cols_start; i < cols_end; ++i)
+        for (int j = rows_start; j < rows_end; ++j) {
+            const double di = (double)i - (double)size0 / 2.0, dj = (double)j - (double)size1 / 2.0;
+            const float sqdist = (float)((di * di + dj * dj) * ((double)resolution * (double)resolution));
+            if ((double)sqdist <= cfg->patch_size_change_distance * cfg->patch_size_change_distance)
+                detect_ground_patch(m, cfg, 3, (size_t)i, (size_t)j);
+            else
+                detect_ground_patch(m, cfg, 5, (size_t)i, (size_t)j);
+        }
+}
+static void *detect_thread(void *p)
+{
+    struct detect_job *j = (struct detect_job *)p;
+    detect_section(j->m, j->cfg, j->section);
+    return NULL;
+}
+
+size_t ggo_filter_cloud_threads(ggo_map *m, const ggo_config *cfg, const ggo_point *cloud, size_t n, const float origin[3],
+                                double base_z, int t_insert, uint8_t *out_label)
+{
+    if (t_insert < 1) t_insert = 1;
+    if (t_insert > 64) t_insert = 64;
+    uint8_t *cls = (uint8_t *)malloc(n ? n : 1);
+    int32_t *cell = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    ggo_stage_reset(m); /* :61-75 */
+    {                   /* :98-109: thread_count threads over consecutive point ranges, joined before the detection */
+        pthread_t th[64];
+        struct insert_job job[64];
+        const size_t per = n / (size_t)t_insert;
+        for (int t = 0; t < t_insert; ++t) {
+            job[t].m = m;
+            job[t].cfg = cfg;
+            job[t].cloud = cloud;
+            job[t].start = per * (size_t)t;
+            job[t].end = t == t_insert - 1 ? n : per * (size_t)(t + 1);
+            job[t].origin = origin;
+            job[t].cls = cls;
+            job[t].cell = cell;
+            pthread_create(&th[t], NULL, insert_thread, &job[t]);
+        }
+        for (int t = 0; t < t_insert; ++t) pthread_join(th[t], NULL);
+    }
+    { /* :323 (done by every detection thread in the reference), then :128-134 four quadrant threads */
+        const size_t C = (size_t)m->rows * (size_t)m->cols;
+        for (size_t k = 0; k < C; ++k) m->layer[GGO_VARIANCE][k] = m->layer[GGO_M2][k] / (m->layer[GGO_POINTS][k] + FLT_MIN);
+        pthread_t th[4];
+        struct detect_job job[4];
+        for (int s4 = 0; s4 < 4; ++s4) {
+            job[s4].m = m;
+            job[s4].cfg = cfg;
+            job[s4].section = s4;
+            pthread_create(&th[s4], NULL, detect_thread, &job[s4]);
+        }
+        for (int s4 = 0; s4 < 4; ++s4) pthread_join(th[s4], NULL);
+    }
+    ggo_stage_spiral(m, cfg, base_z); /* :142 */
+    const size_t C = (size_t)m->rows * (size_t)m->cols;
+    fill(m->layer[GGO_POINTS], C, 0.0f); /* :147 */
+    const double min_dist_fac = cfg->minimum_distance_factor * 5;
+    const double thres = cfg->miminum_point_height_threshold, obs = cfg->minimum_point_height_obstacle_threshold;
+    const int size0 = m->rows, size1 = m->cols;
+    size_t out_n = 0;
+    if (out_label) memset(out_label, GGO_DROPPED, n);
+    for (int pass = 0; pass < 2; ++pass) { /* :150-183 */
+        const uint8_t want = pass == 0 ? GGO_KEPT : GGO_IGNORED;
+        for (size_t i = 0; i < n; ++i) {
+            if (cls[i] != want) continue;
+            const ggo_point *point = &cloud[i];
+            const int gi0 = cell[i] % size0, gi1 = cell[i] / size0;
+            if (size0 <= gi0 + 3 || size1 <= gi1 + 3) continue;
+            const double groundheight = (double)L(m, GGO_GROUND, gi0, gi1);
+            const float variance = L(m, GGO_VARIANCE, gi0, gi1);
+            const float dist = ggo_hypotf(point->x - origin[0], point->y - origin[1]);
+            const double tolerance = std_max_d(std_min_d((min_dist_fac * (double)dist) / (double)variance * thres, thres), obs);
+            uint8_t label = GGO_GROUND_LABEL;
+            if (tolerance + groundheight < (double)point->z) {
+                label = GGO_NONGROUND_LABEL;
+                L(m, GGO_POINTS, gi0, gi1) += 1.0f;
+            }
+            if (out_label) out_label[i] = label;
+            ++out_n;
+        }
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (cls[i] == GGO_OUTLIER) {
+            if (out_label) out_label[i] = GGO_GROUND_LABEL;
+            ++out_n;
+        }
+    free(cls);
+    free(cell);
     return out_n;
 }

@@ -125,6 +125,15 @@ size_t ggo_filter_cloud(ggo_map *m, const ggo_config *cfg, const ggo_point *clou
                         ggo_point *out_points, uint8_t *out_label, int32_t *out_index,
                         uint8_t *out_class, int32_t *out_cell);
 
+/* TIMING ONLY -- the reference's default threading shape (cfg/GroundGrid.cfg:21 thread_count = 8,
+ * src/GroundSegmentation.cpp:98-134): t_insert threads run insert_cloud on consecutive point ranges of the cloud
+ * CONCURRENTLY ON THE SHARED LAYERS, without synchronisation, exactly as the reference does (:101-109) -- a data race there and
+ * here, so layers and labels of this variant are NOT deterministic and are never used as a checker; then 4 threads run
+ * detect_ground_patches on the four quadrants (:128-134), then the serial sweep and label loop.  Returns the number of
+ * output points.  (The per-point lists are concatenated in thread order, :112-117.) */
+size_t ggo_filter_cloud_threads(ggo_map *m, const ggo_config *cfg, const ggo_point *cloud, size_t n, const float origin[3],
+                                double base_z, int t_insert, uint8_t *out_label);
+
 /* stage entry points (each follows the reference function of the same name) */
 void ggo_stage_reset(ggo_map *m);                                   /* :61-75  */
 void ggo_stage_insert(ggo_map *m, const ggo_config *cfg, const ggo_point *cloud, size_t n,

@@ -109,6 +109,9 @@ def lib():
             C.POINTER(_Map), C.POINTER(Config), C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_double,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         ]
+        L.ggo_filter_cloud_threads.restype = C.c_size_t
+        L.ggo_filter_cloud_threads.argtypes = [C.POINTER(_Map), C.POINTER(Config), C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_double,
+                                               C.c_int, C.c_void_p]
         L.ggo_stage_reset.argtypes = [C.POINTER(_Map)]
         L.ggo_stage_insert.argtypes = [
             C.POINTER(_Map), C.POINTER(Config), C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
@@ -226,6 +229,16 @@ class OracleMap:
         sh = (C.c_int * 2)()
         moved = self._L.ggo_map_update(self._m, float(odom_x), float(odom_y), plane, sh)
         return bool(moved), (sh[0], sh[1])
+
+    def filter_cloud_threads(self, cloud: np.ndarray, origin=(0.0, 0.0, 0.0), base_z=0.0, t_insert: int = 8):
+        """TIMING ONLY: the reference's default threading shape (8 racing insertion threads + 4 detection threads, see
+        gg_oracle.h): not deterministic, never a checker.  Returns the label array."""
+        cloud = np.ascontiguousarray(cloud)
+        n = cloud.shape[0]
+        label = np.zeros(max(n, 1), dtype=np.uint8)
+        org = (C.c_float * 3)(*[float(v) for v in origin])
+        self._L.ggo_filter_cloud_threads(self._m, C.byref(self.cfg), cloud.ctypes.data, n, org, float(base_z), int(t_insert), label.ctypes.data)
+        return label[:n]
 
     def layer(self, name: str) -> np.ndarray:
         """View (no copy) of a layer as (rows, cols) Fortran-ordered float32 (Eigen column-major)."""

@@ -1,0 +1,90 @@
+"""BASELINE configs[2] as far as one GPU allows: two processes share GPU 0, 32 of the 64 clouds each (shard_range), each runs
+filter_batch(want_masks=True) on its fresh maps, the 2-bit label masks are all-gathered (gloo: RCCL refuses two ranks on one
+device), and EVERY one of the 64 gathered masks is compared with the CPU oracle's labels for that cloud."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_CLOUDS, N_AZ = 64, 300  # ~17 k points per cloud: 64 oracle runs stay within seconds
+
+
+def cloud_of(b):
+    from groundgrid_amd import synth
+
+    base = synth.hdl64_cloud(seed=500 + b % 8, n_az=N_AZ)
+    ang = np.float32(0.37 * (b // 8))
+    c, s = np.cos(ang), np.sin(ang)
+    out = synth.clone_cloud(base)
+    out["x"] = (c * base["x"] - s * base["y"]).astype(np.float32)
+    out["y"] = (s * base["x"] + c * base["y"]).astype(np.float32)
+    return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, stride, q):
+    import torch
+    import torch.distributed as dist
+
+    from groundgrid_amd import api
+    from groundgrid_amd.dist import all_gather_label_masks, shard_range, unpack_label_masks
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    first, cnt = shard_range(N_CLOUDS, rank, world)
+    clouds = [cloud_of(first + i) for i in range(cnt)]
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=cnt, max_points=stride, device=0)
+    host = np.zeros((cnt, stride), dtype=api.POINT16_DTYPE)
+    for i, c in enumerate(clouds):
+        host[i, : len(c)] = api.pack16(c)
+    pts = torch.from_numpy(host.view(np.uint8).reshape(cnt, stride, 16)).cuda()
+    out = None
+    for _ in range(2):  # second frame: the persistent map state of every slot is in play
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((cnt, 3), np.float32), np.full(cnt, -1.73), out=out, want_masks=True)
+    torch.cuda.synchronize()
+    gathered = all_gather_label_masks(out.label_masks.cpu())  # [64, stride / 4] on every rank
+    labels = unpack_label_masks(gathered, stride).numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+    seg.close()
+    q.put((rank, labels if rank == 0 else None, tuple(gathered.shape)))
+
+
+def test_64_clouds_on_two_ranks_all_gather_of_masks_matches_the_oracle():
+    import torch.multiprocessing as mp
+
+    from oracle import oracle
+
+    clouds = [cloud_of(b) for b in range(N_CLOUDS)]
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, stride, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    labels = [r[1] for r in res if r[1] is not None][0]
+    assert all(r[2] == (N_CLOUDS, stride // 4) for r in res)
+    for b, c in enumerate(clouds):
+        ref = oracle.OracleMap(120.0, 0.33)
+        for _ in range(2):
+            r = ref.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
+        assert np.array_equal(labels[b, : len(c)], r["label"]), f"cloud {b}: gathered mask differs from the oracle's labels"
+        assert not labels[b, len(c):].any()
