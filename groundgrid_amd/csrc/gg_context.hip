@@ -476,6 +476,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_gp2 = carve((size_t)n_slots * a.gp2_stride * 8);
     const size_t o_rec = carve((size_t)n_slots * Npad * 8);
     const size_t o_sorted = carve((size_t)n_slots * Npad * 8);
+    a.zcell_stride = align_up((Npad + (size_t)32 * g.T + 64) * 4, A) / 4;
+    const size_t o_zcell = carve((size_t)n_slots * a.zcell_stride * 4);
     a.hist_stride = align_up((size_t)a.NCH * g.T * 4, A) / 4;
     const size_t o_hist = carve((size_t)n_slots * a.hist_stride * 4);
     a.emit_stride = align_up((size_t)a.NCH * 4 * 4, A) / 4;
@@ -517,6 +519,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.slot_layer_stride = Cpad * GG_NUM_LAYERS;
     a.rec = (uint2 *)(base + o_rec);
     a.sorted = (uint2 *)(base + o_sorted);
+    a.zcell = (float *)(base + o_zcell);
     a.point_stride = Npad;
     a.hist = (uint32_t *)(base + o_hist);
     a.chunk_emit = (uint32_t *)(base + o_emit);

@@ -83,6 +83,7 @@ struct Arena {
     float *layers;  size_t layer_stride;  size_t slot_layer_stride;  // layer l of slot s: layers + s*slot_layer_stride + l*layer_stride
     float2 *gp2;    size_t gp2_stride;    GpLayout gpl;              // (ground, confidence) of slot s: gp2 + s*gp2_stride, element order gp_layout.h
     uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
+    float *zcell;   size_t zcell_stride;  // per slot: the KEPT heights grouped by cell (K2's stable cell sort), Nmax + 32 T + 64
     uint32_t *hist;        size_t hist_stride;   // NCH * T
     uint32_t *chunk_emit;  size_t emit_stride;   // NCH * 4
     uint32_t *totals;      // [slot][4]  (emitted kept, emitted ignored, outliers, in-map)

@@ -1,20 +1,26 @@
 // K2 -- insert_cloud, per-cell part (src/GroundSegmentation.cpp:282-309) fused with the per-call layer
 // reset (:61-75) and the variance layer (:323).
 //
-// One work-group per (cloud, tile); one thread per cell of the 16x16 tile.  The tile's records arrive in
-// cloud order (stable tile sort).  They are staged through LDS in chunks of CH records and counting-sorted
-// by cell INSIDE LDS, stably:
-//   1. every record sets bit `position` in its cell's bitmask (LDS atomic OR: order-free),
-//   2. each cell thread turns its 32 mask words into per-word exclusive popcount prefixes and its total,
-//      a block scan of the 256 totals gives each cell a contiguous segment,
-//   3. every KEPT record computes its rank = prefix[word] + popc(mask[word] & bits below) -- the number of
-//      earlier records of the same cell, i.e. cloud order -- and drops its z into the cell's segment,
-//   4. each cell thread walks its own segment front to back and runs the reference's float32 recurrence
-//      (count, groundCandidates, running mean, planeDist, m2, min, max) in registers -- except for "heavy" cells
-//      (more than LIGHT_MAX points in the pass), whose recurrences are delegated to the lanes of one wave so that
-//      the other three waves do not idle behind one full cell each.
-// Running state stays in registers across chunks (delegated cells: parked in LDS for the pass); the 9 per-call layers are written exactly once, which also
-// performs the reset of cells that received no point (points = 0, min = FLT_MAX, max = FLT_MIN ...).
+// One work-group per (cloud, tile), 256 threads.  The tile's records arrive in cloud order (stable tile sort).  The float32
+// recurrence of a cell (:295-309) is order dependent, so the only parallelism is ACROSS cells -- and point counts per cell
+// are very uneven (most cells hold a handful of points, a few next to the sensor hundreds).  The kernel therefore separates
+// "bring every cell's heights together, in cloud order" from "run the recurrences", so that the second part can hand out
+// cells to lanes by point count:
+//   1. count      each wave takes a contiguous quarter of the tile's records and counts, per cell, its in-map records
+//                 (pointsRaw, :234) and its KEPT records (one 64-bit LDS atomic per record; order free);
+//   2. scan       thread = cell: the cell's total, its segment in the tile's region of `zcell`, the start of every wave's
+//                 share inside that segment, and the cell's slot in an order of DESCENDING point count (counting sort on a
+//                 clipped count);
+//   3. place      each wave walks its quarter again, 64 records at a time, in cloud order.  The records of one cell inside
+//                 a 64-record window rank themselves through a 64-bit lane mask in LDS (ds_or, read back, mbcnt) -- no
+//                 loop over the window's cells, no barrier -- and drop their z into the cell's segment: a stable counting
+//                 sort by cell, so every segment lists the cell's KEPT heights in cloud order;
+//   4. recur      thread = slot of the count order: wave 0 holds the tile's 64 fullest cells, wave 3 the emptiest, and
+//                 the lanes of a wave have similar trip counts.  Each lane streams its segment (16-byte loads, two
+//                 batches in flight) through the reference's recurrence in registers;
+//   5. write      results go back to "thread = cell" through LDS and the 9 per-call layers are written exactly once,
+//                 coalesced, which also performs the reset of cells that received no point (points = 0, min = FLT_MAX ...).
+// All cells start from the per-call reset state (:61-75), so iteration i of every lane sees the same count c = i.
 //
 // Double rounding: the reference computes groundCandidates and planeDist as (float)((double)num / ((double)c + 1.0))
 // with num and c + 1 exactly representable floats (:296, :303).  For binary32 operands a quotient rounded to
@@ -22,29 +28,33 @@
 // "When is double rounding innocuous?", 1995), so the IEEE float division below is bit-identical and keeps the
 // 150-cycle f64 divide off the per-point dependency chain (tests/test_oracle_cpu.py::test_double_rounding_identity).
 //
-// Algorithmic bytes: 8 per in-map record read; 9 (full) or 5 (minimal) layers x 4 B per cell written.
+// Algorithmic bytes: 8 per in-map record read; 9 (full) or 5 (minimal) layers x 4 B per cell written.  (The records are read
+// twice, the second time from L2; each KEPT height takes a 4-byte round trip through `zcell`, L2 resident.)
 #include "gg_device.h"
 
 #include <float.h>
 
 namespace gg {
 
-constexpr int CH = 512;           // records staged per pass (27 KiB of LDS per work-group -> 5 work-groups per CU)
-constexpr int NW = CH / 32;       // mask words per cell
-constexpr int RPT = CH / TILE_CELLS; // records per thread per pass
-constexpr int LIGHT_MAX = 2;      // a cell with more KEPT points in a pass is "heavy": its recurrence is delegated (step 4)
-constexpr int HMAX = 64;          // heavy cells delegated per pass (one wavefront of runners)
+constexpr int NBIN = 64; // count classes of step 2: 0..31 exact, then steps of 16 up to 527, then "more"
+
+struct __attribute__((packed, aligned(4))) zquad {
+    float v[4];
+};
+
+GG_DEV void lds_order() { __asm__ volatile("" ::: "memory"); } // LDS operations of one wave execute in program order
 
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams *__restrict__ params)
 {
-    __shared__ uint32_t mask[NW][TILE_CELLS];   // 16 KiB  bit p%32 of [p/32][cell] <=> staged record p is a KEPT point of cell
-    __shared__ uint16_t wprefix[NW][TILE_CELLS]; // 8 KiB   segment start of the cell + its KEPT records in words < w
-    __shared__ float zsorted[CH];                // 2 KiB   z, grouped by cell, cloud order inside a cell
-    __shared__ uint32_t raw_cnt[TILE_CELLS];     // pointsRaw (:234): every in-map point of the cell
-    __shared__ uint32_t wave_tot[4], wave_heavy[4];
-    __shared__ float hst[8][HMAX];               // running state of the delegated heavy cells (step 4); row 7 = count after the pass
-    __shared__ uint16_t hseg[2][HMAX];           // their segment start / length in zsorted
+    // [wave][cell]: low 32 bits = in-map records, high 32 bits = KEPT records of the wave's quarter; later the result exchange
+    __shared__ unsigned long long cnt64[4][TILE_CELLS];  // 8 KiB
+    __shared__ unsigned long long wmask[4][TILE_CELLS];  // 8 KiB  lane mask of the window's KEPT records per cell (step 3)
+    __shared__ uint32_t woffs[4][TILE_CELLS];            // 4 KiB  next free position of (wave, cell) in the tile's zcell region
+    __shared__ uint32_t cseg[TILE_CELLS], ctot[TILE_CELLS], craw[TILE_CELLS];
+    __shared__ uint16_t perm[TILE_CELLS];                // slot of the count order -> cell
+    __shared__ uint32_t bin_cnt[NBIN], bin_start[NBIN];
+    __shared__ uint32_t wave_tot[4];
 
     // (cloud, tile rank) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD,
     // in Morton order, so vertically adjacent tiles complete each other's 128-byte layer lines in the same L2
@@ -65,7 +75,6 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     // gg_reset_map and by host writes).  Exact: every layer in HBM holds at all times what the reference's would.
     uint8_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     if (start == end && !tile_live[rank]) return; // (uniform)
-    const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
     const float oz = cp.oz;
 
     // per-cell running state == the layer values after :61-75
@@ -76,55 +85,45 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     float m2 = 0.0f;    // m2
     float mx = FLT_MIN; // maxGroundHeight  (numeric_limits<float>::min(), sic, :73)
     float mn = FLT_MAX; // minGroundHeight  (:72)
+    float raw = 0.0f;   // pointsRaw
+    int my_cell = tid;
 
-    raw_cnt[tid] = 0u;
     if (start != end) { // (uniform) tiles without any point only write the reset values below
-#pragma unroll
-        for (int w = 0; w < NW; ++w) mask[w][tid] = 0u;
-    }
-    __syncthreads();
+        const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
+        // the tile's region of zcell starts on its own 64-byte line (a work-group reads back only lines it wrote itself)
+        float *zc = a.zcell + (size_t)cp.slot * a.zcell_stride + (size_t)((start + 15u) & ~15u) + (size_t)rank * 32u;
+        const uint32_t n = end - start;
+        const uint32_t Q = ((n + 255u) >> 8) << 6; // records per wave: a multiple of the window
+        const uint32_t qs = start + (uint32_t)wave * Q, qe = min(qs + Q, end);
 
-    // the records of the NEXT chunk are loaded into registers before the current chunk is processed
-    uint2 nxt[RPT];
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const uint32_t k = start + (uint32_t)(j * TILE_CELLS + tid);
-        nxt[j] = make_uint2(0u, KEY_OUTSIDE);
-        if (k < end) nxt[j] = sorted[k];
-    }
-    for (uint32_t base = start; base < end; base += CH) {
-        const int cnt = (int)min((uint32_t)CH, end - base);
-        // ---- 1. stage: bitmask per cell ----
-        uint2 r[RPT];
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            r[j] = nxt[j];
-            const uint32_t kn = base + CH + (uint32_t)(j * TILE_CELLS + tid);
-            nxt[j] = make_uint2(0u, KEY_OUTSIDE);
-            if (kn < end) nxt[j] = sorted[kn];
+        for (int k = 0; k < 4; ++k) {
+            cnt64[wave][lane + 64 * k] = 0ull;
+            wmask[wave][lane + 64 * k] = 0ull;
         }
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const int k = j * TILE_CELLS + tid;
-            if (k >= cnt) r[j].y = KEY_OUTSIDE;
-            if (k < cnt) {
-                const uint32_t cit = r[j].y & 255u;
-                atomicAdd(&raw_cnt[cit], 1u);
-                if (((r[j].y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT)
-                    atomicOr(&mask[k >> 5][cit], 1u << (k & 31));
-                else
-                    r[j].y = KEY_OUTSIDE; // not a KEPT record: nothing to place
+        if (tid < NBIN) bin_cnt[tid] = 0u;
+        lds_order();
+        // ---- 1. count ----
+        for (uint32_t p0 = qs; p0 < qe; p0 += 64u) {
+            const uint32_t p = p0 + (uint32_t)lane;
+            if (p < qe) {
+                const uint32_t key = sorted[p].y;
+                const unsigned long long kept = ((key >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT ? 1ull : 0ull;
+                atomicAdd(&cnt64[wave][key & 255u], 1ull | (kept << 32));
             }
         }
         __syncthreads();
-        // ---- 2. per-cell word prefixes + block scan of the cell totals ----
-        uint32_t tot = 0;
-        uint32_t pc[NW];
+        // ---- 2. thread = cell: totals, segment, the waves' shares, count class ----
+        uint32_t kw[4], tot = 0u, rawc = 0u;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            pc[w] = (uint32_t)__popc(mask[w][tid]);
-            tot += pc[w];
+        for (int w = 0; w < 4; ++w) {
+            const unsigned long long v = cnt64[w][tid];
+            kw[w] = (uint32_t)(v >> 32);
+            tot += kw[w];
+            rawc += (uint32_t)v;
         }
+        const uint32_t bin = tot < 32u ? tot : min((uint32_t)NBIN - 1u, 32u + ((tot - 32u) >> 4));
+        const uint32_t in_bin = atomicAdd(&bin_cnt[bin], 1u);
         uint32_t inc = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -132,166 +131,118 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
             if (lane >= d) inc += o;
         }
         if (lane == 63) wave_tot[wave] = inc;
-        const bool heavy = tot > (uint32_t)LIGHT_MAX;
-        const unsigned long long hb = __ballot(heavy);
-        if (lane == 0) wave_heavy[wave] = (uint32_t)__popcll(hb);
         __syncthreads();
-        uint32_t wbase = 0, hpos = (uint32_t)__popcll(hb & ((1ull << lane) - 1ull)), n_heavy = 0;
+        if (wave == 3) { // start of every count class in the descending order
+            const uint32_t h = bin_cnt[NBIN - 1 - lane];
+            uint32_t hs = h;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) wbase += wave_tot[w];
-            if (w < wave) hpos += wave_heavy[w];
-            n_heavy += wave_heavy[w];
-        }
-        n_heavy = min(n_heavy, (uint32_t)HMAX);
-        const uint32_t my_start = wbase + inc - tot;
-        const bool delegated = heavy && hpos < (uint32_t)HMAX;
-        if (delegated) { // hand the cell's state to the runner (read after the next barrier)
-            hst[0][hpos] = c;
-            hst[1][hpos] = mean;
-            hst[2][hpos] = m2;
-            hst[3][hpos] = mn;
-            if (FULL) {
-                hst[4][hpos] = gc;
-                hst[5][hpos] = pdm;
-                hst[6][hpos] = mx;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(hs, d, 64);
+                if (lane >= d) hs += o;
             }
-            hseg[0][hpos] = (uint16_t)my_start;
-            hseg[1][hpos] = (uint16_t)tot;
+            bin_start[NBIN - 1 - lane] = hs - h;
         }
+        uint32_t seg = inc - tot;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+            if (w < wave) seg += wave_tot[w];
+        cseg[tid] = seg;
+        ctot[tid] = tot;
+        craw[tid] = rawc;
         {
-            uint32_t run = my_start;
+            uint32_t run = seg;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                wprefix[w][tid] = (uint16_t)run;
-                run += pc[w];
+            for (int w = 0; w < 4; ++w) {
+                woffs[w][tid] = run;
+                run += kw[w];
             }
         }
         __syncthreads();
-        // ---- 3. stable placement ----
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            if (r[j].y != KEY_OUTSIDE) {
-                const int k = j * TILE_CELLS + tid;
-                const uint32_t cit = r[j].y & 255u;
-                const uint32_t m = mask[k >> 5][cit];
-                const uint32_t rk = (uint32_t)wprefix[k >> 5][cit] + (uint32_t)__popc(m & ((1u << (k & 31)) - 1u));
-                zsorted[rk] = __uint_as_float(r[j].x);
-            }
-        }
-        __syncthreads();
-        // ---- 4. ordered per-cell recurrence; clear this cell's masks for the next pass ----
-#pragma unroll
-        for (int w = 0; w < NW; ++w) mask[w][tid] = 0u;
-        // Load balance.  A wavefront is busy for as long as its fullest cell, and point counts per cell are very uneven
-        // (a few cells next to the sensor hold hundreds of points, most a handful): with a strict "thread = cell" every
-        // wave of the tile waited for one of the full cells.  So a cell thread runs its own recurrence only when the
-        // cell is light (<= LIGHT_MAX points in this pass); up to HMAX heavy cells per pass were compacted in step 2 and
-        // are run from state parked in LDS by dedicated waves (below), so no wave idles behind one full cell.  The order INSIDE a cell is untouched.
-        auto recur = [&](uint32_t s0, uint32_t n, float &c_, float &gc_, float &mean_, float &pdm_, float &m2_, float &mx_, float &mn_) {
-            float znext = n ? zsorted[s0] : 0.0f;
-            for (uint32_t i = 0; i < n; ++i) {
-                const float z = znext;
-                if (i + 1 < n) znext = zsorted[s0 + i + 1];
-                // ---- src/GroundSegmentation.cpp:295-309, one KEPT point, `c_` = points before it ----
-                const float planeDist = z - oz;                                       // :295
-                if (FULL) gc_ = (z + c_ * gc_) / (c_ + 1.0f);                         // :296 (see note on double rounding above)
-                if ((double)mean_ == 0.0) mean_ = planeDist;                          // :298-299
-                if (!isnan(planeDist)) {                                              // :300
-                    const float delta = planeDist - mean_;                            // :301
-                    mean_ += delta / (c_ + 1.0f);                                     // :302
-                    if (FULL) pdm_ = (planeDist + c_ * pdm_) / (c_ + 1.0f);           // :303
-                    m2_ += delta * (planeDist - mean_);                               // :304
+        perm[bin_start[bin] + in_bin] = (uint16_t)tid;
+        // ---- 3. place: stable counting sort of the KEPT heights by cell ----
+        for (uint32_t p0 = qs; p0 < qe; p0 += 64u) {
+            const uint32_t p = p0 + (uint32_t)lane;
+            uint2 r = make_uint2(0u, KEY_OUTSIDE);
+            if (p < qe) r = sorted[p];
+            const bool kept = p < qe && ((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT;
+            const uint32_t cit = r.y & 255u;
+            volatile unsigned long long *wm = &wmask[wave][cit];
+            volatile uint32_t *wo = &woffs[wave][cit];
+            if (kept) atomicOr(&wmask[wave][cit], 1ull << lane);
+            lds_order();
+            if (kept) {
+                const unsigned long long mm = *wm; // the window's records of this cell
+                const uint32_t base = *wo;
+                zc[base + (uint32_t)rank_below(mm)] = __uint_as_float(r.x);
+                if ((mm >> lane) == 1ull) { // the cell's last record of the window advances the cell for the next one
+                    *wo = base + (uint32_t)__popcll(mm);
+                    *wm = 0ull;
                 }
-                if (FULL) mx_ = std_max(mx_, z);  // :307
-                mn_ = std_min(mn_, z - 0.0001f);  // :308
-                c_ = (float)((double)c_ + 1.0);   // :309
             }
-        };
-        if (!delegated) recur(my_start, tot, c, gc, mean, pdm, m2, mx, mn);
-        // Delegated cells: the recurrence of one point consists of three chains that only share the point count --
-        // (mean, m2, min), (groundCandidates, max), (planeDist) -- so three waves each run ONE chain for all heavy cells
-        // (lane = heavy cell): a third of the dependent instructions per point on the tile's critical path.  The
-        // roles rotate with the tile so that concurrent work-groups of a CU keep different SIMDs busy.
-        const int role = (wave - rank) & 3; // wave-uniform
-        if ((uint32_t)lane < n_heavy && role < (FULL ? 3 : 1)) {
-            const uint32_t s0 = (uint32_t)hseg[0][lane], n = (uint32_t)hseg[1][lane];
-            float hc = hst[0][lane]; // points before this pass
-            float znext = zsorted[s0];
-            // (`hc` is an integer-valued float < 2^24: hc + 1.0f is the reference's (float)((double)hc + 1.0), :309)
-            if (role == 0) {
-                float hmean = hst[1][lane], hm2 = hst[2][lane], hmn0 = hst[3][lane]; // (min: here only without the other chains)
-                for (uint32_t i = 0; i < n; ++i) {
-                    const float z = znext;
-                    if (i + 1 < n) znext = zsorted[s0 + i + 1];
-                    const float planeDist = z - oz;                   // :295
-                    if (hmean == 0.0f) hmean = planeDist;             // :298-299
-                    if (!isnan(planeDist)) {                          // :300
-                        const float delta = planeDist - hmean;        // :301
-                        hmean += delta / (hc + 1.0f);                 // :302
-                        hm2 += delta * (planeDist - hmean);           // :304
+            lds_order();
+        }
+        __syncthreads(); // (the heights written above are read by other waves of this work-group below)
+        // ---- 4. thread = slot of the count order ----
+        my_cell = (int)perm[tid];
+        const uint32_t np = ctot[my_cell];
+        raw = (float)craw[my_cell];
+        const zquad *zq = reinterpret_cast<const zquad *>(zc + cseg[my_cell]);
+        zquad q0 = {{0.0f, 0.0f, 0.0f, 0.0f}}, q1 = q0;
+        if (np > 0u) q0 = zq[0];
+        if (np > 4u) q1 = zq[1];
+        for (uint32_t i = 0; i < np; i += 4u) {
+            const zquad cur = q0;
+            q0 = q1;
+            if (i + 8u < np) q1 = zq[(i >> 2) + 2u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i + (uint32_t)k < np) {
+                    const float z = cur.v[k];
+                    // ---- src/GroundSegmentation.cpp:295-309, one KEPT point, `c` = points before it ----
+                    const float planeDist = z - oz;                                  // :295
+                    if (FULL) gc = (z + c * gc) / (c + 1.0f);                        // :296 (see note on double rounding above)
+                    if ((double)mean == 0.0) mean = planeDist;                       // :298-299
+                    if (!isnan(planeDist)) {                                         // :300
+                        const float delta = planeDist - mean;                        // :301
+                        mean += delta / (c + 1.0f);                                  // :302
+                        if (FULL) pdm = (planeDist + c * pdm) / (c + 1.0f);          // :303
+                        m2 += delta * (planeDist - mean);                            // :304
                     }
-                    if (!FULL) hmn0 = std_min(hmn0, z - 0.0001f);     // :308
-                    hc += 1.0f;                                       // :309
+                    if (FULL) mx = std_max(mx, z);  // :307
+                    mn = std_min(mn, z - 0.0001f);  // :308
+                    c = (float)((double)c + 1.0);   // :309
                 }
-                if (!FULL) hst[3][lane] = hmn0;
-                hst[1][lane] = hmean;
-                hst[2][lane] = hm2;
-                hst[7][lane] = hc; // points after this pass (row 0 is still being read by the other two chains)
-            } else if (role == 1) {
-                float hgc = hst[4][lane], hmx = hst[6][lane];
-                for (uint32_t i = 0; i < n; ++i) {
-                    const float z = znext;
-                    if (i + 1 < n) znext = zsorted[s0 + i + 1];
-                    hgc = (z + hc * hgc) / (hc + 1.0f);               // :296
-                    hmx = std_max(hmx, z);                            // :307
-                    hc += 1.0f;
-                }
-                hst[4][lane] = hgc;
-                hst[6][lane] = hmx;
-            } else {
-                float hpdm = hst[5][lane], hmn = hst[3][lane];
-                for (uint32_t i = 0; i < n; ++i) {
-                    const float z = znext;
-                    if (i + 1 < n) znext = zsorted[s0 + i + 1];
-                    const float planeDist = z - oz;
-                    if (!isnan(planeDist)) hpdm = (planeDist + hc * hpdm) / (hc + 1.0f); // :300, :303
-                    hmn = std_min(hmn, z - 0.0001f);                  // :308
-                    hc += 1.0f;
-                }
-                hst[5][lane] = hpdm;
-                hst[3][lane] = hmn;
-            }
-        }
-        __syncthreads();
-        if (delegated) { // take the state back
-            c = hst[7][hpos];
-            mean = hst[1][hpos];
-            m2 = hst[2][hpos];
-            mn = hst[3][hpos];
-            if (FULL) {
-                gc = hst[4][hpos];
-                pdm = hst[5][hpos];
-                mx = hst[6][hpos];
             }
         }
     }
 
+    // ---- 5. back to thread = cell, write the per-call layers ----
+    float *ex = reinterpret_cast<float *>(&cnt64[0][0]); // (8 KiB; the counters were last read in step 2, two barriers ago)
+    ex[0 * TILE_CELLS + my_cell] = c;
+    ex[1 * TILE_CELLS + my_cell] = mn;
+    ex[2 * TILE_CELLS + my_cell] = m2;
+    ex[3 * TILE_CELLS + my_cell] = raw;
+    ex[4 * TILE_CELLS + my_cell] = mean;
+    ex[5 * TILE_CELLS + my_cell] = mx; // (minimal layers: these three keep their reset values)
+    ex[6 * TILE_CELLS + my_cell] = gc;
+    ex[7 * TILE_CELLS + my_cell] = pdm;
+    __syncthreads();
     if (tid == 0) tile_live[rank] = start != end;
     const int row = tr * TILE + (tid & 15), col = tc * TILE + (tid >> 4);
     if (row < a.g.rows && col < a.g.cols) {
         const size_t idx = (size_t)row + (size_t)col * a.g.rows;
         float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
         const size_t ls = a.layer_stride;
-        L[GG_LAYER_POINTS * ls + idx] = c;
-        L[GG_LAYER_MINGROUNDHEIGHT * ls + idx] = mn;
-        L[GG_LAYER_M2 * ls + idx] = m2;
-        L[GG_LAYER_VARIANCE * ls + idx] = m2 / (c + FLT_MIN); // :323
-        L[GG_LAYER_POINTSRAW * ls + idx] = (float)raw_cnt[tid];
-        L[GG_LAYER_MEANVARIANCE * ls + idx] = mean;
-        L[GG_LAYER_MAXGROUNDHEIGHT * ls + idx] = mx;
-        L[GG_LAYER_GROUNDCANDIDATES * ls + idx] = gc;
-        L[GG_LAYER_PLANEDIST * ls + idx] = pdm;
+        const float cc = ex[0 * TILE_CELLS + tid], m2c = ex[2 * TILE_CELLS + tid];
+        L[GG_LAYER_POINTS * ls + idx] = cc;
+        L[GG_LAYER_MINGROUNDHEIGHT * ls + idx] = ex[1 * TILE_CELLS + tid];
+        L[GG_LAYER_M2 * ls + idx] = m2c;
+        L[GG_LAYER_VARIANCE * ls + idx] = m2c / (cc + FLT_MIN); // :323
+        L[GG_LAYER_POINTSRAW * ls + idx] = ex[3 * TILE_CELLS + tid];
+        L[GG_LAYER_MEANVARIANCE * ls + idx] = ex[4 * TILE_CELLS + tid];
+        L[GG_LAYER_MAXGROUNDHEIGHT * ls + idx] = ex[5 * TILE_CELLS + tid];
+        L[GG_LAYER_GROUNDCANDIDATES * ls + idx] = ex[6 * TILE_CELLS + tid];
+        L[GG_LAYER_PLANEDIST * ls + idx] = ex[7 * TILE_CELLS + tid];
     }
 }
 
