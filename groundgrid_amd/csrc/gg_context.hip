@@ -527,6 +527,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_start = (uint32_t *)(base + o_tstart);
     a.tile_live = (uint8_t *)(base + o_tlive);
     a.flags = 0;
+    a.k2_debug = getenv("GG_K2_DEBUG") ? atoi(getenv("GG_K2_DEBUG")) : 0;
     ctx->d_params = (CloudParams *)(base + o_params);
     ctx->d_stage_pts = (gg_point16 *)(base + o_spts);
     ctx->d_stage_labels = (uint8_t *)(base + o_slab);

@@ -94,6 +94,7 @@ struct Arena {
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)
     unsigned flags;
+    int k2_debug;        // env GG_K2_DEBUG (measurement only): 1 = k_reduce stops after the tile lookup, 2 = after step 1, 3 = after step 3
     int eigen_reduction; // gg_conventions::eigen_reduction (GG_EIGEN_33 / GG_EIGEN_34_SSE): order of the 5x5 block sums in K3
 };
 

@@ -17,7 +17,8 @@
 //                 sort by cell, so every segment lists the cell's KEPT heights in cloud order;
 //   4. recur      thread = slot of the count order: wave 0 holds the tile's 64 fullest cells, wave 3 the emptiest, and
 //                 the lanes of a wave have similar trip counts.  Each lane streams its segment (16-byte loads, two
-//                 batches in flight) through the reference's recurrence in registers;
+//                 batches in flight) through the reference's recurrence in registers.  In a tile with full cells the
+//                 three chains of the 64 fullest cells (which only share the point count) run in three waves;
 //   5. write      results go back to "thread = cell" through LDS and the 9 per-call layers are written exactly once,
 //                 coalesced, which also performs the reset of cells that received no point (points = 0, min = FLT_MAX ...).
 // All cells start from the per-call reset state (:61-75), so iteration i of every lane sees the same count c = i.
@@ -36,13 +37,145 @@
 
 namespace gg {
 
-constexpr int NBIN = 64; // count classes of step 2: 0..31 exact, then steps of 16 up to 527, then "more"
+constexpr int NBIN = 64;      // count classes of step 2: 0..31 exact, then steps of 16 up to 527, then "more"
+constexpr int RCAP = 4092;    // reciprocal table: 1 / (i + 1) in binary64 for the first RCAP points of a cell (a multiple of 12)
+constexpr int WB = 8;         // 64-record windows a wave keeps in flight in steps 1 and 3
+constexpr int SPLIT_MIN = 24; // a tile with a cell of at least this many points runs its 64 fullest cells one chain per wave
 
 struct __attribute__((packed, aligned(4))) zquad {
     float v[4];
 };
 
+struct RecipTable {
+    double v[RCAP];
+};
+constexpr RecipTable make_recip_table()
+{
+    RecipTable t{};
+    for (int i = 0; i < RCAP; ++i) t.v[i] = 1.0 / (double)(i + 1); // (IEEE binary64 division in the compiler's constant evaluator)
+    return t;
+}
+__constant__ const RecipTable recip_table = make_recip_table();
+
 GG_DEV void lds_order() { __asm__ volatile("" ::: "memory"); } // LDS operations of one wave execute in program order
+
+// The quotients of the recurrence, a / (c + 1) with c + 1 = b an integer in [1, 2^24] (:296, :302, :303).
+// q = (float)((double)a * r), r = RN64(1 / b), is the correctly rounded binary32 quotient whenever |q| >= 2^-100:
+//   * (double)a * r is off from a / b by a relative 2^-53 (r) + 2^-53 (product) < 2^-51.9;
+//   * a / b is never closer than a relative 2^-49 to a rounding boundary M of binary32 (the midpoint of two adjacent
+//     floats, a 25-bit odd integer Mi times a power of two): a - b M = A 2^ea - b Mi 2^em is a non-zero multiple of
+//     2^min(ea, em) -- non-zero because the odd part of b Mi has more than 24 bits while A has at most 24 -- and
+//     when the two terms are comparable ea >= em, so |a / b - M| >= 2^em / b >= 2^-49 |M|;
+//   hence the binary64 product and a / b round to the same float (the argument of gg_device.h index_of).
+// Below 2^-100 (results that are or may become denormal, where the boundaries are coarser and exact ties exist, and
+// q == 0) the caller falls back to the IEEE division; NaN and infinities propagate through the product as through
+// the division.  Bit-identity with the division: tests/test_fast_quotient_cpu.py (the same expression in C over
+// random, boundary and tie operands) and the GPU parity tests.
+GG_DEV float quot(float a, double r) { return (float)((double)a * r); }
+
+enum : int { R_MEAN = 1 /* meanVariance, m2 */, R_GC = 2 /* groundCandidates, maxGroundHeight */, R_PDM = 4 /* planeDist */, R_MN = 8 /* minGroundHeight */ };
+
+struct CellState {
+    float gc, mean, pdm, m2, mx, mn;
+};
+
+// The reference's recurrence (:295-309) of the lane's cell over its `np` heights at `zseg` (cloud order), restricted to
+// the chains in R.  The chains only share the point count, and every cell starts the call at count 0 (:61-75), so point i
+// of every lane has c = i: wave-uniform, and 1 / (c + 1) comes from a table through the scalar cache.
+template <int R>
+GG_DEV void one_point(float z, float c, float c1, double r, bool first, float oz, CellState &s)
+{
+    const float planeDist = z - oz; // :295
+    float a_gc = 0.0f, a_pdm = 0.0f, delta = 0.0f, q_gc = 1.0f, q_pdm = 1.0f, q_mean = 1.0f;
+    if (R & R_GC) {
+        a_gc = z + c * s.gc; // :296
+        q_gc = quot(a_gc, r);
+    }
+    if (R & R_MEAN) {
+        if ((double)s.mean == 0.0) s.mean = planeDist; // :298-299
+        delta = planeDist - s.mean;                    // :301
+        q_mean = quot(delta, r);
+    }
+    if (R & R_PDM) {
+        a_pdm = planeDist + c * s.pdm; // :303
+        q_pdm = quot(a_pdm, r);
+    }
+    if (R & (R_GC | R_MEAN | R_PDM)) {
+        // (first point: b = 1 and the product is exact)
+        const float smallest = fminf(fabsf(q_gc), fminf(fabsf(q_mean), fabsf(q_pdm)));
+        if (!first && __any(smallest < 0x1p-100f)) { // (rare; uniform branch)
+            if (R & R_GC) q_gc = a_gc / c1;
+            if (R & R_MEAN) q_mean = delta / c1;
+            if (R & R_PDM) q_pdm = a_pdm / c1;
+        }
+    }
+    if (R & R_GC) {
+        s.gc = q_gc;             // :296
+        s.mx = std_max(s.mx, z); // :307
+    }
+    if (!isnan(planeDist)) { // :300
+        if (R & R_MEAN) {
+            s.mean += q_mean;                     // :302
+            s.m2 += delta * (planeDist - s.mean); // :304
+        }
+        if (R & R_PDM) s.pdm = q_pdm; // :303
+    }
+    if (R & R_MN) s.mn = std_min(s.mn, z - 0.0001f); // :308
+}
+
+// The reference's recurrence (:295-309) of the lane's cell over its `np` heights at `zseg` (cloud order), restricted to
+// the chains in R.  The chains only share the point count, and every cell starts the call at count 0 (:61-75), so point i
+// of every lane has c = i: wave-uniform, and 1 / (c + 1) comes from a table through the scalar cache.
+template <int R>
+GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s)
+{
+    const zquad *zq = reinterpret_cast<const zquad *>(zseg);
+    uint32_t nmax = np;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    // three 16-byte batches per lane in flight, each refilled right after its four points (no register rotation: a copy
+    // of a load's destination would wait for the load; unconditional loads at a clamped index: no branch around them)
+    const zquad zero = {{0.0f, 0.0f, 0.0f, 0.0f}};
+    const uint32_t qlast = np ? (np - 1u) >> 2 : 0u; // (an empty cell reads 16 bytes of the tile's padded region)
+    zquad qa = zq[0], qb = zq[min(1u, qlast)], qc = zq[min(2u, qlast)];
+    float c = 0.0f; // points before the current one (:309: (float)((double)c + 1.0) == c + 1.0f for integers below 2^24)
+    const uint32_t ntab = min(nmax, (uint32_t)RCAP);
+    auto four_points = [&](const zquad &cur, uint32_t i) {
+        double rr[4]; // (one 32-byte scalar load; RCAP is a multiple of 4)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rr[k] = recip_table.v[i + (uint32_t)k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ii = i + (uint32_t)k; // (uniform)
+            if (ii >= ntab) break;
+            const float c1 = c + 1.0f;
+            if (ii < np) one_point<R>(cur.v[k], c, c1, rr[k], ii == 0u, oz, s);
+            c = c1;
+        }
+    };
+    for (uint32_t i = 0; i < ntab; i += 12u) { // (RCAP is a multiple of 12)
+        four_points(qa, i);
+        qa = zq[min((i >> 2) + 3u, qlast)];
+        if (i + 4u >= ntab) break;
+        four_points(qb, i + 4u);
+        qb = zq[min((i >> 2) + 4u, qlast)];
+        if (i + 8u >= ntab) break;
+        four_points(qc, i + 8u);
+        qc = zq[min((i >> 2) + 5u, qlast)];
+    }
+    for (uint32_t i = (uint32_t)RCAP; i < nmax; i += 4u) { // cells with more than RCAP points: IEEE reciprocal per point
+        zquad cur = zero;
+        if (i < np) cur = zq[i >> 2];
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ii = i + (uint32_t)k;
+            if (ii >= nmax) break;
+            const float c1 = c + 1.0f;
+            if (ii < np) one_point<R>(cur.v[k], c, c1, 1.0 / (double)c1, false, oz, s);
+            c = c1;
+        }
+    }
+}
 
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams *__restrict__ params)
@@ -54,7 +187,7 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     __shared__ uint32_t cseg[TILE_CELLS], ctot[TILE_CELLS], craw[TILE_CELLS];
     __shared__ uint16_t perm[TILE_CELLS];                // slot of the count order -> cell
     __shared__ uint32_t bin_cnt[NBIN], bin_start[NBIN];
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t wave_tot[4], wave_full[4];
 
     // (cloud, tile rank) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD,
     // in Morton order, so vertically adjacent tiles complete each other's 128-byte layer lines in the same L2
@@ -75,18 +208,12 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
     // gg_reset_map and by host writes).  Exact: every layer in HBM holds at all times what the reference's would.
     uint8_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     if (start == end && !tile_live[rank]) return; // (uniform)
+    if (a.k2_debug == 1) return;
     const float oz = cp.oz;
 
-    // per-cell running state == the layer values after :61-75
-    float c = 0.0f;     // points
-    float gc = 0.0f;    // groundCandidates
-    float mean = 0.0f;  // meanVariance
-    float pdm = 0.0f;   // planeDist
-    float m2 = 0.0f;    // m2
-    float mx = FLT_MIN; // maxGroundHeight  (numeric_limits<float>::min(), sic, :73)
-    float mn = FLT_MAX; // minGroundHeight  (:72)
-    float raw = 0.0f;   // pointsRaw
-    int my_cell = tid;
+    // result exchange, [layer value][cell] (8 KiB over the counters of step 1, last read in step 2)
+    float *ex = reinterpret_cast<float *>(&cnt64[0][0]);
+    const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX}; // the layer values after :61-75 (max: numeric_limits<float>::min(), sic, :73)
 
     if (start != end) { // (uniform) tiles without any point only write the reset values below
         const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
@@ -103,16 +230,25 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
         }
         if (tid < NBIN) bin_cnt[tid] = 0u;
         lds_order();
-        // ---- 1. count ----
-        for (uint32_t p0 = qs; p0 < qe; p0 += 64u) {
-            const uint32_t p = p0 + (uint32_t)lane;
-            if (p < qe) {
-                const uint32_t key = sorted[p].y;
-                const unsigned long long kept = ((key >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT ? 1ull : 0ull;
-                atomicAdd(&cnt64[wave][key & 255u], 1ull | (kept << 32));
+        // ---- 1. count ----  (WB windows of records in flight per wave: the loop is otherwise one memory latency per window)
+        for (uint32_t p0 = qs; p0 < qe; p0 += 64u * WB) {
+            uint32_t key[WB];
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                const uint32_t p = p0 + 64u * (uint32_t)j + (uint32_t)lane;
+                key[j] = KEY_OUTSIDE;
+                if (p < qe) key[j] = sorted[p].y;
+            }
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                if (key[j] != KEY_OUTSIDE) {
+                    const unsigned long long kept = ((key[j] >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT ? 1ull : 0ull;
+                    atomicAdd(&cnt64[wave][key[j] & 255u], 1ull | (kept << 32));
+                }
             }
         }
         __syncthreads();
+        if (a.k2_debug == 2) return;
         // ---- 2. thread = cell: totals, segment, the waves' shares, count class ----
         uint32_t kw[4], tot = 0u, rawc = 0u;
 #pragma unroll
@@ -131,6 +267,8 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
             if (lane >= d) inc += o;
         }
         if (lane == 63) wave_tot[wave] = inc;
+        const bool any_full = __any(tot >= (uint32_t)SPLIT_MIN);
+        if (lane == 0) wave_full[wave] = any_full ? 1u : 0u;
         __syncthreads();
         if (wave == 3) { // start of every count class in the descending order
             const uint32_t h = bin_cnt[NBIN - 1 - lane];
@@ -160,72 +298,101 @@ __global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams
         __syncthreads();
         perm[bin_start[bin] + in_bin] = (uint16_t)tid;
         // ---- 3. place: stable counting sort of the KEPT heights by cell ----
-        for (uint32_t p0 = qs; p0 < qe; p0 += 64u) {
-            const uint32_t p = p0 + (uint32_t)lane;
-            uint2 r = make_uint2(0u, KEY_OUTSIDE);
-            if (p < qe) r = sorted[p];
-            const bool kept = p < qe && ((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT;
-            const uint32_t cit = r.y & 255u;
-            volatile unsigned long long *wm = &wmask[wave][cit];
-            volatile uint32_t *wo = &woffs[wave][cit];
-            if (kept) atomicOr(&wmask[wave][cit], 1ull << lane);
-            lds_order();
-            if (kept) {
-                const unsigned long long mm = *wm; // the window's records of this cell
-                const uint32_t base = *wo;
-                zc[base + (uint32_t)rank_below(mm)] = __uint_as_float(r.x);
-                if ((mm >> lane) == 1ull) { // the cell's last record of the window advances the cell for the next one
-                    *wo = base + (uint32_t)__popcll(mm);
-                    *wm = 0ull;
+        for (uint32_t p0 = qs; p0 < qe; p0 += 64u * WB) {
+            uint2 rw[WB];
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                const uint32_t p = p0 + 64u * (uint32_t)j + (uint32_t)lane;
+                rw[j] = make_uint2(0u, KEY_OUTSIDE);
+                if (p < qe) rw[j] = sorted[p];
+            }
+#pragma unroll
+            for (int j = 0; j < WB; ++j) { // window by window, in cloud order
+                const uint2 r = rw[j];
+                const bool kept = r.y != KEY_OUTSIDE && ((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT;
+                const uint32_t cit = r.y & 255u;
+                // (relaxed work-group scope atomics on LDS: plain ds_or / ds_read / ds_write, kept in program order per
+                // address; `volatile` would make the compiler drain the vector memory queue after every access)
+                unsigned long long *wm = &wmask[wave][cit];
+                uint32_t *wo = &woffs[wave][cit];
+                if (kept) {
+                    __hip_atomic_fetch_or(wm, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned long long mm = __hip_atomic_load(wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // the window's records of this cell
+                    const uint32_t base = __hip_atomic_load(wo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    zc[base + (uint32_t)rank_below(mm)] = __uint_as_float(r.x);
+                    if ((mm >> lane) == 1ull) { // the cell's last record of the window advances the cell for the next one
+                        __hip_atomic_store(wo, base + (uint32_t)__popcll(mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(wm, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
-            lds_order();
         }
         __syncthreads(); // (the heights written above are read by other waves of this work-group below)
-        // ---- 4. thread = slot of the count order ----
-        my_cell = (int)perm[tid];
-        const uint32_t np = ctot[my_cell];
-        raw = (float)craw[my_cell];
-        const zquad *zq = reinterpret_cast<const zquad *>(zc + cseg[my_cell]);
-        zquad q0 = {{0.0f, 0.0f, 0.0f, 0.0f}}, q1 = q0;
-        if (np > 0u) q0 = zq[0];
-        if (np > 4u) q1 = zq[1];
-        for (uint32_t i = 0; i < np; i += 4u) {
-            const zquad cur = q0;
-            q0 = q1;
-            if (i + 8u < np) q1 = zq[(i >> 2) + 2u];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (i + (uint32_t)k < np) {
-                    const float z = cur.v[k];
-                    // ---- src/GroundSegmentation.cpp:295-309, one KEPT point, `c` = points before it ----
-                    const float planeDist = z - oz;                                  // :295
-                    if (FULL) gc = (z + c * gc) / (c + 1.0f);                        // :296 (see note on double rounding above)
-                    if ((double)mean == 0.0) mean = planeDist;                       // :298-299
-                    if (!isnan(planeDist)) {                                         // :300
-                        const float delta = planeDist - mean;                        // :301
-                        mean += delta / (c + 1.0f);                                  // :302
-                        if (FULL) pdm = (planeDist + c * pdm) / (c + 1.0f);          // :303
-                        m2 += delta * (planeDist - mean);                            // :304
-                    }
-                    if (FULL) mx = std_max(mx, z);  // :307
-                    mn = std_min(mn, z - 0.0001f);  // :308
-                    c = (float)((double)c + 1.0);   // :309
-                }
+        if (a.k2_debug == 3) return;
+        // ---- 4. recurrences, cells handed out in the count order ----
+        auto put_shared = [&](int cell) { // points, pointsRaw
+            ex[0 * TILE_CELLS + cell] = (float)ctot[cell];
+            ex[3 * TILE_CELLS + cell] = (float)craw[cell];
+        };
+        const bool split = FULL && (wave_full[0] | wave_full[1] | wave_full[2] | wave_full[3]) != 0u; // (uniform)
+        if (!split) {
+            const int cell = (int)perm[tid];
+            CellState st = reset;
+            run_cells<FULL ? (R_MEAN | R_GC | R_PDM | R_MN) : (R_MEAN | R_MN)>(zc + cseg[cell], ctot[cell], oz, st);
+            put_shared(cell);
+            ex[1 * TILE_CELLS + cell] = st.mn;
+            ex[2 * TILE_CELLS + cell] = st.m2;
+            ex[4 * TILE_CELLS + cell] = st.mean;
+            ex[5 * TILE_CELLS + cell] = st.mx; // (minimal layers: these three keep their reset values)
+            ex[6 * TILE_CELLS + cell] = st.gc;
+            ex[7 * TILE_CELLS + cell] = st.pdm;
+        } else if (wave < 3) {
+            // the 64 fullest cells: one chain per wave, so that the tile's longest cell costs a third of the dependent
+            // instructions per point; the fourth wave runs the other 192 (much emptier) cells meanwhile
+            const int cell = (int)perm[lane];
+            CellState st = reset;
+            const float *zseg = zc + cseg[cell];
+            const uint32_t np = ctot[cell];
+            if (wave == 0) {
+                run_cells<R_MEAN>(zseg, np, oz, st);
+                put_shared(cell);
+                ex[2 * TILE_CELLS + cell] = st.m2;
+                ex[4 * TILE_CELLS + cell] = st.mean;
+            } else if (wave == 1) {
+                run_cells<R_GC>(zseg, np, oz, st);
+                ex[5 * TILE_CELLS + cell] = st.mx;
+                ex[6 * TILE_CELLS + cell] = st.gc;
+            } else {
+                run_cells<R_PDM | R_MN>(zseg, np, oz, st);
+                ex[1 * TILE_CELLS + cell] = st.mn;
+                ex[7 * TILE_CELLS + cell] = st.pdm;
+            }
+        } else {
+            for (int g = 1; g < 4; ++g) {
+                const int cell = (int)perm[g * 64 + lane];
+                CellState st = reset;
+                run_cells<R_MEAN | R_GC | R_PDM | R_MN>(zc + cseg[cell], ctot[cell], oz, st);
+                put_shared(cell);
+                ex[1 * TILE_CELLS + cell] = st.mn;
+                ex[2 * TILE_CELLS + cell] = st.m2;
+                ex[4 * TILE_CELLS + cell] = st.mean;
+                ex[5 * TILE_CELLS + cell] = st.mx;
+                ex[6 * TILE_CELLS + cell] = st.gc;
+                ex[7 * TILE_CELLS + cell] = st.pdm;
             }
         }
+    } else {
+        ex[0 * TILE_CELLS + tid] = 0.0f;
+        ex[1 * TILE_CELLS + tid] = reset.mn;
+        ex[2 * TILE_CELLS + tid] = 0.0f;
+        ex[3 * TILE_CELLS + tid] = 0.0f;
+        ex[4 * TILE_CELLS + tid] = 0.0f;
+        ex[5 * TILE_CELLS + tid] = reset.mx;
+        ex[6 * TILE_CELLS + tid] = 0.0f;
+        ex[7 * TILE_CELLS + tid] = 0.0f;
     }
 
     // ---- 5. back to thread = cell, write the per-call layers ----
-    float *ex = reinterpret_cast<float *>(&cnt64[0][0]); // (8 KiB; the counters were last read in step 2, two barriers ago)
-    ex[0 * TILE_CELLS + my_cell] = c;
-    ex[1 * TILE_CELLS + my_cell] = mn;
-    ex[2 * TILE_CELLS + my_cell] = m2;
-    ex[3 * TILE_CELLS + my_cell] = raw;
-    ex[4 * TILE_CELLS + my_cell] = mean;
-    ex[5 * TILE_CELLS + my_cell] = mx; // (minimal layers: these three keep their reset values)
-    ex[6 * TILE_CELLS + my_cell] = gc;
-    ex[7 * TILE_CELLS + my_cell] = pdm;
     __syncthreads();
     if (tid == 0) tile_live[rank] = start != end;
     const int row = tr * TILE + (tid & 15), col = tc * TILE + (tid >> 4);
