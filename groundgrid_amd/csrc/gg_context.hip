@@ -487,6 +487,9 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_tstart = carve((size_t)n_slots * a.tile_start_stride * 4);
     a.tile_live_stride = align_up((size_t)g.T, A);
     const size_t o_tlive = carve((size_t)n_slots * a.tile_live_stride);
+    a.tile_list_stride = align_up((size_t)g.T * 2, A) / 2;
+    const size_t o_tlist = carve((size_t)n_slots * a.tile_list_stride * 2);
+    const size_t o_tlcnt = carve((size_t)n_slots * 2 * 4);
     const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
     const size_t o_spts = carve(max_points * sizeof(gg_point16));
     const size_t o_slab = carve(max_points);
@@ -504,7 +507,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_scroll = carve(a.gp2_stride * 8); // one layer in its device element order (map scroll) / two planes (images)
     const size_t o_image = carve(3 * Cpad * 4);
     const size_t o_bounds = carve(64);
-    const size_t o_dbg = carve(16 * 4 * 8);
+    const size_t o_dbg = carve(2 * 64 * 8); // [0, 64): sweep timing, [64, 128): k_reduce phases
     ctx->arena_bytes = off;
     CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
     char *base = (char *)ctx->d_arena;
@@ -526,8 +529,11 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.totals = (uint32_t *)(base + o_totals);
     a.tile_start = (uint32_t *)(base + o_tstart);
     a.tile_live = (uint8_t *)(base + o_tlive);
+    a.tile_list = (uint16_t *)(base + o_tlist);
+    a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
     a.flags = 0;
     a.k2_debug = getenv("GG_K2_DEBUG") ? atoi(getenv("GG_K2_DEBUG")) : 0;
+    a.k2_dbg = (unsigned long long *)(base + o_dbg) + 64;
     ctx->d_params = (CloudParams *)(base + o_params);
     ctx->d_stage_pts = (gg_point16 *)(base + o_spts);
     ctx->d_stage_labels = (uint8_t *)(base + o_slab);
@@ -1105,6 +1111,16 @@ extern "C" int gg_debug_sweep_timing(gg_context *ctx, unsigned long long out[64]
 {
     if (!ctx || !out || !ctx->d_sweep_dbg) return GG_ERR_INVALID;
     if (hipMemcpy(out, ctx->d_sweep_dbg, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
+    return GG_OK;
+}
+
+// tools only: k_reduce's per-phase cycle sums (GG_K2_DEBUG=9); reset != 0 clears them
+extern "C" int gg_debug_k2_phases(gg_context *ctx, unsigned long long out[64], int reset)
+{
+    if (!ctx || !out || ctx->arena.k2_debug != 9) return GG_ERR_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return GG_ERR_HIP;
+    if (hipMemcpy(out, ctx->arena.k2_dbg, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
+    if (reset && hipMemset(ctx->arena.k2_dbg, 0, 64 * 8) != hipSuccess) return GG_ERR_HIP;
     return GG_OK;
 }
 

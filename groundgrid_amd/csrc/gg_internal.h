@@ -21,6 +21,7 @@ namespace gg {
 constexpr int TILE = 16;             // cells per tile edge (K2 work-group = one tile, one thread per cell)
 constexpr int TILE_CELLS = TILE * TILE;
 constexpr uint32_t KEY_OUTSIDE = 0xFFFFFFFFu;
+constexpr int K2_LIGHT_MAX = 512; // tiles with at most this many records are reduced by a single wavefront (k2_reduce.hip)
 // key = tile_rank << 12 | emit << 10 | class << 8 | cell_in_tile (row_in_tile | col_in_tile << 4)
 constexpr int KEY_TILE_SHIFT = 12;
 constexpr uint32_t KEY_EMIT_BIT = 1u << 10;
@@ -91,10 +92,14 @@ struct Arena {
     uint8_t *tile_live;    size_t tile_live_stride;  // [slot][T] by Morton rank: 1 = the tile's nine per-call layers may hold
                                                      // something else than the per-call reset values (:61-75), i.e. K2 has to
                                                      // rewrite the tile even if this cloud leaves it empty
+    uint16_t *tile_list;   size_t tile_list_stride;  // [slot][T] Morton ranks: K2's light tiles from the front, dense tiles from the back (k_scan)
+    uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)
     unsigned flags;
-    int k2_debug;        // env GG_K2_DEBUG (measurement only): 1 = k_reduce stops after the tile lookup, 2 = after step 1, 3 = after step 3
+    int k2_debug;        // env GG_K2_DEBUG (measurement only): 1 = k_reduce stops after the tile lookup, 2 = after step 1, 3 = after step 3,
+                         // 9 = per-phase cycle counters into k2_dbg (tools/k2_phases.py)
+    unsigned long long *k2_dbg; // [64] when k2_debug == 9
     int eigen_reduction; // gg_conventions::eigen_reduction (GG_EIGEN_33 / GG_EIGEN_34_SSE): order of the 5x5 block sums in K3
 };
 

@@ -1,7 +1,9 @@
 // K2 -- insert_cloud, per-cell part (src/GroundSegmentation.cpp:282-309) fused with the per-call layer
 // reset (:61-75) and the variance layer (:323).
 //
-// One work-group per (cloud, tile), 256 threads.  The tile's records arrive in cloud order (stable tile sort).  The float32
+// Tiles of 16x16 cells; a tile's records arrive in cloud order (stable tile sort).  Tiles with at most K2_LIGHT_MAX records (most
+// of them) are reduced by ONE wavefront each, entirely in registers and LDS (reduce_light_tile below); the others by one
+// work-group of 256 threads per tile, as follows.  The float32
 // recurrence of a cell (:295-309) is order dependent, so the only parallelism is ACROSS cells -- and point counts per cell
 // are very uneven (most cells hold a handful of points, a few next to the sensor hundreds).  The kernel therefore separates
 // "bring every cell's heights together, in cloud order" from "run the recurrences", so that the second part can hand out
@@ -35,11 +37,14 @@
 
 #include <float.h>
 
+#include <algorithm>
+
 namespace gg {
 
 constexpr int NBIN = 64;      // count classes of step 2: 0..31 exact, then steps of 16 up to 527, then "more"
-constexpr int RCAP = 4092;    // reciprocal table: 1 / (i + 1) in binary64 for the first RCAP points of a cell (a multiple of 12)
-constexpr int WB = 8;         // 64-record windows a wave keeps in flight in steps 1 and 3
+constexpr int RCAP = 4080;    // reciprocal table: 1 / (i + 1) in binary64 for the first RCAP points of a cell (a multiple of 12 and 24)
+constexpr int WB = 8;         // 64-record windows a wave keeps in flight in step 3 (and the whole light tile)
+constexpr int WBC = 16;       // ... in step 1 (keys only)
 constexpr int SPLIT_MIN = 24; // a tile with a cell of at least this many points runs its 64 fullest cells one chain per wave
 
 struct __attribute__((packed, aligned(4))) zquad {
@@ -104,6 +109,7 @@ GG_DEV void one_point(float z, float c, float c1, double r, bool first, float oz
         // (first point: b = 1 and the product is exact)
         const float smallest = fminf(fabsf(q_gc), fminf(fabsf(q_mean), fabsf(q_pdm)));
         if (!first && __any(smallest < 0x1p-100f)) { // (rare; uniform branch)
+            __asm__ volatile("; IEEE quotients" ::: "memory"); // (keeps this a branch: if-converted, the divisions would run for every point)
             if (R & R_GC) q_gc = a_gc / c1;
             if (R & R_MEAN) q_mean = delta / c1;
             if (R & R_PDM) q_pdm = a_pdm / c1;
@@ -126,7 +132,7 @@ GG_DEV void one_point(float z, float c, float c1, double r, bool first, float oz
 // The reference's recurrence (:295-309) of the lane's cell over its `np` heights at `zseg` (cloud order), restricted to
 // the chains in R.  The chains only share the point count, and every cell starts the call at count 0 (:61-75), so point i
 // of every lane has c = i: wave-uniform, and 1 / (c + 1) comes from a table through the scalar cache.
-template <int R>
+template <int R, int NB>
 GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s)
 {
     const zquad *zq = reinterpret_cast<const zquad *>(zseg);
@@ -134,11 +140,15 @@ GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
     nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
-    // three 16-byte batches per lane in flight, each refilled right after its four points (no register rotation: a copy
-    // of a load's destination would wait for the load; unconditional loads at a clamped index: no branch around them)
+    // NB 16-byte batches per lane in flight, each refilled right after its four points (no register rotation: a copy of a
+    // load's destination would wait for the load; unconditional loads at a clamped index: no branch around them).  The
+    // heights come back from L2 (this work-group wrote them a moment ago): about 2000 cycles under load, i.e. 16 points of
+    // a single chain -- NB = 6 for those, 3 for the full recurrence.
     const zquad zero = {{0.0f, 0.0f, 0.0f, 0.0f}};
     const uint32_t qlast = np ? (np - 1u) >> 2 : 0u; // (an empty cell reads 16 bytes of the tile's padded region)
-    zquad qa = zq[0], qb = zq[min(1u, qlast)], qc = zq[min(2u, qlast)];
+    zquad q[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) q[b] = zq[min((uint32_t)b, qlast)];
     float c = 0.0f; // points before the current one (:309: (float)((double)c + 1.0) == c + 1.0f for integers below 2^24)
     const uint32_t ntab = min(nmax, (uint32_t)RCAP);
     auto four_points = [&](const zquad &cur, uint32_t i) {
@@ -154,15 +164,13 @@ GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s)
             c = c1;
         }
     };
-    for (uint32_t i = 0; i < ntab; i += 12u) { // (RCAP is a multiple of 12)
-        four_points(qa, i);
-        qa = zq[min((i >> 2) + 3u, qlast)];
-        if (i + 4u >= ntab) break;
-        four_points(qb, i + 4u);
-        qb = zq[min((i >> 2) + 4u, qlast)];
-        if (i + 8u >= ntab) break;
-        four_points(qc, i + 8u);
-        qc = zq[min((i >> 2) + 5u, qlast)];
+    for (uint32_t i = 0; i < ntab; i += 4u * NB) { // (RCAP is a multiple of 4 NB)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b > 0 && i + 4u * (uint32_t)b >= ntab) break;
+            four_points(q[b], i + 4u * (uint32_t)b);
+            q[b] = zq[min((i >> 2) + (uint32_t)(NB + b), qlast)];
+        }
     }
     for (uint32_t i = (uint32_t)RCAP; i < nmax; i += 4u) { // cells with more than RCAP points: IEEE reciprocal per point
         zquad cur = zero;
@@ -177,250 +185,474 @@ GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s)
     }
 }
 
-template <bool FULL>
-__global__ __launch_bounds__(256) void k_reduce(const Arena a, const CloudParams *__restrict__ params)
+// Shared memory of one work-group, carved by hand: the dense path uses it as one 256-cell tile, the light path as
+// four independent wavefront-sized tiles.
+struct DenseLds {
+    unsigned long long cnt64[4][TILE_CELLS];  // 8 KiB  [wave][cell]: low 32 bits = in-map records, high 32 = KEPT records of the
+                                              //        wave's quarter; later the result exchange [layer value][cell]
+    union {
+        unsigned long long wmask[4][TILE_CELLS]; // 8 KiB  lane mask of the window's KEPT records per cell (step 3)
+        struct {                                 //        after step 3: what step 4 needs to know about every cell
+            uint32_t cseg[TILE_CELLS], ctot[TILE_CELLS], craw[TILE_CELLS];
+            uint16_t perm[TILE_CELLS];           //        slot of the count order -> cell
+        };
+    };
+    uint32_t woffs[4][TILE_CELLS];            // 4 KiB  next free position of (wave, cell) in the tile's zcell region
+    uint32_t bin_cnt[NBIN], bin_start[NBIN];
+    uint32_t wave_tot[4], wave_full[4];
+};
+struct LightLds {                             // per wavefront
+    unsigned long long cnt64[TILE_CELLS];     // 2 KiB  counters of step 1; then the heights grouped by cell (float[512])
+    unsigned long long wmask[TILE_CELLS];     // 2 KiB
+    uint32_t woffs[TILE_CELLS];               // 1 KiB
+};
+union ReduceLds {
+    DenseLds dense;
+    LightLds light[4];
+};
+
+// the 9 per-call layers of one cell
+GG_DEV void write_cell(const Arena &a, float *L, int row, int col, float c, float raw, const CellState &st)
 {
-    // [wave][cell]: low 32 bits = in-map records, high 32 bits = KEPT records of the wave's quarter; later the result exchange
-    __shared__ unsigned long long cnt64[4][TILE_CELLS];  // 8 KiB
-    __shared__ unsigned long long wmask[4][TILE_CELLS];  // 8 KiB  lane mask of the window's KEPT records per cell (step 3)
-    __shared__ uint32_t woffs[4][TILE_CELLS];            // 4 KiB  next free position of (wave, cell) in the tile's zcell region
-    __shared__ uint32_t cseg[TILE_CELLS], ctot[TILE_CELLS], craw[TILE_CELLS];
-    __shared__ uint16_t perm[TILE_CELLS];                // slot of the count order -> cell
-    __shared__ uint32_t bin_cnt[NBIN], bin_start[NBIN];
-    __shared__ uint32_t wave_tot[4], wave_full[4];
+    if (row < a.g.rows && col < a.g.cols) {
+        const size_t idx = (size_t)row + (size_t)col * a.g.rows;
+        const size_t ls = a.layer_stride;
+        L[GG_LAYER_POINTS * ls + idx] = c;
+        L[GG_LAYER_MINGROUNDHEIGHT * ls + idx] = st.mn;
+        L[GG_LAYER_M2 * ls + idx] = st.m2;
+        L[GG_LAYER_VARIANCE * ls + idx] = st.m2 / (c + FLT_MIN); // :323
+        L[GG_LAYER_POINTSRAW * ls + idx] = raw;
+        L[GG_LAYER_MEANVARIANCE * ls + idx] = st.mean;
+        L[GG_LAYER_MAXGROUNDHEIGHT * ls + idx] = st.mx; // (minimal layers: these three keep their reset values)
+        L[GG_LAYER_GROUNDCANDIDATES * ls + idx] = st.gc;
+        L[GG_LAYER_PLANEDIST * ls + idx] = st.pdm;
+    }
+}
 
-    // (cloud, tile rank) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD,
-    // in Morton order, so vertically adjacent tiles complete each other's 128-byte layer lines in the same L2
-    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
-    const int cloud = (int)(item / gridDim.x);
-    const CloudParams cp = params[cloud];
-    const int rank = (int)(item % gridDim.x);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int tile = a.rank_tile[rank];
-    const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
+// ---- light tiles: one wavefront per tile, no barrier, nothing leaves LDS but the layers --------------------------------------
+// At most K2_LIGHT_MAX = 8 x 64 records: the wave holds them all in registers.  Lane l owns cells l, l + 64, l + 128, l + 192
+// (4 columns x 16 rows per store instruction: 64-byte row segments, as in the dense path).  A wave walks its share of the
+// cloud's light list and keeps the next tile's loads in flight: its rank two tiles ahead, its record range one tile ahead,
+// its records while the current tile's recurrences run.
+GG_DEV void load_light_records(uint2 (&rw)[WB], const uint2 *sorted, uint32_t start, uint32_t end, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+        const uint32_t p = start + 64u * (uint32_t)j + (uint32_t)lane;
+        rw[j] = make_uint2(0u, KEY_OUTSIDE);
+        if (p < end) rw[j] = sorted[p];
+    }
+}
 
+template <bool FULL>
+GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint16_t *tile_list, int n_light, int first, int stride, LightLds &lds)
+{
+    if (first >= n_light) return;
     const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
-    const uint32_t start = tile_start[rank], end = tile_start[rank + 1];
-    // More than half of the tiles of a sensor cloud receive no point at all, and a tile that received none in the previous
-    // cloud either already holds the per-call reset values (:61-75: they were written when it last went empty): nothing to
-    // do.  tile_live[rank] = "the tile's per-call layers may hold something else" (set by the cloud that put points there, by
-    // gg_reset_map and by host writes).  Exact: every layer in HBM holds at all times what the reference's would.
+    const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
+    float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
     uint8_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
-    if (start == end && !tile_live[rank]) return; // (uniform)
-    if (a.k2_debug == 1) return;
+    const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX};
     const float oz = cp.oz;
+    const bool timing = a.k2_debug == 9;
+    constexpr int RL = FULL ? (R_MEAN | R_GC | R_PDM | R_MN) : (R_MEAN | R_MN);
 
-    // result exchange, [layer value][cell] (8 KiB over the counters of step 1, last read in step 2)
-    float *ex = reinterpret_cast<float *>(&cnt64[0][0]);
-    const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX}; // the layer values after :61-75 (max: numeric_limits<float>::min(), sic, :73)
-
-    if (start != end) { // (uniform) tiles without any point only write the reset values below
-        const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
-        // the tile's region of zcell starts on its own 64-byte line (a work-group reads back only lines it wrote itself)
-        float *zc = a.zcell + (size_t)cp.slot * a.zcell_stride + (size_t)((start + 15u) & ~15u) + (size_t)rank * 32u;
-        const uint32_t n = end - start;
-        const uint32_t Q = ((n + 255u) >> 8) << 6; // records per wave: a multiple of the window
-        const uint32_t qs = start + (uint32_t)wave * Q, qe = min(qs + Q, end);
-
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cnt64[wave][lane + 64 * k] = 0ull;
-            wmask[wave][lane + 64 * k] = 0ull;
+    int rank = (int)tile_list[first];
+    int rank_next = first + stride < n_light ? (int)tile_list[first + stride] : -1;
+    uint32_t start = tile_start[rank], end = tile_start[rank + 1];
+    uint2 rw[WB];
+    load_light_records(rw, sorted, start, end, (int)(threadIdx.x & 63));
+    for (int j = first; j < n_light; j += stride) {
+        int lane = threadIdx.x & 63;
+        __asm__ volatile("" : "+v"(lane)); // (per tile: keeps the lane's address arithmetic out of long-lived registers)
+        const unsigned long long t_begin = timing ? __builtin_readcyclecounter() : 0ull;
+        uint32_t next_start = 0u, next_end = 0u;
+        if (rank_next >= 0) {
+            next_start = tile_start[rank_next];
+            next_end = tile_start[rank_next + 1];
         }
-        if (tid < NBIN) bin_cnt[tid] = 0u;
-        lds_order();
-        // ---- 1. count ----  (WB windows of records in flight per wave: the loop is otherwise one memory latency per window)
-        for (uint32_t p0 = qs; p0 < qe; p0 += 64u * WB) {
-            uint32_t key[WB];
+        const int rank_after = j + 2 * stride < n_light ? (int)tile_list[j + 2 * stride] : -1;
+        const int tile = a.rank_tile[rank];
+        const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
+        if (lane == 0) tile_live[rank] = start != end;
+        uint32_t lane_base = 0u;
+        if (start != end) {
 #pragma unroll
-            for (int j = 0; j < WB; ++j) {
-                const uint32_t p = p0 + 64u * (uint32_t)j + (uint32_t)lane;
-                key[j] = KEY_OUTSIDE;
-                if (p < qe) key[j] = sorted[p].y;
+            for (int k = 0; k < 4; ++k) {
+                lds.cnt64[lane + 64 * k] = 0ull;
+                lds.wmask[lane + 64 * k] = 0ull;
             }
+            // 1. count
 #pragma unroll
-            for (int j = 0; j < WB; ++j) {
-                if (key[j] != KEY_OUTSIDE) {
-                    const unsigned long long kept = ((key[j] >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT ? 1ull : 0ull;
-                    atomicAdd(&cnt64[wave][key[j] & 255u], 1ull | (kept << 32));
+            for (int w = 0; w < WB; ++w) {
+                if (rw[w].y != KEY_OUTSIDE) {
+                    const unsigned long long kept = ((rw[w].y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT ? 1ull : 0ull;
+                    __hip_atomic_fetch_add(&lds.cnt64[rw[w].y & 255u], 1ull | (kept << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-        }
-        __syncthreads();
-        if (a.k2_debug == 2) return;
-        // ---- 2. thread = cell: totals, segment, the waves' shares, count class ----
-        uint32_t kw[4], tot = 0u, rawc = 0u;
+            // 2. the lane's four cells are consecutive segments of the wave's 512 heights
+            uint32_t tot[4], rawc[4], t4 = 0u;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned long long v = cnt64[w][tid];
-            kw[w] = (uint32_t)(v >> 32);
-            tot += kw[w];
-            rawc += (uint32_t)v;
-        }
-        const uint32_t bin = tot < 32u ? tot : min((uint32_t)NBIN - 1u, 32u + ((tot - 32u) >> 4));
-        const uint32_t in_bin = atomicAdd(&bin_cnt[bin], 1u);
-        uint32_t inc = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) wave_tot[wave] = inc;
-        const bool any_full = __any(tot >= (uint32_t)SPLIT_MIN);
-        if (lane == 0) wave_full[wave] = any_full ? 1u : 0u;
-        __syncthreads();
-        if (wave == 3) { // start of every count class in the descending order
-            const uint32_t h = bin_cnt[NBIN - 1 - lane];
-            uint32_t hs = h;
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long v = __hip_atomic_load(&lds.cnt64[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                tot[k] = (uint32_t)(v >> 32);
+                rawc[k] = (uint32_t)v;
+                t4 += tot[k];
+            }
+            uint32_t inc = t4;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(hs, d, 64);
-                if (lane >= d) hs += o;
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
             }
-            bin_start[NBIN - 1 - lane] = hs - h;
-        }
-        uint32_t seg = inc - tot;
+            lane_base = inc - t4;
+            {
+                // woffs[cell] = next free position (low 16 bits, at most 512) | pointsRaw of the cell << 16
+                uint32_t run = lane_base;
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
-            if (w < wave) seg += wave_tot[w];
-        cseg[tid] = seg;
-        ctot[tid] = tot;
-        craw[tid] = rawc;
-        {
-            uint32_t run = seg;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                woffs[w][tid] = run;
-                run += kw[w];
+                for (int k = 0; k < 4; ++k) {
+                    lds.woffs[lane + 64 * k] = run | (rawc[k] << 16);
+                    run += tot[k];
+                }
             }
-        }
-        __syncthreads();
-        perm[bin_start[bin] + in_bin] = (uint16_t)tid;
-        // ---- 3. place: stable counting sort of the KEPT heights by cell ----
-        for (uint32_t p0 = qs; p0 < qe; p0 += 64u * WB) {
-            uint2 rw[WB];
+            // 3. place (the heights take over the counters' memory: every lane has read its counters above, and the LDS
+            //    operations of one wave execute in order)
+            float *zs = reinterpret_cast<float *>(&lds.cnt64[0]);
+            lds_order();
 #pragma unroll
-            for (int j = 0; j < WB; ++j) {
-                const uint32_t p = p0 + 64u * (uint32_t)j + (uint32_t)lane;
-                rw[j] = make_uint2(0u, KEY_OUTSIDE);
-                if (p < qe) rw[j] = sorted[p];
-            }
-#pragma unroll
-            for (int j = 0; j < WB; ++j) { // window by window, in cloud order
-                const uint2 r = rw[j];
+            for (int w = 0; w < WB; ++w) {
+                const uint2 r = rw[w];
                 const bool kept = r.y != KEY_OUTSIDE && ((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT;
-                const uint32_t cit = r.y & 255u;
-                // (relaxed work-group scope atomics on LDS: plain ds_or / ds_read / ds_write, kept in program order per
-                // address; `volatile` would make the compiler drain the vector memory queue after every access)
-                unsigned long long *wm = &wmask[wave][cit];
-                uint32_t *wo = &woffs[wave][cit];
                 if (kept) {
+                    unsigned long long *wm = &lds.wmask[r.y & 255u];
+                    uint32_t *wo = &lds.woffs[r.y & 255u];
                     __hip_atomic_fetch_or(wm, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const unsigned long long mm = __hip_atomic_load(wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // the window's records of this cell
+                    const unsigned long long mm = __hip_atomic_load(wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const uint32_t base = __hip_atomic_load(wo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    zc[base + (uint32_t)rank_below(mm)] = __uint_as_float(r.x);
-                    if ((mm >> lane) == 1ull) { // the cell's last record of the window advances the cell for the next one
+                    zs[(base & 0xFFFFu) + (uint32_t)rank_below(mm)] = __uint_as_float(r.x);
+                    if ((mm >> lane) == 1ull) {
                         __hip_atomic_store(wo, base + (uint32_t)__popcll(mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_store(wm, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
+            lds_order();
         }
-        __syncthreads(); // (the heights written above are read by other waves of this work-group below)
-        if (a.k2_debug == 3) return;
-        // ---- 4. recurrences, cells handed out in the count order ----
-        auto put_shared = [&](int cell) { // points, pointsRaw
-            ex[0 * TILE_CELLS + cell] = (float)ctot[cell];
-            ex[3 * TILE_CELLS + cell] = (float)craw[cell];
-        };
-        const bool split = FULL && (wave_full[0] | wave_full[1] | wave_full[2] | wave_full[3]) != 0u; // (uniform)
-        if (!split) {
-            const int cell = (int)perm[tid];
+        // the next tile's records travel while this tile's recurrences run
+        const bool had_points = start != end;
+        load_light_records(rw, sorted, next_start, next_end, lane);
+        if (had_points) {
+            // 4. + 5. the four cells of the lane, one after the other; point i of every lane's cell has c = i
+            const float *zs = reinterpret_cast<const float *>(&lds.cnt64[0]);
+            uint32_t seg = lane_base; // (the lane's cells are consecutive segments; after step 3 woffs holds each segment's end)
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                CellState st = reset;
+                float c = 0.0f;
+                const uint32_t wv = __hip_atomic_load(&lds.woffs[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t seg_end = wv & 0xFFFFu;
+                const uint32_t np = seg_end - seg;
+                for (uint32_t i = 0; __any(i < np); i += 4u) { // (uniform; at most K2_LIGHT_MAX < RCAP points)
+                    double rr[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rr[q] = recip_table.v[i + (uint32_t)q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t ii = i + (uint32_t)q;
+                        const float c1 = c + 1.0f;
+                        if (ii < np) one_point<RL>(zs[seg + ii], c, c1, rr[q], ii == 0u, oz, st);
+                        c = c1;
+                    }
+                }
+                const int cell = lane + 64 * k;
+                write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), (float)np, (float)(wv >> 16), st);
+                seg = seg_end;
+            }
+            lds_order(); // (the next tile reuses the memory)
+        } else { // only the per-call reset (:61-75) of a tile that held points before
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cell = lane + 64 * k;
+                write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), 0.0f, 0.0f, reset);
+            }
+        }
+        if (timing && lane == 0) {
+            atomicAdd(&a.k2_dbg[had_points ? 8 : 12], 1ull);
+            atomicAdd(&a.k2_dbg[had_points ? 9 : 14], (unsigned long long)(end - start));
+            atomicAdd(&a.k2_dbg[had_points ? 10 : 13], __builtin_readcyclecounter() - t_begin);
+        }
+        rank = rank_next;
+        rank_next = rank_after;
+        start = next_start;
+        end = next_end;
+    }
+}
+
+// ---- dense tiles: one work-group per tile -----------------------------------------------------------------------------------
+template <bool FULL>
+GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, DenseLds &lds, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tile = a.rank_tile[rank];
+    const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
+    const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
+    const uint32_t start = tile_start[rank], end = tile_start[rank + 1];
+    const float oz = cp.oz;
+    float *ex = reinterpret_cast<float *>(&lds.cnt64[0][0]); // result exchange, [layer value][cell] (8 KiB over the counters of step 1)
+    const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX}; // the layer values after :61-75 (max: numeric_limits<float>::min(), sic, :73)
+
+    const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
+    // the tile's region of zcell starts on its own 64-byte line (a work-group reads back only lines it wrote itself)
+    float *zc = a.zcell + (size_t)cp.slot * a.zcell_stride + (size_t)((start + 15u) & ~15u) + (size_t)rank * 32u;
+    const uint32_t n = end - start;
+    const bool timing = a.k2_debug == 9;
+    unsigned long long tmark[6] = {0, 0, 0, 0, 0, 0};
+    if (timing) tmark[0] = __builtin_readcyclecounter();
+    const uint32_t Q = ((n + 255u) >> 8) << 6; // records per wave: a multiple of the window
+    const uint32_t qs = start + (uint32_t)wave * Q, qe = min(qs + Q, end);
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lds.cnt64[wave][lane + 64 * k] = 0ull;
+        lds.wmask[wave][lane + 64 * k] = 0ull;
+    }
+    if (tid < NBIN) lds.bin_cnt[tid] = 0u;
+    lds_order();
+    // ---- 1. count ----  (WB windows of records in flight per wave: the loop is otherwise one memory latency per window)
+    for (uint32_t p0 = qs; p0 < qe; p0 += 64u * WBC) {
+        uint32_t key[WBC];
+#pragma unroll
+        for (int j = 0; j < WBC; ++j) {
+            const uint32_t p = p0 + 64u * (uint32_t)j + (uint32_t)lane;
+            key[j] = KEY_OUTSIDE;
+            if (p < qe) key[j] = sorted[p].y;
+        }
+#pragma unroll
+        for (int j = 0; j < WBC; ++j) {
+            if (key[j] != KEY_OUTSIDE) {
+                const unsigned long long kept = ((key[j] >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT ? 1ull : 0ull;
+                atomicAdd(&lds.cnt64[wave][key[j] & 255u], 1ull | (kept << 32));
+            }
+        }
+    }
+    __syncthreads();
+    if (timing) tmark[1] = __builtin_readcyclecounter();
+    if (a.k2_debug == 2) return;
+    // ---- 2. thread = cell: totals, segment, the waves' shares, count class ----
+    uint32_t kw[4], tot = 0u, rawc = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned long long v = lds.cnt64[w][tid];
+        kw[w] = (uint32_t)(v >> 32);
+        tot += kw[w];
+        rawc += (uint32_t)v;
+    }
+    const uint32_t bin = tot < 32u ? tot : min((uint32_t)NBIN - 1u, 32u + ((tot - 32u) >> 4));
+    const uint32_t in_bin = atomicAdd(&lds.bin_cnt[bin], 1u);
+    uint32_t inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) lds.wave_tot[wave] = inc;
+    const bool any_full = __any(tot >= (uint32_t)SPLIT_MIN);
+    if (lane == 0) lds.wave_full[wave] = any_full ? 1u : 0u;
+    __syncthreads();
+    if (wave == 3) { // start of every count class in the descending order
+        const uint32_t h = lds.bin_cnt[NBIN - 1 - lane];
+        uint32_t hs = h;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(hs, d, 64);
+            if (lane >= d) hs += o;
+        }
+        lds.bin_start[NBIN - 1 - lane] = hs - h;
+    }
+    uint32_t seg = inc - tot;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+        if (w < wave) seg += lds.wave_tot[w];
+    {
+        uint32_t run = seg;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            lds.woffs[w][tid] = run;
+            run += kw[w];
+        }
+    }
+    __syncthreads();
+    if (timing) tmark[2] = __builtin_readcyclecounter();
+    const uint32_t slot_of_cell = lds.bin_start[bin] + in_bin;
+    // ---- 3. place: stable counting sort of the KEPT heights by cell ----
+    for (uint32_t p0 = qs; p0 < qe; p0 += 64u * WB) {
+        uint2 rw[WB];
+#pragma unroll
+        for (int j = 0; j < WB; ++j) {
+            const uint32_t p = p0 + 64u * (uint32_t)j + (uint32_t)lane;
+            rw[j] = make_uint2(0u, KEY_OUTSIDE);
+            if (p < qe) rw[j] = sorted[p];
+        }
+#pragma unroll
+        for (int j = 0; j < WB; ++j) { // window by window, in cloud order
+            const uint2 r = rw[j];
+            const bool kept = r.y != KEY_OUTSIDE && ((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT;
+            const uint32_t cit = r.y & 255u;
+            // (relaxed work-group scope atomics on LDS: plain ds_or / ds_read / ds_write, kept in program order per
+            // address; `volatile` would make the compiler drain the vector memory queue after every access)
+            unsigned long long *wm = &lds.wmask[wave][cit];
+            uint32_t *wo = &lds.woffs[wave][cit];
+            if (kept) {
+                __hip_atomic_fetch_or(wm, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long mm = __hip_atomic_load(wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // the window's records of this cell
+                const uint32_t base = __hip_atomic_load(wo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                zc[base + (uint32_t)rank_below(mm)] = __uint_as_float(r.x);
+                if ((mm >> lane) == 1ull) { // the cell's last record of the window advances the cell for the next one
+                    __hip_atomic_store(wo, base + (uint32_t)__popcll(mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(wm, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+    __syncthreads(); // (the heights written above are read by other waves of this work-group below)
+    if (a.k2_debug == 3) return;
+    lds.cseg[tid] = seg; // (over the lane masks, which are all zero again)
+    lds.ctot[tid] = tot;
+    lds.craw[tid] = rawc;
+    lds.perm[slot_of_cell] = (uint16_t)tid;
+    __syncthreads();
+    if (timing) tmark[3] = __builtin_readcyclecounter();
+    // ---- 4. recurrences, cells handed out in the count order ----
+    auto put_shared = [&](int cell) { // points, pointsRaw
+        ex[0 * TILE_CELLS + cell] = (float)lds.ctot[cell];
+        ex[3 * TILE_CELLS + cell] = (float)lds.craw[cell];
+    };
+    const bool split = FULL && (lds.wave_full[0] | lds.wave_full[1] | lds.wave_full[2] | lds.wave_full[3]) != 0u; // (uniform)
+    if (!split) {
+        const int cell = (int)lds.perm[tid];
+        CellState st = reset;
+        run_cells<FULL ? (R_MEAN | R_GC | R_PDM | R_MN) : (R_MEAN | R_MN), 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st);
+        put_shared(cell);
+        ex[1 * TILE_CELLS + cell] = st.mn;
+        ex[2 * TILE_CELLS + cell] = st.m2;
+        ex[4 * TILE_CELLS + cell] = st.mean;
+        ex[5 * TILE_CELLS + cell] = st.mx; // (minimal layers: these three keep their reset values)
+        ex[6 * TILE_CELLS + cell] = st.gc;
+        ex[7 * TILE_CELLS + cell] = st.pdm;
+    } else if (wave < 3) {
+        // the 64 fullest cells: one chain per wave, so that the tile's longest cell costs a third of the dependent
+        // instructions per point; the fourth wave runs the other 192 (much emptier) cells meanwhile
+        const int cell = (int)lds.perm[lane];
+        CellState st = reset;
+        const float *zseg = zc + lds.cseg[cell];
+        const uint32_t np = lds.ctot[cell];
+        if (wave == 0) {
+            run_cells<R_MEAN, 6>(zseg, np, oz, st);
+            put_shared(cell);
+            ex[2 * TILE_CELLS + cell] = st.m2;
+            ex[4 * TILE_CELLS + cell] = st.mean;
+        } else if (wave == 1) {
+            run_cells<R_GC, 6>(zseg, np, oz, st);
+            ex[5 * TILE_CELLS + cell] = st.mx;
+            ex[6 * TILE_CELLS + cell] = st.gc;
+        } else {
+            run_cells<R_PDM | R_MN, 6>(zseg, np, oz, st);
+            ex[1 * TILE_CELLS + cell] = st.mn;
+            ex[7 * TILE_CELLS + cell] = st.pdm;
+        }
+    } else {
+        for (int g = 1; g < 4; ++g) {
+            const int cell = (int)lds.perm[g * 64 + lane];
             CellState st = reset;
-            run_cells<FULL ? (R_MEAN | R_GC | R_PDM | R_MN) : (R_MEAN | R_MN)>(zc + cseg[cell], ctot[cell], oz, st);
+            run_cells<R_MEAN | R_GC | R_PDM | R_MN, 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st);
             put_shared(cell);
             ex[1 * TILE_CELLS + cell] = st.mn;
             ex[2 * TILE_CELLS + cell] = st.m2;
             ex[4 * TILE_CELLS + cell] = st.mean;
-            ex[5 * TILE_CELLS + cell] = st.mx; // (minimal layers: these three keep their reset values)
+            ex[5 * TILE_CELLS + cell] = st.mx;
             ex[6 * TILE_CELLS + cell] = st.gc;
             ex[7 * TILE_CELLS + cell] = st.pdm;
-        } else if (wave < 3) {
-            // the 64 fullest cells: one chain per wave, so that the tile's longest cell costs a third of the dependent
-            // instructions per point; the fourth wave runs the other 192 (much emptier) cells meanwhile
-            const int cell = (int)perm[lane];
-            CellState st = reset;
-            const float *zseg = zc + cseg[cell];
-            const uint32_t np = ctot[cell];
-            if (wave == 0) {
-                run_cells<R_MEAN>(zseg, np, oz, st);
-                put_shared(cell);
-                ex[2 * TILE_CELLS + cell] = st.m2;
-                ex[4 * TILE_CELLS + cell] = st.mean;
-            } else if (wave == 1) {
-                run_cells<R_GC>(zseg, np, oz, st);
-                ex[5 * TILE_CELLS + cell] = st.mx;
-                ex[6 * TILE_CELLS + cell] = st.gc;
-            } else {
-                run_cells<R_PDM | R_MN>(zseg, np, oz, st);
-                ex[1 * TILE_CELLS + cell] = st.mn;
-                ex[7 * TILE_CELLS + cell] = st.pdm;
-            }
-        } else {
-            for (int g = 1; g < 4; ++g) {
-                const int cell = (int)perm[g * 64 + lane];
-                CellState st = reset;
-                run_cells<R_MEAN | R_GC | R_PDM | R_MN>(zc + cseg[cell], ctot[cell], oz, st);
-                put_shared(cell);
-                ex[1 * TILE_CELLS + cell] = st.mn;
-                ex[2 * TILE_CELLS + cell] = st.m2;
-                ex[4 * TILE_CELLS + cell] = st.mean;
-                ex[5 * TILE_CELLS + cell] = st.mx;
-                ex[6 * TILE_CELLS + cell] = st.gc;
-                ex[7 * TILE_CELLS + cell] = st.pdm;
-            }
+        }
+    }
+    // ---- 5. back to thread = cell, write the per-call layers ----
+    if (timing && lane == 0) { // this wave's own chain time (before the barrier)
+        atomicAdd(&a.k2_dbg[16 + wave], __builtin_readcyclecounter() - tmark[3]);
+        if (split) atomicAdd(&a.k2_dbg[20 + wave], 1ull);
+    }
+    __syncthreads();
+    if (timing) tmark[4] = __builtin_readcyclecounter();
+    if (tid == 0) (a.tile_live + (size_t)cp.slot * a.tile_live_stride)[rank] = 1;
+    CellState st;
+    st.mn = ex[1 * TILE_CELLS + tid];
+    st.m2 = ex[2 * TILE_CELLS + tid];
+    st.mean = ex[4 * TILE_CELLS + tid];
+    st.mx = ex[5 * TILE_CELLS + tid];
+    st.gc = ex[6 * TILE_CELLS + tid];
+    st.pdm = ex[7 * TILE_CELLS + tid];
+    write_cell(a, a.layers + (size_t)cp.slot * a.slot_layer_stride, tr * TILE + (tid & 15), tc * TILE + (tid >> 4), ex[0 * TILE_CELLS + tid],
+               ex[3 * TILE_CELLS + tid], st);
+    if (timing && tid == 0) {
+        tmark[5] = __builtin_readcyclecounter();
+        atomicAdd(&a.k2_dbg[0], 1ull);                       // dense tiles
+        atomicAdd(&a.k2_dbg[1], (unsigned long long)n);      // their records
+        for (int k = 0; k < 5; ++k) atomicAdd(&a.k2_dbg[2 + k], tmark[k + 1] - tmark[k]); // count, scan, place, chains, write
+    }
+}
+
+// grid = (GD + GL, clouds): per cloud, GD work-groups walk the dense list (one tile per work-group at a time) and GL
+// work-groups the light list (one tile per wavefront at a time).  k_scan wrote both lists.  More than half of the tiles of
+// a sensor cloud receive no point at all; a tile that received none in the previous cloud either already holds the
+// per-call reset values (:61-75: they were written when it last went empty) and is on neither list.  tile_live[rank] =
+// "the tile's per-call layers may hold something else" (set by the cloud that put points there, by gg_reset_map and by
+// host writes).  Exact: every layer in HBM holds at all times what the reference's would.
+template <bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
+{
+    __shared__ ReduceLds lds;
+    // (cloud, group) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD, in
+    // Morton order, so vertically adjacent tiles complete each other's 128-byte layer lines in the same L2
+    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int cloud = (int)(item / gridDim.x);
+    const int group = (int)(item % gridDim.x);
+    const CloudParams cp = params[cloud];
+    const uint16_t *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
+    const uint32_t *list_cnt = a.tile_list_cnt + (size_t)cp.slot * 2;
+    if (a.k2_debug == 1) return;
+    const unsigned long long t_wg = a.k2_debug == 9 ? __builtin_readcyclecounter() : 0ull;
+    if (group < n_dense_groups) {
+        const int n_dense = (int)list_cnt[1];
+        for (int j = group; j < n_dense; j += n_dense_groups) {
+            // (the thread index is made opaque per tile: otherwise every address derived from it is computed once, before
+            // the loop, and kept in registers across the whole tile -- 30 VGPRs more)
+            int tid = threadIdx.x;
+            __asm__ volatile("" : "+v"(tid));
+            reduce_dense_tile<FULL>(a, cp, (int)tile_list[a.g.T - 1 - j], lds.dense, tid);
+            __syncthreads(); // (the next tile reuses the shared memory)
         }
     } else {
-        ex[0 * TILE_CELLS + tid] = 0.0f;
-        ex[1 * TILE_CELLS + tid] = reset.mn;
-        ex[2 * TILE_CELLS + tid] = 0.0f;
-        ex[3 * TILE_CELLS + tid] = 0.0f;
-        ex[4 * TILE_CELLS + tid] = 0.0f;
-        ex[5 * TILE_CELLS + tid] = reset.mx;
-        ex[6 * TILE_CELLS + tid] = 0.0f;
-        ex[7 * TILE_CELLS + tid] = 0.0f;
+        const int n_light = (int)list_cnt[0];
+        const int n_waves = ((int)gridDim.x - n_dense_groups) * 4;
+        const int wave = threadIdx.x >> 6;
+        reduce_light_tiles<FULL>(a, cp, tile_list, n_light, (group - n_dense_groups) * 4 + wave, n_waves, lds.light[wave]);
     }
-
-    // ---- 5. back to thread = cell, write the per-call layers ----
-    __syncthreads();
-    if (tid == 0) tile_live[rank] = start != end;
-    const int row = tr * TILE + (tid & 15), col = tc * TILE + (tid >> 4);
-    if (row < a.g.rows && col < a.g.cols) {
-        const size_t idx = (size_t)row + (size_t)col * a.g.rows;
-        float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
-        const size_t ls = a.layer_stride;
-        const float cc = ex[0 * TILE_CELLS + tid], m2c = ex[2 * TILE_CELLS + tid];
-        L[GG_LAYER_POINTS * ls + idx] = cc;
-        L[GG_LAYER_MINGROUNDHEIGHT * ls + idx] = ex[1 * TILE_CELLS + tid];
-        L[GG_LAYER_M2 * ls + idx] = m2c;
-        L[GG_LAYER_VARIANCE * ls + idx] = m2c / (cc + FLT_MIN); // :323
-        L[GG_LAYER_POINTSRAW * ls + idx] = ex[3 * TILE_CELLS + tid];
-        L[GG_LAYER_MEANVARIANCE * ls + idx] = ex[4 * TILE_CELLS + tid];
-        L[GG_LAYER_MAXGROUNDHEIGHT * ls + idx] = ex[5 * TILE_CELLS + tid];
-        L[GG_LAYER_GROUNDCANDIDATES * ls + idx] = ex[6 * TILE_CELLS + tid];
-        L[GG_LAYER_PLANEDIST * ls + idx] = ex[7 * TILE_CELLS + tid];
+    if (a.k2_debug == 9 && threadIdx.x == 0) {
+        const int k = group < n_dense_groups ? 24 : 26;
+        atomicAdd(&a.k2_dbg[k], 1ull);
+        atomicAdd(&a.k2_dbg[k + 1], __builtin_readcyclecounter() - t_wg);
     }
 }
 
 void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)
 {
     if (n_clouds == 0) return;
-    dim3 grid(a.g.T, n_clouds);
+    // about 4096 work-groups per launch (16 per CU), at least 8 + 8 per cloud, never more groups than tiles
+    const int per_cloud = std::min(std::max(4096 / n_clouds, 16), 2 * a.g.T);
+    const int gd = std::max(1, per_cloud / 2), gl = std::max(1, per_cloud - gd);
+    dim3 grid(gd + gl, n_clouds);
     if (a.flags & GG_FLAG_MINIMAL_LAYERS)
-        hipLaunchKernelGGL(k_reduce<false>, grid, dim3(256), 0, s, a, d_params);
+        hipLaunchKernelGGL(k_reduce<false>, grid, dim3(256), 0, s, a, d_params, gd);
     else
-        hipLaunchKernelGGL(k_reduce<true>, grid, dim3(256), 0, s, a, d_params);
+        hipLaunchKernelGGL(k_reduce<true>, grid, dim3(256), 0, s, a, d_params, gd);
 }
 
 } // namespace gg

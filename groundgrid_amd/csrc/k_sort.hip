@@ -3,7 +3,7 @@
 //   k_scan    : one work-group per cloud.  hist[chunk][tile] (written by K1, one row per wave-chunk)
 //               -> exclusive offsets in (tile-major, chunk-minor) order, tile_start[], and the
 //               exclusive prefixes of the per-chunk emission counters (kept / ignored / outliers)
-//               that give every point its position in the returned cloud (K5).
+//               that give every point its position in the returned cloud (K5); and K2's two work lists (light / dense tiles).
 //   k_scatter : same wave <-> chunk mapping as K1.  Each wave re-walks its chunk in cloud order and
 //               places record p at offset[tile] + (number of earlier points of the chunk in that tile):
 //               ranks inside a 64-point window come from ballots (deterministic, no atomics), so the
@@ -54,7 +54,9 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
     uint32_t *hist = a.hist + (size_t)cp.slot * a.hist_stride;
     uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
 
-    uint32_t carry = 0;
+    const uint8_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    uint16_t *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
+    uint32_t carry = 0, lcarry = 0, dcarry = 0;
     for (int t0 = 0; t0 < T; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
         uint32_t s = 0;
@@ -64,6 +66,18 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
         }
         uint32_t total;
         const uint32_t excl = block_exclusive_scan(s, lds, total);
+        {
+            // K2's work lists (k2_reduce.hip): tiles with more than K2_LIGHT_MAX records from the back of tile_list, the
+            // other tiles that need a visit (records, or per-call layers that do not hold the reset values) from the front
+            const bool dense = t < T && s > (uint32_t)K2_LIGHT_MAX;
+            const bool light = t < T && !dense && (s > 0u || tile_live[t] != 0);
+            uint32_t ltotal;
+            const uint32_t lexcl = block_exclusive_scan((light ? 1u : 0u) | (dense ? 0x10000u : 0u), lds, ltotal);
+            if (light) tile_list[lcarry + (lexcl & 0xFFFFu)] = (uint16_t)t;
+            if (dense) tile_list[(uint32_t)T - 1u - (dcarry + (lexcl >> 16))] = (uint16_t)t;
+            lcarry += ltotal & 0xFFFFu;
+            dcarry += ltotal >> 16;
+        }
         if (t < T) {
             uint32_t running = carry + excl;
             tile_start[t] = running;
@@ -76,7 +90,12 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
         }
         carry += total;
     }
-    if (threadIdx.x == 0) tile_start[T] = carry;
+    if (threadIdx.x == 0) {
+        tile_start[T] = carry;
+        uint32_t *lc = a.tile_list_cnt + (size_t)cp.slot * 2;
+        lc[0] = lcarry;
+        lc[1] = dcarry;
+    }
 
     // emission counters: exclusive prefix over chunks for each of the 4 categories
     uint32_t *ce = a.chunk_emit + (size_t)cp.slot * a.emit_stride;
