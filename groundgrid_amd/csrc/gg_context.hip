@@ -507,7 +507,10 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_scroll = carve(a.gp2_stride * 8); // one layer in its device element order (map scroll) / two planes (images)
     const size_t o_image = carve(3 * Cpad * 4);
     const size_t o_bounds = carve(64);
-    const size_t o_dbg = carve(2 * 64 * 8); // [0, 64): sweep timing, [64, 128): k_reduce phases
+    const size_t o_dbg = carve(64 * 8); // sweep timing
+    const bool k2_timing = getenv("GG_K2_DEBUG") && atoi(getenv("GG_K2_DEBUG")) == 9;
+    const size_t K2_DBG_WGS = 32768; // k_reduce phase counters, [work-group][32]
+    const size_t o_k2dbg = carve(k2_timing ? K2_DBG_WGS * 32 * 8 : 64);
     ctx->arena_bytes = off;
     CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
     char *base = (char *)ctx->d_arena;
@@ -533,7 +536,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
     a.flags = 0;
     a.k2_debug = getenv("GG_K2_DEBUG") ? atoi(getenv("GG_K2_DEBUG")) : 0;
-    a.k2_dbg = (unsigned long long *)(base + o_dbg) + 64;
+    a.k2_dbg = (unsigned long long *)(base + o_k2dbg);
     ctx->d_params = (CloudParams *)(base + o_params);
     ctx->d_stage_pts = (gg_point16 *)(base + o_spts);
     ctx->d_stage_labels = (uint8_t *)(base + o_slab);
@@ -1119,8 +1122,12 @@ extern "C" int gg_debug_k2_phases(gg_context *ctx, unsigned long long out[64], i
 {
     if (!ctx || !out || ctx->arena.k2_debug != 9) return GG_ERR_INVALID;
     if (hipDeviceSynchronize() != hipSuccess) return GG_ERR_HIP;
-    if (hipMemcpy(out, ctx->arena.k2_dbg, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
-    if (reset && hipMemset(ctx->arena.k2_dbg, 0, 64 * 8) != hipSuccess) return GG_ERR_HIP;
+    std::vector<unsigned long long> all((size_t)32768 * 32);
+    if (hipMemcpy(all.data(), ctx->arena.k2_dbg, all.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
+    for (int k = 0; k < 64; ++k) out[k] = 0;
+    for (size_t wg = 0; wg < 32768; ++wg)
+        for (int k = 0; k < 32; ++k) out[k] += all[wg * 32 + k];
+    if (reset && hipMemset(ctx->arena.k2_dbg, 0, all.size() * 8) != hipSuccess) return GG_ERR_HIP;
     return GG_OK;
 }
 

@@ -38,6 +38,7 @@
 #include <float.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace gg {
 
@@ -61,6 +62,13 @@ constexpr RecipTable make_recip_table()
     return t;
 }
 __constant__ const RecipTable recip_table = make_recip_table();
+
+// measurement only (GG_K2_DEBUG=9): counters of this work-group, k2_dbg[work-group][32]; few writers per slot
+GG_DEV void dbg_add(const Arena &a, int slot, unsigned long long v)
+{
+    const size_t wg = (size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x;
+    atomicAdd(&a.k2_dbg[wg * 32 + (size_t)slot], v);
+}
 
 GG_DEV void lds_order() { __asm__ volatile("" ::: "memory"); } // LDS operations of one wave execute in program order
 
@@ -87,46 +95,88 @@ struct CellState {
 // The reference's recurrence (:295-309) of the lane's cell over its `np` heights at `zseg` (cloud order), restricted to
 // the chains in R.  The chains only share the point count, and every cell starts the call at count 0 (:61-75), so point i
 // of every lane has c = i: wave-uniform, and 1 / (c + 1) comes from a table through the scalar cache.
+// One point of the recurrence (:295-309) with table quotients; `c` = points before it, r = 1 / (c + 1).  Every quotient's
+// magnitude is folded into `smallest` (except the first point's: b = 1, the product is exact) -- the caller checks it once per
+// four points and, when a quotient came out below 2^-100, repeats those points from the saved state with one_point_exact.
 template <int R>
-GG_DEV void one_point(float z, float c, float c1, double r, bool first, float oz, CellState &s)
+GG_DEV void one_point_fast(float z, float c, double r, bool first, float oz, CellState &s, float &smallest)
 {
     const float planeDist = z - oz; // :295
-    float a_gc = 0.0f, a_pdm = 0.0f, delta = 0.0f, q_gc = 1.0f, q_pdm = 1.0f, q_mean = 1.0f;
-    if (R & R_GC) {
-        a_gc = z + c * s.gc; // :296
-        q_gc = quot(a_gc, r);
-    }
+    float q_gc = 1.0f, q_pdm = 1.0f, q_mean = 1.0f, delta = 0.0f, mean_base = 0.0f;
+    if (R & R_GC) q_gc = quot(z + c * s.gc, r); // :296
     if (R & R_MEAN) {
-        if ((double)s.mean == 0.0) s.mean = planeDist; // :298-299
-        delta = planeDist - s.mean;                    // :301
+        // :298-299 `if (mean == 0) mean = planeDist` then :301 delta = planeDist - mean, as two selects on one comparison
+        // (the subtraction does not wait for the select)
+        const bool unset = (double)s.mean == 0.0;
+        const float d_set = planeDist - s.mean, d_unset = planeDist - planeDist;
+        delta = unset ? d_unset : d_set;
+        mean_base = unset ? planeDist : s.mean;
         q_mean = quot(delta, r);
     }
-    if (R & R_PDM) {
-        a_pdm = planeDist + c * s.pdm; // :303
-        q_pdm = quot(a_pdm, r);
-    }
+    if (R & R_PDM) q_pdm = quot(planeDist + c * s.pdm, r); // :303
     if (R & (R_GC | R_MEAN | R_PDM)) {
-        // (first point: b = 1 and the product is exact)
-        const float smallest = fminf(fabsf(q_gc), fminf(fabsf(q_mean), fabsf(q_pdm)));
-        if (!first && __any(smallest < 0x1p-100f)) { // (rare; uniform branch)
-            __asm__ volatile("; IEEE quotients" ::: "memory"); // (keeps this a branch: if-converted, the divisions would run for every point)
-            if (R & R_GC) q_gc = a_gc / c1;
-            if (R & R_MEAN) q_mean = delta / c1;
-            if (R & R_PDM) q_pdm = a_pdm / c1;
-        }
+        const float m = fminf(fabsf(q_gc), fminf(fabsf(q_mean), fabsf(q_pdm)));
+        smallest = first ? smallest : fminf(smallest, m);
     }
     if (R & R_GC) {
         s.gc = q_gc;             // :296
         s.mx = std_max(s.mx, z); // :307
     }
-    if (!isnan(planeDist)) { // :300
-        if (R & R_MEAN) {
-            s.mean += q_mean;                     // :302
-            s.m2 += delta * (planeDist - s.mean); // :304
-        }
-        if (R & R_PDM) s.pdm = q_pdm; // :303
+    const bool ok = !isnan(planeDist); // :300
+    if (R & R_MEAN) {
+        const float mean_new = mean_base + q_mean;           // :302
+        const float m2_new = s.m2 + delta * (planeDist - mean_new); // :304
+        s.mean = ok ? mean_new : mean_base;
+        s.m2 = ok ? m2_new : s.m2;
     }
+    if (R & R_PDM) s.pdm = ok ? q_pdm : s.pdm; // :303
     if (R & R_MN) s.mn = std_min(s.mn, z - 0.0001f); // :308
+}
+
+// the same point with the reference's expressions as they stand (IEEE divisions)
+template <int R>
+GG_DEV void one_point_exact(float z, float c, float oz, CellState &s)
+{
+    const float c1 = c + 1.0f;
+    const float planeDist = z - oz;                                  // :295
+    if (R & R_GC) s.gc = (z + c * s.gc) / c1;                        // :296 (see the note on double rounding above)
+    if (R & R_MEAN) {
+        if ((double)s.mean == 0.0) s.mean = planeDist;               // :298-299
+    }
+    if (!isnan(planeDist)) {                                         // :300
+        if (R & R_MEAN) {
+            const float delta = planeDist - s.mean;                  // :301
+            s.mean += delta / c1;                                    // :302
+            s.m2 += delta * (planeDist - s.mean);                    // :304
+        }
+        if (R & R_PDM) s.pdm = (planeDist + c * s.pdm) / c1;         // :303
+    }
+    if (R & R_GC) s.mx = std_max(s.mx, z);            // :307
+    if (R & R_MN) s.mn = std_min(s.mn, z - 0.0001f);  // :308
+}
+
+// points i .. i+3 of the lane's cell (z[0..3]); i is wave-uniform, np the lane's point count
+template <int R>
+GG_DEV void four_points(const float (&z)[4], uint32_t i, uint32_t np, const double (&rr)[4], float oz, CellState &s)
+{
+    const CellState saved = s;
+    const float c0 = (float)i; // (:309: (float)((double)c + 1.0) == c + 1.0f for integers below 2^24)
+    float smallest = 1.0f;
+    if (np >= i + 4u) { // all four points: no per-point predicate
+#pragma unroll
+        for (int k = 0; k < 4; ++k) one_point_fast<R>(z[k], c0 + (float)k, rr[k], i == 0u && k == 0, oz, s, smallest);
+    } else if (np > i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + (uint32_t)k < np) one_point_fast<R>(z[k], c0 + (float)k, rr[k], i == 0u && k == 0, oz, s, smallest);
+    }
+    if ((R & (R_GC | R_MEAN | R_PDM)) && __any(smallest < 0x1p-100f)) { // (rare; uniform branch)
+        __asm__ volatile("; IEEE quotients" ::: "memory"); // (keeps this a branch: if-converted, the divisions would run for every point)
+        s = saved;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + (uint32_t)k < np) one_point_exact<R>(z[k], c0 + (float)k, oz, s);
+    }
 }
 
 // The reference's recurrence (:295-309) of the lane's cell over its `np` heights at `zseg` (cloud order), restricted to
@@ -142,45 +192,29 @@ GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s)
     nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
     // NB 16-byte batches per lane in flight, each refilled right after its four points (no register rotation: a copy of a
     // load's destination would wait for the load; unconditional loads at a clamped index: no branch around them).  The
-    // heights come back from L2 (this work-group wrote them a moment ago): about 2000 cycles under load, i.e. 16 points of
-    // a single chain -- NB = 6 for those, 3 for the full recurrence.
-    const zquad zero = {{0.0f, 0.0f, 0.0f, 0.0f}};
+    // heights come back from L2 (this work-group wrote them a moment ago).
     const uint32_t qlast = np ? (np - 1u) >> 2 : 0u; // (an empty cell reads 16 bytes of the tile's padded region)
     zquad q[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) q[b] = zq[min((uint32_t)b, qlast)];
-    float c = 0.0f; // points before the current one (:309: (float)((double)c + 1.0) == c + 1.0f for integers below 2^24)
     const uint32_t ntab = min(nmax, (uint32_t)RCAP);
-    auto four_points = [&](const zquad &cur, uint32_t i) {
-        double rr[4]; // (one 32-byte scalar load; RCAP is a multiple of 4)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rr[k] = recip_table.v[i + (uint32_t)k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ii = i + (uint32_t)k; // (uniform)
-            if (ii >= ntab) break;
-            const float c1 = c + 1.0f;
-            if (ii < np) one_point<R>(cur.v[k], c, c1, rr[k], ii == 0u, oz, s);
-            c = c1;
-        }
-    };
     for (uint32_t i = 0; i < ntab; i += 4u * NB) { // (RCAP is a multiple of 4 NB)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            if (b > 0 && i + 4u * (uint32_t)b >= ntab) break;
-            four_points(q[b], i + 4u * (uint32_t)b);
+            const uint32_t ib = i + 4u * (uint32_t)b;
+            if (b > 0 && ib >= ntab) break;
+            double rr[4]; // (one 32-byte scalar load; RCAP is a multiple of 4)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[k] = recip_table.v[ib + (uint32_t)k];
+            four_points<R>(q[b].v, ib, np, rr, oz, s);
             q[b] = zq[min((i >> 2) + (uint32_t)(NB + b), qlast)];
         }
     }
-    for (uint32_t i = (uint32_t)RCAP; i < nmax; i += 4u) { // cells with more than RCAP points: IEEE reciprocal per point
-        zquad cur = zero;
-        if (i < np) cur = zq[i >> 2];
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ii = i + (uint32_t)k;
-            if (ii >= nmax) break;
-            const float c1 = c + 1.0f;
-            if (ii < np) one_point<R>(cur.v[k], c, c1, 1.0 / (double)c1, false, oz, s);
-            c = c1;
+    for (uint32_t i = (uint32_t)RCAP; i < nmax; i += 4u) { // cells with more than RCAP points: the reference's expressions
+        if (i < np) {
+            const zquad cur = zq[i >> 2];
+            for (int k = 0; k < 4; ++k)
+                if (i + (uint32_t)k < np) one_point_exact<R>(cur.v[k], (float)(i + (uint32_t)k), oz, s);
         }
     }
 }
@@ -348,21 +382,18 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
 #pragma unroll 1
             for (int k = 0; k < 4; ++k) {
                 CellState st = reset;
-                float c = 0.0f;
                 const uint32_t wv = __hip_atomic_load(&lds.woffs[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t seg_end = wv & 0xFFFFu;
                 const uint32_t np = seg_end - seg;
                 for (uint32_t i = 0; __any(i < np); i += 4u) { // (uniform; at most K2_LIGHT_MAX < RCAP points)
                     double rr[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rr[q] = recip_table.v[i + (uint32_t)q];
+                    float zz[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const uint32_t ii = i + (uint32_t)q;
-                        const float c1 = c + 1.0f;
-                        if (ii < np) one_point<RL>(zs[seg + ii], c, c1, rr[q], ii == 0u, oz, st);
-                        c = c1;
+                        rr[q] = recip_table.v[i + (uint32_t)q];
+                        zz[q] = zs[min(seg + i + (uint32_t)q, (uint32_t)K2_LIGHT_MAX - 1u)];
                     }
+                    four_points<RL>(zz, i, np, rr, oz, st);
                 }
                 const int cell = lane + 64 * k;
                 write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), (float)np, (float)(wv >> 16), st);
@@ -377,9 +408,9 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             }
         }
         if (timing && lane == 0) {
-            atomicAdd(&a.k2_dbg[had_points ? 8 : 12], 1ull);
-            atomicAdd(&a.k2_dbg[had_points ? 9 : 14], (unsigned long long)(end - start));
-            atomicAdd(&a.k2_dbg[had_points ? 10 : 13], __builtin_readcyclecounter() - t_begin);
+            dbg_add(a, had_points ? 8 : 12, 1ull);
+            dbg_add(a, had_points ? 9 : 14, (unsigned long long)(end - start));
+            dbg_add(a, had_points ? 10 : 13, __builtin_readcyclecounter() - t_begin);
         }
         rank = rank_next;
         rank_next = rank_after;
@@ -576,8 +607,8 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
     }
     // ---- 5. back to thread = cell, write the per-call layers ----
     if (timing && lane == 0) { // this wave's own chain time (before the barrier)
-        atomicAdd(&a.k2_dbg[16 + wave], __builtin_readcyclecounter() - tmark[3]);
-        if (split) atomicAdd(&a.k2_dbg[20 + wave], 1ull);
+        dbg_add(a, 16 + wave, __builtin_readcyclecounter() - tmark[3]);
+        if (split) dbg_add(a, 20 + wave, 1ull);
     }
     __syncthreads();
     if (timing) tmark[4] = __builtin_readcyclecounter();
@@ -593,9 +624,9 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
                ex[3 * TILE_CELLS + tid], st);
     if (timing && tid == 0) {
         tmark[5] = __builtin_readcyclecounter();
-        atomicAdd(&a.k2_dbg[0], 1ull);                       // dense tiles
-        atomicAdd(&a.k2_dbg[1], (unsigned long long)n);      // their records
-        for (int k = 0; k < 5; ++k) atomicAdd(&a.k2_dbg[2 + k], tmark[k + 1] - tmark[k]); // count, scan, place, chains, write
+        dbg_add(a, 0, 1ull);                       // dense tiles
+        dbg_add(a, 1, (unsigned long long)n);      // their records
+        for (int k = 0; k < 5; ++k) dbg_add(a, 2 + k, tmark[k + 1] - tmark[k]); // count, scan, place, chains, write
     }
 }
 
@@ -606,7 +637,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
 // "the tile's per-call layers may hold something else" (set by the cloud that put points there, by gg_reset_map and by
 // host writes).  Exact: every layer in HBM holds at all times what the reference's would.
 template <bool FULL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
 {
     __shared__ ReduceLds lds;
     // (cloud, group) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD, in
@@ -637,8 +668,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     if (a.k2_debug == 9 && threadIdx.x == 0) {
         const int k = group < n_dense_groups ? 24 : 26;
-        atomicAdd(&a.k2_dbg[k], 1ull);
-        atomicAdd(&a.k2_dbg[k + 1], __builtin_readcyclecounter() - t_wg);
+        dbg_add(a, k, 1ull);
+        dbg_add(a, k + 1, __builtin_readcyclecounter() - t_wg);
     }
 }
 
@@ -647,7 +678,8 @@ void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hi
     if (n_clouds == 0) return;
     // about 4096 work-groups per launch (16 per CU), at least 8 + 8 per cloud, never more groups than tiles
     const int per_cloud = std::min(std::max(4096 / n_clouds, 16), 2 * a.g.T);
-    const int gd = std::max(1, per_cloud / 2), gl = std::max(1, per_cloud - gd);
+    static const int dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 12; // sixteenths of the groups
+    const int gd = std::max(1, per_cloud * dense_share / 16), gl = std::max(1, per_cloud - gd);
     dim3 grid(gd + gl, n_clouds);
     if (a.flags & GG_FLAG_MINIMAL_LAYERS)
         hipLaunchKernelGGL(k_reduce<false>, grid, dim3(256), 0, s, a, d_params, gd);
