@@ -2,24 +2,25 @@
 //
 // `ground` and `groundpatch` are the only state that persists from cloud to cloud, they are always used together, and the
 // kernel that dominates their traffic is the terrain sweep (k_sweep): per step, the 64 lanes of a wavefront -- 64 consecutive
-// rings of one side of the spiral, ring r + 1 three steps behind ring r -- each touch ONE cell.  In a row- or column-major
+// rings of one side of the spiral, ring r + 1 SKEW steps behind ring r -- each touch ONE cell.  In a row- or column-major
 // matrix those 64 cells lie in 64 different 128-byte lines (the texture-address unit then spends ~128 cycles per wave
 // instruction: measured TA_BUSY = kernel time).  The layout below shears each 64-ring wedge so that exactly those 64 cells
 // are 64 CONSECUTIVE elements:
 //
 //   c = n/2 - 1,  dx = row - c,  dy = col - c,  r = max(|dx|, |dy|)  (the ring),  g = (r - 1) / 64,  l = (r - 1) % 64
-//   side A (row = c - r, the cells the sweep's first side walks):   dx == -r && dy <  r      v = col + 4 l
-//   side C (row = c + r):                                            dx ==  r                 v = (n - 1 - col) + 4 l
-//   side B (col = c - r, without the two corners):                   dy == -r                 v = row + 4 l
-//   side D (col = c + r, with the corner (c - r, c + r)):            otherwise                v = (n - 1 - row) + 4 l
-//   index = 1 + ((side * G + g) * VS + v) * 64 + l          (index 0 = the centre cell;  VS = n + 4 * 63)
+//   (SH = GP_SHEAR = SKEW + 1)
+//   side A (row = c - r, the cells the sweep's first side walks):   dx == -r && dy <  r      v = col + SH l
+//   side C (row = c + r):                                            dx ==  r                 v = (n - 1 - col) + SH l
+//   side B (col = c - r, without the two corners):                   dy == -r                 v = row + SH l
+//   side D (col = c + r, with the corner (c - r, c + r)):            otherwise                v = (n - 1 - row) + SH l
+//   index = 1 + ((side * G + g) * VS + v) * 64 + l          (index 0 = the centre cell;  VS = n + SH * 63)
 //
 // A chain lane walks its side with stride 64 elements; at wave-step t every lane of a wavefront is at the same v (its ring
-// is l steps of 3 behind and l cells of 1 further in: 3 + 1 = the 4 in the shear), so a wavefront reads and writes 512
-// contiguous bytes per access.  The outer line of ring r is the own line of ring r + 1: element index + 4 * 64 + 1.
+// is l steps of SKEW behind and l cells of 1 further in: SKEW + 1 = the shear), so a wavefront reads and writes 512
+// contiguous bytes per access.  The outer line of ring r is the own line of ring r + 1: element index + SH * 64 + 1.
 // Every other kernel addresses the layer through gp_index(): their accesses to it are per-point gathers or one element
 // per cell, a small part of their traffic.  The host boundary (gg_get_layer / gg_set_layer) converts to and from Eigen's
-// column-major matrices.  Footprint: 4 * G * (n + 252) * 64 * 8 B (3.8 MB for n = 364 instead of 1.06 MB), of which only
+// column-major matrices.  Footprint: 4 * G * (n + 63 SH) * 64 * 8 B (3.0 MB for n = 364 and SH = 2 instead of 1.06 MB), of which only
 // the n * n cells are ever touched.
 #pragma once
 
@@ -32,12 +33,19 @@
 #define GPL_HD inline
 #endif
 
+// steps between neighbouring rings in the sweep (sweep_core.h SKEW) and the shear that follows from it
+#ifndef GG_SWEEP_SKEW
+#define GG_SWEEP_SKEW 1
+#endif
+
 namespace gg {
+
+constexpr int GP_SHEAR = GG_SWEEP_SKEW + 1;
 
 struct GpLayout {
     int n, c;  // rows = cols, centre index
     int G;     // storage groups of 64 rings (rings 1 .. n - 1 - c)
-    int VS;    // n + 4 * 63: sheared positions per (side, group)
+    int VS;    // n + GP_SHEAR * 63: sheared positions per (side, group)
     int elems; // 1 + 4 * G * VS * 64
 };
 
@@ -48,7 +56,7 @@ GPL_HD GpLayout make_gp_layout(int n)
     L.c = n / 2 - 1;
     const int rmax = n - 1 - L.c;
     L.G = (rmax - 1) / 64 + 1;
-    L.VS = n + 4 * 63;
+    L.VS = n + GP_SHEAR * 63;
     L.elems = 1 + 4 * L.G * L.VS * 64;
     return L;
 }
@@ -74,7 +82,7 @@ GPL_HD int gp_index(const GpLayout &L, int row, int col)
         side = 3;
         v = L.n - 1 - row;
     }
-    return 1 + ((side * L.G + g) * L.VS + v + 4 * l) * 64 + l;
+    return 1 + ((side * L.G + g) * L.VS + v + GP_SHEAR * l) * 64 + l;
 }
 
 } // namespace gg

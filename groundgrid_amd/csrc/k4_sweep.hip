@@ -19,6 +19,9 @@
 #include "gg_device.h"
 #include "sweep_core.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 #include <stdlib.h>
 
 namespace gg {
@@ -30,28 +33,29 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
 
-struct DevMem {
+template <bool DBG> struct DevMemT {
     __amdgpu_buffer_rsrc_t rsrc; // the interleaved (ground, confidence) layer of this cloud
     lds_int *lds;
-    int dbg_mode = 0; // timing experiments only (GG_SWEEP_DEBUG): 1 = drop the result stores, 2 = drop the layer loads, 4 = phase marks
+    int dbg_mode_rt = 0; // timing experiments only (GG_SWEEP_DEBUG): 1 = drop the result stores, 2 = drop the layer loads, 4 = phase marks
     unsigned long long *marks = nullptr, last_mark = 0, acc[6] = {0, 0, 0, 0, 0, 0};
+    GG_DEV int dbg_mode() const { return DBG ? dbg_mode_rt : 0; } // (the production kernel is compiled without any of this)
     GG_DEV void mark(int k)
     {
-        if (!(dbg_mode & 4)) return;
+        if (!(dbg_mode() & 4)) return;
         const unsigned long long now = __builtin_readcyclecounter();
         if (k > 0) acc[k] += now - last_mark;
         last_mark = now;
     }
     GG_DEV void flush_marks()
     {
-        if (dbg_mode & 4)
+        if (dbg_mode() & 4)
             for (int k = 0; k < 6; ++k) marks[k] = acc[k];
     }
     static constexpr uint32_t OOR = 0x80000000u; // beyond the buffer: loads return 0, stores are dropped, no traffic
 
     GG_DEV Cell load_issue(bool valid, int cell) const
     {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (valid && !(dbg_mode & 2)) ? (uint32_t)cell * 8u : OOR, 0, 0);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (valid && !(dbg_mode() & 2)) ? (uint32_t)cell * 8u : OOR, 0, 0);
         return Cell{__uint_as_float(v.x), __uint_as_float(v.y)};
     }
     GG_DEV Cell load_value(const Cell &queued, bool, int) const { return queued; }
@@ -66,7 +70,7 @@ struct DevMem {
         u32x2 d;
         d.x = __float_as_uint(v.g);
         d.y = __float_as_uint(v.w);
-        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (valid && !(dbg_mode & 1)) ? (uint32_t)cell * 8u : OOR, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (valid && !(dbg_mode() & 1)) ? (uint32_t)cell * 8u : OOR, 0, 0);
     }
     // LDS.  Other wavefronts write what is read here: every access is an atomic (relaxed, work-group scope) so that the
     // compiler neither caches nor hoists it; ordering comes from the hardware (in-order DS queue per wavefront).
@@ -106,12 +110,14 @@ GG_DEV float wave_shr1(float v)
 }
 
 // optional instrumentation (gg_debug_sweep_timing): per wavefront {start, end, cycles spent polling, polls that had to wait}
-struct WaveClock {
-    unsigned long long *out; // nullptr: off
+template <bool DBG> struct WaveClockT {
+    unsigned long long *out_rt; // nullptr: off
+    GG_DEV unsigned long long *out_ptr() const { return DBG ? out_rt : nullptr; }
     unsigned long long t0 = 0, polling = 0, waits = 0;
-    GG_DEV void begin() { t0 = out ? __builtin_readcyclecounter() : 0ull; }
+    GG_DEV void begin() { t0 = out_ptr() ? __builtin_readcyclecounter() : 0ull; }
     GG_DEV void end(int wave, int lane)
     {
+        unsigned long long *out = out_ptr();
         if (out && lane == 0) {
             out[wave * 4 + 0] = t0;
             out[wave * 4 + 1] = __builtin_readcyclecounter();
@@ -121,7 +127,7 @@ struct WaveClock {
     }
 };
 
-template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMem &mem, int wave_of_side, int lane, WaveClock &clk)
+template <int SIDE, bool DBG> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int wave_of_side, int lane, WaveClockT<DBG> &clk)
 {
     ChainLane<SIDE> st;
     for (int group = wave_of_side; group < P.groups; group += P.waves_per_side) {
@@ -141,7 +147,7 @@ template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevM
                 const int t = tb + u;
                 sync.advance(t);
                 if (!sync.ok()) { // (rare) something this step reads has not been published yet as far as the cached counters know
-                    const unsigned long long w0 = clk.out ? __builtin_readcyclecounter() : 0ull;
+                    const unsigned long long w0 = clk.out_ptr() ? __builtin_readcyclecounter() : 0ull;
                     sync.refresh(mem);
                     int spins = 0;
                     while (!sync.ok()) {
@@ -149,12 +155,13 @@ template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevM
                         sync.refresh(mem);
                         ++spins;
                     }
-                    if (clk.out) {
+                    if (clk.out_ptr()) {
                         clk.polling += __builtin_readcyclecounter() - w0;
                         clk.waits += spins ? 1 : 0;
                     }
                 }
-                const WP x_in{wave_shr1(st.h3.w), wave_shr1(st.h3.p)};
+                const WP ho = st.handed_over();
+                const WP x_in{wave_shr1(ho.w), wave_shr1(ho.p)};
                 constexpr int t_first_mod = ((-2 - (int)PF) % (int)SKEW + (int)SKEW) % (int)SKEW; // tb = t_first (mod TRIP), TRIP = 0 (mod SKEW)
                 st.step(t, u % (int)PF, (t_first_mod + u) % (int)SKEW, x_in, P, L, group > 0, has_next, group, mem);
             }
@@ -162,7 +169,7 @@ template <int SIDE> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevM
     }
 }
 
-template <int CD> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMem &mem, int lane, WaveClock &clk)
+template <int CD, bool DBG> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, WaveClockT<DBG> &clk)
 {
     (void)clk;
     if (lane != 0) return;
@@ -185,6 +192,7 @@ template <int CD> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMe
 
 // 5 waves per SIMD (<= 96 registers, nothing spilled): two clouds share a CU.  (Measured: forcing 64 registers for three clouds
 // per CU spills and is 1.6x slower at 1024 clouds per launch.)
+template <bool DBG>
 __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const LdsMap L, const CloudParams *__restrict__ params,
                                                    unsigned long long *dbg)
 {
@@ -214,45 +222,52 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     for (int k = threadIdx.x; k < a.g.C; k += nthreads) points[k] = 0.0f;
     __syncthreads(); // the only barrier of the sweep
 
-    DevMem mem;
+    DevMemT<DBG> mem;
     mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, P.gl.elems * 8, 0x00020000);
     mem.lds = (lds_int *)lds;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const int W = P.waves_per_side;
-    WaveClock clk;
-    clk.out = (dbg && blockIdx.x == 0) ? dbg : nullptr;
-    mem.dbg_mode = dbg ? (int)dbg[63] : 0;
-    mem.marks = dbg ? dbg + 48 + ((threadIdx.x >> 6) & 1) * 6 : nullptr; // (the two corner wavefronts have consecutive wave ids)
+    WaveClockT<DBG> clk;
+    clk.out_rt = (DBG && dbg && blockIdx.x == 0) ? dbg : nullptr;
+    mem.dbg_mode_rt = (DBG && dbg) ? (int)dbg[63] : 0;
+    mem.marks = (DBG && dbg) ? dbg + 48 + ((threadIdx.x >> 6) & 1) * 6 : nullptr; // (the two corner wavefronts have consecutive wave ids)
     clk.begin();
     if (wave < W)
-        run_chain<SIDE_A>(P, L, mem, wave, lane, clk);
+        run_chain<SIDE_A, DBG>(P, L, mem, wave, lane, clk);
     else if (wave < 2 * W)
-        run_chain<SIDE_B>(P, L, mem, wave - W, lane, clk);
+        run_chain<SIDE_B, DBG>(P, L, mem, wave - W, lane, clk);
     else if (wave < 3 * W)
-        run_chain<SIDE_C>(P, L, mem, wave - 2 * W, lane, clk);
+        run_chain<SIDE_C, DBG>(P, L, mem, wave - 2 * W, lane, clk);
     else if (wave < 4 * W)
-        run_chain<SIDE_D>(P, L, mem, wave - 3 * W, lane, clk);
+        run_chain<SIDE_D, DBG>(P, L, mem, wave - 3 * W, lane, clk);
     else if (wave == 4 * W)
-        run_corner<0>(P, L, mem, lane, clk);
+        run_corner<0, DBG>(P, L, mem, lane, clk);
     else
-        run_corner<1>(P, L, mem, lane, clk);
+        run_corner<1, DBG>(P, L, mem, lane, clk);
     clk.end(wave, lane);
 }
 
 size_t sweep_lds_bytes(const Params &P) { return (size_t)lds_layout(P.c, P.groups).words * 4; }
 
-void launch_sweep(const Arena &a, const Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s, unsigned long long *dbg)
+void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_params, int n_clouds, hipStream_t s, unsigned long long *dbg)
 {
-    if (n_clouds == 0 || P.rings <= 0) return;
+    if (n_clouds == 0 || P_in.rings <= 0) return;
+    // Latency setting: a launch that leaves CUs idle anyway gives every 64-ring group of a side its own wavefront (up to 3)
+    Params P = P_in;
+    if (n_clouds <= 128 && !getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(P.groups, 3));
     const LdsMap L = lds_layout(P.c, P.groups);
     const size_t lds = (size_t)L.words * 4;
     static bool big_lds_ok = false;
     if (lds > 64 * 1024 && !big_lds_ok) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         big_lds_ok = true;
     }
     const int threads = (4 * P.waves_per_side + 2) * 64;
-    hipLaunchKernelGGL(k_sweep, dim3(n_clouds), dim3(threads), lds, s, a, P, L, d_params, dbg);
+    if (dbg) // (GG_SWEEP_TIMING: the instrumented twin)
+        hipLaunchKernelGGL(k_sweep<true>, dim3(n_clouds), dim3(threads), lds, s, a, P, L, d_params, dbg);
+    else
+        hipLaunchKernelGGL(k_sweep<false>, dim3(n_clouds), dim3(threads), lds, s, a, P, L, d_params, dbg);
 }
 
 } // namespace gg

@@ -54,8 +54,8 @@ enum { SIDE_A = 0, SIDE_B = 1, SIDE_C = 2, SIDE_D = 3 };
 // 2-deep own line: a loop body of TRIP steps can carry every value in a fixed register.  The sweep is bound by instruction
 // issue, not by memory (dropping every load and store changes nothing): PF = 3 steps (~4000 cycles) is ample and keeps the
 // queue at 12 registers.
-enum { LANES = 64, SKEW = 3, PF = 3, TRIP = 6 };
-static_assert(SKEW == 3 && PF % SKEW == 0 && TRIP % PF == 0 && TRIP % 2 == 0, "the step code names t mod SKEW residues");
+enum { LANES = 64, SKEW = GG_SWEEP_SKEW, PF = 3, TRIP = 6 };
+static_assert(SKEW >= 1 && SKEW <= 3 && TRIP % SKEW == 0 && TRIP % PF == 0 && TRIP % 2 == 0, "the step code names t mod SKEW residues");
 
 struct WP {
     float w, p; // confidence, confidence * ground
@@ -133,6 +133,16 @@ SW_HD double sw_max(double a, double b) { return (a < b) ? b : a; } // libstdc++
 // are monotonic, so if the two ends of the +-2^-48 interval convert to the same float the exact value does too; otherwise
 // (about 1 visit in 10^7, NaN, or an unusual config) the divide decides.
 SW_HD float sw_maxf(float a, float b) { return (a < b) ? b : a; }
+// "does any lane of the wavefront need this?" -- the device takes rare paths as wave-uniform branches (a divergent branch costs
+// half a dozen scalar instructions of exec-mask bookkeeping in EVERY step); on the host a lane is its own wavefront
+#if defined(__HIP_DEVICE_COMPILE__)
+SW_HD bool sw_any(bool b) { return __any(b) != 0; }
+#define SW_KEEP_BRANCH() __asm__ volatile("; rare path" ::: "memory")
+#else
+SW_HD bool sw_any(bool b) { return b; }
+#define SW_KEEP_BRANCH() ((void)0)
+#endif
+
 SW_HD float decayed_confidence(float occupied, bool decay, const Params &P)
 {
     // (float)std::max(v, 0.001) == max((float)v, (float)0.001) with the same NaN behaviour: the conversion is monotonic
@@ -142,7 +152,12 @@ SW_HD float decayed_confidence(float occupied, bool decay, const Params &P)
     const float lo = sw_maxf((float)(t * (1.0 - 0x1p-48)), floor_f);
     const float hi = sw_maxf((float)(t * (1.0 + 0x1p-48)), floor_f);
     float d = lo;
-    if (!(P.decay_fast && lo == hi) && decay) d = (float)sw_max(x - x / P.decrease, 0.001);
+    const bool exact = !(P.decay_fast && lo == hi) && decay;
+    if (sw_any(exact)) {
+        SW_KEEP_BRANCH();
+        const float de = (float)sw_max(x - x / P.decrease, 0.001);
+        d = exact ? de : d;
+    }
     return decay ? d : occupied;
 }
 
@@ -228,8 +243,8 @@ template <int SIDE> struct ChainSync {
     enum { NEVER = 0x7fffffff };
     int need_corner, need_join, need_bnd;       // what step t requires
     int have_corner, have_join, have_bnd;       // cached counter values (lower bounds)
-    int start_t, start_r, r_last;               // next lane start: time, ring
-    int join_t, join_r, join_r_last;            // next join: time, join ring
+    int start_t0, start_r0, n_start;            // first lane start: time, ring; number of lanes with a chain
+    int join_t0, join_r0;                       // first join: time, join ring (one per started lane, every SKEW + 2 steps)
     int bnd_end;                                // lane 0 reads the previous group's chain for 0 <= t < bnd_end
     int w_corner, w_join, w_bnd;                // LDS words of the three counters
 
@@ -245,28 +260,24 @@ template <int SIDE> struct ChainSync {
         // lanes with a chain (len >= 1) start at t = SKEW * l and join (s = len - 2) at t = (SKEW + 2) l + 2 r0 + b - 2
         int l1 = (1 - b + 1) / 2 - r0; // smallest l with 2 (r0 + l) + b >= 1
         if (l1 < 0) l1 = 0;
-        start_t = l1 < nl ? SKEW * l1 : (int)NEVER;
-        start_r = r0 + l1;
-        r_last = r0 + nl - 1;
-        join_t = l1 < nl ? (SKEW + 2) * l1 + 2 * r0 + b - 2 : (int)NEVER;
-        join_r = (SIDE == SIDE_A || SIDE == SIDE_B) ? r0 + l1 - 1 : r0 + l1;
-        join_r_last = (SIDE == SIDE_A || SIDE == SIDE_B) ? r_last - 1 : r_last;
+        n_start = l1 < nl ? nl - l1 : 0;
+        start_t0 = l1 < nl ? SKEW * l1 : (int)NEVER;
+        start_r0 = r0 + l1;
+        join_t0 = l1 < nl ? (SKEW + 2) * l1 + 2 * r0 + b - 2 : (int)NEVER;
+        join_r0 = (SIDE == SIDE_A || SIDE == SIDE_B) ? r0 + l1 - 1 : r0 + l1;
         bnd_end = group > 0 ? chain_len<SIDE>(r0) - 2 : 0;
     }
-    // requirements of wave-step t (call with t increasing by one)
+    // requirements of wave-step t: non-decreasing step functions of t in closed form -- integer scalar arithmetic only (no
+    // flags carried from step to step: the compiler kept those as lane masks and converted them through vector registers)
     SW_HD void advance(int t)
     {
-        if (t == start_t) {
-            need_corner = start_r;
-            start_r += 1;
-            start_t = start_r <= r_last ? start_t + SKEW : (int)NEVER;
-        }
-        if (t == join_t) {
-            need_join = join_r;
-            join_r += 1;
-            join_t = join_r <= join_r_last ? join_t + SKEW + 2 : (int)NEVER;
-        }
-        need_bnd = (t >= 0 && t < bnd_end) ? t + 1 : need_bnd;
+        const int ds = t - start_t0, dj = t - join_t0; // (NEVER: negative for every t)
+        const int ks = (int)((unsigned)ds / (unsigned)SKEW), kj = (int)((unsigned)dj / ((unsigned)SKEW + 2u)); // (only used when non-negative)
+        const int last = n_start - 1;
+        need_corner = ds < 0 ? 0 : start_r0 + (ks < last ? ks : last);
+        need_join = dj < 0 ? 0 : join_r0 + (kj < last ? kj : last);
+        const int tb = t + 1 < bnd_end ? t + 1 : bnd_end;
+        need_bnd = tb > 0 ? tb : 0;
     }
     SW_HD bool ok() const { return have_corner >= need_corner && have_join >= need_join && have_bnd >= need_bnd; }
     template <class Mem> SW_HD void refresh(Mem &mem)
@@ -293,11 +304,16 @@ template <int SIDE> struct ChainLane {
     int xold_cell, own_end; // layer elements of S[len + 1] and of the own line's far end k0 + len (it belongs to another side)
     int a_s0, a_s1, a_pred, a_join, a_bnd, a_pub; // LDS words: S[0], S[1], predecessor, join, previous group's chain, own join slot
     int r2c, r2r;       // (x-c)^2 + (y-c)^2 of the visited cell = r2r + (t + r2c)^2
+    // wave-uniform constants of the group (scalar registers on the device): which steps can contain the rare per-lane events
+    int u_start_last;   // lanes take their corner values at steps 0, SKEW, .. <= u_start_last
+    int u_join_first, u_join_last; // a lane reads its join at t = lend - 2: only for t in this range
+    int u_len0;         // chain length of lane 0 (it reads the previous group's boundary chain while t < u_len0)
+    int u_l3_last, u_lend_last; // the last lane's first step and end (its results are the next group's boundary chain)
     // window: inner and outer lines as (w, p); own line: predecessor (w, p) new, self and successor old (g, w, p)
     WP I[3], U[3], OP;
     float Sg, Sw, Sp, Ng, Nw, Np;
     WP xold;            // S[len + 1]
-    WP h1, h2, h3;      // results of the last three steps (what lane l + 1 reads three steps later)
+    WP h1, h2, h3;      // results of the last three steps (lane l + 1 reads the one of SKEW steps ago: handed_over())
     Cell q_own[PF], q_out[PF]; // layer loads in flight, one slot per wave-step mod PF
 
     SW_HD void init(int lane, int r0, int nl, int group, const Params &P, const LdsMap &L)
@@ -344,13 +360,21 @@ template <int SIDE> struct ChainLane {
         // A, B) or r - (k0 + s) (C, D); its square is the same
         r2c = k0 - r - l3;
         r2r = r * r;
+        u_start_last = SKEW * (nl - 1);
+        u_len0 = chain_len<SIDE>(r0);
+        u_join_first = u_len0 - 2;
+        u_l3_last = SKEW * (LANES - 1);
+        u_lend_last = SKEW * (nl - 1) + chain_len<SIDE>(r0 + nl - 1); // (lends grow with the lane)
+        u_join_last = u_lend_last - 2;
         I[0] = I[1] = I[2] = U[0] = U[1] = U[2] = OP = xold = h1 = h2 = h3 = WP{0.f, 0.f};
         Sg = Sw = Sp = Ng = Nw = Np = 0.f;
         for (int k = 0; k < PF; ++k) q_own[k] = q_out[k] = Cell{0.f, 0.f};
     }
 
+    SW_HD WP handed_over() const { return SKEW == 1 ? h1 : SKEW == 2 ? h2 : h3; }
+
     // One wave-step.  `slot` = wave-step mod PF and tmod = ((t mod SKEW) + SKEW) mod SKEW, both compile-time constants in the
-    // device's unrolled loop; x_in = (lane l - 1).h3 as it was BEFORE this step (lane 0: anything); lane0 = (l == 0).
+    // device's unrolled loop; x_in = (lane l - 1).handed_over() as it was BEFORE this step (lane 0: anything); lane0 = (l == 0).
     template <class Mem>
     SW_HD void step(int t, int slot, int tmod, WP x_in, const Params &P, const LdsMap &L, bool has_prev_group, bool has_next_group, int group, Mem &mem)
     {
@@ -359,9 +383,10 @@ template <int SIDE> struct ChainLane {
         const int ao = t + r2c;
         const float w_new = decayed_confidence(Nw, r2r + ao * ao >= P.r2min, P); // (the successor of the last step becomes "self" now)
         // ---- LDS: everything this lane could need, every step (garbage until published; selected only when it is)
-        const WP c_join = mem.get(a_join);
-        const int sb = t < 0 ? 0 : t; // (lane 0: s = t)
-        const WP c_bnd = mem.get(a_bnd + ((has_prev_group && l == 0 && t < len) ? 2 * sb : 0));
+        //      -- but only in the (wave-uniform) ranges of steps in which some lane can be at that event
+        WP c_join{0.f, 0.f}, c_bnd{0.f, 0.f};
+        if (t >= u_join_first && t <= u_join_last) c_join = mem.get(a_join);
+        if (has_prev_group && t >= 0 && t < u_len0) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
         // ---- the column that arrives now (along-position k0 + s + 1), requested PF steps ago into this slot; the own-line
         //      request of step -2 (the predecessor's cell, which is never read from the layer) carries the old cell S[len + 1].
         //      (mem.fresh: on the device a real register copy -- the arriving values stay live for two or three more steps
@@ -369,12 +394,18 @@ template <int SIDE> struct ChainLane {
         //      copy freshly requested registers at the loop's back edge, which would be a wait for loads just issued)
         const unsigned ua = (unsigned)(t + 2 - l3); // s + 2
         const bool col = ua < (unsigned)lim;
-        const Cell own = mem.fresh(mem.load_value(q_own[slot], col, ua == 0u ? xold_cell : (int)ua == len + 1 ? own_end : ownA + 64 * (t + 1)));
+        const int own_col = ownA + 64 * (t + 1);
+        int own_now = (int)ua == len + 1 ? own_end : own_col;
+        own_now = ua == 0u ? xold_cell : own_now;
+        const Cell own = mem.fresh(mem.load_value(q_own[slot], col, own_now));
         const Cell out = mem.fresh(mem.load_value(q_out[slot], col, outA + 64 * (t + 1)));
         // ---- and the one to request for step s + PF
         const unsigned uq = ua + (unsigned)PF;
         const bool colq = uq < (unsigned)lim;
-        q_own[slot] = mem.load_issue(colq, uq == 0u ? xold_cell : (int)uq == len + 1 ? own_end : ownA + 64 * (t + 1 + PF));
+        const int own_colq = ownA + 64 * (t + 1 + PF);
+        int own_req = (int)uq == len + 1 ? own_end : own_colq; // (two selects on ready values: no branch)
+        own_req = uq == 0u ? xold_cell : own_req;
+        q_own[slot] = mem.load_issue(colq, own_req);
         q_out[slot] = mem.load_issue(colq, outA + 64 * (t + 1 + PF));
         // ---- advance the window
         Sg = Ng;
@@ -383,7 +414,7 @@ template <int SIDE> struct ChainLane {
         Ng = own.g;
         Nw = own.w;
         Np = own.w * own.g;
-        xold = (tmod == 1 && ua == 0u) ? WP{own.w, Np} : xold; // step -2: t + 2 = 3 l, i.e. only when t = 1 (mod SKEW = 3)
+        xold = (tmod == (2 * SKEW - 2) % SKEW && ua == 0u) ? WP{own.w, Np} : xold; // step -2: t + 2 = SKEW l, i.e. only when t = -2 (mod SKEW)
         U[0] = U[1];
         U[1] = U[2];
         U[2] = WP{out.w, out.w * out.g};
@@ -395,7 +426,7 @@ template <int SIDE> struct ChainLane {
         I[0] = I[1];
         I[1] = I[2];
         I[2] = x;
-        if (tmod == 0) { // a lane's first step (t = 3 l): the corner values
+        if (tmod == 0 && t >= 0 && t <= u_start_last) { // a lane's first step (t = SKEW l): the corner values
             const WP c_s0 = mem.get(a_s0), c_s1 = mem.get(a_s1), c_pred = mem.get(a_pred);
             const bool first = t == l3;
             I[0] = first ? c_s0 : I[0];
@@ -428,8 +459,10 @@ template <int SIDE> struct ChainLane {
         h2 = h1;
         h1 = res;
         // ---- publish what other wavefronts wait for (data first, then the counter)
-        if (t + 1 == lend && len > 0) mem.publish(a_pub, res, L.join_done + SIDE, r);
-        if (has_next_group && l == LANES - 1 && active)
+        if (t >= u_join_first + 1 && t <= u_join_last + 1) {
+            if (t + 1 == lend && len > 0) mem.publish(a_pub, res, L.join_done + SIDE, r);
+        }
+        if (has_next_group && t >= u_l3_last && t < u_lend_last && l == LANES - 1 && active)
             mem.publish(L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) + (t - l3)), res, L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
     }
 };
@@ -462,16 +495,16 @@ template <int CD> struct CornerLane {
         const int side = CD ? (a >= b ? 2 : 3) : (a >= b ? 0 : 1);
         const int along = a >= b ? b : a; // the coordinate that runs along the side, in outward units
         const int v = CD ? P.n - 1 - (z + along) : z - along;
-        return 1 + ((side * P.gl.G + g) * P.gl.VS + v + 4 * l) * 64 + l;
+        return 1 + ((side * P.gl.G + g) * P.gl.VS + v + GP_SHEAR * l) * 64 + l;
     }
-    // Elements of ring r's cells given ring r - 1's: one ring out, every cell moves one lane up and three sheared positions on
-    // (+ 3 * 64 + 1) as long as its own ring stays in the same 64-ring storage group; near group boundaries, recompute.
+    // Elements of ring r's cells given ring r - 1's: one ring out, every cell moves one lane up and SKEW sheared positions on
+    // (+ SKEW * 64 + 1) as long as its own ring stays in the same 64-ring storage group; near group boundaries, recompute.
     SW_HD static void advance(Addr &ad, int r, const Params &P)
     {
         const int rr = r <= P.rings ? r : P.rings;
         const bool recompute = r > P.rings || r <= 3 || (r & 63) <= 2;
         for (int a = -1; a <= 1; ++a)
-            for (int b = -2; b <= 1; ++b) ad.e[a + 1][b + 2] = recompute ? cell_at(P, rr, a, b) : ad.e[a + 1][b + 2] + 3 * 64 + 1;
+            for (int b = -2; b <= 1; ++b) ad.e[a + 1][b + 2] = recompute ? cell_at(P, rr, a, b) : ad.e[a + 1][b + 2] + (GP_SHEAR - 1) * 64 + 1;
     }
     SW_HD static bool is_old(int r, int a, int b)
     {

@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <vector>
+#include <cstdlib>
+#include <algorithm>
 
 #include "groundgrid_hip.h"
 #include "sweep_core.h"
@@ -118,7 +120,7 @@ template <int SIDE> struct ChainWave : WaveBase {
         }
         if (group > 0 && t >= 0 && t + 2 < lane[0].len && mem.counter(sync.w_bnd) < t + 1) plan_mismatch = true;
         WP x_in[LANES];
-        for (int l = 0; l < LANES; ++l) x_in[l] = l ? lane[l - 1].h3 : WP{0.f, 0.f}; // wave shift right by one, before anybody moves
+        for (int l = 0; l < LANES; ++l) x_in[l] = l ? lane[l - 1].handed_over() : WP{0.f, 0.f}; // wave shift right by one, before anybody moves
         const int slot = ((t % PF) + PF) % PF, tmod = ((t % SKEW) + SKEW) % SKEW;
         for (int l = 0; l < LANES; ++l) lane[l].step(t, slot, tmod, x_in[l], P, L, group > 0, group + 1 < P.groups, group, mem);
         ++steps;
@@ -170,7 +172,11 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
     P.c = n / 2 - 1;
     P.rings = P.c - 1 > 0 ? P.c - 1 : 0;
     P.groups = (P.rings + LANES - 1) / LANES;
-    P.waves_per_side = P.groups <= 1 ? 1 : P.groups <= 3 ? 2 : 3; // groups g and g + 2 do not overlap in time up to 3 groups
+    // Throughput setting (many clouds per launch): few wavefronts per cloud, so that two clouds share a CU.  launch_sweep raises it
+    // to one wavefront per group (at most 3 per side: 14 wavefronts) when the launch has fewer clouds than the chip has CUs:
+    // with SKEW = 1 group g + 1 starts only 64 steps after group g, and a wavefront that still works on group g - 1 delays it.
+    P.waves_per_side = P.groups <= 1 ? 1 : P.groups <= 3 ? 2 : 3;
+    if (getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(std::min(P.groups, 3), atoi(getenv("GG_SWEEP_WAVES")))); // (tests, tools)
     // :463 (pow((float)x - center, 2.0) + pow((float)y - center, 2.0)) * pow(resolution, 2.0f) > minDistSquared: the left side is a
     // non-decreasing function of the integer (x-c)^2 + (y-c)^2, so the test is an integer threshold
     int r2 = 0;
