@@ -93,12 +93,29 @@ template <bool DBG> struct DevMemT {
         d.y = __float_as_uint(v.p);
         asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(da), "v"(d), "v"(ca), "v"(value) : "memory");
     }
+    GG_DEV void publish_if(bool c, int lane, const LdsMap &L, int data_word, WP v, int counter_word, int value) const
+    {
+        const int sw = (L.scratch + 1 + 3 * lane) & ~1; // (8-byte aligned data slot, the counter slot behind it)
+        publish(c ? data_word : sw, v, c ? counter_word : sw + 2, value);
+    }
     GG_DEV int counter(int word) const
     {
         int v;
         const uint32_t ca = (uint32_t)(word * 4) + lds_base();
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ca) : "memory");
         return __builtin_amdgcn_readfirstlane(v);
+    }
+    GG_DEV void counters3(int w0, int w1, int w2, int &v0, int &v1, int &v2) const
+    {
+        int a, b, c;
+        const uint32_t a0 = (uint32_t)(w0 * 4) + lds_base(), a1 = (uint32_t)(w1 * 4) + lds_base(), a2 = (uint32_t)(w2 * 4) + lds_base();
+        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a), "=&v"(b), "=&v"(c)
+                     : "v"(a0), "v"(a1), "v"(a2)
+                     : "memory");
+        v0 = __builtin_amdgcn_readfirstlane(a);
+        v1 = __builtin_amdgcn_readfirstlane(b);
+        v2 = __builtin_amdgcn_readfirstlane(c);
     }
     GG_DEV uint32_t lds_base() const { return (uint32_t)(uintptr_t)lds; } // LDS byte address of word 0 (an address-space-3 pointer IS the offset)
 };

@@ -169,6 +169,31 @@ SW_HD float interpolated_height(const float (&w)[9], const float (&p)[9], float 
     return (1.0f - occupied) * avg + occupied * height;  // :460
 }
 
+// the same with the window as (w, p) pairs: both trees have one shape, so every addition is one packed instruction on the device
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float sw_f2 __attribute__((ext_vector_type(2)));
+SW_HD float interpolated_height2(const WP (&e)[9], float height, float occupied)
+{
+    sw_f2 v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = sw_f2{e[k].w, e[k].p};
+    const sw_f2 sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + (v[7] + v[8])));
+    const float gvlSum = sum.x + FLT_MIN;                // :457
+    const float avg = sum.y / gvlSum;                    // :458
+    return (1.0f - occupied) * avg + occupied * height;  // :460
+}
+#else
+SW_HD float interpolated_height2(const WP (&e)[9], float height, float occupied)
+{
+    float w[9], p[9];
+    for (int k = 0; k < 9; ++k) {
+        w[k] = e[k].w;
+        p[k] = e[k].p;
+    }
+    return interpolated_height(w, p, height, occupied);
+}
+#endif
+
 SW_HD Cell visit(const float (&w)[9], const float (&p)[9], float height, float occupied, bool decay, const Params &P)
 {
     Cell out;
@@ -188,6 +213,7 @@ struct LdsMap {
     int join;        // WP[4][c]      last chain value per side and ring
     int bnd;         // WP[4][bnd_words / 2]   full chains of the group-boundary rings
     int bnd_stride;  // WP entries per side
+    int scratch;     // per-lane dummy targets of conditional publishes (2 data words + 1 counter word per lane, 8-byte aligned)
     int words;       // total size
 };
 
@@ -211,6 +237,8 @@ SW_HD LdsMap lds_layout(int c, int groups)
     m.bnd_stride = bnd_offset(groups > 0 ? groups - 1 : 0);
     m.bnd = o;
     o += 4 * m.bnd_stride * 2;
+    m.scratch = o; // [64][3]: where the lanes that have nothing to publish write (publish_if, device)
+    o += LANES * 3 + 1;
     m.words = o;
     return m;
 }
@@ -224,7 +252,10 @@ SW_HD LdsMap lds_layout(int c, int groups)
 //   void  mark(int k)                     timing instrumentation point (no-op unless a tool asks for it)
 //   void  store(bool valid, int cell, Cell v)
 //   int   counter(int word)               read a progress counter (LDS)
+//   void  counters3(w0, w1, w2, &v0, &v1, &v2)   three of them in one round trip
 //   void  publish(int data_word, WP v, int counter_word, int value)    LDS data, then counter -- in this order
+//   void  publish_if(bool c, int lane, ...)   the same for the lanes with c; branch-free on the device (the others write to
+//                                             their scratch words: a divergent branch is ~7 scalar instructions of exec bookkeeping)
 //   void  put(int data_word, WP v)  /  WP get(int data_word)
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -280,12 +311,7 @@ template <int SIDE> struct ChainSync {
         need_bnd = tb > 0 ? tb : 0;
     }
     SW_HD bool ok() const { return have_corner >= need_corner && have_join >= need_join && have_bnd >= need_bnd; }
-    template <class Mem> SW_HD void refresh(Mem &mem)
-    {
-        have_corner = mem.counter(w_corner);
-        have_join = mem.counter(w_join);
-        have_bnd = mem.counter(w_bnd);
-    }
+    template <class Mem> SW_HD void refresh(Mem &mem) { mem.counters3(w_corner, w_join, w_bnd, have_corner, have_join, have_bnd); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -435,23 +461,19 @@ template <int SIDE> struct ChainLane {
         }
         // ---- the visit
         const bool active = (unsigned)(t - l3) < (unsigned)len;
-        float w[9], p[9];
-#define SW_PUT(line, pos, W_, P_)                 \
-    w[tree_pos<SIDE>(line, pos)] = (W_);          \
-    p[tree_pos<SIDE>(line, pos)] = (P_);
-        SW_PUT(0, 0, I[0].w, I[0].p)
-        SW_PUT(0, 1, I[1].w, I[1].p)
-        SW_PUT(0, 2, I[2].w, I[2].p)
-        SW_PUT(1, 0, OP.w, OP.p)
-        SW_PUT(1, 1, Sw, Sp)
-        SW_PUT(1, 2, Nw, Np)
-        SW_PUT(2, 0, U[0].w, U[0].p)
-        SW_PUT(2, 1, U[1].w, U[1].p)
-        SW_PUT(2, 2, U[2].w, U[2].p)
-#undef SW_PUT
+        WP win[9];
+        win[tree_pos<SIDE>(0, 0)] = I[0];
+        win[tree_pos<SIDE>(0, 1)] = I[1];
+        win[tree_pos<SIDE>(0, 2)] = I[2];
+        win[tree_pos<SIDE>(1, 0)] = OP;
+        win[tree_pos<SIDE>(1, 1)] = WP{Sw, Sp};
+        win[tree_pos<SIDE>(1, 2)] = WP{Nw, Np};
+        win[tree_pos<SIDE>(2, 0)] = U[0];
+        win[tree_pos<SIDE>(2, 1)] = U[1];
+        win[tree_pos<SIDE>(2, 2)] = U[2];
         Cell v;
         v.w = w_new;
-        v.g = interpolated_height(w, p, Sg, Sw);
+        v.g = interpolated_height2(win, Sg, Sw);
         mem.store(active, ownA + 64 * t, v);
         const WP res = WP{v.w, v.w * v.g};
         OP = active ? res : OP;
@@ -459,11 +481,10 @@ template <int SIDE> struct ChainLane {
         h2 = h1;
         h1 = res;
         // ---- publish what other wavefronts wait for (data first, then the counter)
-        if (t >= u_join_first + 1 && t <= u_join_last + 1) {
-            if (t + 1 == lend && len > 0) mem.publish(a_pub, res, L.join_done + SIDE, r);
-        }
-        if (has_next_group && t >= u_l3_last && t < u_lend_last && l == LANES - 1 && active)
-            mem.publish(L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) + (t - l3)), res, L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
+        mem.publish_if(t + 1 == lend && len > 0, l, L, a_pub, res, L.join_done + SIDE, r);
+        if (has_next_group && t >= u_l3_last && t < u_lend_last) // (uniform: only while the last lane runs)
+            mem.publish_if(l == LANES - 1 && active, l, L, L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) + (t - l3)), res,
+                           L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
     }
 };
 

@@ -39,6 +39,12 @@ struct HostMem {
         gp2[cell] = v;
     }
     int counter(int word) { return lds[(size_t)word]; }
+    void counters3(int w0, int w1, int w2, int &v0, int &v1, int &v2)
+    {
+        v0 = counter(w0);
+        v1 = counter(w1);
+        v2 = counter(w2);
+    }
     void put(int word, WP v)
     {
         ++lds_ops;
@@ -55,6 +61,10 @@ struct HostMem {
     {
         put(data_word, v);
         lds[(size_t)counter_word] = value;
+    }
+    void publish_if(bool c, int, const LdsMap &, int data_word, WP v, int counter_word, int value)
+    {
+        if (c) publish(data_word, v, counter_word, value);
     }
 };
 
