@@ -98,6 +98,11 @@ template <bool DBG> struct DevMemT {
         const int sw = (L.scratch + 1 + 3 * lane) & ~1; // (8-byte aligned data slot, the counter slot behind it)
         publish(c ? data_word : sw, v, c ? counter_word : sw + 2, value);
     }
+    GG_DEV void put_if(bool c, int lane, const LdsMap &L, int word, WP v) const { put(c ? word : (L.scratch + 1 + 3 * lane) & ~1, v); }
+    GG_DEV WP bcast(WP v, int lane) const
+    {
+        return WP{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.w), lane)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.p), lane))};
+    }
     GG_DEV int counter(int word) const
     {
         int v;
@@ -189,20 +194,27 @@ template <int SIDE, bool DBG> GG_DEV void run_chain(const Params &P, const LdsMa
 template <int CD, bool DBG> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, WaveClockT<DBG> &clk)
 {
     (void)clk;
-    if (lane != 0) return;
-    // the old cells of a ring are requested one ring ahead; two rings per trip so that the two register sets swap roles by
-    // name instead of being copied (a copy of a register that is being loaded is a wait for that load)
-    typename CornerLane<CD>::Addr ad;
-    CornerLane<CD>::advance(ad, 1, P);
-    typename CornerLane<CD>::Old a = CornerLane<CD>::load(1, ad, P, mem);
-    for (int r = 1; r <= P.rings; r += 2) {
-        CornerLane<CD>::advance(ad, r + 1, P);
-        const typename CornerLane<CD>::Old b = CornerLane<CD>::load(r + 1, ad, P, mem);
-        while (!CornerLane<CD>::ready(r, L, mem)) __builtin_amdgcn_s_sleep(1);
-        CornerLane<CD>::ring(r, a, P, L, mem);
-        CornerLane<CD>::advance(ad, r + 2, P);
-        a = CornerLane<CD>::load(r + 2, ad, P, mem);
-        if (r + 1 <= P.rings) CornerLane<CD>::ring(r + 1, b, P, L, mem);
+    CornerRing<CD> st;
+    for (int group = 0; group < P.groups; ++group) {
+        const int r0 = LANES * group + 1;
+        const int nl = min(P.rings - (r0 - 1), (int)LANES);
+        // prepare: 64 rings at once
+        st.issue(r0 + lane, P, mem);
+        st.finish(P, mem);
+        const int prev = L.corner + 2 * ((CD * P.c + r0 - 1) * 2);
+        WP in_corner = mem.get(prev + 2); // Y_0 of the ring before the group (ring 0: the centre) -- written by this wavefront
+        WP in_x1 = r0 > 1 ? mem.get(prev) : WP{0.f, 0.f};
+        // recur: ring after ring
+        for (int l = 0; l < nl; ++l) {
+            if (CD && r0 + l == 1) {
+                while (!CornerRing<CD>::ready(1, L, mem)) __builtin_amdgcn_s_sleep(1);
+                in_x1 = mem.get(L.join + 2 * (SIDE_B * P.c + 1));
+            }
+            WP x1, y0;
+            st.recur(lane == l, lane, in_corner, in_x1, P, L, mem, x1, y0);
+            in_corner = mem.bcast(y0, l);
+            in_x1 = mem.bcast(x1, l);
+        }
     }
     mem.flush_marks();
 }

@@ -256,7 +256,8 @@ SW_HD LdsMap lds_layout(int c, int groups)
 //   void  publish(int data_word, WP v, int counter_word, int value)    LDS data, then counter -- in this order
 //   void  publish_if(bool c, int lane, ...)   the same for the lanes with c; branch-free on the device (the others write to
 //                                             their scratch words: a divergent branch is ~7 scalar instructions of exec bookkeeping)
-//   void  put(int data_word, WP v)  /  WP get(int data_word)
+//   void  put(int data_word, WP v)  /  WP get(int data_word)  /  put_if(bool c, int lane, L, word, v)
+//   WP    bcast(WP v, int lane)           lane's value in every lane (device: v_readlane)
 // ---------------------------------------------------------------------------------------------------------------------
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -493,18 +494,31 @@ SW_HD int group_first_step() { return -2 - PF; }
 template <int SIDE> SW_HD int group_last_step(int r0, int nl) { return SKEW * (nl - 1) + chain_len<SIDE>(r0 + nl - 1) - 1; }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// the corner lanes: AB walks (rp, rp), CD walks (R, R); three visits per ring (see the header comment)
+// the corner wavefronts: AB walks (rp, rp), CD walks (R, R); three visits per ring (see the header comment).
+//
+// The three visits of a ring chain on each other and on the previous ring's (height(X_0) -> height(X_1) -> height(Y_0) ->
+// next ring), but only through FOUR window elements; everything else in the three windows is OLD and known before the
+// sweep starts, and so are the three new confidences (they depend on old confidences only).  So a corner wavefront works
+// in groups of 64 rings, lane = ring:
+//   prepare   every lane loads the 10 old cells of its ring, forms their products w * g and the ring's three confidences
+//             -- 64 rings at once, off the critical path (old cells are only overwritten by visits that come after the
+//             ring's corner visits, so they can be fetched arbitrarily early);
+//   recur     ring after ring, the three dependent heights; the wavefront executes them for all lanes but only lane
+//             (ring - r0) holds meaningful operands: its X_1 and Y_0 results are broadcast (v_readlane) as the next
+//             ring's inner corner and inner X_1, stored and published.  ~1/5 of the instructions per ring of a lone lane
+//             doing everything.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int CD> struct CornerLane {
+template <int CD> struct CornerRing {
     // CD = 0: corner z = c - r, "outward" o = -1;  CD = 1: z = c + r, o = +1.  Cell (z + o a, z + o b): a, b = -1 inner, 0, +1 outer.
     // Old cells of ring r: rows a = -1..1, columns b = -2..1 without (-1, -1) [Y_0 of ring r-1] and (-1, -2) [X_1 of ring r-1].
-    struct Addr {
-        int e[3][4]; // layer element of cell [a + 1][b + 2] of some ring
-    };
-    struct Old {
-        Cell v[3][4]; // [a + 1][b + 2]
-        int e00, e0m1; // elements of (0, 0) and (0, -1): where this ring's results go
-    };
+    int r;              // this lane's ring
+    bool live;          // r <= rings
+    Cell q[3][4];       // loads in flight [a + 1][b + 2]
+    int e00, e0m1;      // elements of (0, 0) and (0, -1): where this ring's results go
+    float g00, g0m1;    // old heights of (0, 0) and (0, -1)
+    float ow[3][4], op[3][4]; // old confidences and products w * g
+    float x0w, x1w, y0w; // the three new confidences
+
     SW_HD static int cell_at(const Params &P, int r, int a, int b)
     {
         const int o = CD ? 1 : -1, z = P.c + o * r;
@@ -518,103 +532,85 @@ template <int CD> struct CornerLane {
         const int v = CD ? P.n - 1 - (z + along) : z - along;
         return 1 + ((side * P.gl.G + g) * P.gl.VS + v + GP_SHEAR * l) * 64 + l;
     }
-    // Elements of ring r's cells given ring r - 1's: one ring out, every cell moves one lane up and SKEW sheared positions on
-    // (+ SKEW * 64 + 1) as long as its own ring stays in the same 64-ring storage group; near group boundaries, recompute.
-    SW_HD static void advance(Addr &ad, int r, const Params &P)
-    {
-        const int rr = r <= P.rings ? r : P.rings;
-        const bool recompute = r > P.rings || r <= 3 || (r & 63) <= 2;
-        for (int a = -1; a <= 1; ++a)
-            for (int b = -2; b <= 1; ++b) ad.e[a + 1][b + 2] = recompute ? cell_at(P, rr, a, b) : ad.e[a + 1][b + 2] + (GP_SHEAR - 1) * 64 + 1;
-    }
     SW_HD static bool is_old(int r, int a, int b)
     {
         // ring 1 of AB: (-1, -2) is D_1(1), still old (ring 0 has no X_1)
         return !(a == -1 && b == -1) && !(a == -1 && b == -2 && !(r == 1 && !CD));
     }
-    template <class Mem> SW_HD static Old load(int r, const Addr &ad, const Params &P, Mem &mem)
-    {
-        Old o_;
-        const bool ring_ok = r <= P.rings;
-        for (int a = -1; a <= 1; ++a)
-            for (int b = -2; b <= 1; ++b) o_.v[a + 1][b + 2] = mem.load_issue(ring_ok && is_old(r, a, b), ad.e[a + 1][b + 2]);
-        o_.e00 = ad.e[1][2];
-        o_.e0m1 = ad.e[1][1];
-        return o_;
-    }
     // block index of cell (z + o a, z + o b) in the 3x3 block centred at (z + o ca, z + o cb)
-    SW_HD static int q(int a, int b, int ca, int cb)
+    SW_HD static int q9(int a, int b, int ca, int cb)
     {
         const int o = CD ? 1 : -1;
         return (o * (a - ca) + 1) + 3 * (o * (b - cb) + 1);
     }
-    // ring r: first-side visits X_0 = (z, z), X_1 = (z, z - o) (A_1 / C_1), then the revisit Y_0 = (z, z) (B_0 / D_0).
-    // Written for a lone lane, which is bound by instruction issue and by the length of its dependent chain: every product
-    // w * g of an old cell is formed once, the three new confidences (they depend on old confidences only; Y_0 decays X_0's)
-    // come first -- their rare exact-divide path is the only branch --, and what is left is one basic block whose critical
-    // path is height(X_0) -> height(X_1) -> height(Y_0).
-    template <class Mem> SW_HD static void ring(int r, const Old &queued, const Params &P, const LdsMap &L, Mem &mem)
+
+    // ---- prepare, part 1: request the ring's old cells
+    template <class Mem> SW_HD void issue(int ring, const Params &P, Mem &mem)
     {
-        const int base = L.corner + 2 * ((CD * P.c + r) * 2), prev = L.corner + 2 * ((CD * P.c + r - 1) * 2);
-        float og[3][4], ow[3][4], op[3][4]; // old cells [a + 1][b + 2]: height, confidence, product
-        mem.mark(0);
+        live = ring <= P.rings;
+        r = live ? ring : P.rings; // (idle lanes keep valid addresses)
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -2; b <= 1; ++b) q[a + 1][b + 2] = mem.load_issue(live && is_old(r, a, b), cell_at(P, r, a, b));
+        e00 = cell_at(P, r, 0, 0);
+        e0m1 = cell_at(P, r, 0, -1);
+    }
+    // ---- prepare, part 2: products and the three confidences
+    template <class Mem> SW_HD void finish(const Params &P, Mem &mem)
+    {
         for (int a = -1; a <= 1; ++a)
             for (int b = -2; b <= 1; ++b) {
-                const Cell v = mem.load_value(queued.v[a + 1][b + 2], is_old(r, a, b), cell_at(P, r, a, b)); // (the element only matters to the host's late loads)
-                og[a + 1][b + 2] = v.g;
+                const Cell v = mem.load_value(q[a + 1][b + 2], live && is_old(r, a, b), cell_at(P, r, a, b)); // (the element only matters to the host's late loads)
                 ow[a + 1][b + 2] = v.w;
                 op[a + 1][b + 2] = v.w * v.g;
+                if (a == 0 && b == 0) g00 = v.g;
+                if (a == 0 && b == -1) g0m1 = v.g;
             }
         const bool decay0 = 2 * r * r >= P.r2min, decay1 = r * r + (r - 1) * (r - 1) >= P.r2min;
-        const float x0w = decayed_confidence(ow[1][2], decay0, P); // X_0: (0, 0)
-        const float x1w = decayed_confidence(ow[1][1], decay1, P); // X_1: (0, -1)
-        const float y0w = decayed_confidence(x0w, decay0, P);      // Y_0: (0, 0) again
-        mem.mark(1);
-        const WP in_corner = mem.get(prev + 2); // (z - o, z - o): Y_0 of ring r - 1 (ring 0: the centre)
-        // (z - o, z - 2o): X_1 of ring r - 1.  Ring 1 has no such predecessor ring: for AB that cell is D_1(1), still OLD;
-        // for CD it is B_1(1) = B_last(1), already NEW (sides A and B of a ring come before C and D).
-        const WP in_x1 = r > 1 ? mem.get(prev) : !CD ? WP{ow[0][0], op[0][0]} : mem.get(L.join + 2 * (SIDE_B * P.c + 1));
-        float w[9], p[9];
+        x0w = decayed_confidence(ow[1][2], decay0, P); // X_0: (0, 0)
+        x1w = decayed_confidence(ow[1][1], decay1, P); // X_1: (0, -1)
+        y0w = decayed_confidence(x0w, decay0, P);      // Y_0: (0, 0) again
+    }
+    // ---- recur: ring r's first-side visits X_0 = (z, z), X_1 = (z, z - o) (A_1 / C_1), then the revisit Y_0 = (z, z) (B_0 / D_0),
+    //      given in_corner = Y_0 of ring r - 1 at (-1, -1) (ring 0: the centre) and in_x1 = X_1 of ring r - 1 at (-1, -2).
+    //      `mine`: this lane's ring is the one being computed (its results are stored and published).
+    template <class Mem>
+    SW_HD void recur(bool mine, int lane, WP in_corner, WP in_x1_ring, const Params &P, const LdsMap &L, Mem &mem, WP &x1_out, WP &y0_out)
+    {
+        // Ring 1 has no predecessor ring: for AB the cell (-1, -2) is D_1(1), still OLD; for CD it is B_1(1) = B_last(1),
+        // already NEW (sides A and B of a ring come before C and D) -- the caller passes the join in that case.
+        const WP in_x1 = (r == 1 && !CD) ? WP{ow[0][0], op[0][0]} : in_x1_ring;
+        WP win[9];
         // ---- X_0 at (0, 0): everything old except the inner corner (-1, -1)
         for (int a = -1; a <= 1; ++a)
-            for (int b = -1; b <= 1; ++b) {
-                const bool nc = a == -1 && b == -1;
-                w[q(a, b, 0, 0)] = nc ? in_corner.w : ow[a + 1][b + 2];
-                p[q(a, b, 0, 0)] = nc ? in_corner.p : op[a + 1][b + 2];
-            }
-        const float x0g = interpolated_height(w, p, og[1][2], ow[1][2]);
+            for (int b = -1; b <= 1; ++b) win[q9(a, b, 0, 0)] = (a == -1 && b == -1) ? in_corner : WP{ow[a + 1][b + 2], op[a + 1][b + 2]};
+        const float x0g = interpolated_height2(win, g00, ow[1][2]);
         const WP x0{x0w, x0w * x0g};
-        mem.mark(2);
         // ---- X_1 at (0, -1): new = X_0 at (0, 0), inner corner (-1, -1), X_1(r-1) at (-1, -2)
         for (int a = -1; a <= 1; ++a)
-            for (int b = -2; b <= 0; ++b) {
-                const WP v = (a == 0 && b == 0) ? x0 : (a == -1 && b == -1) ? in_corner : (a == -1 && b == -2) ? in_x1 : WP{ow[a + 1][b + 2], op[a + 1][b + 2]};
-                w[q(a, b, 0, -1)] = v.w;
-                p[q(a, b, 0, -1)] = v.p;
-            }
-        const float x1g = interpolated_height(w, p, og[1][1], ow[1][1]);
+            for (int b = -2; b <= 0; ++b)
+                win[q9(a, b, 0, -1)] = (a == 0 && b == 0) ? x0 : (a == -1 && b == -1) ? in_corner : (a == -1 && b == -2) ? in_x1 : WP{ow[a + 1][b + 2], op[a + 1][b + 2]};
+        const float x1g = interpolated_height2(win, g0m1, ow[1][1]);
         const WP x1{x1w, x1w * x1g};
-        mem.mark(3);
         // ---- Y_0 at (0, 0) again: new = itself (X_0), X_1 at (0, -1), inner corner
         for (int a = -1; a <= 1; ++a)
-            for (int b = -1; b <= 1; ++b) {
-                const WP v = (a == 0 && b == 0) ? x0 : (a == 0 && b == -1) ? x1 : (a == -1 && b == -1) ? in_corner : WP{ow[a + 1][b + 2], op[a + 1][b + 2]};
-                w[q(a, b, 0, 0)] = v.w;
-                p[q(a, b, 0, 0)] = v.p;
-            }
-        const float y0g = interpolated_height(w, p, x0g, x0w);
+            for (int b = -1; b <= 1; ++b)
+                win[q9(a, b, 0, 0)] = (a == 0 && b == 0) ? x0 : (a == 0 && b == -1) ? x1 : (a == -1 && b == -1) ? in_corner : WP{ow[a + 1][b + 2], op[a + 1][b + 2]};
+        const float y0g = interpolated_height2(win, x0g, x0w);
         const WP y0{y0w, y0w * y0g};
-        mem.mark(4);
-        mem.store(true, queued.e00, Cell{y0g, y0w});
-        mem.store(true, queued.e0m1, Cell{x1g, x1w});
-        mem.put(base, x1);
-        mem.publish(base + 2, y0, L.corner_done + CD, r);
-        if (!CD && r == 1) mem.publish(L.join + 2 * (SIDE_A * P.c + 1), x1, L.join_done + SIDE_A, 1); // A_last(1) = A_1(1): side A of ring 1 has no chain
-        mem.mark(5);
+        mem.store(mine, e00, Cell{y0g, y0w});
+        mem.store(mine, e0m1, Cell{x1g, x1w});
+        const int base = L.corner + 2 * ((CD * P.c + r) * 2);
+        mem.put_if(mine, lane, L, base, x1);
+        mem.publish_if(mine, lane, L, base + 2, y0, L.corner_done + CD, r);
+        if (!CD) // A_last(1) = A_1(1): side A of ring 1 has no chain
+            mem.publish_if(mine && r == 1, lane, L, L.join + 2 * (SIDE_A * P.c + 1), x1, L.join_done + SIDE_A, 1);
+        x1_out = x1;
+        y0_out = y0;
     }
-    template <class Mem> SW_HD static bool ready(int r, const LdsMap &L, Mem &mem)
+    // CD's first ring reads B_last(1)
+    template <class Mem> SW_HD static bool ready(int ring, const LdsMap &L, Mem &mem)
     {
-        return !(CD && r == 1) || mem.counter(L.join_done + SIDE_B) >= 1;
+        return !(CD && ring == 1) || mem.counter(L.join_done + SIDE_B) >= 1;
     }
 };
 

@@ -62,6 +62,10 @@ struct HostMem {
         put(data_word, v);
         lds[(size_t)counter_word] = value;
     }
+    void put_if(bool c, int, const LdsMap &, int word, WP v)
+    {
+        if (c) put(word, v);
+    }
     void publish_if(bool c, int, const LdsMap &, int data_word, WP v, int counter_word, int value)
     {
         if (c) publish(data_word, v, counter_word, value);
@@ -143,29 +147,31 @@ template <int SIDE> struct ChainWave : WaveBase {
 template <int CD> struct CornerWave : WaveBase {
     const Params &P;
     const LdsMap &L;
-    int r = 1;
-    bool primed = false, bad_addr = false;
-    bool bad() const override { return bad_addr; }
-    typename CornerLane<CD>::Old cur;
-    typename CornerLane<CD>::Addr ad;
+    int r = 1;            // next ring of the recurrence
+    bool prepared = false; // the current group's lanes have their old cells
+    CornerRing<CD> lane[LANES];
+    WP in_corner{0.f, 0.f}, in_x1{0.f, 0.f};
     CornerWave(const Params &p, const LdsMap &l) : P(p), L(l) {}
     bool done() const override { return r > P.rings; }
     bool try_step(HostMem &mem) override
     {
-        if (done() || !CornerLane<CD>::ready(r, L, mem)) return false;
-        if (!primed) {
-            CornerLane<CD>::advance(ad, r, P);
-            cur = CornerLane<CD>::load(r, ad, P, mem);
-            primed = true;
+        if (done() || !CornerRing<CD>::ready(r, L, mem)) return false;
+        const int l = (r - 1) % LANES, r0 = r - l;
+        if (!prepared) { // like the device: the whole group's old cells, requested and consumed at the start of the group
+            for (int k = 0; k < LANES; ++k) lane[k].issue(r0 + k, P, mem);
+            for (int k = 0; k < LANES; ++k) lane[k].finish(P, mem);
+            const int prev = L.corner + 2 * ((CD * P.c + r0 - 1) * 2);
+            in_corner = mem.get(prev + 2);
+            in_x1 = r0 > 1 ? mem.get(prev) : WP{0.f, 0.f};
+            prepared = true;
         }
-        CornerLane<CD>::advance(ad, r + 1, P);
-        for (int a = -1; a <= 1 && r + 1 <= P.rings; ++a) // the incremental addressing against the generic index
-            for (int b = -2; b <= 1; ++b)
-                if (ad.e[a + 1][b + 2] != gp_index(P.gl, P.c + (CD ? 1 : -1) * (r + 1 + a), P.c + (CD ? 1 : -1) * (r + 1 + b))) bad_addr = true;
-        const typename CornerLane<CD>::Old next = CornerLane<CD>::load(r + 1, ad, P, mem); // one ring ahead, like the device
-        CornerLane<CD>::ring(r, cur, P, L, mem);
-        cur = next;
+        if (CD && r == 1) in_x1 = mem.get(L.join + 2 * (SIDE_B * P.c + 1));
+        WP x1, y0;
+        lane[l].recur(true, l, in_corner, in_x1, P, L, mem, x1, y0);
+        in_corner = y0;
+        in_x1 = x1;
         ++r;
+        if (l == LANES - 1) prepared = false;
         return true;
     }
 };

@@ -12,9 +12,11 @@ L = _lib.load()
 out = (C.c_ulonglong * 64)()
 L.gg_debug_sweep_timing.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert L.gg_debug_sweep_timing(seg._ctx, out) == 0
-v = np.array(list(out), dtype=np.int64).reshape(16, 4)
-t0 = v[:10, 0].min()
-names = ["A0", "A1", "B0", "B1", "C0", "C1", "D0", "D1", "cornerAB", "cornerCD"]
+v = np.array(list(out), dtype=np.int64)[:48].reshape(12, 4)  # (the first 12 wavefronts; the corner phase marks follow)
+W = 3 if os.environ.get("GG_SWEEP_WAVES") is None else int(os.environ["GG_SWEEP_WAVES"])
+names = [f"{s}{w}" for s in "ABCD" for w in range(W)] + ["cornerAB", "cornerCD"]
+names = names[:12]
+t0 = v[:len(names), 0].min()
 for k, nm in enumerate(names):
     print(f"{nm:9s} start {v[k,0]-t0:9d} end {v[k,1]-t0:9d} cycles  polling {v[k,2]:9d}  waits {v[k,3]:6d}")
 m = np.array(list(out), dtype=np.int64)[48:60].reshape(2, 6)
