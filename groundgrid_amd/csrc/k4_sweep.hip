@@ -168,11 +168,11 @@ template <int SIDE, bool DBG> GG_DEV void run_chain(const Params &P, const LdsMa
             for (int u = 0; u < TRIP; ++u) {
                 const int t = tb + u;
                 sync.advance(t);
-                if (!sync.ok()) { // (rare) something this step reads has not been published yet as far as the cached counters know
+                auto wait_for = [&](auto ready) { // (rare) something the next half step reads has not been published yet as far as the cached counters know
                     const unsigned long long w0 = clk.out_ptr() ? __builtin_readcyclecounter() : 0ull;
                     sync.refresh(mem);
                     int spins = 0;
-                    while (!sync.ok()) {
+                    while (!ready()) {
                         __builtin_amdgcn_s_sleep(1);
                         sync.refresh(mem);
                         ++spins;
@@ -181,11 +181,15 @@ template <int SIDE, bool DBG> GG_DEV void run_chain(const Params &P, const LdsMa
                         clk.polling += __builtin_readcyclecounter() - w0;
                         clk.waits += spins ? 1 : 0;
                     }
-                }
+                };
+                if (!sync.ok_a()) wait_for([&]() { return sync.ok_a(); });
                 const WP ho = st.handed_over();
                 const WP x_in{wave_shr1(ho.w), wave_shr1(ho.p)};
                 constexpr int t_first_mod = ((-2 - (int)PF) % (int)SKEW + (int)SKEW) % (int)SKEW; // tb = t_first (mod TRIP), TRIP = 0 (mod SKEW)
-                st.step(t, u % (int)PF, (t_first_mod + u) % (int)SKEW, x_in, P, L, group > 0, has_next, group, mem);
+                const int tmod = (t_first_mod + u) % (int)SKEW;
+                st.step_a(t, u % (int)PF, tmod, x_in, P, L, group > 0, mem);
+                if (!sync.ok_b()) wait_for([&]() { return sync.ok_b(); });
+                st.step_b(t, tmod, P, L, has_next, group, mem);
             }
         }
     }

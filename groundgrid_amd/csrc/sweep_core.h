@@ -311,7 +311,8 @@ template <int SIDE> struct ChainSync {
         const int tb = t + 1 < bnd_end ? t + 1 : bnd_end;
         need_bnd = tb > 0 ? tb : 0;
     }
-    SW_HD bool ok() const { return have_corner >= need_corner && have_join >= need_join && have_bnd >= need_bnd; }
+    SW_HD bool ok_a() const { return have_corner >= need_corner && have_bnd >= need_bnd; } // what step_a reads
+    SW_HD bool ok_b() const { return have_join >= need_join; }                              // what step_b reads
     template <class Mem> SW_HD void refresh(Mem &mem) { mem.counters3(w_corner, w_join, w_bnd, have_corner, have_join, have_bnd); }
 };
 
@@ -342,6 +343,9 @@ template <int SIDE> struct ChainLane {
     WP xold;            // S[len + 1]
     WP h1, h2, h3;      // results of the last three steps (lane l + 1 reads the one of SKEW steps ago: handed_over())
     Cell q_own[PF], q_out[PF]; // layer loads in flight, one slot per wave-step mod PF
+    // handed from the first half of a step to the second
+    WP xa, cs0, cs1, cpred;
+    float w_new_;
 
     SW_HD void init(int lane, int r0, int nl, int group, const Params &P, const LdsMap &L)
     {
@@ -402,18 +406,29 @@ template <int SIDE> struct ChainLane {
 
     // One wave-step.  `slot` = wave-step mod PF and tmod = ((t mod SKEW) + SKEW) mod SKEW, both compile-time constants in the
     // device's unrolled loop; x_in = (lane l - 1).handed_over() as it was BEFORE this step (lane 0: anything); lane0 = (l == 0).
+    //
+    // The step comes in two halves.  step_a is everything that does not need the JOIN (the partner side's last value of the
+    // ring inside): the new confidence, the layer loads, the own and outer window lines, the corner and boundary values.
+    // step_b takes the join, completes the inner line and makes the visit.  A wavefront waits for the join between the two:
+    // the sides of a ring hand their ends to each other ring after ring (B -> C -> B ..., A -> D -> A ...), that cycle is the
+    // sweep's critical path, and this way only the second half of a step sits on it.
     template <class Mem>
-    SW_HD void step(int t, int slot, int tmod, WP x_in, const Params &P, const LdsMap &L, bool has_prev_group, bool has_next_group, int group, Mem &mem)
+    SW_HD void step_a(int t, int slot, int tmod, WP x_in, const Params &P, const LdsMap &L, bool has_prev_group, Mem &mem)
     {
+        (void)L;
         // ---- the visited cell's new confidence depends on its old one only (its rare exact path is the step's only branch
         //      besides the publishes at the end: what follows is one basic block for the instruction scheduler)
         const int ao = t + r2c;
-        const float w_new = decayed_confidence(Nw, r2r + ao * ao >= P.r2min, P); // (the successor of the last step becomes "self" now)
-        // ---- LDS: everything this lane could need, every step (garbage until published; selected only when it is)
-        //      -- but only in the (wave-uniform) ranges of steps in which some lane can be at that event
-        WP c_join{0.f, 0.f}, c_bnd{0.f, 0.f};
-        if (t >= u_join_first && t <= u_join_last) c_join = mem.get(a_join);
+        w_new_ = decayed_confidence(Nw, r2r + ao * ao >= P.r2min, P); // (the successor of the last step becomes "self" now)
+        // ---- LDS: what this lane could need (garbage until published; selected only when it is) -- but only in the
+        //      (wave-uniform) ranges of steps in which some lane can be at that event
+        WP c_bnd{0.f, 0.f};
         if (has_prev_group && t >= 0 && t < u_len0) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
+        if (tmod == 0 && t >= 0 && t <= u_start_last) { // a lane's first step (t = SKEW l): the corner values
+            cs0 = mem.get(a_s0);
+            cs1 = mem.get(a_s1);
+            cpred = mem.get(a_pred);
+        }
         // ---- the column that arrives now (along-position k0 + s + 1), requested PF steps ago into this slot; the own-line
         //      request of step -2 (the predecessor's cell, which is never read from the layer) carries the old cell S[len + 1].
         //      (mem.fresh: on the device a real register copy -- the arriving values stay live for two or three more steps
@@ -445,20 +460,28 @@ template <int SIDE> struct ChainLane {
         U[0] = U[1];
         U[1] = U[2];
         U[2] = WP{out.w, out.w * out.g};
-        // stream element S[s + 2]: the inner lane's step s (three wave-steps ago; lane 0: the previous group's boundary chain),
-        // at the ends the join and the old cell
-        WP x = l == 0 ? c_bnd : x_in;
-        x = t + 2 == lend ? c_join : x; // s + 2 == len
-        x = t + 1 == lend ? xold : x;   // s + 2 == len + 1
+        // stream element S[s + 2]: the inner lane's step s (SKEW wave-steps ago; lane 0: the previous group's boundary chain),
+        // at the far end the old cell; the join comes in step_b
+        xa = l == 0 ? c_bnd : x_in;
+        xa = t + 1 == lend ? xold : xa; // s + 2 == len + 1
+    }
+
+    template <class Mem>
+    SW_HD void step_b(int t, int tmod, const Params &P, const LdsMap &L, bool has_next_group, int group, Mem &mem)
+    {
+        WP x = xa;
+        if (t >= u_join_first && t <= u_join_last) {
+            const WP c_join = mem.get(a_join);
+            x = t + 2 == lend ? c_join : x; // s + 2 == len
+        }
         I[0] = I[1];
         I[1] = I[2];
         I[2] = x;
-        if (tmod == 0 && t >= 0 && t <= u_start_last) { // a lane's first step (t = SKEW l): the corner values
-            const WP c_s0 = mem.get(a_s0), c_s1 = mem.get(a_s1), c_pred = mem.get(a_pred);
+        if (tmod == 0 && t >= 0 && t <= u_start_last) {
             const bool first = t == l3;
-            I[0] = first ? c_s0 : I[0];
-            I[1] = first ? c_s1 : I[1];
-            OP = first ? c_pred : OP;
+            I[0] = first ? cs0 : I[0];
+            I[1] = first ? cs1 : I[1];
+            OP = first ? cpred : OP;
         }
         // ---- the visit
         const bool active = (unsigned)(t - l3) < (unsigned)len;
@@ -473,7 +496,7 @@ template <int SIDE> struct ChainLane {
         win[tree_pos<SIDE>(2, 1)] = U[1];
         win[tree_pos<SIDE>(2, 2)] = U[2];
         Cell v;
-        v.w = w_new;
+        v.w = w_new_;
         v.g = interpolated_height2(win, Sg, Sw);
         mem.store(active, ownA + 64 * t, v);
         const WP res = WP{v.w, v.w * v.g};

@@ -114,29 +114,43 @@ template <int SIDE> struct ChainWave : WaveBase {
     }
     bool done() const override { return group >= P.groups; }
     bool bad() const override { return plan_mismatch; }
+    bool half = false; // step_a of wave-step t is done, step_b waits for the join
     bool try_step(HostMem &mem) override
     {
         if (done()) return false;
-        if (!advanced) { // requirements of step t, once
-            sync.advance(t);
-            advanced = true;
+        const int tmod = ((t % SKEW) + SKEW) % SKEW;
+        if (!half) {
+            if (!advanced) { // requirements of step t, once
+                sync.advance(t);
+                advanced = true;
+            }
+            if (!sync.ok_a()) {
+                sync.refresh(mem);
+                if (!sync.ok_a()) return false;
+            }
+            // the cached counters are lower bounds of what the step reads: hold the lazily polled protocol to the exact needs
+            for (int l = 0; l < nl; ++l) {
+                const ChainLane<SIDE> &c = lane[l];
+                if (c.len > 0 && t - c.l3 == 0 && mem.counter(sync.w_corner) < c.r) plan_mismatch = true;
+            }
+            if (group > 0 && t >= 0 && t + 2 < lane[0].len && mem.counter(sync.w_bnd) < t + 1) plan_mismatch = true;
+            WP x_in[LANES];
+            for (int l = 0; l < LANES; ++l) x_in[l] = l ? lane[l - 1].handed_over() : WP{0.f, 0.f}; // wave shift right by one, before anybody moves
+            const int slot = ((t % PF) + PF) % PF;
+            for (int l = 0; l < LANES; ++l) lane[l].step_a(t, slot, tmod, x_in[l], P, L, group > 0, mem);
+            half = true;
         }
-        if (!sync.ok()) {
+        if (!sync.ok_b()) {
             sync.refresh(mem);
-            if (!sync.ok()) return false;
+            if (!sync.ok_b()) return false; // (other wavefronts run between the two halves)
         }
-        // the cached counters are lower bounds of what the step reads: hold the lazily polled protocol to the exact needs
         for (int l = 0; l < nl; ++l) {
             const ChainLane<SIDE> &c = lane[l];
             const int s_ = t - c.l3;
-            if (c.len > 0 && s_ == 0 && mem.counter(sync.w_corner) < c.r) plan_mismatch = true;
             if (c.len > 0 && s_ == c.len - 2 && s_ >= -1 && mem.counter(sync.w_join) < ((SIDE == SIDE_A || SIDE == SIDE_B) ? c.r - 1 : c.r)) plan_mismatch = true;
         }
-        if (group > 0 && t >= 0 && t + 2 < lane[0].len && mem.counter(sync.w_bnd) < t + 1) plan_mismatch = true;
-        WP x_in[LANES];
-        for (int l = 0; l < LANES; ++l) x_in[l] = l ? lane[l - 1].handed_over() : WP{0.f, 0.f}; // wave shift right by one, before anybody moves
-        const int slot = ((t % PF) + PF) % PF, tmod = ((t % SKEW) + SKEW) % SKEW;
-        for (int l = 0; l < LANES; ++l) lane[l].step(t, slot, tmod, x_in[l], P, L, group > 0, group + 1 < P.groups, group, mem);
+        for (int l = 0; l < LANES; ++l) lane[l].step_b(t, tmod, P, L, group + 1 < P.groups, group, mem);
+        half = false;
         ++steps;
         advanced = false;
         if (++t > t_last) next_group();
