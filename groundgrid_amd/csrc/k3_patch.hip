@@ -3,13 +3,15 @@
 // A pure read-neighbours / write-self stencil: each interior cell reads an SxS block (S = 3 inside
 // patch_size_change_distance, else 5) of `points`, `variance`, `minGroundHeight` and updates only its own
 // `ground` / `groundpatch`, so the reference's four quadrant threads are order-free and one thread per
-// cell is exact.  Work-group = 32 rows x 8 cols of cells (rows are the contiguous dimension of the
-// column-major layers), inputs staged in LDS with a 2-cell halo.  The block sums use Eigen's unrolled
+// cell is exact.  Blocks of 32 rows x 8 cols of cells (rows are the contiguous dimension of the
+// column-major layers), inputs staged in LDS with a 2-cell halo; one work-group walks a band of blocks (k_patch).  The block sums use Eigen's unrolled
 // tree order (gg_device.h tree9/tree25).
 //
 // Algorithmic bytes per cell: 6 layers read (points, variance, min, ground, groundpatch, expectedPoints),
 // 2 written.
 #include "gg_device.h"
+
+#include <algorithm>
 
 namespace gg {
 
@@ -36,6 +38,7 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
 
     // :364-365
     if ((double)pointsblockSum < std_max(floor(cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) return;
+    if (a.k3_debug == 3) return;
 
     const int gidx = gp_idx(a, i, j); // the (ground, confidence) layer has its own element order (gp_layout.h)
     const float2 old = gp2[gidx];
@@ -86,58 +89,143 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
     }
 }
 
-__global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams *__restrict__ params)
+// One work-group per (cloud, band of PR rows); it walks the band's blocks of PC columns from left to right with a rolling
+// window of LC = PC + 4 columns in LDS (a ring of 16 column slots; slots 0..3 are mirrored at 16..19 so that both block
+// parities read 12 CONSECUTIVE slots), keeps the next block's columns in flight in registers while it computes the current
+// one, and skips the blocks that no KEPT point can reach: a cell only changes if its block of `points` sums to at least 3
+// (:364), and `points` is zero in every 16x16 tile without records (K2 reset it, :61-75) -- the record counts of the band's
+// three tile rows are folded into one flag per tile column when the work-group starts.  (540 blocks per cloud as separate
+// work-groups spent 0.6 ms of 1.6 on launching work-groups and another 0.4 on their first loads.)
+constexpr int RING = 16, SLOTS = RING + 4, MAXTC = 256;
+
+__global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams *__restrict__ params, int n_bands, int blocks_per_segment)
 {
-    __shared__ float pts[LC][LR], var[LC][LR], mnl[LC][LR];
-    const int cloud = blockIdx.z;
+    __shared__ float pts[SLOTS][LR], var[SLOTS][LR], mnl[SLOTS][LR];
+    __shared__ uint32_t col_has_points[MAXTC]; // per tile column: records in the band's tile rows
+    // XCD-aware (gg_device.h): the bands of one cloud run on one XCD.  A launch with few clouds cuts every band into segments
+    // of blocks_per_segment blocks (one work-group each) so that the chip is still covered.
+    const uint32_t item = xcd_contiguous_item(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int cloud = (int)(item / gridDim.x), band = (int)(item % gridDim.x) % n_bands, segment = (int)(item % gridDim.x) / n_bands;
     const CloudParams cp = params[cloud];
     const int rows = a.g.rows, cols = a.g.cols;
-    const int r0 = HALO + blockIdx.x * PR, c0 = HALO + blockIdx.y * PC; // first output cell of this block
+    const int r0 = HALO + band * PR; // first output row of the band
+    const int b_first = segment * blocks_per_segment;
+    const int n_blocks = min((cols - 2 * HALO + PC - 1) / PC, b_first + blocks_per_segment); // (end of this work-group's blocks)
+    const int tid = threadIdx.x;
+
+    // ---- which tile columns hold records in the band's tile rows
+    const int tiles_c = a.g.tiles_c;
+    for (int k = tid; k < tiles_c; k += 256) col_has_points[k] = 0u;
+    __syncthreads();
+    {
+        const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
+        const int tr_lo = (r0 - HALO) / TILE, tr_hi = min((r0 + PR + HALO - 1) / TILE, a.g.tiles_r - 1);
+        const int ntr = tr_hi - tr_lo + 1;
+        for (int k = tid; k < ntr * tiles_c; k += 256) {
+            const int tc = k / ntr, tile = (tr_lo + k % ntr) + tc * a.g.tiles_r;
+            const int rank = a.tile_rank[tile];
+            if (tile_start[rank + 1] != tile_start[rank]) col_has_points[tc] = 1u;
+        }
+    }
+    __syncthreads();
+    if (a.k3_debug == 1) return;
+    auto block_has_points = [&](int b) { // reads cover columns [PC b, PC b + LC)
+        const int tc_lo = (PC * b) / TILE, tc_hi = min((PC * b + LC - 1) / TILE, tiles_c - 1);
+        return (col_has_points[tc_lo] | col_has_points[tc_hi]) != 0u; // (LC <= TILE: at most two tile columns)
+    };
+    auto next_block = [&](int b) {
+        while (b < n_blocks && !block_has_points(b)) ++b;
+        return b;
+    };
 
     const float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
     const float *gp_pts = L + GG_LAYER_POINTS * a.layer_stride;
     const float *gp_var = L + GG_LAYER_VARIANCE * a.layer_stride;
     const float *gp_min = L + GG_LAYER_MINGROUNDHEIGHT * a.layer_stride;
-
-    for (int k = threadIdx.x; k < LR * LC; k += 256) {
-        const int lr = k % LR, lc = k / LR;
-        const int gr = r0 - HALO + lr, gcol = c0 - HALO + lc;
-        float p = 0.0f, v = 0.0f, m = 0.0f;
-        if (gr < rows && gcol < cols) {
-            const size_t idx = (size_t)gr + (size_t)gcol * rows;
-            p = gp_pts[idx];
-            v = gp_var[idx];
-            m = gp_min[idx];
-        }
-        pts[lc][lr] = p;
-        var[lc][lr] = v;
-        mnl[lc][lr] = m;
-    }
-    __syncthreads();
-
-    const int tr = threadIdx.x % PR, tcl = threadIdx.x / PR;
-    const int i = r0 + tr, j = c0 + tcl;
-    // the four quadrants (:325-328) cover rows [2, 2 * (cols / 2) - 2) -- the FIRST loop variable, bounded by cols / 2, is
-    // used as the row index -- and cols [2, rows - 2): for odd sizes row n - 3 is never visited
-    if (i >= 2 * (cols / 2) - 2 || j >= rows - 2) return;
-
-    // :332
-    const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
-    const float sqdist = (float)((di * di + dj * dj) * ((double)a.g.resolution_f * (double)a.g.resolution_f));
     float2 *gp2 = gp2_ptr(a, cp.slot);
-    if ((double)sqdist <= a.cfg.patch_size_change_distance_sq) // :334
-        detect_ground_patch<3>(a, pts, var, mnl, tr + HALO, tcl + HALO, i, j, sqdist, gp2);
-    else
-        detect_ground_patch<5>(a, pts, var, mnl, tr + HALO, tcl + HALO, i, j, sqdist, gp2);
+
+    // staging registers: up to LC columns x LR rows = 432 cells, two per thread
+    float sp[2], sv[2], sm[2];
+    auto request = [&](int b, int first_col, int n_cols) { // columns [first_col, first_col + n_cols) of block b's window
+        (void)b;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = tid + 256 * h;
+            const int lr = k % LR, lc = k / LR;
+            const int gr = r0 - HALO + lr, gcol = first_col + lc;
+            sp[h] = sv[h] = sm[h] = 0.0f;
+            if (lc < n_cols && gr < rows && gcol < cols) {
+                const size_t idx = (size_t)gr + (size_t)gcol * rows;
+                sp[h] = gp_pts[idx];
+                sv[h] = gp_var[idx];
+                sm[h] = gp_min[idx];
+            }
+        }
+    };
+    auto deposit = [&](int first_col, int n_cols) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = tid + 256 * h;
+            const int lr = k % LR, lc = k / LR;
+            if (lc < n_cols) {
+                const int slot = (first_col + lc) & (RING - 1);
+                pts[slot][lr] = sp[h];
+                var[slot][lr] = sv[h];
+                mnl[slot][lr] = sm[h];
+                if (slot < SLOTS - RING) { // the mirror
+                    pts[slot + RING][lr] = sp[h];
+                    var[slot + RING][lr] = sv[h];
+                    mnl[slot + RING][lr] = sm[h];
+                }
+            }
+        }
+    };
+
+    const int tr = tid % PR, tcl = tid / PR;
+    const int i = r0 + tr;
+    int b = next_block(b_first);
+    int req_first = PC * b, req_cols = LC; // what the staging registers hold
+    if (b < n_blocks) request(b, req_first, req_cols);
+    while (b < n_blocks) {
+        deposit(req_first, req_cols);
+        __syncthreads();
+        if (a.k3_debug == 2) return;
+        // the next block that can change anything: its new columns travel while this one is computed
+        const int nb = next_block(b + 1);
+        if (nb < n_blocks) {
+            req_first = nb == b + 1 ? PC * nb + (LC - PC) : PC * nb; // (a neighbour: only the PC columns beyond this window)
+            req_cols = nb == b + 1 ? PC : LC;
+            request(nb, req_first, req_cols);
+        }
+        const int j = HALO + PC * b + tcl;
+        // the four quadrants (:325-328) cover rows [2, 2 * (cols / 2) - 2) -- the FIRST loop variable, bounded by cols / 2, is
+        // used as the row index -- and cols [2, rows - 2): for odd sizes row n - 3 is never visited
+        if (!(i >= 2 * (cols / 2) - 2 || j >= rows - 2)) {
+            const int base = (PC * b) & (RING - 1); // 0 or 8: the window is slots base .. base + LC - 1
+            // :332
+            const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
+            const float sqdist = (float)((di * di + dj * dj) * ((double)a.g.resolution_f * (double)a.g.resolution_f));
+            if ((double)sqdist <= a.cfg.patch_size_change_distance_sq) // :334
+                detect_ground_patch<3>(a, pts + base, var + base, mnl + base, tr + HALO, tcl + HALO, i, j, sqdist, gp2);
+            else
+                detect_ground_patch<5>(a, pts + base, var + base, mnl + base, tr + HALO, tcl + HALO, i, j, sqdist, gp2);
+        }
+        __syncthreads(); // (the window is overwritten next)
+        b = nb;
+    }
 }
 
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)
 {
     if (n_clouds == 0) return;
     const int ir = a.g.rows - 2 * HALO, ic = a.g.cols - 2 * HALO;
-    if (ir <= 0 || ic <= 0) return;
-    dim3 grid((ir + PR - 1) / PR, (ic + PC - 1) / PC, n_clouds);
-    hipLaunchKernelGGL(k_patch, grid, dim3(256), 0, s, a, d_params);
+    if (ir <= 0 || ic <= 0 || a.g.tiles_c > MAXTC) return;
+    const int n_bands = (ir + PR - 1) / PR, n_blocks = (ic + PC - 1) / PC;
+    // about 8192 work-groups per launch: whole bands when there are many clouds, segments of a band when there are few
+    const int segments = std::max(1, std::min(n_blocks, 8192 / std::max(1, n_clouds * n_bands)));
+    const int per_segment = (n_blocks + segments - 1) / segments;
+    dim3 grid(n_bands * ((n_blocks + per_segment - 1) / per_segment), n_clouds);
+    hipLaunchKernelGGL(k_patch, grid, dim3(256), 0, s, a, d_params, n_bands, per_segment);
 }
 
 } // namespace gg
