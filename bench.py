@@ -166,7 +166,7 @@ def main():
                 self.pending[k].wait()  # orders the compute stream after the gather that still reads outs[k].label_masks
                 self.pending[k] = None
             if self.cold:  # every cloud meets a freshly initialised map: ground := 0, groundpatch := 1e-7 (one launch, timed)
-                self.seg.reset_maps(0, self.pts.shape[0], odom_z=0.0, persistent_only=True)
+                self.seg.reset_maps(0, self.pts.shape[0], odom_z=0.0, persistent_only=True, on_torch_stream=True)
             self.outs[k] = self.seg.filter_batch(self.pts, self.npts, self.org, self.bz, out=self.outs[k], want_masks=dist is not None)
             self.out = self.outs[k]
             if dist:

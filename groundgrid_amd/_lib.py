@@ -140,7 +140,7 @@ def load():
     L.gg_last_error.argtypes = [vp]
     L.gg_last_error.restype = C.c_char_p
     L.gg_reset_map.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_float]
-    L.gg_reset_maps.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float, C.c_int]
+    L.gg_reset_maps.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float, C.c_int, vp]
     L.gg_set_map_position.argtypes = [vp, C.c_int, C.c_double, C.c_double]
     L.gg_move_map.argtypes = [vp, C.c_int, C.c_double, C.c_double, P(C.c_double), P(C.c_int)]
     L.gg_get_map_position.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_double)]

@@ -196,12 +196,20 @@ class GroundSegmentation:
     def map(self, slot: int = 0) -> GridMap:
         return self._maps[slot]
 
-    def reset_maps(self, first_slot: int = 0, n_slots: Optional[int] = None, odom_z: float = 0.0, pos=(0.0, 0.0), persistent_only: bool = False):
+    def reset_maps(self, first_slot: int = 0, n_slots: Optional[int] = None, odom_z: float = 0.0, pos=(0.0, 0.0), persistent_only: bool = False,
+                   on_torch_stream: bool = False):
         """GroundGrid::initGroundGrid values (src/GroundGrid.cpp:71-75) for a range of map states in one launch; with
-        persistent_only just ground / groundpatch, the state that outlives a cloud (a "cold" start)."""
+        persistent_only just ground / groundpatch, the state that outlives a cloud (a "cold" start).  on_torch_stream: enqueue on
+        the current torch stream (where filter_batch runs) instead of the context's own."""
         n = self.n_slots - first_slot if n_slots is None else n_slots
+        stream = None
+        if on_torch_stream:
+            import torch
+
+            h = torch.cuda.current_stream(self.device).cuda_stream
+            stream = C.c_void_p(h) if h else C.c_void_p(-1)  # (0 = torch's default stream = GG_STREAM_DEFAULT)
         _check(self._L, self._ctx, self._L.gg_reset_maps(self._ctx, first_slot, n, float(pos[0]), float(pos[1]), C.c_float(odom_z),
-                                                          1 if persistent_only else 0), "gg_reset_maps")
+                                                          1 if persistent_only else 0, stream), "gg_reset_maps")
         for s in range(first_slot, first_slot + n):
             self._maps[s]._pos = (float(pos[0]), float(pos[1]))
 

@@ -507,6 +507,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_scroll = carve(a.gp2_stride * 8); // one layer in its device element order (map scroll) / two planes (images)
     const size_t o_image = carve(3 * Cpad * 4);
     const size_t o_bounds = carve(64);
+    const size_t gp_valid_words = ((size_t)a.gpl.elems + 31) / 32;
+    const size_t o_gpvalid = carve(gp_valid_words * 4);
     const size_t o_dbg = carve(64 * 8); // sweep timing
     const bool k2_timing = getenv("GG_K2_DEBUG") && atoi(getenv("GG_K2_DEBUG")) == 9;
     const size_t K2_DBG_WGS = 32768; // k_reduce phase counters, [work-group][32]
@@ -555,6 +557,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_scroll_scratch = (float *)(base + o_scroll);
     ctx->d_image = (float *)(base + o_image);
     ctx->d_bounds = (float *)(base + o_bounds);
+    a.gp_valid = (const uint32_t *)(base + o_gpvalid);
     if (getenv("GG_SWEEP_TIMING")) {
         ctx->d_sweep_dbg = (unsigned long long *)(base + o_dbg);
         const unsigned long long mode = getenv("GG_SWEEP_DEBUG") ? strtoull(getenv("GG_SWEEP_DEBUG"), nullptr, 0) : 0ull;
@@ -562,6 +565,13 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         hipMemcpy(ctx->d_sweep_dbg + 63, &mode, 8, hipMemcpyHostToDevice);
     }
 
+    std::vector<uint32_t> gp_valid(gp_valid_words, 0u);
+    for (int col = 0; col < n; ++col)
+        for (int row = 0; row < n; ++row) {
+            const int e = gp_index(a.gpl, row, col);
+            gp_valid[(size_t)e >> 5] |= 1u << (e & 31);
+        }
+    CREATE_CHK(hipMemcpyAsync(base + o_gpvalid, gp_valid.data(), gp_valid_words * 4, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_rtile, rank_tile.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
@@ -736,13 +746,19 @@ int gg_get_geometry(const gg_context *ctx, double *resolution, double *length_x,
 
 const char *gg_last_error(const gg_context *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
-int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double pos_y, float odom_z, int persistent_only)
+int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double pos_y, float odom_z, int persistent_only, void *stream)
 {
     if (!ctx) return GG_ERR_INVALID;
     if (n < 0 || first_slot < 0 || first_slot + n > ctx->n_slots) return GG_ERR_CAPACITY;
     if (n == 0) return GG_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
+    const hipStream_t st = pick_stream(ctx, stream);
+    if (st == ctx->stream) {
+        if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
+    } else { // ordered like a batch on the caller's stream
+        if (ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->map_event, 0));
+        if (ctx->have_batch_event && ctx->last_batch_stream != st) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->batch_event, 0));
+    }
     const Arena &a = ctx->arena;
     const size_t C = (size_t)a.g.C;
     for (int s = first_slot; s < first_slot + n; ++s) {
@@ -756,19 +772,23 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
     if (!persistent_only) {
         for (int l = 0; l < GG_NUM_LAYERS; ++l)
             if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH)
-                launch_fill_strided(layer_ptr(a, first_slot, l), C, a.slot_layer_stride, n, init[l], ctx->stream);
+                launch_fill_strided(layer_ptr(a, first_slot, l), C, a.slot_layer_stride, n, init[l], st);
         // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
-        launch_fill_bytes(a.tile_live + (size_t)first_slot * a.tile_live_stride, (size_t)n * a.tile_live_stride, 1, ctx->stream);
+        launch_fill_bytes(a.tile_live + (size_t)first_slot * a.tile_live_stride, (size_t)n * a.tile_live_stride, 1, st);
     }
-    launch_fill2_strided(gp2_ptr(a, first_slot), (size_t)a.gpl.elems, a.gp2_stride, n, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], ctx->stream);
+    launch_fill2_strided(gp2_ptr(a, first_slot), (size_t)a.gpl.elems, a.gp2_stride, n, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], a.gp_valid, st);
     HIPCHK(ctx, hipGetLastError());
-    return own_stream_mutated_map(ctx);
+    if (st == ctx->stream) return own_stream_mutated_map(ctx);
+    HIPCHK(ctx, hipEventRecord(ctx->batch_event, st));
+    ctx->have_batch_event = true;
+    ctx->last_batch_stream = st;
+    return GG_OK;
 }
 
 int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float odom_z)
 {
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
-    return gg_reset_maps(ctx, slot, 1, pos_x, pos_y, odom_z, 0);
+    return gg_reset_maps(ctx, slot, 1, pos_x, pos_y, odom_z, 0, nullptr);
 }
 
 int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y)

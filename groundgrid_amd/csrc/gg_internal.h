@@ -82,6 +82,7 @@ struct Arena {
     const uint16_t *rank_tile;    // [T] Morton rank -> tile
     // per slot (slot s at base + s * stride)
     float *layers;  size_t layer_stride;  size_t slot_layer_stride;  // layer l of slot s: layers + s*slot_layer_stride + l*layer_stride
+    const uint32_t *gp_valid;     // one bit per element of the gp2 order: is it a cell (the rest is padding)
     float2 *gp2;    size_t gp2_stride;    GpLayout gpl;              // (ground, confidence) of slot s: gp2 + s*gp2_stride, element order gp_layout.h
     uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
     float *zcell;   size_t zcell_stride;  // per slot: the KEPT heights grouped by cell (K2's stable cell sort), Nmax + 32 T + 64
@@ -146,7 +147,7 @@ void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
 void launch_fill_bytes(uint8_t *dst, size_t n, uint8_t v, hipStream_t s);
 void launch_fill_strided(float *dst, size_t n, size_t stride, int count, float v, hipStream_t s);   // count regions of n floats, `stride` apart
-void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float x, float y, hipStream_t s);
+void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float x, float y, const uint32_t *valid, hipStream_t s);
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
 void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s); // sheared layer -> column-major plane
 void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, hipStream_t s);

@@ -174,8 +174,11 @@ const char *gg_last_error(const gg_context *ctx);
 int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float odom_z);
 /* The same for n_slots consecutive map states in one launch (position (pos_x, pos_y) and height odom_z for all).  With
  * persistent_only != 0 only the state that outlives a cloud is re-initialised -- ground := odom_z, groundpatch := 1e-7 -- which
- * is all a "cold" start needs: the nine per-call layers are rewritten by the next filter call anyway (:61-75). */
-int gg_reset_maps(gg_context *ctx, int first_slot, int n_slots, double pos_x, double pos_y, float odom_z, int persistent_only);
+ * is all a "cold" start needs: the nine per-call layers are rewritten by the next filter call anyway (:61-75).
+ * `stream`: NULL = the context's stream (like every other map mutation); a caller stream (or GG_STREAM_DEFAULT) enqueues the
+ * fills there, ordered like a batch on that stream -- a server that re-initialises maps between batches on its own stream
+ * then has no cross-stream hand-over in its loop. */
+int gg_reset_maps(gg_context *ctx, int first_slot, int n_slots, double pos_x, double pos_y, float odom_z, int persistent_only, void *stream);
 /* map position after grid_map::move (src/GroundGrid.cpp:97); layers unchanged */
 int gg_set_map_position(gg_context *ctx, int slot, double pos_x, double pos_y);
 /* GroundGrid::update for an initialised map (src/GroundGrid.cpp:83-147): grid_map::GridMap::move to the odometry
