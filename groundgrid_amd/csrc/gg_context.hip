@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include <chrono>
 
 #include "gg_internal.h"
 #include "sweep_core.h"
@@ -72,6 +73,8 @@ struct gg_context {
     } async_slot[GG_ASYNC_DEPTH];
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     int next_ticket = 0, oldest_ticket = 0;
+    double host_t[4] = {0, 0, 0, 0}; // GG_HOST_TIMING: pack+upload, enqueue, wait, copy-out
+    long host_calls = 0;
 
     // per-call parameter ring (pinned host + device)
     CloudParams *h_params = nullptr; // [PARAM_RING][n_slots] pinned
@@ -1015,8 +1018,17 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
     HIPCHK(ctx, hipSetDevice(ctx->device));
     gg_context::AsyncSlot &as = ctx->async_slot[ctx->next_ticket % GG_ASYNC_DEPTH];
 
-    pack_points(cloud, as.h_pts, n); // overlaps the device work of the previous ticket
-    if (n) HIPCHK(ctx, hipMemcpyAsync(as.d_pts, as.h_pts, n * sizeof(gg_point16), hipMemcpyHostToDevice, ctx->h2d_stream));
+    static const bool host_timing = getenv("GG_HOST_TIMING") != nullptr; // (tools: where does the host call spend its time)
+    const auto t_pack0 = std::chrono::steady_clock::now();
+    // pack and upload in four pieces: the copy of a piece travels while the next one is packed (and all of it overlaps the
+    // device work of the previous ticket)
+    for (int c = 0; c < 4; ++c) {
+        const size_t lo = n * c / 4, hi = n * (c + 1) / 4;
+        if (hi == lo) continue;
+        pack_points(cloud + lo, as.h_pts + lo, hi - lo);
+        HIPCHK(ctx, hipMemcpyAsync(as.d_pts + lo, as.h_pts + lo, (hi - lo) * sizeof(gg_point16), hipMemcpyHostToDevice, ctx->h2d_stream));
+    }
+    if (host_timing) ctx->host_t[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack0).count();
     HIPCHK(ctx, hipEventRecord(as.uploaded, ctx->h2d_stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, as.uploaded, 0));
 
@@ -1054,6 +1066,7 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
     if (tf) memcpy(as.tf, tf, sizeof as.tf);
     as.ticket = ctx->next_ticket;
     *ticket = ctx->next_ticket++;
+    if (host_timing) ctx->host_t[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack0).count();
     return GG_OK;
 }
 
@@ -1064,7 +1077,10 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
     HIPCHK(ctx, hipSetDevice(ctx->device));
     gg_context::AsyncSlot &as = ctx->async_slot[ticket % GG_ASYNC_DEPTH];
     ctx->oldest_ticket = ticket + 1; // (also on error below: the slot is reusable either way)
+    static const bool host_timing = getenv("GG_HOST_TIMING") != nullptr;
+    const auto t_w0 = std::chrono::steady_clock::now();
     HIPCHK(ctx, hipEventSynchronize(as.downloaded));
+    const auto t_w1 = std::chrono::steady_clock::now();
     const size_t n = as.n;
     if (out_n) *out_n = (size_t)as.h_counts[0];
     if (out_label && n) memcpy(out_label, as.h_labels, n);
@@ -1084,6 +1100,15 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
                 out_cloud[k].z = (float)(((tf[8] * dx + tf[9] * dy) + tf[10] * dz) + tf[11]);
             }
             out_cloud[k].intensity = (float)as.h_labels[i];
+        }
+    }
+    if (host_timing) {
+        ctx->host_t[2] += std::chrono::duration<double>(t_w1 - t_w0).count();
+        ctx->host_t[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w1).count();
+        if (++ctx->host_calls % 256 == 0) {
+            fprintf(stderr, "gg host path, ms per call: pack+upload calls %.3f, whole enqueue %.3f, wait %.3f, copy-out + assemble %.3f\n",
+                    1e3 * ctx->host_t[0] / 256, 1e3 * ctx->host_t[1] / 256, 1e3 * ctx->host_t[2] / 256, 1e3 * ctx->host_t[3] / 256);
+            ctx->host_t[0] = ctx->host_t[1] = ctx->host_t[2] = ctx->host_t[3] = 0.0;
         }
     }
     return GG_OK;
