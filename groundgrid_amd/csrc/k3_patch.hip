@@ -52,8 +52,7 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
     float localmin = mnl[lc - ci][lr - ci]; // :373 minCoeff (this layer never holds NaN)
 #pragma unroll
     for (int s = 1; s < SS; ++s) {
-        const float v = mnl[lc - ci + s / S][lr - ci + s % S];
-        if (v < localmin) localmin = v;
+        localmin = fminf(localmin, mnl[lc - ci + s / S][lr - ci + s % S]); // (no NaN in this layer: one v_min instead of compare + select)
     }
     // :374
     float maxVar;
