@@ -638,3 +638,31 @@ def test_batch_on_torch_default_stream_is_ordered_with_torch_ops():
         assert np.array_equal(snapshot.cpu().numpy(), r["label"]), f
         # ... and the library orders its own stream behind the batch: no torch.cuda.synchronize() before reading layers
         assert nan_equal(seg.map(0)["ground"], ref.layer("ground")), f
+
+
+def test_reduce_tile_classes_long_cells_and_quotient_fallbacks():
+    """k_reduce's corner cases: tiles with exactly 512 / 513 records (wavefront path / work-group path), a cell with more points
+    than the reciprocal table holds (IEEE tail), constant heights (every delta is 0: all quotients take the exact path),
+    heights so small that quotients fall below 2^-100, huge heights, and a second frame on the live tiles."""
+    rng = np.random.default_rng(77)
+    res = 0.33
+    parts = []
+
+    def cell_points(cx, cy, n, z):
+        xy = np.column_stack([np.full(n, cx), np.full(n, cy)]) + rng.uniform(0.01, res - 0.01, size=(n, 2))
+        return np.column_stack([xy, z])
+
+    # one cell with 5000 points (> RCAP = 4080), noisy heights
+    parts.append(cell_points(6 * res, 6 * res, 5000, rng.normal(-1.7, 0.03, 5000)))
+    # one cell, constant height: mean == planeDist from the second point on
+    parts.append(cell_points(-9 * res, 4 * res, 700, np.full(700, -1.5, np.float32)))
+    # tiny and huge heights
+    parts.append(cell_points(12 * res, -7 * res, 300, rng.normal(0, 1, 300) * 1e-36))
+    parts.append(cell_points(-14 * res, -11 * res, 300, rng.normal(0, 1, 300) * 1e30))
+    # a tile of 16x16 cells holding exactly 512 records and one holding 513 (spread over its cells)
+    for tile_x, count in ((40, 512), (60, 513)):
+        xy = np.column_stack([rng.uniform(tile_x * res + 0.02, (tile_x + 15) * res, count), rng.uniform(-90 * res, -76 * res, count)])
+        parts.append(np.column_stack([xy, rng.normal(-1.7, 0.05, count)]))
+    pts = np.concatenate(parts).astype(np.float32)
+    rng.shuffle(pts)
+    run_pair(synth.make_cloud(pts, ring=rng.integers(0, 64, len(pts))), frames=2)
