@@ -149,6 +149,11 @@ template <bool DBG> struct WaveClockT {
     }
 };
 
+#ifndef GG_SWEEP_SLEEP_LONG
+#define GG_SWEEP_SLEEP_LONG 6
+#endif
+constexpr int SLEEP_LONG = GG_SWEEP_SLEEP_LONG;
+
 template <int SIDE, bool DBG> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int wave_of_side, int lane, WaveClockT<DBG> &clk)
 {
     ChainLane<SIDE> st;
@@ -173,7 +178,12 @@ template <int SIDE, bool DBG> GG_DEV void run_chain(const Params &P, const LdsMa
                     sync.refresh(mem);
                     int spins = 0;
                     while (!ready()) {
-                        __builtin_amdgcn_s_sleep(1);
+                        // a waiting wavefront's polls take issue slots from the working wavefronts of its SIMD: back off after
+                        // the first few (the hand-over it waits for is then several steps away)
+                        if (spins < 4)
+                            __builtin_amdgcn_s_sleep(1);
+                        else
+                            __builtin_amdgcn_s_sleep(SLEEP_LONG);
                         sync.refresh(mem);
                         ++spins;
                     }
@@ -285,9 +295,9 @@ size_t sweep_lds_bytes(const Params &P) { return (size_t)lds_layout(P.c, P.group
 void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_params, int n_clouds, hipStream_t s, unsigned long long *dbg)
 {
     if (n_clouds == 0 || P_in.rings <= 0) return;
-    // Latency setting: a launch that leaves CUs idle anyway gives every 64-ring group of a side its own wavefront (up to 3)
+    // Latency setting: a launch of at most one cloud per CU gives every 64-ring group of a side its own wavefront (up to 3)
     Params P = P_in;
-    if (n_clouds <= 128 && !getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(P.groups, 3));
+    if (n_clouds <= 256 && !getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(P.groups, 3));
     const LdsMap L = lds_layout(P.c, P.groups);
     const size_t lds = (size_t)L.words * 4;
     static bool big_lds_ok = false;
