@@ -365,24 +365,27 @@ def main():
         seq = [clouds[b % min(B, 8)] for b in range(64)]
         for c in seq[:4]:
             chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
-        t0 = time.perf_counter()
-        for c in seq:
-            chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
-        t_sync = (time.perf_counter() - t0) / len(seq)
-        t0 = time.perf_counter()
-        tick = chk.filter_cloud_async(seq[0], (0.0, 0.0, 0.0), -1.73)
-        for k in range(len(seq)):
-            nxt = chk.filter_cloud_async(seq[k + 1], (0.0, 0.0, 0.0), -1.73) if k + 1 < len(seq) else None
-            chk.filter_cloud_wait(tick)
-            tick = nxt
-        t_pipe = (time.perf_counter() - t0) / len(seq)
+        t_sync = t_pipe = float("inf")
+        for _rep in range(3):  # best of three passes (the leg is host-bound: page placement and clocks of the box vary)
+            t0 = time.perf_counter()
+            for c in seq:
+                chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
+            t_sync = min(t_sync, (time.perf_counter() - t0) / len(seq))
+            t0 = time.perf_counter()
+            tick = chk.filter_cloud_async(seq[0], (0.0, 0.0, 0.0), -1.73)
+            for k in range(len(seq)):
+                nxt = chk.filter_cloud_async(seq[k + 1], (0.0, 0.0, 0.0), -1.73) if k + 1 < len(seq) else None
+                chk.filter_cloud_wait(tick)
+                tick = nxt
+            t_pipe = min(t_pipe, (time.perf_counter() - t0) / len(seq))
         result["host_api"] = {
             "sync_clouds_per_s": round(1.0 / t_sync, 1), "pipelined_clouds_per_s": round(1.0 / t_pipe, 1),
             "sync_ms": round(1e3 * t_sync, 4), "pipelined_ms": round(1e3 * t_pipe, 4),
             "vs_cpu_1thread": round((1.0 / t_pipe) / (donew / tw), 1),  # (consecutive clouds on one map: the warm CPU figure)
             "sync_vs_cpu_1thread": round((1.0 / t_sync) / (donew / tw), 1),
             "note": "gg_filter_cloud: 32-byte PointXYZIR cloud in host memory -> returned cloud in host memory, one map, consecutive clouds; "
-                    "pipelined = gg_filter_cloud_async two clouds deep (pack + upload of cloud k+1 overlap the kernels of cloud k)",
+                    "pipelined = gg_filter_cloud_async two clouds deep (pack + upload of cloud k+1 overlap the kernels of cloud k); 64 clouds of 8 "
+                    "different scenes in turn, best of three passes",
         }
 
         # single-cloud latency through the same kernels (one cloud per launch, device-resident input)
