@@ -666,3 +666,36 @@ def test_reduce_tile_classes_long_cells_and_quotient_fallbacks():
     pts = np.concatenate(parts).astype(np.float32)
     rng.shuffle(pts)
     run_pair(synth.make_cloud(pts, ring=rng.integers(0, 64, len(pts))), frames=2)
+
+
+def test_reset_maps_on_the_callers_stream_is_ordered_with_batches():
+    """gg_reset_maps(..., stream) between batches on the same torch stream: no event hand-over to the context's stream, same
+    results as a fresh context (cold maps every step, as bench.py's headline does)."""
+    import torch
+
+    clouds = [synth.hdl64_cloud(seed=31 + k, n_az=600) for k in range(3)]
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=3, max_points=stride)
+    host = np.zeros((3, stride), dtype=api.POINT16_DTYPE)
+    n = []
+    for b, c in enumerate(clouds):
+        host[b, :len(c)] = api.pack16(c)
+        n.append(len(c))
+    pts = torch.from_numpy(host.view(np.uint8).reshape(3, stride, 16)).cuda()
+    org = np.zeros((3, 3), np.float32)
+    bz = np.full(3, -1.73)
+    side = torch.cuda.Stream()
+    out = None
+    with torch.cuda.stream(side):
+        for step in range(3):  # warm the maps, then re-initialise them on the same stream and run again: the last step is cold
+            if step == 2:
+                seg.reset_maps(0, 3, odom_z=0.0, persistent_only=True, on_torch_stream=True)
+            out = seg.filter_batch(pts, n, org, bz, out=out)
+    side.synchronize()
+    labels = out.labels.cpu().numpy()
+    for b, c in enumerate(clouds):
+        ref = oracle.OracleMap(120.0, 0.33)
+        r = ref.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
+        assert np.array_equal(labels[b, :len(c)], r["label"]), f"cloud {b}"
+        assert nan_equal(seg.map(b)["ground"], ref.layer("ground")), f"cloud {b} ground"
+    seg.close()
