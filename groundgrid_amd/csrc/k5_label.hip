@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             r[j] = rec[valid[j] ? p : base];
             if (!valid[j]) r[j].y = KEY_OUTSIDE;
         }
-        size_t cidx[ITEMS];
+        uint32_t cidx[ITEMS]; // (C < 2^32)
         float gh[ITEMS], var[ITEMS], x[ITEMS], y[ITEMS];
         bool lab[ITEMS];
 #pragma unroll
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             lab[j] = inmap && (key & KEY_EMIT_BIT) && cls != GG_CLASS_OUTLIER; // kept or ignored, not on the border (:167)
             int row = 0, col = 0;
             if (lab[j]) key_to_cell(a, key, row, col);
-            cidx[j] = (size_t)row + (size_t)col * rows;
+            cidx[j] = (uint32_t)row + (uint32_t)col * (uint32_t)rows;
             gh[j] = gp2[gp_idx(a, row, col)].x; // :162
             var[j] = variance[cidx[j]]; // :165
             const uint2 xy = reinterpret_cast<const uint2 *>(pts)[(size_t)(valid[j] ? p : base) * (FMT == GG_POINT16 ? 2 : 4)];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             // atomic instruction per window, no loop over cells.
             {
                 const bool ng = label == GG_LABEL_NONGROUND;
-                const uint32_t c = (uint32_t)cidx[j];
+                const uint32_t c = cidx[j];
                 const uint32_t c_prev = (uint32_t)__shfl_up((int)c, 1, 64);
                 const unsigned long long ngm = __ballot(ng);
                 const bool joins = ng && lane > 0 && ((ngm >> (lane - 1)) & 1ull) && c == c_prev; // continues the previous lane's run
