@@ -18,14 +18,25 @@ namespace gg {
 constexpr int PR = 32, PC = 8, HALO = 2;
 constexpr int LR = PR + 2 * HALO, LC = PC + 2 * HALO; // 36 x 12
 
+// What a cell's visit has found out from the staged layers, carried to the next block's turn: the cell's old (ground,
+// confidence) is loaded from HBM meanwhile, so that no work-group waits for that gather (nor for `expectedPoints`, which is
+// requested a block ahead together with the layers).
+struct PatchCarry {
+    bool live;          // the block sum passed :364-365
+    int gidx;           // element of the cell in the (ground, confidence) layer
+    float2 old;         // (ground, confidence), in flight
+    float pointsblockSum, expected, localmin, maxVar, groundlevel, sqdist;
+    int S;
+};
+
+// first half: everything that needs the LDS window (:352-375); issues the load of the old cell
 template <int S>
-GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const float (*var)[LR], const float (*mnl)[LR],
-                                int lr, int lc, int i, int j, float sqdist, float2 *gp2)
+GG_DEV void detect_ground_patch_a(const Arena &a, const float (*pts)[LR], const float (*var)[LR], const float (*mnl)[LR], int lr, int lc,
+                                  int i, int j, float sqdist, float expected, const float2 *gp2, PatchCarry &pc)
 {
     constexpr int SS = S * S;
     constexpr int ci = S / 2; // :352
     const DevConfig &cfg = a.cfg;
-    const int rows = a.g.rows;
     float e[SS];
     // :355 pointsBlock, column-major linear index s -> (row s % S, col s / S)
 #pragma unroll
@@ -33,58 +44,62 @@ GG_DEV void detect_ground_patch(const Arena &a, const float (*pts)[LR], const fl
     const bool e34 = a.eigen_reduction == GG_EIGEN_34_SSE; // (uniform) which Eigen the reference was built against
     auto sum25 = [&](const float *v) { return e34 ? tree25_eigen34(v) : tree25(v); };
     const float pointsblockSum = (S == 3) ? tree9(e) : sum25(e); // :359
-    const size_t idx = (size_t)i + (size_t)j * rows;
-    const float expected = a.expected[idx]; // :358
-
     // :364-365
     if ((double)pointsblockSum < std_max(floor(cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) return;
     if (a.k3_debug == 3) return;
-
-    const int gidx = gp_idx(a, i, j); // the (ground, confidence) layer has its own element order (gp_layout.h)
-    const float2 old = gp2[gidx];
-    const float oldConfidence = old.y;   // :360
-    const float oldGroundheight = old.x; // :361
-
-    // :369
-    const float varThresholdsq =
-        (float)std_min(std_max((double)sqdist * cfg.distance_factor_sq, cfg.minimum_distance_factor_sq), cfg.minimum_distance_factor_x10_sq);
+    pc.gidx = gp_idx(a, i, j); // the (ground, confidence) layer has its own element order (gp_layout.h)
+    pc.old = gp2[pc.gidx];     // :360-361, used in the second half
+    pc.live = true;
+    pc.S = S;
+    pc.pointsblockSum = pointsblockSum;
+    pc.expected = expected;
+    pc.sqdist = sqdist;
     const float variance = var[lc][lr]; // :372
     float localmin = mnl[lc - ci][lr - ci]; // :373 minCoeff (this layer never holds NaN)
 #pragma unroll
-    for (int s = 1; s < SS; ++s) {
-        localmin = fminf(localmin, mnl[lc - ci + s / S][lr - ci + s % S]); // (no NaN in this layer: one v_min instead of compare + select)
-    }
+    for (int s = 1; s < SS; ++s) localmin = fminf(localmin, mnl[lc - ci + s / S][lr - ci + s % S]); // (no NaN: one v_min)
+    pc.localmin = localmin;
     // :374
-    float maxVar;
     if (e[ci + ci * S] >= (float)cfg.point_count_cell_variance_threshold) {
-        maxVar = variance;
+        pc.maxVar = variance;
     } else {
         float pr[SS];
 #pragma unroll
         for (int s = 0; s < SS; ++s) pr[s] = e[s] * var[lc - ci + s / S][lr - ci + s % S];
-        maxVar = ((S == 3) ? tree9(pr) : sum25(pr)) / pointsblockSum;
+        pc.maxVar = ((S == 3) ? tree9(pr) : sum25(pr)) / pointsblockSum;
     }
     // :375
     float pm[SS];
 #pragma unroll
     for (int s = 0; s < SS; ++s) pm[s] = e[s] * mnl[lc - ci + s / S][lr - ci + s % S];
-    const float groundlevel = ((S == 3) ? tree9(pm) : sum25(pm)) / pointsblockSum;
+    pc.groundlevel = ((S == 3) ? tree9(pm) : sum25(pm)) / pointsblockSum;
+}
+
+// second half (:360-393): the decision against the old cell, one block later
+GG_DEV void detect_ground_patch_b(const Arena &a, const PatchCarry &pc, float2 *gp2)
+{
+    if (!pc.live) return;
+    const DevConfig &cfg = a.cfg;
+    const float oldConfidence = pc.old.y;   // :360
+    const float oldGroundheight = pc.old.x; // :361
+    const float pointsblockSum = pc.pointsblockSum, groundlevel = pc.groundlevel, maxVar = pc.maxVar;
+    // :369
+    const float varThresholdsq =
+        (float)std_min(std_max((double)pc.sqdist * cfg.distance_factor_sq, cfg.minimum_distance_factor_sq), cfg.minimum_distance_factor_x10_sq);
     // :376
     const float groundDiff = std_max((groundlevel - oldGroundheight) * (2.0f * oldConfidence), 1.0f);
-
     // :379-380
     if ((double)oldConfidence > 0.5 && (double)groundlevel >= (double)oldGroundheight + cfg.outlier_tolerance) return;
-
     // :382
     if ((double)varThresholdsq > (double)maxVar * (double)maxVar && maxVar > 0.0f &&
-        (double)pointsblockSum > (double)((groundDiff * expected) * (float)S) * cfg.gpd_min_point_count_threshold) {
+        (double)pointsblockSum > (double)((groundDiff * pc.expected) * (float)pc.S) * cfg.gpd_min_point_count_threshold) {
         const float newConfidence = (float)std_min((double)pointsblockSum / cfg.occupied_cells_point_count_factor, 1.0); // :383
         const float G = (groundlevel * newConfidence + (oldConfidence * oldGroundheight) * 2.0f) / (newConfidence + oldConfidence * 2.0f); // :385
         const float Cf =
             (float)std_min(((double)pointsblockSum / cfg.occupied_cells_point_count_factor_x2 + (double)oldConfidence) / 2.0, 1.0); // :387
-        gp2[gidx] = make_float2(G, Cf);
-    } else if (localmin < oldGroundheight) { // :389
-        gp2[gidx] = make_float2(localmin, std_min(oldConfidence + 0.1f, 0.5f)); // :391, :393
+        gp2[pc.gidx] = make_float2(G, Cf);
+    } else if (pc.localmin < oldGroundheight) { // :389
+        gp2[pc.gidx] = make_float2(pc.localmin, std_min(oldConfidence + 0.1f, 0.5f)); // :391, :393
     }
 }
 
@@ -145,8 +160,19 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
 
     // staging registers: up to LC columns x LR rows = 432 cells, two per thread
     float sp[2], sv[2], sm[2];
+    float exp_next = 0.0f; // expectedPoints of this thread's cell in the requested block
+    const int tr = tid % PR, tcl = tid / PR;
+    const int i = r0 + tr;
+    auto cell_visited = [&](int jj) {
+        // the four quadrants (:325-328) cover rows [2, 2 * (cols / 2) - 2) -- the FIRST loop variable, bounded by cols / 2, is
+        // used as the row index -- and cols [2, rows - 2): for odd sizes row n - 3 is never visited
+        return !(i >= 2 * (cols / 2) - 2 || jj >= rows - 2);
+    };
     auto request = [&](int b, int first_col, int n_cols) { // columns [first_col, first_col + n_cols) of block b's window
-        (void)b;
+        {
+            const int jj = HALO + PC * b + tcl;
+            exp_next = cell_visited(jj) ? a.expected[(size_t)i + (size_t)jj * rows] : 0.0f; // :358
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = tid + 256 * h;
@@ -180,13 +206,14 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         }
     };
 
-    const int tr = tid % PR, tcl = tid / PR;
-    const int i = r0 + tr;
     int b = next_block(b_first);
     int req_first = PC * b, req_cols = LC; // what the staging registers hold
     if (b < n_blocks) request(b, req_first, req_cols);
+    PatchCarry carry;
+    carry.live = false;
     while (b < n_blocks) {
         deposit(req_first, req_cols);
+        const float expected = exp_next;
         __syncthreads();
         if (a.k3_debug == 2) return;
         // the next block that can change anything: its new columns travel while this one is computed
@@ -197,21 +224,24 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             request(nb, req_first, req_cols);
         }
         const int j = HALO + PC * b + tcl;
-        // the four quadrants (:325-328) cover rows [2, 2 * (cols / 2) - 2) -- the FIRST loop variable, bounded by cols / 2, is
-        // used as the row index -- and cols [2, rows - 2): for odd sizes row n - 3 is never visited
-        if (!(i >= 2 * (cols / 2) - 2 || j >= rows - 2)) {
+        PatchCarry now;
+        now.live = false;
+        if (cell_visited(j)) {
             const int base = (PC * b) & (RING - 1); // 0 or 8: the window is slots base .. base + LC - 1
             // :332
             const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
             const float sqdist = (float)((di * di + dj * dj) * ((double)a.g.resolution_f * (double)a.g.resolution_f));
             if ((double)sqdist <= a.cfg.patch_size_change_distance_sq) // :334
-                detect_ground_patch<3>(a, pts + base, var + base, mnl + base, tr + HALO, tcl + HALO, i, j, sqdist, gp2);
+                detect_ground_patch_a<3>(a, pts + base, var + base, mnl + base, tr + HALO, tcl + HALO, i, j, sqdist, expected, gp2, now);
             else
-                detect_ground_patch<5>(a, pts + base, var + base, mnl + base, tr + HALO, tcl + HALO, i, j, sqdist, gp2);
+                detect_ground_patch_a<5>(a, pts + base, var + base, mnl + base, tr + HALO, tcl + HALO, i, j, sqdist, expected, gp2, now);
         }
+        detect_ground_patch_b(a, carry, gp2); // the previous block's cell: its old (ground, confidence) has arrived meanwhile
+        carry = now;
         __syncthreads(); // (the window is overwritten next)
         b = nb;
     }
+    detect_ground_patch_b(a, carry, gp2);
 }
 
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)
