@@ -518,8 +518,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_gpvalid = carve(gp_valid_words * 4);
     const size_t o_dbg = carve(64 * 8); // sweep timing
     const bool k2_timing = getenv("GG_K2_DEBUG") && atoi(getenv("GG_K2_DEBUG")) == 9;
-    const size_t K2_DBG_WGS = 32768; // k_reduce phase counters, [work-group][32]
-    const size_t o_k2dbg = carve(k2_timing ? K2_DBG_WGS * 32 * 8 : 64);
+    const size_t o_k2dbg = carve(k2_timing ? (size_t)K2_DBG_WGS * 32 * 8 : 64);
     ctx->arena_bytes = off;
     CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
     char *base = (char *)ctx->d_arena;

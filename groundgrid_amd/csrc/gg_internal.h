@@ -21,6 +21,7 @@ namespace gg {
 constexpr int TILE = 16;             // cells per tile edge (K2 work-group = one tile, one thread per cell)
 constexpr int TILE_CELLS = TILE * TILE;
 constexpr uint32_t KEY_OUTSIDE = 0xFFFFFFFFu;
+constexpr int K2_DBG_WGS = 32768;  // slots of k_reduce's phase counters (GG_K2_DEBUG=9)
 constexpr int K2_LIGHT_MAX = 512; // tiles with at most this many records are reduced by a single wavefront (k2_reduce.hip)
 // key = tile_rank << 12 | emit << 10 | class << 8 | cell_in_tile (row_in_tile | col_in_tile << 4)
 constexpr int KEY_TILE_SHIFT = 12;

@@ -66,7 +66,7 @@ __constant__ const RecipTable recip_table = make_recip_table();
 // measurement only (GG_K2_DEBUG=9): counters of this work-group, k2_dbg[work-group][32]; few writers per slot
 GG_DEV void dbg_add(const Arena &a, int slot, unsigned long long v)
 {
-    const size_t wg = (size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x;
+    const size_t wg = ((size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x) % (size_t)K2_DBG_WGS; // (more work-groups than slots: shared)
     atomicAdd(&a.k2_dbg[wg * 32 + (size_t)slot], v);
 }
 
