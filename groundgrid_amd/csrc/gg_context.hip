@@ -600,8 +600,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         CREATE_CHK(hipEventCreateWithFlags(&as.downloaded, hipEventDisableTiming));
     }
 
-    for (int s = 0; s < n_slots; ++s) {
-        const int rc = gg_reset_map(ctx, s, 0.0, 0.0, 0.0f);
+    {
+        const int rc = gg_reset_maps(ctx, 0, n_slots, 0.0, 0.0, 0.0f, 0, nullptr); // (one strided fill per layer for all slots)
         if (rc != GG_OK) {
             gg_destroy(ctx);
             return rc;
