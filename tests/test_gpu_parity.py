@@ -699,3 +699,29 @@ def test_reset_maps_on_the_callers_stream_is_ordered_with_batches():
         assert np.array_equal(labels[b, :len(c)], r["label"]), f"cloud {b}"
         assert nan_equal(seg.map(b)["ground"], ref.layer("ground")), f"cloud {b} ground"
     seg.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_fuzz(seed):
+    """Random geometry, random clusters (one of them packing tens of thousands of points into a single 16x16 tile), random map
+    position / origin / base height, three frames: everything compared with the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    # (GroundSegmentation::init takes the dimension as size_t: whole metres)
+    length, resolution = [(20.0, 0.2), (30.0, 0.25), (40.0, 0.33), (50.0, 0.5), (64.0, 0.33), (80.0, 0.33), (45.0, 0.2), (33.0, 0.25)][
+        int(rng.integers(0, 8))]
+    n_clusters = int(rng.integers(3, 9))
+    parts = []
+    for k in range(n_clusters):
+        centre = rng.uniform(-0.55 * length, 0.55 * length, size=2)  # some clusters straddle or miss the map
+        spread = float(rng.choice([0.05, 0.3, 1.5, 6.0, 20.0]))
+        m = int(rng.integers(50, 40000 if k == 0 else 6000))
+        xy = centre + rng.normal(0, spread, size=(m, 2))
+        z = rng.normal(rng.uniform(-2.5, 0.5), rng.choice([0.0, 0.02, 0.4]), size=m)
+        parts.append(np.column_stack([xy, z]))
+    pts = np.concatenate(parts).astype(np.float32)
+    rng.shuffle(pts)
+    pos = tuple(np.round(rng.uniform(-3, 3, size=2), 2))
+    origin = (float(pos[0]) + float(rng.uniform(-1, 1)), float(pos[1]) + float(rng.uniform(-1, 1)), float(rng.uniform(-0.2, 0.2)))
+    cloud = synth.make_cloud(pts + np.array([pos[0], pos[1], 0.0], np.float32), ring=rng.integers(0, 64, len(pts)))
+    run_pair(cloud, length=length, resolution=resolution, pos=pos, origin=origin, base_z=float(rng.uniform(-2.0, -1.4)), frames=3,
+             odom_z=float(rng.uniform(-0.5, 0.5)))
