@@ -183,7 +183,7 @@ GG_DEV void four_points(const float (&z)[4], uint32_t i, uint32_t np, const doub
 // the chains in R.  The chains only share the point count, and every cell starts the call at count 0 (:61-75), so point i
 // of every lane has c = i: wave-uniform, and 1 / (c + 1) comes from a table through the scalar cache.
 template <int R, int NB>
-GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s)
+GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s, bool dbg_one_line = false)
 {
     const zquad *zq = reinterpret_cast<const zquad *>(zseg);
     uint32_t nmax = np;
@@ -193,7 +193,7 @@ GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s)
     // NB 16-byte batches per lane in flight, each refilled right after its four points (no register rotation: a copy of a
     // load's destination would wait for the load; unconditional loads at a clamped index: no branch around them).  The
     // heights come back from L2 (this work-group wrote them a moment ago).
-    const uint32_t qlast = np ? (np - 1u) >> 2 : 0u; // (an empty cell reads 16 bytes of the tile's padded region)
+    const uint32_t qlast = (np && !dbg_one_line) ? (np - 1u) >> 2 : 0u; // (an empty cell reads 16 bytes of the tile's padded region)
     zquad q[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) q[b] = zq[min((uint32_t)b, qlast)];
@@ -578,16 +578,16 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
         const float *zseg = zc + lds.cseg[cell];
         const uint32_t np = lds.ctot[cell];
         if (wave == 0) {
-            run_cells<R_MEAN, 6>(zseg, np, oz, st);
+            run_cells<R_MEAN, 6>(zseg, np, oz, st, a.k2_debug == 4);
             put_shared(cell);
             ex[2 * TILE_CELLS + cell] = st.m2;
             ex[4 * TILE_CELLS + cell] = st.mean;
         } else if (wave == 1) {
-            run_cells<R_GC, 6>(zseg, np, oz, st);
+            run_cells<R_GC, 6>(zseg, np, oz, st, a.k2_debug == 4);
             ex[5 * TILE_CELLS + cell] = st.mx;
             ex[6 * TILE_CELLS + cell] = st.gc;
         } else {
-            run_cells<R_PDM | R_MN, 6>(zseg, np, oz, st);
+            run_cells<R_PDM | R_MN, 6>(zseg, np, oz, st, a.k2_debug == 4);
             ex[1 * TILE_CELLS + cell] = st.mn;
             ex[7 * TILE_CELLS + cell] = st.pdm;
         }
