@@ -11,20 +11,23 @@
 //
 // Dependences (Appendix F of SURVEY.md, re-derived here).  Along a side every visit needs its predecessor (a first-order
 // chain); from the ring inside it needs three NEW cells; the two doubly visited corners chain three visits per ring
-// (A_0 -> A_1 -> B_0, C_0 -> C_1 -> D_0) and read nothing new from anybody else.  The critical path is 5 visits per ring:
-// no schedule is shorter than ~5 (c - 1) steps (904 for n = 364), and one exists that is exactly that long:
-//   * two CORNER lanes walk the corner chains ring by ring (3 visits per ring) and publish A_1, B_0 / C_1, D_0;
+// (A_0 -> A_1 -> B_0, C_0 -> C_1 -> D_0) and read nothing new from anybody else.  What limits a schedule is where two sides
+// meet: the last visit of B's chain of ring r is the JOIN of C's chain of ring r (needed by C's last-but-one visit), and C's
+// last visit is the join of B's chain of ring r + 1 -- likewise A and D.  So the ends of the sides advance by 4 visits per
+// ring (two of B, two of C, alternating), ~4 (c - 1) visits in all; everything else keeps up with that when ring r + 1 follows
+// ring r by SKEW = 1 step (a chain of ring r + 1 is 2 visits longer: SKEW + 2 = 3 steps of work per ring and wavefront):
+//   * two CORNER wavefronts walk the corner chains ring by ring (3 visits per ring) and publish A_1, B_0 / C_1, D_0;
 //   * every (side, ring) is a CHAIN owned by one lane: A_2..A_{2r-1}, B_1..B_{2r-1}, C_2..C_{2r}, D_1..D_{2r};
-//     lanes of one wavefront = 64 consecutive rings of one side, ring r+1 running 3 steps behind ring r.
+//     lanes of one wavefront = 64 consecutive rings of one side, ring r+1 running SKEW steps behind ring r.
 // With k0 = first chain index (2, 1, 2, 1) and len = chain length (2r-2, 2r-1, 2r-1, 2r), step s of a chain needs the
 // stream S[s], S[s+1], S[s+2] from the inner side, where -- for all four sides alike --
 //     S[0], S[1]            corner values (A: B_0(r-1), A_1(r-1)   B: A_1(r), B_0(r-1)   C: D_0(r-1), C_1(r-1)   D: C_1(r), D_0(r-1))
-//     S[m], 2 <= m < len    result of step m-2 of the SAME side's chain of ring r-1   (lane l-1, three steps ago)
+//     S[m], 2 <= m < len    result of step m-2 of the SAME side's chain of ring r-1   (lane l-1, SKEW steps ago)
 //     S[len]                the JOIN: last value of another side (A: D_last(r-1)  B: C_last(r-1)  C: B_last(r)  D: A_last(r))
 //     S[len+1]              an OLD cell (it belongs to a chain of ring r that has not got there yet)
 // Everything else in a window is OLD and streams from the layer, prefetched: one cell of the own line and one of the outer
-// line per step.  NEW values never travel through memory: lane to lane inside a wavefront (a 3-deep history read with a
-// wave shift), through LDS between wavefronts (corner values, joins, the chain of the last ring of a 64-ring group), each
+// line per step.  NEW values never travel through memory: lane to lane inside a wavefront (the previous step's result read
+// with a wave shift), through LDS between wavefronts (corner values, joins, the chain of the last ring of a 64-ring group), each
 // LDS hand-over guarded by a monotonic progress counter that the consumer polls.  No barriers, no descriptors, no
 // per-visit tables: the schedule is arithmetic on (side, ring, step).
 //
