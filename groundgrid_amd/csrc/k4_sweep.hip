@@ -2,11 +2,13 @@
 // ring-per-lane dataflow of sweep_core.h on gfx950.
 //
 // One work-group per cloud: 4 x W chain wavefronts (sides A, B, C, D of the rings; a wavefront owns groups of 64
-// consecutive rings, lane = ring, ring r + 1 three steps behind ring r) + two corner wavefronts (one active lane each).
+// consecutive rings, lane = ring, ring r + 1 SKEW = 1 step behind ring r) + two corner wavefronts (lane = ring as well: 64 rings
+// are prepared at once, the three dependent corner visits then run ring after ring, sweep_core.h CornerRing).
 // There is no barrier after start-up and no table: every wavefront free-runs through its steps; what a step needs from
 // other wavefronts arrives through LDS behind monotonic progress counters that the consumer polls (LDS operations of a
 // wavefront are executed in issue order, so "data, then counter" needs no fence), what it needs from the inner ring of the
-// same side arrives by a wave shift (DPP wave_shr:1) of a value computed three steps earlier -- off the critical path.
+// same side arrives by a wave shift (DPP wave_shr:1) of the previous step's result.  A step comes in two halves with the wait
+// for the partner side's join between them (ChainLane::step_a / step_b).
 // The dependent chain of a step is: product with the predecessor's new height -> 3 adds of the Eigen tree -> IEEE divide
 // -> blend; everything else (all confidence sums, the other 8 products, the decay of the confidence) is independent of it.
 //
