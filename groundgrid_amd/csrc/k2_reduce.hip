@@ -372,6 +372,8 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             }
             lds_order();
         }
+        const unsigned long long t_p1 = timing ? __builtin_readcyclecounter() : 0ull;
+        if (timing && lane == 0 && start != end) dbg_add(a, 29, t_p1 - t_begin); // prologue + wait for the records + count + place
         // the next tile's records travel while this tile's recurrences run
         const bool had_points = start != end;
         load_light_records(rw, sorted, next_start, next_end, lane);
@@ -400,6 +402,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                 seg = seg_end;
             }
             lds_order(); // (the next tile reuses the memory)
+            if (timing && lane == 0) dbg_add(a, 28, __builtin_readcyclecounter() - t_p1); // chains + writes
         } else { // only the per-call reset (:61-75) of a tile that held points before
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

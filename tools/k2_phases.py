@@ -37,6 +37,7 @@ def run(batch):
     print(f"  chain phase per wave (own time): " + " ".join(f"w{w}={v[16+w]/nd:.0f}" for w in range(4)) + f"   split tiles {int(v[20])}")
     nl = max(v[8], 1)
     print(f"  light tiles {int(v[8])} ({v[8]/batch:.1f}/cloud), records/tile {v[9]/nl:.0f}, cycles/tile {v[10]/nl:.0f};  reset-only tiles {int(v[12])}, cycles {v[13]/max(v[12],1):.0f}")
+    print(f"  light tile split: head (lookups, records, count, place) {v[29]/nl:.0f}, chains + layer writes {v[28]/nl:.0f}")
     print(f"  work-groups: dense {int(v[24])} x {v[25]/max(v[24],1):.0f} cycles, light {int(v[26])} x {v[27]/max(v[26],1):.0f} cycles")
     seg.close()
 
