@@ -11,6 +11,8 @@
 // 2 written.
 #include "gg_device.h"
 
+#include <float.h>
+
 #include <algorithm>
 
 namespace gg {
@@ -29,6 +31,57 @@ struct PatchCarry {
     int S;
 };
 
+// Eigen's block-sum orders over elements delivered one at a time, in column-major order s = 0 .. S*S-1, in groups separated by
+// a compiler fence: the LDS reads of a group are issued, waited for and consumed before the next group's -- at most a dozen
+// values are live at any time.  (With the 25 values of each of the three blocks of a cell read up front, the kernel needed
+// 150 VGPRs: three wavefronts per SIMD for a kernel that lives on hiding LDS and memory latency.)
+GG_DEV void group_fence() { __asm__ volatile("" ::: "memory"); }
+
+template <class F> GG_DEV float stream_tree9(F get)
+{
+    const float x0 = get(0), x1 = get(1), x2 = get(2), x3 = get(3);
+    const float l = (x0 + x1) + (x2 + x3);
+    group_fence();
+    const float x4 = get(4), x5 = get(5), x6 = get(6), x7 = get(7), x8 = get(8);
+    return l + ((x4 + x5) + (x6 + (x7 + x8)));
+}
+template <class F> GG_DEV float stream_six(F get, int s0)
+{
+    const float x0 = get(s0), x1 = get(s0 + 1), x2 = get(s0 + 2), x3 = get(s0 + 3), x4 = get(s0 + 4), x5 = get(s0 + 5);
+    return (x0 + (x1 + x2)) + (x3 + (x4 + x5));
+}
+template <class F> GG_DEV float stream_tree25(F get)
+{
+    const float a = stream_six(get, 0);
+    group_fence();
+    const float b = stream_six(get, 6);
+    group_fence();
+    const float ab = a + b;
+    const float c = stream_six(get, 12);
+    group_fence();
+    const float x18 = get(18), x19 = get(19), x20 = get(20), x21 = get(21), x22 = get(22), x23 = get(23), x24 = get(24);
+    const float d = (x18 + (x19 + x20)) + ((x21 + x22) + (x23 + x24));
+    return ab + (c + d);
+}
+template <class F> GG_DEV float stream_tree25_eigen34(F get)
+{
+    float p[4], tail[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = get(5 * j + r);
+            p[r] = j == 0 ? x : p[r] + x;
+        }
+        tail[j] = get(5 * j + 4);
+        group_fence();
+    }
+    float res = (p[0] + p[2]) + (p[1] + p[3]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) res = res + tail[j];
+    return res;
+}
+
 // first half: everything that needs the LDS window (:352-375); issues the load of the old cell
 template <int S>
 GG_DEV void detect_ground_patch_a(const Arena &a, const float (*pts)[LR], const float (*var)[LR], const float (*mnl)[LR], int lr, int lc,
@@ -37,13 +90,11 @@ GG_DEV void detect_ground_patch_a(const Arena &a, const float (*pts)[LR], const 
     constexpr int SS = S * S;
     constexpr int ci = S / 2; // :352
     const DevConfig &cfg = a.cfg;
-    float e[SS];
-    // :355 pointsBlock, column-major linear index s -> (row s % S, col s / S)
-#pragma unroll
-    for (int s = 0; s < SS; ++s) e[s] = pts[lc - ci + s / S][lr - ci + s % S];
     const bool e34 = a.eigen_reduction == GG_EIGEN_34_SSE; // (uniform) which Eigen the reference was built against
-    auto sum25 = [&](const float *v) { return e34 ? tree25_eigen34(v) : tree25(v); };
-    const float pointsblockSum = (S == 3) ? tree9(e) : sum25(e); // :359
+    auto block_sum = [&](auto get) { return (S == 3) ? stream_tree9(get) : e34 ? stream_tree25_eigen34(get) : stream_tree25(get); };
+    // element s of a block, column-major: row s % S, col s / S (:355)
+    auto P = [&](int s) { return pts[lc - ci + s / S][lr - ci + s % S]; };
+    const float pointsblockSum = block_sum(P); // :359
     // :364-365
     if ((double)pointsblockSum < std_max(floor(cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) return;
     if (a.k3_debug == 3) return;
@@ -54,25 +105,23 @@ GG_DEV void detect_ground_patch_a(const Arena &a, const float (*pts)[LR], const 
     pc.pointsblockSum = pointsblockSum;
     pc.expected = expected;
     pc.sqdist = sqdist;
-    const float variance = var[lc][lr]; // :372
-    float localmin = mnl[lc - ci][lr - ci]; // :373 minCoeff (this layer never holds NaN)
-#pragma unroll
-    for (int s = 1; s < SS; ++s) localmin = fminf(localmin, mnl[lc - ci + s / S][lr - ci + s % S]); // (no NaN: one v_min)
-    pc.localmin = localmin;
+    group_fence();
     // :374
-    if (e[ci + ci * S] >= (float)cfg.point_count_cell_variance_threshold) {
-        pc.maxVar = variance;
-    } else {
-        float pr[SS];
-#pragma unroll
-        for (int s = 0; s < SS; ++s) pr[s] = e[s] * var[lc - ci + s / S][lr - ci + s % S];
-        pc.maxVar = ((S == 3) ? tree9(pr) : sum25(pr)) / pointsblockSum;
-    }
-    // :375
-    float pm[SS];
-#pragma unroll
-    for (int s = 0; s < SS; ++s) pm[s] = e[s] * mnl[lc - ci + s / S][lr - ci + s % S];
-    pc.groundlevel = ((S == 3) ? tree9(pm) : sum25(pm)) / pointsblockSum;
+    if (pts[lc][lr] >= (float)cfg.point_count_cell_variance_threshold)
+        pc.maxVar = var[lc][lr]; // :372
+    else
+        pc.maxVar = block_sum([&](int s) { return P(s) * var[lc - ci + s / S][lr - ci + s % S]; }) / pointsblockSum;
+    group_fence();
+    // :373 minCoeff (this layer never holds NaN: v_min) and :375
+    float localmin = FLT_MAX;
+    pc.groundlevel = block_sum([&](int s) {
+                         const float m = mnl[lc - ci + s / S][lr - ci + s % S];
+                         localmin = fminf(localmin, m);
+                         return P(s) * m;
+                     }) /
+                     pointsblockSum;
+    pc.localmin = localmin;
+    (void)SS;
 }
 
 // second half (:360-393): the decision against the old cell, one block later
