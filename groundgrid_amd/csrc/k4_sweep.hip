@@ -292,14 +292,18 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     mem.dbg_mode_rt = (DBG && dbg) ? (int)dbg[63] : 0;
     mem.marks = (DBG && dbg) ? dbg + 48 + ((threadIdx.x >> 6) & 1) * 6 : nullptr; // (the two corner wavefronts have consecutive wave ids)
     clk.begin();
-    if (wave < W)
-        run_chain<SIDE_A, DBG>(P, L, mem, wave, lane, clk);
-    else if (wave < 2 * W)
-        run_chain<SIDE_B, DBG>(P, L, mem, wave - W, lane, clk);
-    else if (wave < 3 * W)
-        run_chain<SIDE_C, DBG>(P, L, mem, wave - 2 * W, lane, clk);
+    // wavefront id -> (side, wavefront of the side): the four sides of one ring group work at the same time and the wavefronts of
+    // a work-group go to the CU's four SIMDs round-robin, so ids 4 w + side put them on four different SIMDs (with the sides'
+    // wavefronts numbered consecutively, A_w and C_w shared one SIMD and B_w and D_w another while two SIMDs idled)
+    const int side = wave & 3, w_of_side = wave >> 2;
+    if (wave < 4 * W && side == SIDE_A)
+        run_chain<SIDE_A, DBG>(P, L, mem, w_of_side, lane, clk);
+    else if (wave < 4 * W && side == SIDE_B)
+        run_chain<SIDE_B, DBG>(P, L, mem, w_of_side, lane, clk);
+    else if (wave < 4 * W && side == SIDE_C)
+        run_chain<SIDE_C, DBG>(P, L, mem, w_of_side, lane, clk);
     else if (wave < 4 * W)
-        run_chain<SIDE_D, DBG>(P, L, mem, wave - 3 * W, lane, clk);
+        run_chain<SIDE_D, DBG>(P, L, mem, w_of_side, lane, clk);
     else if (wave == 4 * W)
         run_corner<0, DBG>(P, L, mem, lane, clk);
     else

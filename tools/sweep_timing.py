@@ -14,7 +14,7 @@ L.gg_debug_sweep_timing.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert L.gg_debug_sweep_timing(seg._ctx, out) == 0
 v = np.array(list(out), dtype=np.int64)[:48].reshape(12, 4)  # (the first 12 wavefronts; the corner phase marks follow)
 W = 3 if os.environ.get("GG_SWEEP_WAVES") is None else int(os.environ["GG_SWEEP_WAVES"])
-names = [f"{s}{w}" for s in "ABCD" for w in range(W)] + ["cornerAB", "cornerCD"]
+names = [f"{s}{w}" for w in range(W) for s in "ABCD"] + ["cornerAB", "cornerCD"]  # wavefront id = 4 w + side
 names = names[:12]
 t0 = v[:len(names), 0].min()
 for k, nm in enumerate(names):
