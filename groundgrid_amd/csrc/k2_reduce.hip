@@ -86,6 +86,26 @@ GG_DEV void lds_order() { __asm__ volatile("" ::: "memory"); } // LDS operations
 // random, boundary and tie operands) and the GPU parity tests.
 GG_DEV float quot(float a, double r) { return (float)((double)a * r); }
 
+// Runs.  A scan line crosses a cell several returns at a time, so the records of a 64-record window mostly come as runs of
+// consecutive lanes with the same cell -- and same-address LDS atomics execute one lane at a time.  The first lane of a run
+// speaks for the whole run: `head` and the run's lane mask.  `id` = the lane's cell, or any value the runs of interest never
+// take for lanes that do not take part (they split runs, which is only conservative).
+struct LaneRun {
+    bool head;
+    unsigned long long mask;
+};
+GG_DEV LaneRun lane_run(uint32_t id, int lane)
+{
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)id, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    LaneRun r;
+    r.head = lane == 0 || id != prev;
+    const unsigned long long hm = __ballot(r.head);
+    const unsigned long long above = (hm >> 1) >> lane; // heads after this lane
+    const unsigned long long upto = above & (0ull - above); // the next head, as a bit relative to lane + 1 (0: none)
+    r.mask = ((upto << 1) - 1ull) << lane; // lanes [lane, next head); upto == 0 -> all lanes from this one up
+    return r;
+}
+
 enum : int { R_MEAN = 1 /* meanVariance, m2 */, R_GC = 2 /* groundCandidates, maxGroundHeight */, R_PDM = 4 /* planeDist */, R_MN = 8 /* minGroundHeight */ };
 
 struct CellState {
@@ -319,10 +339,13 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             // 1. count
 #pragma unroll
             for (int w = 0; w < WB; ++w) {
-                if (rw[w].y != KEY_OUTSIDE) {
-                    const unsigned long long kept = ((rw[w].y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT ? 1ull : 0ull;
-                    __hip_atomic_fetch_add(&lds.cnt64[rw[w].y & 255u], 1ull | (kept << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                const bool in = rw[w].y != KEY_OUTSIDE;
+                const unsigned long long km = __ballot(in && ((rw[w].y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT);
+                const LaneRun run = lane_run(in ? (rw[w].y & 255u) : 256u, lane);
+                if (in && run.head)
+                    __hip_atomic_fetch_add(&lds.cnt64[rw[w].y & 255u],
+                                           (unsigned long long)__popcll(run.mask) | ((unsigned long long)__popcll(run.mask & km) << 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // 2. the lane's four cells are consecutive segments of the wave's 512 heights
             uint32_t tot[4], rawc[4], t4 = 0u;
@@ -357,10 +380,11 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             for (int w = 0; w < WB; ++w) {
                 const uint2 r = rw[w];
                 const bool kept = r.y != KEY_OUTSIDE && ((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT;
+                const LaneRun run = lane_run(kept ? (r.y & 255u) : 256u, lane);
                 if (kept) {
                     unsigned long long *wm = &lds.wmask[r.y & 255u];
                     uint32_t *wo = &lds.woffs[r.y & 255u];
-                    __hip_atomic_fetch_or(wm, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (run.head) __hip_atomic_fetch_or(wm, run.mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const unsigned long long mm = __hip_atomic_load(wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const uint32_t base = __hip_atomic_load(wo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     zs[(base & 0xFFFFu) + (uint32_t)rank_below(mm)] = __uint_as_float(r.x);
@@ -463,10 +487,12 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
         }
 #pragma unroll
         for (int j = 0; j < WBC; ++j) {
-            if (key[j] != KEY_OUTSIDE) {
-                const unsigned long long kept = ((key[j] >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT ? 1ull : 0ull;
-                atomicAdd(&lds.cnt64[wave][key[j] & 255u], 1ull | (kept << 32));
-            }
+            const bool in = key[j] != KEY_OUTSIDE;
+            const unsigned long long km = __ballot(in && ((key[j] >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT);
+            const LaneRun run = lane_run(in ? (key[j] & 255u) : 256u, lane);
+            if (in && run.head)
+                atomicAdd(&lds.cnt64[wave][key[j] & 255u],
+                          (unsigned long long)__popcll(run.mask) | ((unsigned long long)__popcll(run.mask & km) << 32));
         }
     }
     __syncthreads();
@@ -536,8 +562,9 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
             // address; `volatile` would make the compiler drain the vector memory queue after every access)
             unsigned long long *wm = &lds.wmask[wave][cit];
             uint32_t *wo = &lds.woffs[wave][cit];
+            const LaneRun run = lane_run(kept ? cit : 256u, lane);
             if (kept) {
-                __hip_atomic_fetch_or(wm, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (run.head) __hip_atomic_fetch_or(wm, run.mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const unsigned long long mm = __hip_atomic_load(wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // the window's records of this cell
                 const uint32_t base = __hip_atomic_load(wo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 zc[base + (uint32_t)rank_below(mm)] = __uint_as_float(r.x);
