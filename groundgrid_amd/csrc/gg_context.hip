@@ -477,6 +477,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_expected = carve(C * 4);
     const size_t o_trank = carve((size_t)g.T * 2);
     const size_t o_rtile = carve((size_t)g.T * 2);
+    const size_t o_rcell0 = carve((size_t)g.T * 4);
     const size_t o_layers = carve((size_t)n_slots * GG_NUM_LAYERS * Cpad * 4);
     a.gpl = make_gp_layout(n);
     a.gp2_stride = align_up((size_t)a.gpl.elems * 8, A) / 8;
@@ -527,6 +528,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.expected = (const float *)(base + o_expected);
     a.tile_rank = (const uint16_t *)(base + o_trank);
     a.rank_tile = (const uint16_t *)(base + o_rtile);
+    a.rank_cell0 = (const uint32_t *)(base + o_rcell0);
     a.layers = (float *)(base + o_layers);
     a.gp2 = (float2 *)(base + o_gp2);
     a.layer_stride = Cpad;
@@ -581,6 +583,12 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipMemcpyAsync(base + o_expected, ctx->h_expected.data(), C * 4, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_trank, tile_rank.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipMemcpyAsync(base + o_rtile, rank_tile.data(), (size_t)g.T * 2, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint32_t> rank_cell0(g.T);
+    for (int r = 0; r < g.T; ++r) {
+        const int tile = rank_tile[r];
+        rank_cell0[r] = (uint32_t)((tile % g.tiles_r) * TILE) | ((uint32_t)((tile / g.tiles_r) * TILE) << 16);
+    }
+    CREATE_CHK(hipMemcpyAsync(base + o_rcell0, rank_cell0.data(), (size_t)g.T * 4, hipMemcpyHostToDevice, ctx->stream));
     CREATE_CHK(hipStreamSynchronize(ctx->stream)); // the host vectors above go out of scope
 
     CREATE_CHK(hipHostMalloc((void **)&ctx->h_params, sizeof(CloudParams) * PARAM_RING * n_slots, hipHostMallocDefault));

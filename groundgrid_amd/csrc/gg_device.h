@@ -117,10 +117,9 @@ GG_DEV int rank_below(unsigned long long mask)
 // cell (row, col) of a key
 GG_DEV void key_to_cell(const Arena &a, uint32_t key, int &row, int &col)
 {
-    const int tile = a.rank_tile[key >> KEY_TILE_SHIFT];
-    const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
-    row = tr * TILE + (int)(key & 15u);
-    col = tc * TILE + (int)((key >> 4) & 15u);
+    const uint32_t c0 = a.rank_cell0[key >> KEY_TILE_SHIFT];
+    row = (int)(c0 & 0xFFFFu) + (int)(key & 15u);
+    col = (int)(c0 >> 16) + (int)((key >> 4) & 15u);
 }
 
 

@@ -81,6 +81,7 @@ struct Arena {
     const float *expected;        // [C]
     const uint16_t *tile_rank;    // [T] tile (tr + tc*tiles_r) -> Morton rank
     const uint16_t *rank_tile;    // [T] Morton rank -> tile
+    const uint32_t *rank_cell0;   // [T] Morton rank -> first row | first col << 16 of the tile (per-point lookups: no division)
     // per slot (slot s at base + s * stride)
     float *layers;  size_t layer_stride;  size_t slot_layer_stride;  // layer l of slot s: layers + s*slot_layer_stride + l*layer_stride
     const uint32_t *gp_valid;     // one bit per element of the gp2 order: is it a cell (the rest is padding)

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             gh[j] = gp2[gp_idx(a, row, col)].x; // :162
             var[j] = variance[cidx[j]]; // :165
             const float cx = cell0_x - ((float)row + 0.5f) * res_f, cy = cell0_y - ((float)col + 0.5f) * res_f;
-            dc[j] = sqrtf(cx * cx + cy * cy); // distance of the cell's centre from the origin
+            dc[j] = __builtin_amdgcn_sqrtf(cx * cx + cy * cy); // distance of the cell's centre from the origin (1 ulp: it is a bound)
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             } else if (lab[j]) { // :158-182
                 const float z = __uint_as_float(r[j].x);
                 double tolerance;
-                const float s_v = fac_f / var[j] * thres_f;
+                const float s_v = fac_f * __builtin_amdgcn_rcpf(var[j]) * thres_f; // (v_rcp_f32, 1 ulp; inf / NaN / negative fall through below)
                 const float t_lo = fmaxf(dc[j] - cell_reach, 0.0f) * s_v, t_hi = (dc[j] + cell_reach) * s_v;
                 if (normal_cfg && t_lo > thres_f * 1.001f) {
                     tolerance = tol_hi;
