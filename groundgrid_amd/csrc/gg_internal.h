@@ -84,7 +84,7 @@ struct Arena {
     const uint32_t *rank_cell0;   // [T] Morton rank -> first row | first col << 16 of the tile (per-point lookups: no division)
     // per slot (slot s at base + s * stride)
     float *layers;  size_t layer_stride;  size_t slot_layer_stride;  // layer l of slot s: layers + s*slot_layer_stride + l*layer_stride
-    const uint32_t *gp_valid;     // one bit per element of the gp2 order: is it a cell (the rest is padding)
+    const uint32_t *gp_valid;     // one bit per element of the gp2 order: does gg_reset_maps fill it (the 128-byte lines that hold cells; the rest is padding)
     float2 *gp2;    size_t gp2_stride;    GpLayout gpl;              // (ground, confidence) of slot s: gp2 + s*gp2_stride, element order gp_layout.h
     uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
     float *zcell;   size_t zcell_stride;  // per slot: the KEPT heights grouped by cell (K2's stable cell sort), Nmax + 32 T + 64
