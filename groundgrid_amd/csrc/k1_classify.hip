@@ -206,11 +206,7 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { // index math for all windows, then all old-ground gathers in flight together
             inmap_[j] = locate_point(a, cp, pt[j], gi0[j], gi1[j]) && valid[j];
-            og[j] = 0.0f;
-        }
-        if (!cp.no_confidence) { // (uniform) the old ground height only enters the line-of-sight test, which a fresh map cannot fire
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) og[j] = gp2[inmap_[j] ? gp_idx(a, gi0[j], gi1[j]) : 0].x; // :243
+            og[j] = gp2[inmap_[j] ? gp_idx(a, gi0[j], gi1[j]) : 0].x; // :243
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
