@@ -115,41 +115,46 @@ struct CellState {
 // The reference's recurrence (:295-309) of the lane's cell over its `np` heights at `zseg` (cloud order), restricted to
 // the chains in R.  The chains only share the point count, and every cell starts the call at count 0 (:61-75), so point i
 // of every lane has c = i: wave-uniform, and 1 / (c + 1) comes from a table through the scalar cache.
-// One point of the recurrence (:295-309) with table quotients; `c` = points before it, r = 1 / (c + 1).  Every quotient's
-// magnitude is folded into `smallest` (except the first point's: b = 1, the product is exact) -- the caller checks it once per
-// four points and, when a quotient came out below 2^-100, repeats those points from the saved state with one_point_exact.
-template <int R>
-GG_DEV void one_point_fast(float z, float c, double r, bool first, float oz, CellState &s, float &smallest)
+// One point of the recurrence (:295-309) with table quotients; `c` = points before it, r = 1 / (c + 1).  It is the COMMON case
+// only, so that nothing but the arithmetic sits on the dependency chain of a cell (sub, cvt, mul, cvt, add for the mean):
+//   * every quotient's magnitude is folded into `smallest` (except the first point's: b = 1, the product is exact);
+//   * a point other than the cell's first takes `mean != 0` (:298) for granted and folds |mean| into `smallest` as well;
+//   * `planeDist` is taken to be a number (:300); the caller looks at the four heights.
+// The caller checks once per four points and, when a quotient came out below 2^-100, the mean was zero or a height was NaN,
+// repeats those points from the saved state with one_point_exact.
+template <int R, bool FIRST>
+GG_DEV void one_point_fast(float z, float c, double r, float oz, CellState &s, float &smallest)
 {
     const float planeDist = z - oz; // :295
-    float q_gc = 1.0f, q_pdm = 1.0f, q_mean = 1.0f, delta = 0.0f, mean_base = 0.0f;
+    float q_gc = 1.0f, q_pdm = 1.0f, q_mean = 1.0f, delta = 0.0f, mean_base = 0.0f, mean_was = 1.0f;
     if (R & R_GC) q_gc = quot(z + c * s.gc, r); // :296
     if (R & R_MEAN) {
-        // :298-299 `if (mean == 0) mean = planeDist` then :301 delta = planeDist - mean, as two selects on one comparison
-        // (the subtraction does not wait for the select)
-        const bool unset = (double)s.mean == 0.0;
-        const float d_set = planeDist - s.mean, d_unset = planeDist - planeDist;
-        delta = unset ? d_unset : d_set;
-        mean_base = unset ? planeDist : s.mean;
-        q_mean = quot(delta, r);
+        if (FIRST) { // :298-299 the cell's first point finds mean == 0 (:66): mean = planeDist, delta = planeDist - planeDist
+            mean_base = planeDist;
+            delta = planeDist - planeDist;
+            q_mean = delta; // (r = 1)
+        } else {
+            mean_was = s.mean;
+            mean_base = s.mean;
+            delta = planeDist - s.mean; // :301
+            q_mean = quot(delta, r);
+        }
     }
     if (R & R_PDM) q_pdm = quot(planeDist + c * s.pdm, r); // :303
-    if (R & (R_GC | R_MEAN | R_PDM)) {
-        const float m = fminf(fabsf(q_gc), fminf(fabsf(q_mean), fabsf(q_pdm)));
-        smallest = first ? smallest : fminf(smallest, m);
+    if (!FIRST && (R & (R_GC | R_MEAN | R_PDM))) {
+        const float m = fminf(fminf(fabsf(q_gc), fabsf(mean_was)), fminf(fabsf(q_mean), fabsf(q_pdm)));
+        smallest = fminf(smallest, m);
     }
     if (R & R_GC) {
         s.gc = q_gc;             // :296
         s.mx = std_max(s.mx, z); // :307
     }
-    const bool ok = !isnan(planeDist); // :300
     if (R & R_MEAN) {
-        const float mean_new = mean_base + q_mean;           // :302
-        const float m2_new = s.m2 + delta * (planeDist - mean_new); // :304
-        s.mean = ok ? mean_new : mean_base;
-        s.m2 = ok ? m2_new : s.m2;
+        const float mean_new = mean_base + q_mean;          // :302
+        s.m2 = s.m2 + delta * (planeDist - mean_new);       // :304
+        s.mean = mean_new;
     }
-    if (R & R_PDM) s.pdm = ok ? q_pdm : s.pdm; // :303
+    if (R & R_PDM) s.pdm = q_pdm; // :303
     if (R & R_MN) s.mn = std_min(s.mn, z - 0.0001f); // :308
 }
 
@@ -183,12 +188,26 @@ GG_DEV void four_points(const float (&z)[4], uint32_t i, uint32_t np, const doub
     const float c0 = (float)i; // (:309: (float)((double)c + 1.0) == c + 1.0f for integers below 2^24)
     float smallest = 1.0f;
     if (np >= i + 4u) { // all four points: no per-point predicate
+        if (i == 0u) // (uniform)
+            one_point_fast<R, true>(z[0], c0, rr[0], oz, s, smallest);
+        else
+            one_point_fast<R, false>(z[0], c0, rr[0], oz, s, smallest);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) one_point_fast<R>(z[k], c0 + (float)k, rr[k], i == 0u && k == 0, oz, s, smallest);
+        for (int k = 1; k < 4; ++k) one_point_fast<R, false>(z[k], c0 + (float)k, rr[k], oz, s, smallest);
     } else if (np > i) {
+        if (i == 0u)
+            one_point_fast<R, true>(z[0], c0, rr[0], oz, s, smallest);
+        else
+            one_point_fast<R, false>(z[0], c0, rr[0], oz, s, smallest);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (i + (uint32_t)k < np) one_point_fast<R>(z[k], c0 + (float)k, rr[k], i == 0u && k == 0, oz, s, smallest);
+        for (int k = 1; k < 4; ++k)
+            if (i + (uint32_t)k < np) one_point_fast<R, false>(z[k], c0 + (float)k, rr[k], oz, s, smallest);
+    }
+    // a NaN among the heights (:300 skips the mean and planeDist updates): the sum of the four is NaN then (and for inf - inf,
+    // which only costs the detour); heights beyond np are other cells' or padding
+    if (R & (R_MEAN | R_PDM)) {
+        const float chk = ((z[0] + z[1]) + (z[2] + z[3])) - oz;
+        smallest = (chk != chk) ? 0.0f : smallest;
     }
     if ((R & (R_GC | R_MEAN | R_PDM)) && __any(smallest < 0x1p-100f)) { // (rare; uniform branch)
         __asm__ volatile("; IEEE quotients" ::: "memory"); // (keeps this a branch: if-converted, the divisions would run for every point)

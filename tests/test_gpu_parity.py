@@ -668,6 +668,48 @@ def test_reduce_tile_classes_long_cells_and_quotient_fallbacks():
     run_pair(synth.make_cloud(pts, ring=rng.integers(0, 64, len(pts))), frames=2)
 
 
+def test_reduce_recurrence_rare_cases_off_the_fast_path():
+    """k_reduce's fast recurrence assumes `mean != 0` after a cell's first point and heights that are numbers; four points
+    that break either are redone with the reference's expressions.  Cells whose running mean is or returns to exactly zero,
+    NaN / +-inf heights at every position of a four-point block, -0.0, in a light tile (one wavefront), in a dense tile
+    (work-group, count-sorted lanes) and in a tile whose fullest cells run one chain per wavefront."""
+    rng = np.random.default_rng(123)
+    res = 0.33
+    seqs = [
+        [0.0, 0.0, 0.5, -0.5, 0.25, 0.0, 1.0],
+        [1.0, -1.0, 3.0, 0.125, -0.125],          # the mean returns to exactly 0 after the second point
+        [-0.0, 2.0, -2.0, -0.0, 0.0, 7.0],
+        [2.0, 2.0, -4.0, 1.0, 1.0, 1.0, 1.0, -4.0],
+        [-1.7, np.inf, -1.6, -np.inf, -1.5, -1.4],
+    ]
+    for k in range(9):                               # a NaN at position k
+        z = list(rng.normal(-1.7, 0.02, 12))
+        z[k] = np.nan
+        seqs.append(z)
+    long_cell = list(rng.normal(-1.7, 0.02, 40))    # >= 24 points: the tile's fullest cells run one chain per wavefront
+    long_cell[17] = 0.0
+    long_cell[23] = np.nan
+    long_cell[24] = 0.0
+    long_cell[25] = 0.0
+    seqs.append(long_cell)
+
+    def region(x0, y0, fillers):
+        """the sequences in cells (x0 + k, y0) ... of one 16x16 tile, `fillers` more points spread over the tile's other rows"""
+        parts = []
+        for k, z in enumerate(seqs):
+            cx, cy = (x0 + k % 16) * res, (y0 + k // 16) * res
+            xy = np.column_stack([np.full(len(z), cx), np.full(len(z), cy)]) + rng.uniform(0.02, res - 0.02, size=(len(z), 2))
+            parts.append(np.column_stack([xy, np.asarray(z, np.float64)]))
+        if fillers:
+            xy = np.column_stack([rng.uniform(x0 * res + 0.02, (x0 + 15) * res, fillers), rng.uniform((y0 + 3) * res, (y0 + 12) * res, fillers)])
+            parts.append(np.column_stack([xy, rng.normal(-1.7, 0.05, fillers)]))
+        return np.concatenate(parts)
+
+    # (a region straddles up to four tiles: enough fillers that its tiles leave the single-wavefront path / split their chains)
+    pts = np.concatenate([region(30, 30, 0), region(-70, 30, 3000), region(30, -70, 12000)]).astype(np.float32)
+    run_pair(synth.make_cloud(pts, ring=rng.integers(0, 64, len(pts))), frames=2)
+
+
 def test_reset_maps_on_the_callers_stream_is_ordered_with_batches():
     """gg_reset_maps(..., stream) between batches on the same torch stream: no event hand-over to the context's stream, same
     results as a fresh context (cold maps every step, as bench.py's headline does)."""
