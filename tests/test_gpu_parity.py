@@ -710,6 +710,46 @@ def test_reduce_recurrence_rare_cases_off_the_fast_path():
     run_pair(synth.make_cloud(pts, ring=rng.integers(0, 64, len(pts))), frames=2)
 
 
+@pytest.mark.parametrize("mdf,thres,obs", [(0.0005, 0.3, 0.1), (2e-5, 0.3, 0.1), (2e-6, 0.3, 0.1), (1e-7, 0.3, 0.1), (0.0005, 0.1, 0.3),
+                                           (0.0005, 0.0, 0.1), (-0.0005, 0.3, 0.1), (0.02, 0.3, 0.299)])
+def test_label_tolerance_branches(mdf, thres, obs):
+    """k_label decides the clamp of the tolerance (:170-171) from the point's CELL (its distance from the origin to within
+    0.75 cell) and reads x, y only when the two ends of that bound disagree.  Factors that put most points above the clamp,
+    inside the band, below it; thresholds in the unusual order, zero, a negative factor; origin off the map centre."""
+    def edit(c):
+        c.minimum_distance_factor = mdf
+        c.miminum_point_height_threshold = thres
+        c.minimum_point_height_obstacle_threshold = obs
+    r = run_pair(synth.hdl64_cloud(seed=33, n_az=500), origin=(3.7, -2.2, 0.1), frames=2, cfg_edit=edit)
+    assert len(np.unique(r["label"])) >= 2
+
+
+def test_label_tolerance_band_in_the_sensor_frame():
+    """the same with the cloud handed over in the sensor frame (x, y of the exact branch come from the transform)"""
+    from groundgrid_amd import kitti
+
+    base = synth.hdl64_cloud(seed=34, n_az=500)
+    q = np.array([0.02, 0.01, np.sin(-0.3), np.cos(-0.3)])
+    q /= np.linalg.norm(q)
+    R, t = kitti.matrix_from_quaternion(q), np.array([-2.5, 4.0, 0.05])
+    cloud_map = kitti.transform_cloud(base, R, t)
+    tf = np.hstack([R, t[:, None]])
+    origin = tuple(np.float32(v) for v in t)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(base))
+    ref = oracle.OracleMap(120.0, 0.33)
+    ref.cfg.minimum_distance_factor = 2e-6
+    c = seg.getConfig()
+    c.minimum_distance_factor = 2e-6
+    seg.setConfig(c)
+    for frame in range(2):
+        out, labels, index = seg.filter_cloud(base, origin, -1.66, return_details=True, map_from_cloud=tf)
+        r = ref.filter_cloud(cloud_map, origin, -1.66)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), frame
+        assert out.tobytes() == r["out_points"].tobytes(), frame
+        assert_same_state(seg.map(0), ref, f"frame {frame}")
+    seg.close()
+
+
 def test_reset_maps_on_the_callers_stream_is_ordered_with_batches():
     """gg_reset_maps(..., stream) between batches on the same torch stream: no event hand-over to the context's stream, same
     results as a fresh context (cold maps every step, as bench.py's headline does)."""

@@ -29,6 +29,7 @@ def run(batch, same, steps=6):
     return {k: v[0] / max(1, v[1]) for k, v in kt.items()}
 
 print("GG_K3_DEBUG =", os.environ.get("GG_K3_DEBUG"))
-for batch, same in ((1, True), (8, True), (8, False), (64, False), (1024, False)):
+cases = ((1024, False),) if len(sys.argv) > 1 and sys.argv[1] == 'big' else ((1, True), (8, True), (8, False), (64, False), (1024, False))
+for batch, same in cases:
     kt = run(batch, same)
-    print(f"batch {batch:5d} same={same}: reduce {kt['k_patch']:.4f} ms", flush=True)
+    print(f"batch {batch:5d} same={same}: patch {kt['k_patch']:.4f} ms", flush=True)
