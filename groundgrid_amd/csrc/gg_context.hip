@@ -494,7 +494,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_start_stride = align_up((size_t)(g.T + 1) * 4, A) / 4;
     const size_t o_tstart = carve((size_t)n_slots * a.tile_start_stride * 4);
     a.tile_live_stride = align_up((size_t)g.T, A);
-    const size_t o_tlive = carve((size_t)n_slots * a.tile_live_stride);
+    const size_t o_tlive = carve((size_t)n_slots * a.tile_live_stride * 2);
     a.tile_list_stride = align_up((size_t)g.T * 2, A) / 2;
     const size_t o_tlist = carve((size_t)n_slots * a.tile_list_stride * 2);
     const size_t o_tlcnt = carve((size_t)n_slots * 2 * 4);
@@ -518,7 +518,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t gp_valid_words = ((size_t)a.gpl.elems + 31) / 32;
     const size_t o_gpvalid = carve(gp_valid_words * 4);
     const size_t o_dbg = carve(64 * 8); // sweep timing
-    const bool k2_timing = getenv("GG_K2_DEBUG") && atoi(getenv("GG_K2_DEBUG")) == 9;
+    const bool k2_timing = getenv("GG_K2_DEBUG") && (atoi(getenv("GG_K2_DEBUG")) == 9 || atoi(getenv("GG_K2_DEBUG")) == 5);
     const size_t o_k2dbg = carve(k2_timing ? (size_t)K2_DBG_WGS * 32 * 8 : 64);
     ctx->arena_bytes = off;
     CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
@@ -541,7 +541,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.chunk_emit = (uint32_t *)(base + o_emit);
     a.totals = (uint32_t *)(base + o_totals);
     a.tile_start = (uint32_t *)(base + o_tstart);
-    a.tile_live = (uint8_t *)(base + o_tlive);
+    a.tile_live = (uint16_t *)(base + o_tlive);
     a.tile_list = (uint16_t *)(base + o_tlist);
     a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
     a.flags = 0;
@@ -804,7 +804,7 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
             if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH)
                 launch_fill_strided(layer_ptr(a, first_slot, l), C, a.slot_layer_stride, n, init[l], st);
         // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
-        launch_fill_bytes(a.tile_live + (size_t)first_slot * a.tile_live_stride, (size_t)n * a.tile_live_stride, 1, st);
+        launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)first_slot * a.tile_live_stride), (size_t)n * a.tile_live_stride * 2, 0xFF, st);
     }
     launch_fill2_strided(gp2_ptr(a, first_slot), (size_t)a.gpl.elems, a.gp2_stride, n, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], a.gp_valid, st);
     HIPCHK(ctx, hipGetLastError());
@@ -879,7 +879,7 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
     } else {
         HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
         // the host wrote a per-call layer: it may hold anything now, the next cloud rewrites every tile
-        launch_fill_bytes(ctx->arena.tile_live + (size_t)slot * ctx->arena.tile_live_stride, (size_t)ctx->arena.g.T, 1, ctx->stream);
+        launch_fill_bytes((uint8_t *)(ctx->arena.tile_live + (size_t)slot * ctx->arena.tile_live_stride), (size_t)ctx->arena.g.T * 2, 0xFF, ctx->stream);
     }
     if (const int rc = own_stream_mutated_map(ctx)) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1187,6 +1187,20 @@ extern "C" int gg_debug_sweep_timing(gg_context *ctx, unsigned long long out[64]
 {
     if (!ctx || !out || !ctx->d_sweep_dbg) return GG_ERR_INVALID;
     if (hipMemcpy(out, ctx->d_sweep_dbg, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
+    return GG_OK;
+}
+
+// tools only: k_reduce's work-group census by CU (GG_K2_DEBUG=5): 1024 keys x 8 counters; reset != 0 re-arms it
+extern "C" int gg_debug_k2_census(gg_context *ctx, unsigned long long *out, int reset)
+{
+    if (!ctx || !out || ctx->arena.k2_debug != 5) return GG_ERR_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return GG_ERR_HIP;
+    if (hipMemcpy(out, ctx->arena.k2_dbg, 1024 * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
+    if (reset) {
+        std::vector<unsigned long long> z(1024 * 8, 0ull);
+        for (int k = 0; k < 1024; ++k) z[(size_t)k * 8 + 4] = ~0ull; // (first start: a minimum)
+        if (hipMemcpy(ctx->arena.k2_dbg, z.data(), z.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return GG_ERR_HIP;
+    }
     return GG_OK;
 }
 

@@ -92,9 +92,10 @@ struct Arena {
     uint32_t *chunk_emit;  size_t emit_stride;   // NCH * 4
     uint32_t *totals;      // [slot][4]  (emitted kept, emitted ignored, outliers, in-map)
     uint32_t *tile_start;  size_t tile_start_stride; // T + 1
-    uint8_t *tile_live;    size_t tile_live_stride;  // [slot][T] by Morton rank: 1 = the tile's nine per-call layers may hold
-                                                     // something else than the per-call reset values (:61-75), i.e. K2 has to
-                                                     // rewrite the tile even if this cloud leaves it empty
+    uint16_t *tile_live;   size_t tile_live_stride;  // [slot][T] by Morton rank: bit k = column k of the tile (16 cells, one 64-byte row
+                                                     // segment per layer) may hold something else than the per-call reset values
+                                                     // (:61-75) in the nine per-call layers, i.e. K2 has to rewrite it even if this
+                                                     // cloud leaves it empty.  0: the tile needs no visit unless it receives records
     uint16_t *tile_list;   size_t tile_list_stride;  // [slot][T] Morton ranks: K2's light tiles from the front, dense tiles from the back (k_scan)
     uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
     int PW;    // points per wave-chunk

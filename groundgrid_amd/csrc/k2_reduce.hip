@@ -302,6 +302,14 @@ GG_DEV void write_cell(const Arena &a, float *L, int row, int col, float c, floa
     }
 }
 
+// Which of a tile's 16 columns hold records: `held` = ballot of "my cell holds an in-map record" over a wavefront whose lanes
+// 16 j .. 16 j + 15 are the cells of one column (four columns per wavefront / per k).  Returns the four column bits.
+GG_DEV uint32_t column_bits(unsigned long long held)
+{
+    return ((held & 0xFFFFull) ? 1u : 0u) | ((held & 0xFFFF0000ull) ? 2u : 0u) | ((held & 0xFFFF00000000ull) ? 4u : 0u) |
+           ((held & 0xFFFF000000000000ull) ? 8u : 0u);
+}
+
 // ---- light tiles: one wavefront per tile, no barrier, nothing leaves LDS but the layers --------------------------------------
 // At most K2_LIGHT_MAX = 8 x 64 records: the wave holds them all in registers.  Lane l owns cells l, l + 64, l + 128, l + 192
 // (4 columns x 16 rows per store instruction: 64-byte row segments, as in the dense path).  A wave walks its share of the
@@ -324,7 +332,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
     const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
     const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
     float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
-    uint8_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX};
     const float oz = cp.oz;
     const bool timing = a.k2_debug == 9;
@@ -347,7 +355,10 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
         const int rank_after = j + 2 * stride < n_light ? (int)tile_list[j + 2 * stride] : -1;
         const int tile = a.rank_tile[rank];
         const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
-        if (lane == 0) tile_live[rank] = start != end;
+        // columns that the previous clouds left with something else than the reset values; only those and the ones that hold
+        // records now are written (a light tile has records in ~60 % of its columns: a third of the layer bytes stay unwritten)
+        const uint32_t cols_before = tile_live[rank];
+        uint32_t cols_now = 0u;
         uint32_t lane_base = 0u;
         if (start != end) {
 #pragma unroll
@@ -441,18 +452,23 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                     four_points<RL>(zz, i, np, rr, oz, st);
                 }
                 const int cell = lane + 64 * k;
-                write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), (float)np, (float)(wv >> 16), st);
+                const uint32_t cb = column_bits(__ballot((wv >> 16) != 0u)); // (pointsRaw > 0: the cell holds an in-map record)
+                cols_now |= cb << (4 * k);
+                if (((cb | (cols_before >> (4 * k))) >> (lane >> 4)) & 1u)
+                    write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), (float)np, (float)(wv >> 16), st);
                 seg = seg_end;
             }
             lds_order(); // (the next tile reuses the memory)
             if (timing && lane == 0) dbg_add(a, 28, __builtin_readcyclecounter() - t_p1); // chains + writes
-        } else { // only the per-call reset (:61-75) of a tile that held points before
+        } else { // only the per-call reset (:61-75) of the columns that held points before
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int cell = lane + 64 * k;
-                write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), 0.0f, 0.0f, reset);
+                if ((cols_before >> (4 * k + (lane >> 4))) & 1u)
+                    write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), 0.0f, 0.0f, reset);
             }
         }
+        if (lane == 0) tile_live[rank] = (uint16_t)cols_now;
         if (timing && lane == 0) {
             dbg_add(a, had_points ? 8 : 12, 1ull);
             dbg_add(a, had_points ? 9 : 14, (unsigned long long)(end - start));
@@ -661,7 +677,12 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
     }
     __syncthreads();
     if (timing) tmark[4] = __builtin_readcyclecounter();
-    if (tid == 0) (a.tile_live + (size_t)cp.slot * a.tile_live_stride)[rank] = 1;
+    // (columns: see reduce_light_tiles; thread = cell, a wavefront holds four columns)
+    uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    const uint32_t cols_before = tile_live[rank];
+    const uint32_t cb = column_bits(__ballot(ex[3 * TILE_CELLS + tid] != 0.0f));
+    if (lane == 0) lds.wave_full[wave] = cb; // (the split flags were read before the recurrences; combined after the caller's barrier)
+    const bool column_written = (((cb | (cols_before >> (4 * wave))) >> (lane >> 4)) & 1u) != 0u;
     CellState st;
     st.mn = ex[1 * TILE_CELLS + tid];
     st.m2 = ex[2 * TILE_CELLS + tid];
@@ -669,8 +690,9 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
     st.mx = ex[5 * TILE_CELLS + tid];
     st.gc = ex[6 * TILE_CELLS + tid];
     st.pdm = ex[7 * TILE_CELLS + tid];
-    write_cell(a, a.layers + (size_t)cp.slot * a.slot_layer_stride, tr * TILE + (tid & 15), tc * TILE + (tid >> 4), ex[0 * TILE_CELLS + tid],
-               ex[3 * TILE_CELLS + tid], st);
+    if (column_written)
+        write_cell(a, a.layers + (size_t)cp.slot * a.slot_layer_stride, tr * TILE + (tid & 15), tc * TILE + (tid >> 4), ex[0 * TILE_CELLS + tid],
+                   ex[3 * TILE_CELLS + tid], st);
     if (timing && tid == 0) {
         tmark[5] = __builtin_readcyclecounter();
         dbg_add(a, 0, 1ull);                       // dense tiles
@@ -706,8 +728,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             // the loop, and kept in registers across the whole tile -- 30 VGPRs more)
             int tid = threadIdx.x;
             __asm__ volatile("" : "+v"(tid));
-            reduce_dense_tile<FULL>(a, cp, (int)tile_list[a.g.T - 1 - j], lds.dense, tid);
+            const int rank = (int)tile_list[a.g.T - 1 - j];
+            reduce_dense_tile<FULL>(a, cp, rank, lds.dense, tid);
             __syncthreads(); // (the next tile reuses the shared memory)
+            if (tid == 0) // the tile's columns that hold records now (every wavefront left its four bits)
+                (a.tile_live + (size_t)cp.slot * a.tile_live_stride)[rank] = (uint16_t)(lds.dense.wave_full[0] | (lds.dense.wave_full[1] << 4) |
+                                                                                         (lds.dense.wave_full[2] << 8) | (lds.dense.wave_full[3] << 12));
         }
     } else {
         const int n_light = (int)list_cnt[0];

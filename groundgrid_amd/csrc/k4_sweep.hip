@@ -264,19 +264,21 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
         }
     }
     // :147 map["points"].setConstant(0.0) -- K3 was the last reader of the KEPT counts; K5 re-counts non-ground points.  Only the
-    // tiles that received records hold anything but 0 (K2's tile_live invariant): one wavefront per such tile, 4 cells per lane
+    // columns of tiles that received records hold anything but 0 (K2's tile_live invariant): one wavefront per such tile, 4 cells
+    // per lane
     {
-        const uint8_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+        const uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
         const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6, nwaves = nthreads >> 6;
         for (int rank = wave_; rank < a.g.T; rank += nwaves) {
-            if (!tile_live[rank]) continue; // (uniform)
+            const uint32_t cols_live = tile_live[rank];
+            if (!cols_live) continue; // (uniform)
             const int tile = a.rank_tile[rank];
             const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int cell = lane_ + 64 * k;
                 const int row = tr * TILE + (cell & 15), col = tc * TILE + (cell >> 4);
-                if (row < a.g.rows && col < a.g.cols) points[(size_t)row + (size_t)col * a.g.rows] = 0.0f;
+                if (row < a.g.rows && col < a.g.cols && ((cols_live >> (cell >> 4)) & 1u)) points[(size_t)row + (size_t)col * a.g.rows] = 0.0f;
             }
         }
     }

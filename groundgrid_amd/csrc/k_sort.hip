@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
     uint32_t *hist = a.hist + (size_t)cp.slot * a.hist_stride;
     uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
 
-    const uint8_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    const uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     uint16_t *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
     uint32_t carry = 0, lcarry = 0, dcarry = 0;
     for (int t0 = 0; t0 < T; t0 += 1024) {
