@@ -697,7 +697,16 @@ int gg_get_config(const gg_context *ctx, gg_config *cfg)
 int gg_set_flags(gg_context *ctx, unsigned flags)
 {
     if (!ctx) return GG_ERR_INVALID;
+    const bool back_to_all_layers = (ctx->flags & GG_FLAG_MINIMAL_LAYERS) && !(flags & GG_FLAG_MINIMAL_LAYERS);
     ctx->flags = flags;
+    if (back_to_all_layers) {
+        // three layers were not maintained meanwhile: the next cloud rewrites every column of every tile
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
+        launch_fill_bytes((uint8_t *)ctx->arena.tile_live, (size_t)ctx->n_slots * ctx->arena.tile_live_stride * 2, 0xFF, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        return own_stream_mutated_map(ctx);
+    }
     return GG_OK;
 }
 

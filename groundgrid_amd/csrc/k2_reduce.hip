@@ -284,7 +284,8 @@ union ReduceLds {
     LightLds light[4];
 };
 
-// the 9 per-call layers of one cell
+// the 9 per-call layers of one cell (minimal layers: the three that nothing in the path reads are not maintained)
+template <bool FULL>
 GG_DEV void write_cell(const Arena &a, float *L, int row, int col, float c, float raw, const CellState &st)
 {
     if (row < a.g.rows && col < a.g.cols) {
@@ -296,9 +297,11 @@ GG_DEV void write_cell(const Arena &a, float *L, int row, int col, float c, floa
         L[GG_LAYER_VARIANCE * ls + idx] = st.m2 / (c + FLT_MIN); // :323
         L[GG_LAYER_POINTSRAW * ls + idx] = raw;
         L[GG_LAYER_MEANVARIANCE * ls + idx] = st.mean;
-        L[GG_LAYER_MAXGROUNDHEIGHT * ls + idx] = st.mx; // (minimal layers: these three keep their reset values)
-        L[GG_LAYER_GROUNDCANDIDATES * ls + idx] = st.gc;
-        L[GG_LAYER_PLANEDIST * ls + idx] = st.pdm;
+        if (FULL) {
+            L[GG_LAYER_MAXGROUNDHEIGHT * ls + idx] = st.mx;
+            L[GG_LAYER_GROUNDCANDIDATES * ls + idx] = st.gc;
+            L[GG_LAYER_PLANEDIST * ls + idx] = st.pdm;
+        }
     }
 }
 
@@ -455,7 +458,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                 const uint32_t cb = column_bits(__ballot((wv >> 16) != 0u)); // (pointsRaw > 0: the cell holds an in-map record)
                 cols_now |= cb << (4 * k);
                 if (((cb | (cols_before >> (4 * k))) >> (lane >> 4)) & 1u)
-                    write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), (float)np, (float)(wv >> 16), st);
+                    write_cell<FULL>(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), (float)np, (float)(wv >> 16), st);
                 seg = seg_end;
             }
             lds_order(); // (the next tile reuses the memory)
@@ -465,7 +468,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             for (int k = 0; k < 4; ++k) {
                 const int cell = lane + 64 * k;
                 if ((cols_before >> (4 * k + (lane >> 4))) & 1u)
-                    write_cell(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), 0.0f, 0.0f, reset);
+                    write_cell<FULL>(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), 0.0f, 0.0f, reset);
             }
         }
         if (lane == 0) tile_live[rank] = (uint16_t)cols_now;
@@ -691,7 +694,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
     st.gc = ex[6 * TILE_CELLS + tid];
     st.pdm = ex[7 * TILE_CELLS + tid];
     if (column_written)
-        write_cell(a, a.layers + (size_t)cp.slot * a.slot_layer_stride, tr * TILE + (tid & 15), tc * TILE + (tid >> 4), ex[0 * TILE_CELLS + tid],
+        write_cell<FULL>(a, a.layers + (size_t)cp.slot * a.slot_layer_stride, tr * TILE + (tid & 15), tc * TILE + (tid >> 4), ex[0 * TILE_CELLS + tid],
                    ex[3 * TILE_CELLS + tid], st);
     if (timing && tid == 0) {
         tmark[5] = __builtin_readcyclecounter();

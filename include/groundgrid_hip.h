@@ -112,8 +112,9 @@ enum { GG_CLASS_OUTSIDE = 0, GG_CLASS_IGNORED = 1, GG_CLASS_OUTLIER = 2, GG_CLAS
 
 /* gg_set_flags bits */
 enum {
-    GG_FLAG_MINIMAL_LAYERS = 1, /* skip the four layers nothing in the path reads (groundCandidates, planeDist,
-                                   maxGroundHeight, meanVariance are still zero/initial-filled); default off */
+    GG_FLAG_MINIMAL_LAYERS = 1, /* do not maintain the three layers nothing in the path reads (groundCandidates, planeDist,
+                                   maxGroundHeight: their content is unspecified while the flag is set; clearing it makes
+                                   the next cloud rewrite them everywhere); default off */
     GG_FLAG_PROFILE = 2         /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
 };
 

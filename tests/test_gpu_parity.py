@@ -268,6 +268,13 @@ def test_minimal_layers_flag_keeps_labels_and_terrain():
         assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"])
         for name in ("ground", "groundpatch", "points", "variance", "m2", "minGroundHeight", "pointsRaw", "meanVariance"):
             assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+    # back to all layers: the three that were not maintained are rewritten everywhere by the next cloud
+    seg.set_flags(minimal_layers=False)
+    moved = synth.hdl64_cloud(seed=9, n_az=600)
+    _, labels, _ = seg.filter_cloud(moved, ORIGIN0, -1.73, return_details=True)
+    r = ref.filter_cloud(moved, ORIGIN0, -1.73)
+    assert np.array_equal(labels, r["label"])
+    assert_same_state(seg.map(0), ref, "after leaving minimal layers")
 
 
 def test_largest_supported_grid_and_ring_group_counts():
