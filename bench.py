@@ -68,7 +68,7 @@ def algorithmic_bytes(n_pts, n_in, n_kept, C, T, nch, full_layers=True):
         "k_classify": 16 * n_pts + 4 * n_in + 4 * n_pts + 1 * n_pts,
         "k_scan": 2 * 4 * nch * T,
         "k_scatter": 8 * n_in + 8 * n_in,
-        "k_reduce": 8 * n_in + (9 if full_layers else 5) * 4 * C,
+        "k_reduce": 8 * n_in + (9 if full_layers else 6) * 4 * C,
         "k_patch": 6 * 4 * C + 3 * 4 * C,
         "k_sweep": 2 * 2 * 4 * C,
         "k_label": 16 * n_pts + 4 * n_pts + 8 * n_pts + 1 * n_pts,
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="independent (cloud, map) pairs per GPU per step")
-    ap.add_argument("--minimal-layers", action="store_true", help="skip the four layers nothing in the path reads")
+    ap.add_argument("--minimal-layers", action="store_true", help="do not maintain the three layers nothing in the path reads")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no warm / config3 / config4 / host_api / CPU legs)")
