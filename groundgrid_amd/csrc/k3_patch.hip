@@ -82,30 +82,24 @@ template <class F> GG_DEV float stream_tree25_eigen34(F get)
     return res;
 }
 
-// first half: everything that needs the LDS window (:352-375); issues the load of the old cell
-template <int S>
-GG_DEV void detect_ground_patch_a(const Arena &a, const float (*pts)[LR], const float (*var)[LR], const float (*mnl)[LR], int lr, int lc,
-                                  int i, int j, float sqdist, float expected, const float2 *gp2, PatchCarry &pc)
+// first half, in two pieces around the (unconditional) load of the old cell: the block's point count and the test of
+// :364-365, then the two weighted sums (:372-375).  Everything that needs the LDS window.
+template <int S, class Win> GG_DEV float patch_point_count(const Arena &a, const Win &pts, int lr, int lc)
 {
-    constexpr int SS = S * S;
     constexpr int ci = S / 2; // :352
-    const DevConfig &cfg = a.cfg;
     const bool e34 = a.eigen_reduction == GG_EIGEN_34_SSE; // (uniform) which Eigen the reference was built against
+    auto P = [&](int s) { return pts[lc - ci + s / S][lr - ci + s % S]; }; // element s of a block, column-major (:355)
+    return (S == 3) ? stream_tree9(P) : e34 ? stream_tree25_eigen34(P) : stream_tree25(P); // :359
+}
+template <int S>
+GG_DEV void patch_sums(const Arena &a, const float (*pts)[LR], const float (*var)[LR], const float (*mnl)[LR], int lr, int lc, PatchCarry &pc)
+{
+    constexpr int ci = S / 2;
+    const DevConfig &cfg = a.cfg;
+    const bool e34 = a.eigen_reduction == GG_EIGEN_34_SSE;
     auto block_sum = [&](auto get) { return (S == 3) ? stream_tree9(get) : e34 ? stream_tree25_eigen34(get) : stream_tree25(get); };
-    // element s of a block, column-major: row s % S, col s / S (:355)
     auto P = [&](int s) { return pts[lc - ci + s / S][lr - ci + s % S]; };
-    const float pointsblockSum = block_sum(P); // :359
-    // :364-365
-    if ((double)pointsblockSum < std_max(floor(cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) return;
-    if (a.k3_debug == 3) return;
-    pc.gidx = gp_idx(a, i, j); // the (ground, confidence) layer has its own element order (gp_layout.h)
-    pc.old = gp2[pc.gidx];     // :360-361, used in the second half
-    pc.live = true;
-    pc.S = S;
-    pc.pointsblockSum = pointsblockSum;
-    pc.expected = expected;
-    pc.sqdist = sqdist;
-    group_fence();
+    const float pointsblockSum = pc.pointsblockSum;
     // :374
     if (pts[lc][lr] >= (float)cfg.point_count_cell_variance_threshold)
         pc.maxVar = var[lc][lr]; // :372
@@ -121,7 +115,6 @@ GG_DEV void detect_ground_patch_a(const Arena &a, const float (*pts)[LR], const 
                      }) /
                      pointsblockSum;
     pc.localmin = localmin;
-    (void)SS;
 }
 
 // second half (:360-393): the decision against the old cell, one block later
@@ -217,23 +210,28 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         // used as the row index -- and cols [2, rows - 2): for odd sizes row n - 3 is never visited
         return !(i >= 2 * (cols / 2) - 2 || jj >= rows - 2);
     };
+    // Every load of the walk is UNCONDITIONAL (lanes with nothing to fetch read element 0, one broadcast line): loads and
+    // stores share one in-order counter, and the compiler can only leave younger loads in flight across a wait when it knows how
+    // many there are.  With a load under a branch every wait became vmcnt(0): the block's sums waited for the NEXT block's
+    // columns, requested a moment earlier.
     auto request = [&](int b, int first_col, int n_cols) { // columns [first_col, first_col + n_cols) of block b's window
         {
             const int jj = HALO + PC * b + tcl;
-            exp_next = cell_visited(jj) ? a.expected[(size_t)i + (size_t)jj * rows] : 0.0f; // :358
+            const bool v = cell_visited(jj) && jj < cols;
+            const float e = a.expected[v ? (size_t)i + (size_t)jj * rows : (size_t)0]; // :358
+            exp_next = v ? e : 0.0f;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = tid + 256 * h;
             const int lr = k % LR, lc = k / LR;
             const int gr = r0 - HALO + lr, gcol = first_col + lc;
-            sp[h] = sv[h] = sm[h] = 0.0f;
-            if (lc < n_cols && gr < rows && gcol < cols) {
-                const size_t idx = (size_t)gr + (size_t)gcol * rows;
-                sp[h] = gp_pts[idx];
-                sv[h] = gp_var[idx];
-                sm[h] = gp_min[idx];
-            }
+            const bool ok = lc < n_cols && gr < rows && gcol < cols;
+            const size_t idx = ok ? (size_t)gr + (size_t)gcol * rows : (size_t)0;
+            const float p = gp_pts[idx], v = gp_var[idx], m = gp_min[idx];
+            sp[h] = ok ? p : 0.0f;
+            sv[h] = ok ? v : 0.0f;
+            sm[h] = ok ? m : 0.0f;
         }
     };
     auto deposit = [&](int first_col, int n_cols) {
@@ -258,39 +256,64 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     int b = next_block(b_first);
     int req_first = PC * b, req_cols = LC; // what the staging registers hold
     if (b < n_blocks) request(b, req_first, req_cols);
-    PatchCarry carry;
-    carry.live = false;
-    while (b < n_blocks) {
+    // One block: `produce` receives what this block's cells found out (and their old cell, in flight), `consume` is the block
+    // before, decided now.  Two carries take turns (the loop below is unrolled by two) so that the old cell's load lands in the
+    // register it is consumed from one block later: a copy at the loop's back edge would wait for the load where it is issued.
+    // Vector-memory schedule of a block: 7 loads (the next block's columns and expectedPoints), the stores of the block before
+    // (conditional), 1 load (this block's old cells) -- the next wait for the columns leaves that one load in flight.
+    auto block_step = [&](PatchCarry &produce, PatchCarry &consume) {
         deposit(req_first, req_cols);
         const float expected = exp_next;
         __syncthreads();
-        if (a.k3_debug == 2) return;
-        // the next block that can change anything: its new columns travel while this one is computed
+        // the next block that can change anything: its new columns travel while this one is computed (past the last block: a
+        // request that fetches nothing)
         const int nb = next_block(b + 1);
-        if (nb < n_blocks) {
-            req_first = nb == b + 1 ? PC * nb + (LC - PC) : PC * nb; // (a neighbour: only the PC columns beyond this window)
-            req_cols = nb == b + 1 ? PC : LC;
-            request(nb, req_first, req_cols);
-        }
+        req_first = nb == b + 1 ? PC * nb + (LC - PC) : PC * nb; // (a neighbour: only the PC columns beyond this window)
+        req_cols = nb == b + 1 ? PC : LC;
+        request(nb, req_first, req_cols);
+        detect_ground_patch_b(a, consume, gp2); // the previous block's cell: its old (ground, confidence) has arrived meanwhile
+        consume.live = false;
+
         const int j = HALO + PC * b + tcl;
-        PatchCarry now;
-        now.live = false;
-        if (cell_visited(j)) {
-            const int base = (PC * b) & (RING - 1); // 0 or 8: the window is slots base .. base + LC - 1
-            // :332
-            const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
-            const float sqdist = (float)((di * di + dj * dj) * ((double)a.g.resolution_f * (double)a.g.resolution_f));
-            if ((double)sqdist <= a.cfg.patch_size_change_distance_sq) // :334
-                detect_ground_patch_a<3>(a, pts + base, var + base, mnl + base, tr + HALO, tcl + HALO, i, j, sqdist, expected, gp2, now);
+        const int base = (PC * b) & (RING - 1); // 0 or 8: the window is slots base .. base + LC - 1
+        const int lr = tr + HALO, lc = tcl + HALO;
+        // :332
+        const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
+        const float sqdist = (float)((di * di + dj * dj) * ((double)a.g.resolution_f * (double)a.g.resolution_f));
+        const bool visited = cell_visited(j), near = (double)sqdist <= a.cfg.patch_size_change_distance_sq; // :334
+        float pointsblockSum = 0.0f;
+        if (visited) pointsblockSum = near ? patch_point_count<3>(a, pts + base, lr, lc) : patch_point_count<5>(a, pts + base, lr, lc);
+        const int S = near ? 3 : 5;
+        // :364-365
+        const bool pass = visited && !((double)pointsblockSum < std_max(floor(a.cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) &&
+                          a.k3_debug != 3;
+        produce.gidx = pass ? gp_idx(a, i, j) : 0; // the (ground, confidence) layer has its own element order (gp_layout.h)
+        produce.old = gp2[produce.gidx];           // :360-361, used one block later
+        produce.live = pass;
+        produce.S = S;
+        produce.pointsblockSum = pointsblockSum;
+        produce.expected = expected;
+        produce.sqdist = sqdist;
+        group_fence();
+        if (pass) {
+            if (near)
+                patch_sums<3>(a, pts + base, var + base, mnl + base, lr, lc, produce);
             else
-                detect_ground_patch_a<5>(a, pts + base, var + base, mnl + base, tr + HALO, tcl + HALO, i, j, sqdist, expected, gp2, now);
+                patch_sums<5>(a, pts + base, var + base, mnl + base, lr, lc, produce);
         }
-        detect_ground_patch_b(a, carry, gp2); // the previous block's cell: its old (ground, confidence) has arrived meanwhile
-        carry = now;
         __syncthreads(); // (the window is overwritten next)
         b = nb;
+    };
+    PatchCarry c0, c1;
+    c0.live = c1.live = false;
+    while (b < n_blocks) {
+        if (a.k3_debug == 2) return;
+        block_step(c0, c1);
+        if (b >= n_blocks) break;
+        block_step(c1, c0);
     }
-    detect_ground_patch_b(a, carry, gp2);
+    detect_ground_patch_b(a, c0, gp2);
+    detect_ground_patch_b(a, c1, gp2);
 }
 
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)
