@@ -264,13 +264,13 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     auto block_step = [&](PatchCarry &produce, PatchCarry &consume) {
         deposit(req_first, req_cols);
         const float expected = exp_next;
-        __syncthreads();
         // the next block that can change anything: its new columns travel while this one is computed (past the last block: a
-        // request that fetches nothing)
+        // request that fetches nothing); requested as soon as the staging registers are free, before the barrier
         const int nb = next_block(b + 1);
         req_first = nb == b + 1 ? PC * nb + (LC - PC) : PC * nb; // (a neighbour: only the PC columns beyond this window)
         req_cols = nb == b + 1 ? PC : LC;
         request(nb, req_first, req_cols);
+        __syncthreads();
         detect_ground_patch_b(a, consume, gp2); // the previous block's cell: its old (ground, confidence) has arrived meanwhile
         consume.live = false;
 
