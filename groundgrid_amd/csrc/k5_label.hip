@@ -39,6 +39,11 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
     const int chunk = bx * 4 + wave;
     const int n = cp.n_points;
     const int nch = (n + a.PW - 1) / a.PW;
+    // tile rank -> first cell of the tile, staged once per work-group: the lookup sits between a point's record and its two
+    // gathers, and from LDS it is not a third round trip through the caches
+    extern __shared__ uint32_t lds_cell0[]; // [T]
+    for (int t = threadIdx.x; t < a.g.T; t += 256) lds_cell0[t] = a.rank_cell0[t];
+    __syncthreads();
 
     const uint32_t *totals = a.totals + (size_t)cp.slot * 4;
     if (io.d_out_counts && bx == 0 && threadIdx.x == 0) {
@@ -106,7 +111,11 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             const int cls = (int)((key >> KEY_CLASS_SHIFT) & 3u);
             lab[j] = inmap && (key & KEY_EMIT_BIT) && cls != GG_CLASS_OUTLIER; // kept or ignored, not on the border (:167)
             int row = 0, col = 0;
-            if (lab[j]) key_to_cell(a, key, row, col);
+            if (lab[j]) {
+                const uint32_t c0 = lds_cell0[key >> KEY_TILE_SHIFT];
+                row = (int)(c0 & 0xFFFFu) + (int)(key & 15u);
+                col = (int)(c0 >> 16) + (int)((key >> 4) & 15u);
+            }
             cidx[j] = (uint32_t)row + (uint32_t)col * (uint32_t)rows;
             gh[j] = gp2[gp_idx(a, row, col)].x; // :162
             var[j] = variance[cidx[j]]; // :165
@@ -204,10 +213,11 @@ void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io
     int nch = (max_n + a.PW - 1) / a.PW;
     if (nch == 0) nch = 1; // still publish the (all-zero) counts
     dim3 grid((nch + 3) / 4, n_clouds);
+    const size_t lds = (size_t)a.g.T * sizeof(uint32_t);
     if (io.point_format == GG_POINT16)
-        hipLaunchKernelGGL(k_label<GG_POINT16>, grid, dim3(256), 0, s, a, d_params, io);
+        hipLaunchKernelGGL(k_label<GG_POINT16>, grid, dim3(256), lds, s, a, d_params, io);
     else
-        hipLaunchKernelGGL(k_label<GG_POINT32>, grid, dim3(256), 0, s, a, d_params, io);
+        hipLaunchKernelGGL(k_label<GG_POINT32>, grid, dim3(256), lds, s, a, d_params, io);
 }
 
 } // namespace gg
