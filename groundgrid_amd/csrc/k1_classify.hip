@@ -149,11 +149,11 @@ GG_DEV bool ray_walk_hits_lane(const Arena &a, const CloudParams &cp, const floa
     return false;
 }
 
-GG_DEV uint32_t make_key(const Arena &a, int gi0, int gi1, int cls)
+GG_DEV uint32_t make_key(const Arena &a, const uint16_t *tile_rank, int gi0, int gi1, int cls)
 {
     const Geometry &g = a.g;
     const uint32_t emit = (g.rows <= gi0 + 3 || g.cols <= gi1 + 3) ? 0u : KEY_EMIT_BIT; // :167-168 (decided by the cell only)
-    const uint32_t tile = (uint32_t)a.tile_rank[(gi0 / TILE) + (gi1 / TILE) * g.tiles_r];
+    const uint32_t tile = (uint32_t)tile_rank[(gi0 / TILE) + (gi1 / TILE) * g.tiles_r];
     return (tile << KEY_TILE_SHIFT) | emit | ((uint32_t)cls << KEY_CLASS_SHIFT) | (uint32_t)(gi0 % TILE) |
            ((uint32_t)(gi1 % TILE) << 4);
 }
@@ -170,9 +170,13 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
     const int chunk = bx * 4 + wave;
     const int n = cp.n_points;
     const int nch = (n + a.PW - 1) / a.PW;
+    const int T = a.g.T;
+    // tile -> Morton rank, staged once per work-group (behind the four histograms): a point's key waits for this lookup
+    uint16_t *lds_tile_rank = reinterpret_cast<uint16_t *>(lds_hist + 4 * T);
+    for (int t = threadIdx.x; t < T; t += 256) lds_tile_rank[t] = a.tile_rank[t];
+    __syncthreads();
     if (chunk >= nch) return;
 
-    const int T = a.g.T;
     uint32_t *hist = lds_hist + wave * T;
     for (int t = lane; t < T; t += 64) hist[t] = 0u;
 
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
                 if (lane == src && hit) cls = GG_CLASS_OUTLIER;
             }
             uint32_t key = KEY_OUTSIDE;
-            if (inmap_[j]) key = make_key(a, gi0[j], gi1[j], cls);
+            if (inmap_[j]) key = make_key(a, lds_tile_rank, gi0[j], gi1[j], cls);
             if (valid[j]) rec[p] = make_uint2(__float_as_uint(pt[j].z), key);
             const bool inmap = key != KEY_OUTSIDE;
             if (inmap) atomicAdd(&hist[key >> KEY_TILE_SHIFT], 1u);
@@ -253,7 +257,7 @@ void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO 
     const int nch = (max_n + a.PW - 1) / a.PW;
     if (nch == 0 || n_clouds == 0) return;
     dim3 grid((nch + 3) / 4, n_clouds);
-    const size_t lds = (size_t)4 * a.g.T * sizeof(uint32_t);
+    const size_t lds = (size_t)4 * a.g.T * sizeof(uint32_t) + (((size_t)a.g.T * 2 + 3) & ~(size_t)3);
     // per-wave tile histograms beyond the 64 KiB default (grids above ~1024 cells per side) need the explicit opt-in
     static bool big_lds_ok = false;
     if (lds > 64 * 1024 && !big_lds_ok) {
