@@ -495,8 +495,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_tstart = carve((size_t)n_slots * a.tile_start_stride * 4);
     a.tile_live_stride = align_up((size_t)g.T, A);
     const size_t o_tlive = carve((size_t)n_slots * a.tile_live_stride * 2);
-    a.tile_list_stride = align_up((size_t)g.T * 2, A) / 2;
-    const size_t o_tlist = carve((size_t)n_slots * a.tile_list_stride * 2);
+    a.tile_list_stride = align_up((size_t)g.T * 16, A) / 16;
+    const size_t o_tlist = carve((size_t)n_slots * a.tile_list_stride * 16);
     const size_t o_tlcnt = carve((size_t)n_slots * 2 * 4);
     const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
     const size_t o_spts = carve(max_points * sizeof(gg_point16));
@@ -542,7 +542,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.totals = (uint32_t *)(base + o_totals);
     a.tile_start = (uint32_t *)(base + o_tstart);
     a.tile_live = (uint16_t *)(base + o_tlive);
-    a.tile_list = (uint16_t *)(base + o_tlist);
+    a.tile_list = (uint4 *)(base + o_tlist);
     a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
     a.flags = 0;
     a.k2_debug = getenv("GG_K2_DEBUG") ? atoi(getenv("GG_K2_DEBUG")) : 0;

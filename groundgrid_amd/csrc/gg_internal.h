@@ -96,7 +96,10 @@ struct Arena {
                                                      // segment per layer) may hold something else than the per-call reset values
                                                      // (:61-75) in the nine per-call layers, i.e. K2 has to rewrite it even if this
                                                      // cloud leaves it empty.  0: the tile needs no visit unless it receives records
-    uint16_t *tile_list;   size_t tile_list_stride;  // [slot][T] Morton ranks: K2's light tiles from the front, dense tiles from the back (k_scan)
+    uint4 *tile_list;      size_t tile_list_stride;  // [slot][T] K2's work lists (k_scan): light tiles from the front, dense tiles from the back; an
+                                                     // entry is everything K2 needs to know about the tile without another dependent
+                                                     // lookup: x = Morton rank | tile_live (before this cloud) << 16, y / z = first / end
+                                                     // of its records in `sorted`, w = first row | first col << 16
     uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)

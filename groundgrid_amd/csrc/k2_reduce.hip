@@ -329,10 +329,9 @@ GG_DEV void load_light_records(uint2 (&rw)[WB], const uint2 *sorted, uint32_t st
 }
 
 template <bool FULL>
-GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint16_t *tile_list, int n_light, int first, int stride, LightLds &lds)
+GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint4 *tile_list, int n_light, int first, int stride, LightLds &lds)
 {
     if (first >= n_light) return;
-    const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
     const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
     float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
     uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
@@ -341,26 +340,25 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
     const bool timing = a.k2_debug == 9;
     constexpr int RL = FULL ? (R_MEAN | R_GC | R_PDM | R_MN) : (R_MEAN | R_MN);
 
-    int rank = (int)tile_list[first];
-    int rank_next = first + stride < n_light ? (int)tile_list[first + stride] : -1;
-    uint32_t start = tile_start[rank], end = tile_start[rank + 1];
+    // the work list's entries say everything about a tile (gg_internal.h); the entry of the tile after this one is requested a
+    // tile ahead (unconditionally, at a clamped index), its records while this tile's recurrences run
+    uint4 ent = tile_list[first];
+    uint4 ent_next = tile_list[min(first + stride, n_light - 1)];
+    uint32_t start = ent.y, end = ent.z;
     uint2 rw[WB];
     load_light_records(rw, sorted, start, end, (int)(threadIdx.x & 63));
     for (int j = first; j < n_light; j += stride) {
         int lane = threadIdx.x & 63;
         __asm__ volatile("" : "+v"(lane)); // (per tile: keeps the lane's address arithmetic out of long-lived registers)
         const unsigned long long t_begin = timing ? __builtin_readcyclecounter() : 0ull;
-        uint32_t next_start = 0u, next_end = 0u;
-        if (rank_next >= 0) {
-            next_start = tile_start[rank_next];
-            next_end = tile_start[rank_next + 1];
-        }
-        const int rank_after = j + 2 * stride < n_light ? (int)tile_list[j + 2 * stride] : -1;
-        const int tile = a.rank_tile[rank];
-        const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
+        const bool has_next = j + stride < n_light;
+        const uint32_t next_start = has_next ? ent_next.y : 0u, next_end = has_next ? ent_next.z : 0u;
+        const uint4 ent_after = tile_list[min(j + 2 * stride, n_light - 1)];
+        const int rank = (int)(ent.x & 0xFFFFu);
+        const int row0 = (int)(ent.w & 0xFFFFu), col0 = (int)(ent.w >> 16);
         // columns that the previous clouds left with something else than the reset values; only those and the ones that hold
         // records now are written (a light tile has records in ~60 % of its columns: a third of the layer bytes stay unwritten)
-        const uint32_t cols_before = tile_live[rank];
+        const uint32_t cols_before = ent.x >> 16;
         uint32_t cols_now = 0u;
         uint32_t lane_base = 0u;
         if (start != end) {
@@ -458,7 +456,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                 const uint32_t cb = column_bits(__ballot((wv >> 16) != 0u)); // (pointsRaw > 0: the cell holds an in-map record)
                 cols_now |= cb << (4 * k);
                 if (((cb | (cols_before >> (4 * k))) >> (lane >> 4)) & 1u)
-                    write_cell<FULL>(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), (float)np, (float)(wv >> 16), st);
+                    write_cell<FULL>(a, L, row0 + (cell & 15), col0 + (cell >> 4), (float)np, (float)(wv >> 16), st);
                 seg = seg_end;
             }
             lds_order(); // (the next tile reuses the memory)
@@ -468,7 +466,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             for (int k = 0; k < 4; ++k) {
                 const int cell = lane + 64 * k;
                 if ((cols_before >> (4 * k + (lane >> 4))) & 1u)
-                    write_cell<FULL>(a, L, tr * TILE + (cell & 15), tc * TILE + (cell >> 4), 0.0f, 0.0f, reset);
+                    write_cell<FULL>(a, L, row0 + (cell & 15), col0 + (cell >> 4), 0.0f, 0.0f, reset);
             }
         }
         if (lane == 0) tile_live[rank] = (uint16_t)cols_now;
@@ -477,8 +475,8 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             dbg_add(a, had_points ? 9 : 14, (unsigned long long)(end - start));
             dbg_add(a, had_points ? 10 : 13, __builtin_readcyclecounter() - t_begin);
         }
-        rank = rank_next;
-        rank_next = rank_after;
+        ent = ent_next;
+        ent_next = ent_after;
         start = next_start;
         end = next_end;
     }
@@ -486,13 +484,12 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
 
 // ---- dense tiles: one work-group per tile -----------------------------------------------------------------------------------
 template <bool FULL>
-GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, DenseLds &lds, int tid)
+GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4 ent, DenseLds &lds, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    const int tile = a.rank_tile[rank];
-    const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
-    const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
-    const uint32_t start = tile_start[rank], end = tile_start[rank + 1];
+    const int rank = (int)(ent.x & 0xFFFFu);
+    const int row0 = (int)(ent.w & 0xFFFFu), col0 = (int)(ent.w >> 16);
+    const uint32_t start = ent.y, end = ent.z;
     const float oz = cp.oz;
     float *ex = reinterpret_cast<float *>(&lds.cnt64[0][0]); // result exchange, [layer value][cell] (8 KiB over the counters of step 1)
     const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX}; // the layer values after :61-75 (max: numeric_limits<float>::min(), sic, :73)
@@ -681,8 +678,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
     __syncthreads();
     if (timing) tmark[4] = __builtin_readcyclecounter();
     // (columns: see reduce_light_tiles; thread = cell, a wavefront holds four columns)
-    uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
-    const uint32_t cols_before = tile_live[rank];
+    const uint32_t cols_before = ent.x >> 16;
     const uint32_t cb = column_bits(__ballot(ex[3 * TILE_CELLS + tid] != 0.0f));
     if (lane == 0) lds.wave_full[wave] = cb; // (the split flags were read before the recurrences; combined after the caller's barrier)
     const bool column_written = (((cb | (cols_before >> (4 * wave))) >> (lane >> 4)) & 1u) != 0u;
@@ -694,7 +690,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, int rank, D
     st.gc = ex[6 * TILE_CELLS + tid];
     st.pdm = ex[7 * TILE_CELLS + tid];
     if (column_written)
-        write_cell<FULL>(a, a.layers + (size_t)cp.slot * a.slot_layer_stride, tr * TILE + (tid & 15), tc * TILE + (tid >> 4), ex[0 * TILE_CELLS + tid],
+        write_cell<FULL>(a, a.layers + (size_t)cp.slot * a.slot_layer_stride, row0 + (tid & 15), col0 + (tid >> 4), ex[0 * TILE_CELLS + tid],
                    ex[3 * TILE_CELLS + tid], st);
     if (timing && tid == 0) {
         tmark[5] = __builtin_readcyclecounter();
@@ -720,7 +716,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int cloud = (int)(item / gridDim.x);
     const int group = (int)(item % gridDim.x);
     const CloudParams cp = params[cloud];
-    const uint16_t *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
+    const uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
     const uint32_t *list_cnt = a.tile_list_cnt + (size_t)cp.slot * 2;
     if (a.k2_debug == 1) return;
     const unsigned long long t_wg = a.k2_debug == 9 ? __builtin_readcyclecounter() : 0ull;
@@ -731,8 +727,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             // the loop, and kept in registers across the whole tile -- 30 VGPRs more)
             int tid = threadIdx.x;
             __asm__ volatile("" : "+v"(tid));
-            const int rank = (int)tile_list[a.g.T - 1 - j];
-            reduce_dense_tile<FULL>(a, cp, rank, lds.dense, tid);
+            const uint4 ent = tile_list[a.g.T - 1 - j];
+            const int rank = (int)(ent.x & 0xFFFFu);
+            reduce_dense_tile<FULL>(a, cp, ent, lds.dense, tid);
             __syncthreads(); // (the next tile reuses the shared memory)
             if (tid == 0) // the tile's columns that hold records now (every wavefront left its four bits)
                 (a.tile_live + (size_t)cp.slot * a.tile_live_stride)[rank] = (uint16_t)(lds.dense.wave_full[0] | (lds.dense.wave_full[1] << 4) |
