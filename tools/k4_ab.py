@@ -5,7 +5,7 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 from groundgrid_amd import api, synth
 
 def run(batch, levels, steps=8):
-    clouds = [synth.hdl64_cloud(seed=20240113 + k) for k in range(min(batch, 4))]
+    clouds = [synth.hdl64_cloud(seed=20240113 + k) for k in range(min(batch, int(os.environ.get("NCLOUDS", "4"))))]
     stride = (max(len(c) for c in clouds) + 63) // 64 * 64
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=batch, max_points=stride)
     seg.set_flags(profile=True, minimal_layers=bool(os.environ.get('MINIMAL')))
