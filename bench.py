@@ -5,28 +5,35 @@ A "step" = one pass of filter_cloud semantics (src/GroundSegmentation.cpp:50-197
 (cloud, map-state) pairs per GPU: BASELINE.json configs[1] (synthetic Velodyne HDL-64E, ~120 k points, 120 m / 0.33 m grid
 -> 364 x 364 cells), `--batch` clouds per GPU per step, every cloud meeting a FRESHLY INITIALISED map (the "cold" contract
 case of SURVEY.md 8(d): ground := 0, groundpatch := 1e-7, GroundGrid.cpp:71-75; the re-initialisation of the persistent state
-is part of the timed step).  Inputs are resident in HBM (packed 16-B records) before the timed region.  For N > 1 the clouds
+is part of the timed step).  The clouds ROTATE over the map slots from step to step (cloud b meets slot (b + 37 i) mod B in
+step i, gg_batch.slots), so no map sees the same cloud twice in a row: the tiles K2 has to clean change every step, as they
+do for a driving vehicle.  Inputs are resident in HBM (packed 16-B records) before the timed region.  For N > 1 the clouds
 shard across ranks (no data-path collective) and each step ends with one RCCL all-gather of the 2-bit label masks
 (BASELINE.json configs[2]).  Rank 0 prints ONE JSON line; besides the headline it carries
 
   roofline        dominant KERNEL of the timed steps: algorithmic GB/s vs the 8 TB/s HBM peak (+ PMC traffic from profiles/)
   kernels         every kernel: avg ms per launch, algorithmic bytes, fraction of peak;  scatter_read_frac (north star)
-  warm_map        the steady state (same clouds re-applied to their warm maps), as in round 1
+  parity_checked_in_run   the TIMED batch's own outputs (labels, returned-cloud order, counts, ground, groundpatch of sampled
+                  slots after the last timed step) against the oracle, bit-exact
+  warm_map        the steady state (clouds keep rotating over warm maps), sampled slots replayed on the oracle
   config3         BASELINE configs[2]: 64 clouds in total, sharded 64 / N per GPU, fresh maps, all-gather of the masks
-  config4         BASELINE configs[3]: dense 2.1 M-point clouds on a 1000 x 1000 grid (rank 0, N = 1 only)
-  host_api        the drop-in call gg_filter_cloud (host buffers in and out over PCIe), synchronous and pipelined
-  cpu_baseline    the oracle (1 thread) on the same clouds on this box's host cores;  cpu_baseline_8p4: the reference's
-                  default 8 + 4 thread shape (timing only)
+  config4         BASELINE configs[3]: dense 2.1 M-point clouds on a 1000 x 1000 grid, a GPU-filling batch and one cloud
+  host_api        the drop-in call gg_filter_cloud (host buffers in and out over PCIe): synchronous, pipelined, and the
+                  reference-typed binding's shape (sync call + download of all 11 layers)
+  cpu_baseline    the oracle (1 thread) on the same clouds on this box's host cores (cold and warm);  cpu_baseline_8p4: the
+                  reference's default 8 + 4 thread shape (timing only)
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]        (N > 1: re-launches itself under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --kitti-dir <.../sequences/00>     BASELINE configs[0] / configs[4]: replay a SemanticKITTI sequence
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -37,9 +44,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+ROT = 37               # slots a cloud advances per step (see the module docstring)
+N_SCENES = 32          # distinct ray-cast scenes per GPU; the other clouds of a batch are yaw rotations of them
 
 
-def make_clouds(batch: int, rank: int, n_scenes: int = 8, seed0: int = 20240113):
+def make_clouds(batch: int, rank: int, n_scenes: int = N_SCENES, seed0: int = 20240113):
     """`batch` distinct synthetic HDL-64E clouds: n_scenes ray-cast scenes (seeds 20240113 + ...) x yaw rotations."""
     from groundgrid_amd import synth
 
@@ -98,6 +107,27 @@ def pmc_traffic(kernel, clouds_per_launch):
         return None
 
 
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_under_torchrun(n: int):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    (one process per GPU), the command line the driver uses for N > 1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvp(cmd[0], cmd)
+
+
+def nan_equal(a, b):
+    return bool(np.array_equal(a, b, equal_nan=True))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,7 +138,16 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no warm / config3 / config4 / host_api / CPU legs)")
+    ap.add_argument("--no-rotate", action="store_true", help="every step applies cloud b to slot b (round 2's workload)")
+    ap.add_argument("--config4-batch", type=int, default=128, help="clouds per launch of the configs[3] leg (GPU-filling)")
+    ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the N ranks only (gloo when no GPU is visible): launch-path check")
+    ap.add_argument("--kitti-dir", default=None, help="SemanticKITTI sequence directory: replay it instead of the synthetic bench")
+    ap.add_argument("--kitti-max-frames", type=int, default=0)
+    ap.add_argument("--kitti-euler-roundtrip", action="store_true", help="model the player's quaternion -> euler -> quaternion round trip")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args.gpus)  # does not return
 
     import torch
 
@@ -116,14 +155,41 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
-            sys.exit(2)
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    if args.dry_launch:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        on_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+        if world > 1 or "MASTER_PORT" in os.environ:
+            dist_mod.init_process_group(backend="nccl" if on_gpu else "gloo", rank=rank, world_size=world)
+            t = torch.tensor([rank + 1], dtype=torch.int64, device=f"cuda:{local_rank}" if on_gpu else "cpu")
+            dist_mod.all_reduce(t)
+            ok = int(t.item()) == world * (world + 1) // 2
+            backend = dist_mod.get_backend()
+            ranks = dist_mod.get_world_size()
+            dist_mod.barrier()
+            dist_mod.destroy_process_group()
+        else:
+            ok, backend, ranks = True, "none", 1
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "ranks": ranks, "backend": backend, "all_reduce_ok": ok}))
+        sys.exit(0 if ok else 1)
+
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.kitti_dir:
+        return kitti_leg(args, local_rank)
 
     dist = None
     if world > 1:
@@ -143,22 +209,33 @@ def main():
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride, device=local_rank)
     seg.set_flags(minimal_layers=args.minimal_layers, profile=not args.no_profile)
 
-    host = np.zeros((B, stride), dtype=api.POINT16_DTYPE)
-    for b, c in enumerate(clouds):
-        host[b, : len(c)] = api.pack16(c)
-    points = torch.from_numpy(host.view(np.uint8).reshape(B, stride, 16)).to(dev)
+    def to_device(cl, st):
+        host = np.zeros((max(len(cl), 1), st), dtype=api.POINT16_DTYPE)
+        for b, c in enumerate(cl):
+            host[b, : len(c)] = api.pack16(c)
+        return torch.from_numpy(host.view(np.uint8).reshape(host.shape[0], st, 16)).to(dev)[: len(cl)].contiguous()
+
+    points = to_device(clouds, stride)
     origins = np.zeros((B, 3), dtype=np.float32)
     base_z = np.full(B, -1.73)
 
     class Pipeline:
         """Double-buffered outputs: the all-gather of step i's label masks (RCCL's own stream, async_op) overlaps step i+1's
-        kernels; buffer i % 2 is reused only after its gather completed."""
+        kernels; buffer i % 2 is reused only after its gather completed.  shifts[i] = how far the clouds were rotated over the
+        slots in step i (cloud b -> slot (b + shift) mod nb)."""
 
-        def __init__(self, seg_, pts, npts, org, bz, cold):
+        def __init__(self, seg_, pts, npts, org, bz, cold, rotate=True, first_shift=0):
             self.seg, self.pts, self.npts, self.org, self.bz, self.cold = seg_, pts, npts, org, bz, cold
             self.outs, self.pending, self.step_no, self.out = [None, None], [None, None], 0, None
-            nb = pts.shape[0]
+            self.nb = nb = pts.shape[0]
+            self.rotate = rotate and not args.no_rotate and nb > 1
+            self.shift = first_shift
+            self.shifts = []
+            self.ids = np.arange(nb, dtype=np.int64)
             self.gathered = [torch.empty((world * nb, pts.shape[1] // 4), dtype=torch.uint8, device=dev) for _ in range(2)] if dist else None
+
+        def slots_of(self, shift):
+            return ((self.ids + shift) % self.nb).astype(np.int32)
 
         def step(self):
             k = self.step_no % 2
@@ -166,8 +243,12 @@ def main():
                 self.pending[k].wait()  # orders the compute stream after the gather that still reads outs[k].label_masks
                 self.pending[k] = None
             if self.cold:  # every cloud meets a freshly initialised map: ground := 0, groundpatch := 1e-7 (one launch, timed)
-                self.seg.reset_maps(0, self.pts.shape[0], odom_z=0.0, persistent_only=True, on_torch_stream=True)
-            self.outs[k] = self.seg.filter_batch(self.pts, self.npts, self.org, self.bz, out=self.outs[k], want_masks=dist is not None)
+                self.seg.reset_maps(0, self.nb, odom_z=0.0, persistent_only=True, on_torch_stream=True)
+            if self.rotate:
+                self.shift = (self.shift + ROT) % self.nb
+            self.shifts.append(self.shift)
+            self.outs[k] = self.seg.filter_batch(self.pts, self.npts, self.org, self.bz, out=self.outs[k], want_masks=dist is not None,
+                                                 slots=self.slots_of(self.shift) if self.rotate else None)
             self.out = self.outs[k]
             if dist:
                 self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.outs[k].label_masks, async_op=True)
@@ -202,6 +283,36 @@ def main():
             kt = self.seg.kernel_times(reset=True) if not args.no_profile else {}
             return elapsed, kt
 
+    def check_timed_outputs(pipe, cl, length, resolution, history_of=None, n_check=8, seed=1):
+        """The outputs the timed steps left behind against the oracle, bit-exact: labels, returned-cloud order and counts of
+        `n_check` random clouds of the LAST step's batch, and the ground / groundpatch / variance / points layers of the maps
+        they met.  history_of(slot) -> the clouds (indices) that slot saw since its last reset, in order (default: the last
+        step's cloud on a fresh map = a cold step)."""
+        from oracle import oracle
+
+        rng = np.random.default_rng(seed)
+        nb = pipe.nb
+        last = pipe.shifts[-1]
+        labels, index, counts = pipe.out.labels, pipe.out.out_index, pipe.out.counts.cpu().numpy()
+        ok, checked = True, []
+        for b in sorted(rng.choice(nb, size=min(n_check, nb), replace=False).tolist()):
+            slot = int((b + last) % nb)
+            hist = history_of(slot) if history_of else [b]
+            ref = oracle.OracleMap(length, resolution)
+            r = None
+            for cb in hist:
+                r = ref.filter_cloud(cl[cb], (0.0, 0.0, 0.0), -1.73)
+            assert hist[-1] == b
+            n = len(cl[b])
+            good = bool(np.array_equal(labels[b, :n].cpu().numpy(), r["label"]) and np.array_equal(index[b, :n].cpu().numpy(), r["index"]))
+            good &= int(counts[b, 0]) == len(r["out_points"]) and int(counts[b, 3]) == int((r["cls"] == oracle.OUTLIER).sum())
+            m = pipe.seg.map(slot)
+            for layer in ("ground", "groundpatch", "variance", "points"):
+                good &= nan_equal(m[layer], ref.layer(layer))
+            ok &= good
+            checked.append({"cloud": b, "slot": slot, "frames": len(hist), "ok": good})
+        return ok, checked
+
     # ---------------------------------------------------------------- headline: cold maps, K timed steps
     pipe = Pipeline(seg, points, n_points, origins, base_z, cold=True)
     elapsed, ktimes = pipe.timed(args.steps, args.warmup)
@@ -220,11 +331,12 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32+f64 (the reference's mixed float/double arithmetic, bit-exact)",
-        "data": "synthetic (seeded HDL-64E ray caster, 8 scenes x yaw rotations per GPU; no dataset on the box)",
+        "data": f"synthetic (seeded HDL-64E ray caster, {min(N_SCENES, B)} scenes x yaw rotations per GPU; no dataset on the box)",
         "config": {
             "workload": "BASELINE configs[1]: synthetic Velodyne HDL-64E cloud, 364x364 grid @ 0.33 m, "
                         f"{B} independent (cloud, map-state) pairs per GPU per step, COLD maps (each step re-initialises the persistent "
                         "state of its maps -- ground 0, groundpatch 1e-7 -- inside the timed region, then filters)"
+                        + ("" if args.no_rotate else f"; the clouds rotate over the map slots by {ROT} per step")
                         + ("; + RCCL all-gather of the 2-bit label masks per step (configs[2])" if world > 1 else ""),
             "clouds_per_gpu_per_step": B,
             "points_per_cloud_mean": int(np.mean(n_points)),
@@ -236,6 +348,9 @@ def main():
                            + (", 1 all-gather of label masks per step overlapped with the next step" if world > 1 else ""),
         },
     }
+    if dist:
+        result["collective"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                                "bytes_per_rank_per_step": int(B * stride // 4)}
 
     rows, C = seg.rows, seg.rows * seg.rows
     T = ((rows + 15) // 16) ** 2
@@ -245,7 +360,8 @@ def main():
         n_mean = float(np.mean(n_points))
         n_in = float(np.mean(counts[:, 1] + counts[:, 2] + counts[:, 3]))  # emitted kept + ignored + outliers ~ in-map
         n_kept = float(np.mean(counts[:, 1]))
-        alg = algorithmic_bytes(n_mean, n_in, n_kept, C, T, (stride + 1023) // 1024, full_layers=not args.minimal_layers)
+        pw = seg.debug_set_tuning("pw", 0)  # points per wave chunk of this context (K1 / scan / scatter / K5)
+        alg = algorithmic_bytes(n_mean, n_in, n_kept, C, T, (stride + pw - 1) // pw, full_layers=not args.minimal_layers)
         table = kernel_table(ktimes, alg, B)
         dominant = max(table, key=lambda k: table[k]["avg_ms"])
         g = table[dominant]
@@ -266,28 +382,42 @@ def main():
         result["all_kernels_frac_hbm"] = round(whole / HBM_PEAK_GBS, 4)
 
     extras = not args.no_extras
-    # ---------------------------------------------------------------- warm steady state (round 1's headline), all ranks
+    do_checks = rank == 0 and extras and args.cpu_seconds > 0
+    # ---------------------------------------------------------------- the timed batch's own outputs against the oracle
+    if do_checks:
+        ok, checked = check_timed_outputs(pipe, clouds, 120.0, 0.33)
+        result["parity_checked_in_run"] = ok
+        result["parity_check"] = {"what": "outputs of the LAST TIMED STEP of the headline batch vs the oracle, bit-exact: labels, returned-cloud "
+                                          "order, counts, and the ground / groundpatch / variance / points layers of the slots the sampled clouds met",
+                                  "sampled": checked}
+
+    # ---------------------------------------------------------------- warm steady state, all ranks
     if extras:
-        warm = Pipeline(seg, points, n_points, origins, base_z, cold=False)
+        cold_last = pipe.shifts[-1]
+        warm = Pipeline(seg, points, n_points, origins, base_z, cold=False, first_shift=cold_last)
         w_steps = max(4, args.steps // 2)
         w_elapsed, w_kt = warm.timed(w_steps, 2)
         if rank == 0:
             result["warm_map"] = {"clouds_per_s": round(world * B * w_steps / w_elapsed, 1), "ms_per_step": round(1e3 * w_elapsed / w_steps, 4),
                                   "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in w_kt.items()},
-                                  "note": "same clouds re-applied to their warm maps (no re-initialisation in the step)"}
+                                  "note": "no re-initialisation: the maps keep their terrain from step to step while the clouds keep rotating "
+                                          "over them (every map meets a different cloud in every step)"}
+            if do_checks:
+                hist_shifts = [cold_last] + warm.shifts  # what every slot saw since its last reset (the cold leg's last step)
+                okw, chk = check_timed_outputs(warm, clouds, 120.0, 0.33, n_check=2, seed=2,
+                                               history_of=lambda slot: [int((slot - s) % B) for s in hist_shifts])
+                result["warm_map"]["parity_checked_in_run"] = okw
+                result["warm_map"]["parity_frames_replayed"] = len(hist_shifts)
 
     # ---------------------------------------------------------------- configs[2]: 64 clouds in total, 64 / N per GPU
     if extras:
         first, cnt = shard_range(64, rank, world)
-        c3_clouds = make_clouds(64, 0, seed0=20240113)[first:first + cnt]  # cloud b = seed 20240113 + b % 8 (+ yaw): same set at every N
+        c3_clouds = make_clouds(64, 0, n_scenes=8, seed0=20240113)[first:first + cnt]  # the same 64 clouds at every N
         c3_np = [len(c) for c in c3_clouds]
         c3_stride = common_stride(max(c3_np) if c3_np else 64, device=dev)
         seg3 = api.GroundSegmentation().init(120.0, 0.33, n_slots=max(cnt, 1), max_points=c3_stride, device=local_rank)
-        h3 = np.zeros((max(cnt, 1), c3_stride), dtype=api.POINT16_DTYPE)
-        for b, c in enumerate(c3_clouds):
-            h3[b, : len(c)] = api.pack16(c)
-        p3 = torch.from_numpy(h3.view(np.uint8).reshape(max(cnt, 1), c3_stride, 16)).to(dev)[:cnt].contiguous() if cnt else None
-        pipe3 = Pipeline(seg3, p3, c3_np, np.zeros((cnt, 3), np.float32), np.full(cnt, -1.73), cold=True)
+        p3 = to_device(c3_clouds, c3_stride) if cnt else None
+        pipe3 = Pipeline(seg3, p3, c3_np, np.zeros((cnt, 3), np.float32), np.full(cnt, -1.73), cold=True, rotate=False)
         c3_steps = max(10, args.steps)
         e3, _ = pipe3.timed(c3_steps, 3)
         ok3 = None
@@ -300,9 +430,11 @@ def main():
         if rank == 0:
             result["config3"] = {"clouds_total": 64, "clouds_per_gpu": cnt, "clouds_per_s": round(64 * c3_steps / e3, 1),
                                  "ms_per_step": round(1e3 * e3 / c3_steps, 4), "scaling": "strong", "map_state": "cold",
-                                 "gathered_masks_match_labels": ok3,
+                                 "gathered_masks_match_labels": ok3, "rccl_ranks": dist.get_world_size() if dist else 1,
                                  "note": "BASELINE configs[2]: 64 independent clouds sharded 64/N per GPU + one all-gather of the 2-bit "
                                          "label masks per step (N = 1: no collective)"}
+            if do_checks:
+                result["config3"]["parity_checked_in_run"] = check_timed_outputs(pipe3, c3_clouds, 120.0, 0.33, n_check=8, seed=3)[0]
         seg3.close()
 
     # ---------------------------------------------------------------- rank 0, N = 1: CPU legs, host API, config 4, latency
@@ -324,17 +456,23 @@ def main():
                       f"steps), {t_cpu:.1f} s, oracle/gg_oracle.c gcc -O2 single thread (the reference's deterministic thread_count=1)",
             "host_cores_available": os.cpu_count(),
         }
-        result["speedup_vs_cpu_1thread"] = round(value / (done / t_cpu), 1)
         # the same thread on WARM maps (the steady state of a drive: the map keeps its terrain from cloud to cloud; the cold CPU
-        # path is three times slower because every road return of a fresh map starts a line-of-sight walk, :243-275)
+        # path is three times slower because every road return of a fresh map starts a line-of-sight walk, :243-275, that the
+        # HIP path skips with a host-side flag -- so the like-for-like ratio is warm / warm)
         donew, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < max(3.0, args.cpu_seconds / 3):
             for b in range(n_cpu):
-                maps[b].filter_cloud(clouds[b], (0.0, 0.0, 0.0), -1.73)
+                maps[b].filter_cloud(clouds[(b + donew) % n_cpu], (0.0, 0.0, 0.0), -1.73)
             donew += n_cpu
         tw = time.perf_counter() - t0
         result["cpu_baseline_warm"] = {"value": round(donew / tw, 2), "unit": "clouds/s", "cores": 1, "kind": "port",
                                        "sample": f"{donew} calls, {tw:.1f} s, maps kept from call to call"}
+        result["speedup_vs_cpu_1thread"] = {
+            "cold_over_cold": round(value / (done / t_cpu), 1),
+            "warm_over_warm": round(result["warm_map"]["clouds_per_s"] / (donew / tw), 1),
+            "note": "the >= 10x target of the north star is judged on warm_over_warm (like for like: on a fresh map the CPU path walks a "
+                    "line of sight for every road return and the HIP path provably need not); a reported ratio, not a kernel-quality figure",
+        }
         done8, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < max(3.0, args.cpu_seconds / 3):
             for b in range(n_cpu):
@@ -348,24 +486,13 @@ def main():
                       "threads, cfg/GroundGrid.cfg:21, src/GroundSegmentation.cpp:98-134) -- timing only, not deterministic",
         }
 
-        # parity gate in the same run: fresh maps, 2 frames, first clouds of the batch
-        chk = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=stride, device=local_rank)
-        ok = True
-        for b in range(min(2, B)):
-            ref = oracle.OracleMap(120.0, 0.33)
-            chk.map(0).reset()
-            for _ in range(2):
-                _, lab, idx = chk.filter_cloud(clouds[b], (0.0, 0.0, 0.0), -1.73, return_details=True)
-                r = ref.filter_cloud(clouds[b], (0.0, 0.0, 0.0), -1.73)
-                ok &= bool(np.array_equal(lab, r["label"]) and np.array_equal(idx, r["index"]))
-                ok &= bool(np.max(np.abs(chk.map(0)["ground"] - ref.layer("ground"))) <= 1e-4)
-        result["parity_checked_in_run"] = ok
-
         # the drop-in call: gg_filter_cloud with host buffers in and out (PCIe both ways), one map, a stream of clouds
+        chk = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=stride, device=local_rank)
         seq = [clouds[b % min(B, 8)] for b in range(64)]
         for c in seq[:4]:
             chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
-        t_sync = t_pipe = float("inf")
+        t_sync = t_pipe = t_bind = float("inf")
+        layer_buf = {}
         for _rep in range(3):  # best of three passes (the leg is host-bound: page placement and clocks of the box vary)
             t0 = time.perf_counter()
             for c in seq:
@@ -378,79 +505,45 @@ def main():
                 chk.filter_cloud_wait(tick)
                 tick = nxt
             t_pipe = min(t_pipe, (time.perf_counter() - t0) / len(seq))
+            t0 = time.perf_counter()
+            for c in seq[:32]:  # what the reference-typed binding does per callback (GROUNDGRID_HIP_LAYERS=all)
+                chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
+                layer_buf = chk.map(0).layers()
+            t_bind = min(t_bind, (time.perf_counter() - t0) / 32)
+        cpu_warm = donew / tw
         result["host_api"] = {
             "sync_clouds_per_s": round(1.0 / t_sync, 1), "pipelined_clouds_per_s": round(1.0 / t_pipe, 1),
-            "sync_ms": round(1e3 * t_sync, 4), "pipelined_ms": round(1e3 * t_pipe, 4),
-            "vs_cpu_1thread": round((1.0 / t_pipe) / (donew / tw), 1),  # (consecutive clouds on one map: the warm CPU figure)
-            "sync_vs_cpu_1thread": round((1.0 / t_sync) / (donew / tw), 1),
+            "binding_like_clouds_per_s": round(1.0 / t_bind, 1),
+            "sync_ms": round(1e3 * t_sync, 4), "pipelined_ms": round(1e3 * t_pipe, 4), "binding_like_ms": round(1e3 * t_bind, 4),
+            "vs_cpu_1thread": round((1.0 / t_pipe) / cpu_warm, 1),  # (consecutive clouds on one map: the warm CPU figure)
+            "sync_vs_cpu_1thread": round((1.0 / t_sync) / cpu_warm, 1),
+            "binding_like_vs_cpu_1thread": round((1.0 / t_bind) / cpu_warm, 1),
             "note": "gg_filter_cloud: 32-byte PointXYZIR cloud in host memory -> returned cloud in host memory, one map, consecutive clouds; "
-                    "pipelined = gg_filter_cloud_async two clouds deep (pack + upload of cloud k+1 overlap the kernels of cloud k); 64 clouds of 8 "
-                    "different scenes in turn, best of three passes",
+                    "pipelined = gg_filter_cloud_async two clouds deep (pack + upload of cloud k+1 overlap the kernels of cloud k); binding_like = "
+                    "the synchronous call followed by the download of all 11 layers (what groundgrid_amd/host/ros/GroundSegmentationHip.cpp does "
+                    "per callback when every layer is published); 64 clouds of 8 different scenes in turn, best of three passes",
         }
+        del layer_buf
 
         # single-cloud latency through the same kernels (one cloud per launch, device-resident input)
+        chk.set_flags(profile=True)
         p1 = points[:1].contiguous()
         o1 = None
         for _ in range(5):
             o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
         chk.synchronize()
+        chk.kernel_times(reset=True)
         t1 = time.perf_counter()
         for _ in range(20):
             o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
         chk.synchronize()
         result["single_cloud_latency_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+        result["single_cloud_kernel_ms"] = {k: round(v[0] / max(1, v[1]), 4) for k, v in chk.kernel_times(reset=True).items()}
         chk.close()
 
         # BASELINE configs[3]: dense OS-128-style clouds, 200 m / 0.2 m -> 1000 x 1000 cells
         try:
-            from groundgrid_amd import synth
-
-            seg.close()
-            del points
-            B4 = 8
-            base4 = synth.os128_cloud_fast(seed=20240113)  # ~2.1 M returns; the other clouds of the batch are yaw rotations of it
-            c4 = []
-            for b in range(B4):
-                ang = np.float32(2.0 * np.pi * b / B4)
-                cc, ss = np.cos(ang), np.sin(ang)
-                o = synth.clone_cloud(base4)
-                o["x"] = (cc * base4["x"] - ss * base4["y"]).astype(np.float32)
-                o["y"] = (ss * base4["x"] + cc * base4["y"]).astype(np.float32)
-                c4.append(o)
-            n4 = [len(c) for c in c4]
-            s4 = (max(n4) + 63) // 64 * 64
-            seg4 = api.GroundSegmentation().init(200.0, 0.2, n_slots=B4, max_points=s4, device=local_rank)
-            seg4.set_flags(profile=True)
-            h4 = np.zeros((B4, s4), dtype=api.POINT16_DTYPE)
-            for b, c in enumerate(c4):
-                h4[b, : len(c)] = api.pack16(c)
-            p4 = torch.from_numpy(h4.view(np.uint8).reshape(B4, s4, 16)).to(dev)
-            pipe4 = Pipeline(seg4, p4, n4, np.zeros((B4, 3), np.float32), np.full(B4, -1.73), cold=True)
-            e4, kt4 = pipe4.timed(6, 2)
-            cnt4 = pipe4.out.counts.cpu().numpy()
-            C4, T4 = seg4.rows * seg4.rows, ((seg4.rows + 15) // 16) ** 2
-            alg4 = algorithmic_bytes(float(np.mean(n4)), float(np.mean(cnt4[:, 1] + cnt4[:, 2] + cnt4[:, 3])), float(np.mean(cnt4[:, 1])), C4, T4,
-                                     (s4 + 8191) // 8192)
-            tab4 = kernel_table(kt4, alg4, B4)
-            dom4 = max(tab4, key=lambda k: tab4[k]["avg_ms"])
-            m4 = oracle.OracleMap(200.0, 0.2)
-            t0 = time.perf_counter()
-            r4 = m4.filter_cloud(c4[0], (0.0, 0.0, 0.0), -1.73)
-            t4 = time.perf_counter() - t0
-            lab4 = pipe4.out.labels[0, : n4[0]].cpu().numpy()
-            ins4 = sum(tab4[k]["avg_ms"] for k in ("k_classify", "k_scan", "k_scatter", "k_reduce"))
-            result["config4"] = {
-                "workload": f"BASELINE configs[3]: {int(np.mean(n4))} points per cloud (128 rings x 16384 azimuths), 1000x1000 grid @ 0.2 m, "
-                            f"{B4} clouds per launch, cold maps",
-                "clouds_per_s": round(B4 * 6 / e4, 2), "ms_per_step": round(1e3 * e4 / 6, 4),
-                "roofline": {"kernel": dom4, "bound": "hbm", "achieved": tab4[dom4]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": tab4[dom4]["frac_hbm"], "traffic": None},
-                "kernels": tab4,
-                "scatter_read_frac": round(20.0 * float(np.mean(n4)) * B4 / (ins4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "cpu_baseline": {"value": round(1.0 / t4, 3), "unit": "clouds/s", "cores": 1, "kind": "port", "sample": f"1 call, {t4:.2f} s"},
-                "labels_match_oracle": bool(np.array_equal(lab4, r4["label"])),
-            }
-            seg4.close()
+            result["config4"] = config4_leg(args, api, torch, dev, local_rank, seg, Pipeline, check_timed_outputs, to_device)
         except Exception as e:  # the headline must not depend on the stress configuration
             result["config4"] = {"error": repr(e)}
 
@@ -459,6 +552,109 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def config4_leg(args, api, torch, dev, local_rank, seg_main, Pipeline, check_timed_outputs, to_device):
+    """BASELINE configs[3] at a GPU-filling batch (the batched fraction) and as single-cloud latency."""
+    from groundgrid_amd import synth
+    from oracle import oracle
+
+    seg_main.close()  # frees the headline's 12 GB arena
+    torch.cuda.empty_cache()
+    B4 = max(1, args.config4_batch)
+    base4 = synth.os128_cloud_fast(seed=20240113)  # ~2.1 M returns; the other clouds of the batch are yaw rotations of it
+
+    class Rotations:
+        """cloud b = the base cloud rotated by 2 pi b / B4 about z -- regenerated on demand (128 clouds of 67 MB each are not
+        kept in host memory: the device holds the packed records, the checks re-make the few clouds they look at)."""
+
+        def __len__(self):
+            return B4
+
+        def __getitem__(self, b):
+            if b == 0:
+                return base4
+            ang = np.float32(2.0 * np.pi * b / B4)
+            cc, ss = np.cos(ang), np.sin(ang)
+            o = synth.clone_cloud(base4)
+            o["x"] = (cc * base4["x"] - ss * base4["y"]).astype(np.float32)
+            o["y"] = (ss * base4["x"] + cc * base4["y"]).astype(np.float32)
+            return o
+
+    c4 = Rotations()
+    n4 = [len(base4)] * B4
+    s4 = (len(base4) + 63) // 64 * 64
+    seg4 = api.GroundSegmentation().init(200.0, 0.2, n_slots=B4, max_points=s4, device=local_rank)
+    seg4.set_flags(profile=True)
+    p4 = torch.zeros((B4, s4, 16), dtype=torch.uint8, device=dev)
+    for b in range(B4):
+        p4[b, : n4[b]] = torch.from_numpy(api.pack16(c4[b]).view(np.uint8).reshape(-1, 16)).to(dev)
+    pipe4 = Pipeline(seg4, p4, n4, np.zeros((B4, 3), np.float32), np.full(B4, -1.73), cold=True)
+    steps4 = 4
+    e4, kt4 = pipe4.timed(steps4, 2)
+    cnt4 = pipe4.out.counts.cpu().numpy()
+    C4, T4 = seg4.rows * seg4.rows, ((seg4.rows + 15) // 16) ** 2
+    alg4 = algorithmic_bytes(float(np.mean(n4)), float(np.mean(cnt4[:, 1] + cnt4[:, 2] + cnt4[:, 3])), float(np.mean(cnt4[:, 1])), C4, T4,
+                             (s4 + seg4.debug_set_tuning("pw", 0) - 1) // seg4.debug_set_tuning("pw", 0))
+    tab4 = kernel_table(kt4, alg4, B4)
+    dom4 = max(tab4, key=lambda k: tab4[k]["avg_ms"])
+    ins4 = sum(tab4[k]["avg_ms"] for k in ("k_classify", "k_scan", "k_scatter", "k_reduce"))
+    ok4, chk4 = check_timed_outputs(pipe4, c4, 200.0, 0.2, n_check=min(4, B4), seed=4)
+    m4 = oracle.OracleMap(200.0, 0.2)
+    t0 = time.perf_counter()
+    n_cpu4 = 0
+    while time.perf_counter() - t0 < 2.0:
+        m4.reset_state()
+        m4.filter_cloud(c4[n_cpu4 % B4], (0.0, 0.0, 0.0), -1.73)
+        n_cpu4 += 1
+    t4 = (time.perf_counter() - t0) / n_cpu4
+    out = {
+        "workload": f"BASELINE configs[3]: {int(np.mean(n4))} points per cloud (128 rings x 16384 azimuths), 1000x1000 grid @ 0.2 m, "
+                    f"{B4} clouds per launch (rotating over the slots), cold maps",
+        "clouds_per_s": round(B4 * steps4 / e4, 2), "ms_per_step": round(1e3 * e4 / steps4, 4), "ms_per_cloud": round(1e3 * e4 / steps4 / B4, 4),
+        "roofline": {"kernel": dom4, "bound": "hbm", "achieved": tab4[dom4]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": tab4[dom4]["frac_hbm"], "traffic": None},
+        "kernels": tab4,
+        "all_kernels_frac_hbm": round(sum(alg4.values()) * B4 / (1e-3 * sum(r["avg_ms"] for r in tab4.values())) / 1e9 / HBM_PEAK_GBS, 4),
+        "scatter_read_frac": round(20.0 * float(np.mean(n4)) * B4 / (ins4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "cpu_baseline": {"value": round(1.0 / t4, 3), "unit": "clouds/s", "cores": 1, "kind": "port", "sample": f"{n_cpu4} calls, cold maps, {t4 * n_cpu4:.2f} s"},
+        "parity_checked_in_run": ok4, "parity_sampled": chk4,
+    }
+    # one cloud per launch: the latency a single dense sensor would see (device-resident input)
+    p1 = p4[:1].contiguous()
+    del p4
+    pipe1 = Pipeline(seg4, p1, n4[:1], np.zeros((1, 3), np.float32), np.full(1, -1.73), cold=True)
+    e1, kt1 = pipe1.timed(10, 3)
+    ok1, _ = check_timed_outputs(pipe1, [base4], 200.0, 0.2, n_check=1, seed=5)
+    out["single_cloud"] = {"latency_ms": round(1e3 * e1 / 10, 4), "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kt1.items()},
+                           "parity_checked_in_run": ok1}
+    seg4.close()
+    return out
+
+
+def kitti_leg(args, local_rank):
+    """BASELINE configs[0] / configs[4]: replay a SemanticKITTI sequence on one GPU (device-resident map scroll), print clouds/s
+    and the evaluator's per-label table, and diff it against the reference's published sequence-00 table
+    (tests/golden/readme_seq00_table.json = /root/reference/README.md:57-94; a close-match target: the ROS pipeline's tf timing
+    is not part of the data)."""
+    from groundgrid_amd import kitti, replay
+
+    seq = kitti.KittiSequence(args.kitti_dir, euler_roundtrip=args.kitti_euler_roundtrip)
+    n = len(seq) if not args.kitti_max_frames else min(len(seq), args.kitti_max_frames)
+    t0 = time.perf_counter()
+    ev, spent = replay.replay((seq.frame(i) for i in range(n)), replay.DeviceBackend(device=local_rank))
+    wall = time.perf_counter() - t0
+    result = {
+        "metric": "point clouds/s (SemanticKITTI sequence replay, one map, consecutive clouds)", "value": round(n / spent, 2), "unit": "clouds/s",
+        "n_gpus": 1, "clouds": n, "seconds_in_device_path": round(spent, 3), "seconds_wall_incl_io": round(wall, 3),
+        "data": f"SemanticKITTI-format sequence at {args.kitti_dir}", "higher_is_better": True,
+        "table": ev.rows(),
+    }
+    golden = os.path.join(ROOT, "tests", "golden", "readme_seq00_table.json")
+    if os.path.exists(golden):
+        result["vs_readme_seq00"] = ev.compare_with(json.load(open(golden)), tolerance_pct=1.0)
+    print(ev.table(), file=sys.stderr)
+    print(json.dumps(result))
 
 
 if __name__ == "__main__":

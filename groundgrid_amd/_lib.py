@@ -99,6 +99,7 @@ class GGBatch(C.Structure):
         ("d_out_clouds", C.c_void_p),
         ("d_out_counts", C.c_void_p),
         ("d_label_masks", C.c_void_p),
+        ("slots", C.POINTER(C.c_int32)),
     ]
 
 

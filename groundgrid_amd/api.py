@@ -291,7 +291,7 @@ class GroundSegmentation:
     # -- batched device-resident form
     def filter_batch(self, points, n_points: Sequence[int], origins, base_z, *, first_slot: int = 0,
                      out: Optional[BatchOutputs] = None, want_clouds: bool = False, want_masks: bool = False, stream=None,
-                     transforms=None) -> BatchOutputs:
+                     transforms=None, slots=None) -> BatchOutputs:
         """points: CUDA torch tensor [B, stride, 16] (packed gg_point16) or [B, stride, 32] (PointXYZIR), uint8.
         Enqueues on the current torch stream and returns without synchronising."""
         import torch
@@ -321,6 +321,9 @@ class GroundSegmentation:
         if transforms is not None:  # [B, 3, 4] map <- cloud frame: the per-point transform is fused into K1
             tfs = np.ascontiguousarray(np.asarray(transforms, dtype=np.float64).reshape(B, 12))
             b.transforms = tfs.ctypes.data_as(C.POINTER(C.c_double))
+        if slots is not None:  # cloud b meets map slot slots[b] (distinct) instead of first_slot + b
+            sl = (C.c_int32 * B)(*[int(v) for v in slots])
+            b.slots = sl
         b.d_labels = out.labels.data_ptr()
         b.d_out_index = out.out_index.data_ptr()
         b.d_out_clouds = out.out_clouds.data_ptr() if out.out_clouds is not None else None
@@ -377,6 +380,17 @@ class GroundSegmentation:
         if return_details:
             return seg, labels[:n], index[:n]
         return seg
+
+    def debug_set_tuning(self, key: str, value: int) -> int:
+        """Tools / tests: force a launch geometry the library would otherwise derive from the batch size ("sweep_waves",
+        "k2_per_cloud", "k2_dense_share"; 0 = default); key "pw" returns the context's points per wave chunk."""
+        fn = self._L.gg_debug_set_tuning
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        rc = fn(self._ctx, key.encode(), int(value))
+        if rc < 0:
+            raise GroundGridError(f"gg_debug_set_tuning({key}): {_lib.STATUS.get(rc, rc)}")
+        return rc
 
     def set_conventions(self, eigen_reduction: int = 0):
         """Which Eigen the reference is built against (0 = 3.3.x order of the 5x5 block sums, 1 = 3.4.x SSE2)."""

@@ -46,6 +46,7 @@ struct gg_context {
     size_t arena_bytes = 0;
     std::vector<float> h_expected;
     std::vector<double> pos_x, pos_y; // per slot map position
+    std::vector<char> slot_seen;      // scratch of gg_filter_batch's check of gg_batch.slots
     std::vector<char> no_confidence;  // per slot: groundpatch <= 0.01 everywhere for sure (set by gg_reset_map, cleared by any writer)
 
     gg_conventions conv{};
@@ -238,7 +239,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     CloudParams *dp = ctx->d_params + (size_t)g * ctx->n_slots;
     int max_n = 0;
     for (int i = 0; i < nb; ++i) {
-        const int slot = b->first_slot + i;
+        const int slot = b->slots ? b->slots[i] : b->first_slot + i;
         CloudParams &p = hp[i];
         p.slot = slot;
         p.n_points = b->n_points[i];
@@ -433,8 +434,15 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     // points per wavefront chunk of K1 / scatter / K5: the chunk histograms (K1 -> k_scan -> k_scatter) shrink with it, the
     // number of wavefronts per cloud too -- contexts for big batches take 2048 (k_scan 0.18 -> 0.11 ms per 1024 clouds), small
     // ones 1024 (one cloud: 0.56 instead of 0.60 ms)
-    a.PW = g.T <= 1024 ? (n_slots >= 128 ? 2048 : 1024) : 8192;
-    if (getenv("GG_PW")) a.PW = atoi(getenv("GG_PW")); // (tools: points per wavefront chunk of K1 / scatter / K5)
+    a.PW = g.T <= 1024 ? (n_slots >= PW_BIG_CONTEXT_SLOTS ? 2048 : 1024) : 8192;
+    if (getenv("GG_PW")) a.PW = atoi(getenv("GG_PW")); // (tools, tests: points per wavefront chunk of K1 / scatter / K5)
+    if (a.PW < 64 || a.PW % 64 != 0) {
+        gg_destroy(ctx);
+        return GG_ERR_INVALID;
+    }
+    a.tune_sweep_waves = getenv("GG_SWEEP_WAVES") ? atoi(getenv("GG_SWEEP_WAVES")) : 0;
+    a.tune_k2_per_cloud = getenv("GG_K2_PER_CLOUD") ? atoi(getenv("GG_K2_PER_CLOUD")) : 0;
+    a.tune_k2_dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 0;
     a.NCH = (int)((max_points + a.PW - 1) / a.PW);
     make_dev_config(ctx->cfg, a.cfg);
 
@@ -1007,8 +1015,19 @@ int gg_get_expected_points(const gg_context *ctx, float *dst)
 int gg_filter_batch(gg_context *ctx, const gg_batch *b, void *stream)
 {
     if (!ctx || !b) return GG_ERR_INVALID;
-    if (b->n_clouds < 0 || b->first_slot < 0 || b->first_slot + b->n_clouds > ctx->n_slots) return fail(ctx, GG_ERR_CAPACITY, "slot range");
+    if (b->n_clouds < 0 || b->n_clouds > ctx->n_slots) return fail(ctx, GG_ERR_CAPACITY, "slot range");
+    if (!b->slots && (b->first_slot < 0 || b->first_slot + b->n_clouds > ctx->n_slots)) return fail(ctx, GG_ERR_CAPACITY, "slot range");
     if (b->n_clouds == 0) return GG_OK;
+    if (b->slots) { // distinct and in range: two clouds of one launch on one map would race
+        std::vector<char> &seen = ctx->slot_seen;
+        seen.assign((size_t)ctx->n_slots, 0);
+        for (int i = 0; i < b->n_clouds; ++i) {
+            const int s = b->slots[i];
+            if (s < 0 || s >= ctx->n_slots) return fail(ctx, GG_ERR_CAPACITY, "gg_batch.slots entry outside the context");
+            if (seen[(size_t)s]) return fail(ctx, GG_ERR_INVALID, "gg_batch.slots entries must be distinct");
+            seen[(size_t)s] = 1;
+        }
+    }
     if (!b->d_points || !b->n_points || !b->origins || !b->base_z) return fail(ctx, GG_ERR_INVALID, "null batch field");
     if (b->point_format != GG_POINT32 && b->point_format != GG_POINT16) return fail(ctx, GG_ERR_INVALID, "point_format");
     if (b->d_out_clouds && b->point_format != GG_POINT32) return fail(ctx, GG_ERR_INVALID, "d_out_clouds needs GG_POINT32 input");
@@ -1188,6 +1207,20 @@ int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class
     if (out_class) HIPCHK(ctx, hipMemcpyAsync(out_class, ctx->d_stage_class, n, hipMemcpyDeviceToHost, ctx->stream));
     if (out_cell) HIPCHK(ctx, hipMemcpyAsync(out_cell, ctx->d_stage_cell, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+// tools and tests only (not in the header): override the launch geometry the library would pick from the batch size (0 = back
+// to the default).  key: "sweep_waves", "k2_per_cloud", "k2_dense_share".  Returns the chunk size PW for key "pw" (read-only:
+// the arena is carved for it at gg_create; set GG_PW in the environment before gg_create to change it).
+extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
+{
+    if (!ctx || !key || value < 0) return GG_ERR_INVALID;
+    if (!strcmp(key, "pw")) return ctx->arena.PW;
+    if (!strcmp(key, "sweep_waves")) ctx->arena.tune_sweep_waves = value;
+    else if (!strcmp(key, "k2_per_cloud")) ctx->arena.tune_k2_per_cloud = value;
+    else if (!strcmp(key, "k2_dense_share")) ctx->arena.tune_k2_dense_share = std::min(value, 15);
+    else return GG_ERR_INVALID;
     return GG_OK;
 }
 

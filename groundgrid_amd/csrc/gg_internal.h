@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "groundgrid_hip.h"
 #include "gp_layout.h"
 
@@ -22,6 +24,11 @@ constexpr int TILE = 16;             // cells per tile edge (K2 work-group = one
 constexpr int TILE_CELLS = TILE * TILE;
 constexpr uint32_t KEY_OUTSIDE = 0xFFFFFFFFu;
 constexpr int K2_DBG_WGS = 32768;  // slots of k_reduce's phase counters (GG_K2_DEBUG=9)
+// Launch geometry that changes with the batch size -- named here because docs and tests refer to it:
+constexpr int PW_BIG_CONTEXT_SLOTS = 128;      // contexts with at least this many slots use 2048-point wave chunks (else 1024)
+constexpr int SWEEP_LATENCY_MAX_CLOUDS = 256;  // launches of at most this many clouds give every 64-ring group of a side its own
+                                               // wavefront (up to 3 per side); bigger ones use make_params' throughput setting
+constexpr int K2_MIN_GROUPS_PER_CLOUD = 64;    // k_reduce: work-groups per cloud = max(4096 / clouds, this)
 constexpr int K2_LIGHT_MAX = 512; // tiles with at most this many records are reduced by a single wavefront (k2_reduce.hip)
 // key = tile_rank << 12 | emit << 10 | class << 8 | cell_in_tile (row_in_tile | col_in_tile << 4)
 constexpr int KEY_TILE_SHIFT = 12;
@@ -103,6 +110,12 @@ struct Arena {
     uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)
+    // launch geometry overrides (0 = the launchers' defaults).  Set at gg_create from the environment (GG_SWEEP_WAVES,
+    // GG_K2_PER_CLOUD, GG_K2_DENSE_SHARE; GG_PW above) or per context by gg_debug_set_tuning: tools measure with them, and the
+    // parity tests force every geometry the launchers can pick (tests/test_gpu_parity.py) at small batch sizes.
+    int tune_sweep_waves;   // chain wavefronts per side of k_sweep
+    int tune_k2_per_cloud;  // minimum work-groups per cloud of k_reduce
+    int tune_k2_dense_share; // sixteenths of them that walk the dense list
     unsigned flags;
     int k2_debug;        // env GG_K2_DEBUG (measurement only): 1 = k_reduce stops after the tile lookup, 2 = after step 1, 3 = after step 3,
                          // 9 = per-phase cycle counters into k2_dbg (tools/k2_phases.py)
@@ -135,6 +148,18 @@ struct BatchIO {
     int32_t *d_out_counts;
     uint8_t *d_label_masks;
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: the launchers that need more than 64 KiB of dynamic
+// LDS opt in once per DEVICE (a process may hold contexts on several GPUs), tracked in a bit mask indexed by the current device.
+inline bool first_use_on_this_device(std::atomic<uint64_t> &seen)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (seen.load(std::memory_order_relaxed) & bit) return false;
+    seen.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
 
 // kernel launchers (one per .hip file)
 void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);

@@ -259,11 +259,10 @@ void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO 
     dim3 grid((nch + 3) / 4, n_clouds);
     const size_t lds = (size_t)4 * a.g.T * sizeof(uint32_t) + (((size_t)a.g.T * 2 + 3) & ~(size_t)3);
     // per-wave tile histograms beyond the 64 KiB default (grids above ~1024 cells per side) need the explicit opt-in
-    static bool big_lds_ok = false;
-    if (lds > 64 * 1024 && !big_lds_ok) {
+    static std::atomic<uint64_t> big_lds_devices{0};
+    if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices)) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big_lds_ok = true;
     }
     if (io.point_format == GG_POINT16)
         hipLaunchKernelGGL(k_classify<GG_POINT16>, grid, dim3(256), lds, s, a, d_params, io);

@@ -753,9 +753,9 @@ void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hi
     if (n_clouds == 0) return;
     // at least 64 work-groups per cloud (48 on the dense list, 16 on the light one: measured 1.62 ms per 1024 clouds against 1.72
     // with 16; finer shares balance better than fewer, longer walks), about 4096 per launch when there are few clouds
-    static const int min_per_cloud = getenv("GG_K2_PER_CLOUD") ? atoi(getenv("GG_K2_PER_CLOUD")) : 64;
+    const int min_per_cloud = a.tune_k2_per_cloud > 0 ? a.tune_k2_per_cloud : K2_MIN_GROUPS_PER_CLOUD;
     const int per_cloud = std::min(std::max(4096 / n_clouds, min_per_cloud), 2 * a.g.T);
-    static const int dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 12; // sixteenths of the groups
+    const int dense_share = a.tune_k2_dense_share > 0 ? a.tune_k2_dense_share : 12; // sixteenths of the groups
     const int gd = std::max(1, per_cloud * dense_share / 16), gl = std::max(1, per_cloud - gd);
     dim3 grid(gd + gl, n_clouds);
     if (a.flags & GG_FLAG_MINIMAL_LAYERS)

@@ -320,14 +320,16 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
     if (n_clouds == 0 || P_in.rings <= 0) return;
     // Latency setting: a launch of at most one cloud per CU gives every 64-ring group of a side its own wavefront (up to 3)
     Params P = P_in;
-    if (n_clouds <= 256 && !getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(P.groups, 3));
+    if (a.tune_sweep_waves > 0)
+        P.waves_per_side = std::max(1, std::min(std::min(P.groups, 3), a.tune_sweep_waves));
+    else if (n_clouds <= SWEEP_LATENCY_MAX_CLOUDS)
+        P.waves_per_side = std::max(1, std::min(P.groups, 3));
     const LdsMap L = lds_layout(P.c, P.groups);
     const size_t lds = (size_t)L.words * 4;
-    static bool big_lds_ok = false;
-    if (lds > 64 * 1024 && !big_lds_ok) {
+    static std::atomic<uint64_t> big_lds_devices{0};
+    if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices)) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big_lds_ok = true;
     }
     const int threads = (4 * P.waves_per_side + 2) * 64;
     if (dbg) // (GG_SWEEP_TIMING: the instrumented twin)

@@ -174,11 +174,9 @@ void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, i
     if (nch == 0 || n_clouds == 0) return;
     dim3 grid((nch + 3) / 4, n_clouds);
     const size_t lds = (size_t)4 * a.g.T * sizeof(uint32_t);
-    static bool big_lds_ok = false; // (see launch_classify)
-    if (lds > 64 * 1024 && !big_lds_ok) {
+    static std::atomic<uint64_t> big_lds_devices{0}; // (see launch_classify)
+    if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices))
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big_lds_ok = true;
-    }
     hipLaunchKernelGGL(k_scatter, grid, dim3(256), lds, s, a, d_params);
 }
 

@@ -206,7 +206,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
     // to one wavefront per group (at most 3 per side: 14 wavefronts) when the launch has fewer clouds than the chip has CUs:
     // with SKEW = 1 group g + 1 starts only 64 steps after group g, and a wavefront that still works on group g - 1 delays it.
     P.waves_per_side = P.groups <= 1 ? 1 : P.groups <= 3 ? 2 : 3;
-    if (getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(std::min(P.groups, 3), atoi(getenv("GG_SWEEP_WAVES")))); // (tests, tools)
+    if (getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(std::min(P.groups, 3), atoi(getenv("GG_SWEEP_WAVES")))); // (the host emulation: tests/test_sweep_emul_cpu.py)
     // :463 (pow((float)x - center, 2.0) + pow((float)y - center, 2.0)) * pow(resolution, 2.0f) > minDistSquared: the left side is a
     // non-decreasing function of the integer (x-c)^2 + (y-c)^2, so the test is an integer threshold
     int r2 = 0;

@@ -88,6 +88,41 @@ class GroundEvaluator:
             "iou_ground": div(tp, fp + gt_ground),
         }
 
+    def rows(self) -> dict:
+        """The table as data: per label (non-ground %, ground %, non-ground, total) for labels that occurred, + the summary."""
+        out = {}
+        for name in LABELS.values():
+            tot = self.total[name]
+            if tot:
+                ng = self.non_ground[name]
+                out[name] = {"nonground_pct": round(100.0 * ng / tot, 2), "ground_pct": round(100.0 * (1.0 - ng / tot), 2), "nonground": ng, "total": tot}
+        return {"clouds": self.cloud_count, "labels": out, "summary": {k: (round(100.0 * v, 2) if isinstance(v, float) else v) for k, v in self.summary().items()}}
+
+    def compare_with(self, published: dict, tolerance_pct: float = 1.0) -> dict:
+        """Difference to a published table of the form tests/golden/readme_seq00_table.json (the reference's README.md:57-94):
+        per label the non-ground percentage (absolute difference in percentage points) and the point total (relative), and the
+        five summary percentages.  `within_tolerance` = every percentage within tolerance_pct points and every total within
+        tolerance_pct percent -- a close-match criterion: the live ROS pipeline's tf timing is not part of the data."""
+        mine = self.rows()
+        diff, ok = {}, self.cloud_count == published.get("clouds", self.cloud_count)
+        for name, row in published["labels"].items():
+            got = mine["labels"].get(name)
+            if got is None:
+                diff[name] = {"missing": True}
+                ok = False
+                continue
+            d_pct = got["nonground_pct"] - row["nonground_pct"]
+            d_tot = 100.0 * (got["total"] - row["total"]) / row["total"]
+            diff[name] = {"nonground_pct_delta": round(d_pct, 3), "total_rel_pct": round(d_tot, 3)}
+            ok &= abs(d_pct) <= tolerance_pct and abs(d_tot) <= tolerance_pct
+        summary = {}
+        for key, name in (("precision", "Precision"), ("recall", "Recall"), ("f1", "F1"), ("accuracy", "Accuracy"), ("iou_ground", "IoUg")):
+            d = mine["summary"][key] - published["summary"][name][0]
+            summary[name] = {"mine": mine["summary"][key], "published": published["summary"][name][0], "delta": round(d, 3)}
+            ok &= abs(d) <= tolerance_pct
+        return {"clouds": self.cloud_count, "published_clouds": published.get("clouds"), "tolerance_pct": tolerance_pct,
+                "within_tolerance": bool(ok), "labels": diff, "summary": summary}
+
     def table(self) -> str:
         """The text eval_groundpoint_classifier.py:135-195 prints."""
         lines = ["Stats", f"Received {self.cloud_count} point clouds.", "label\t\t\tnonground %\tground %\tnonground\ttotal"]

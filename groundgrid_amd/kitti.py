@@ -94,6 +94,41 @@ def quaternion_from_matrix(M: np.ndarray) -> np.ndarray:
     return q
 
 
+def euler_roundtrip_quaternion(q) -> np.ndarray:
+    """What the player actually broadcasts as map <- kitti_base_link (scripts/kitti_data_publisher.py:201-214): not the pose's
+    quaternion q but quaternion_from_euler(*euler_from_quaternion(q_new)) with q_new = quaternion_multiply((0, 0, 0, 1), q) --
+    a round trip through roll / pitch / yaw ("sxyz") in tf.transformations (restated from transformations.py as shipped with
+    ROS Noetic's tf; third-party, unpinned like the other conventions).  The result differs from q in the last ulps."""
+    import math
+
+    x0, y0, z0, w0 = (float(v) for v in q)
+    x1, y1, z1, w1 = 0.0, 0.0, 0.0, 1.0  # quaternion_from_euler(0, 0, 0)
+    qn = np.array((x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0, -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0,
+                   x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0, -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0), dtype=np.float64)
+    eps = np.finfo(float).eps * 4.0
+    # euler_from_quaternion = euler_from_matrix(quaternion_matrix(q), 'sxyz')
+    qq = np.array(qn, dtype=np.float64, copy=True)
+    nq = np.dot(qq, qq)
+    if nq < eps:
+        M = np.identity(3)
+    else:
+        qq *= math.sqrt(2.0 / nq)
+        o = np.outer(qq, qq)
+        M = np.array(((1.0 - o[1, 1] - o[2, 2], o[0, 1] - o[2, 3], o[0, 2] + o[1, 3]),
+                      (o[0, 1] + o[2, 3], 1.0 - o[0, 0] - o[2, 2], o[1, 2] - o[0, 3]),
+                      (o[0, 2] - o[1, 3], o[1, 2] + o[0, 3], 1.0 - o[0, 0] - o[1, 1])), dtype=np.float64)
+    cy = math.sqrt(M[0, 0] * M[0, 0] + M[1, 0] * M[1, 0])
+    if cy > eps:
+        ax, ay, az = math.atan2(M[2, 1], M[2, 2]), math.atan2(-M[2, 0], cy), math.atan2(M[1, 0], M[0, 0])
+    else:
+        ax, ay, az = math.atan2(-M[1, 2], M[1, 1]), math.atan2(-M[2, 0], cy), 0.0
+    # quaternion_from_euler(ax, ay, az, 'sxyz')
+    ai, aj, ak = ax / 2.0, ay / 2.0, az / 2.0
+    ci, si, cj, sj, ck, sk = math.cos(ai), math.sin(ai), math.cos(aj), math.sin(aj), math.cos(ak), math.sin(ak)
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+    return np.array((cj * sc - sj * cs, cj * ss + sj * cc, cj * cs - sj * sc, cj * cc + sj * ss), dtype=np.float64)
+
+
 # Which rotation matrix tf2::doTransform(PointStamped) -- the overload the reference calls for the cloud transform, the
 # cloud origin and GroundGrid::update (src/GroundGridNodelet.cpp:146,176, src/GroundGrid.cpp:129) -- builds from the message
 # quaternion is a third-party convention (tools/pin/ decides it on a ROS box): ROS Melodic / Noetic route that overload
@@ -146,8 +181,9 @@ class Frame:
 class KittiSequence:
     """Iterates a SemanticKITTI sequence directory (``.../sequences/00``) in the reference pipeline's conventions."""
 
-    def __init__(self, directory: str):
+    def __init__(self, directory: str, euler_roundtrip: bool = False):
         self.dir = directory
+        self.euler_roundtrip = euler_roundtrip  # model the player's quaternion -> euler -> quaternion round trip (:208-214)
         self.poses = read_poses(os.path.join(directory, "poses.txt"))
         self.n = len(self.poses)
         self.have_labels = os.path.isdir(os.path.join(directory, "labels"))
@@ -158,15 +194,17 @@ class KittiSequence:
     def frame(self, i: int) -> Frame:
         scan = read_bin(os.path.join(self.dir, "velodyne", f"{i:06d}.bin"))
         labels = read_labels(os.path.join(self.dir, "labels", f"{i:06d}.label")) if self.have_labels else None
-        return make_frame(i, make_cloud(scan, labels), self.poses[i])
+        return make_frame(i, make_cloud(scan, labels), self.poses[i], euler_roundtrip=self.euler_roundtrip)
 
     def __iter__(self) -> Iterator[Frame]:
         for i in range(self.n):
             yield self.frame(i)
 
 
-def make_frame(i: int, cloud_sensor: np.ndarray, pose: np.ndarray) -> Frame:
+def make_frame(i: int, cloud_sensor: np.ndarray, pose: np.ndarray, euler_roundtrip: bool = False) -> Frame:
     q = quaternion_from_matrix(pose)                  # player: quaternion of the pose (:199)
+    if euler_roundtrip:                               # ... which it broadcasts after a trip through euler angles (:208-214)
+        q = euler_roundtrip_quaternion(q)
     R = matrix_from_quaternion(q)                     # nodelet: doTransform rebuilds the rotation from the quaternion
     t = np.array([pose[0, 3], pose[1, 3], pose[2, 3]])
     cloud_map = transform_cloud(cloud_sensor, R, t)

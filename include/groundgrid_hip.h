@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 2
+#define GG_ABI_VERSION 3
 
 typedef enum gg_status {
     GG_OK = 0,
@@ -236,7 +236,7 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
                          int32_t *out_index);
 
 /* Batched, device-resident form of the same call: n_clouds independent (cloud, map-state) pairs in
- * one set of launches, slot first_slot + b for cloud b.  Pointers prefixed d_ are device memory.
+ * one set of launches, slot first_slot + b (or slots[b]) for cloud b.  Pointers prefixed d_ are device memory.
  * Enqueues on `stream` (a hipStream_t passed as void*; NULL = the context's own stream, GG_STREAM_DEFAULT = the legacy
  * default ("null") stream, which as a hipStream_t is itself 0) and returns without waiting.
  * Ordering across streams is the library's job, not the caller's: a batch waits (hipStreamWaitEvent) for every earlier
@@ -265,6 +265,9 @@ typedef struct gg_batch {
                                 2*(p%4).. of byte p/4: 0 dropped, 1 ground (49), 2 non-ground (99) -- what a multi-GPU
                                 caller all-gathers (a quarter of d_labels).  cloud_stride must be a multiple of 4; only the bytes
                                 covering points < n_points (rounded up to a multiple of 64) are written */
+    const int32_t *slots;    /* host [n_clouds], nullable (ABI v3): cloud b meets map slot slots[b] instead of first_slot + b
+                                (first_slot is ignored then).  Entries must be distinct and inside the context: a server that
+                                holds many streams' maps filters whichever of them received a cloud, in one set of launches */
 } gg_batch;
 #define GG_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int gg_filter_batch(gg_context *ctx, const gg_batch *batch, void *stream);

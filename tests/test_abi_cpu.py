@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_kernel_names(lib):
-    assert lib.gg_abi_version() == 2  # v2: gg_move_map takes matrix entries, conventions, async host call
+    assert lib.gg_abi_version() == 3  # v2: gg_move_map takes matrix entries, conventions, async host call; v3: gg_batch.slots
     names = [lib.gg_kernel_name(k).decode() for k in range(_lib.GG_NUM_KERNELS)]
     assert names == ["k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_sweep", "k_label"]
 
@@ -48,7 +48,7 @@ def test_abi_version_and_kernel_names(lib):
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.GGGeometry) == 16
     assert C.sizeof(_lib.GGConfig) == 104          # 2 int, 11 double, 1 int (+pad) as the C compiler lays it out
-    assert C.sizeof(_lib.GGBatch) == 104
+    assert C.sizeof(_lib.GGBatch) == 112           # ABI v3: + slots
     assert C.sizeof(_lib.GGConventions) == 32
     from groundgrid_amd import api, synth
     assert synth.POINT_DTYPE.itemsize == 32 and api.POINT16_DTYPE.itemsize == 16

@@ -231,6 +231,107 @@ def test_batched_independent_maps(fmt):
     assert (seg.map(0)["ground"] == 0).all()
 
 
+def _mixed_small_clouds(count, seed0):
+    """Distinct small clouds (6-7 k points; every 16th ~36 k so that dense K2 tiles and several 2048-point chunks occur)."""
+    return [synth.hdl64_cloud(seed=seed0 + k, n_az=(600 if k % 16 == 5 else 100 + (k % 7) * 3)) for k in range(count)]
+
+
+def _check_batch_against_oracle(seg, clouds, pts, origins, base_z, frames, layer_slots, first_slot=0, tag=""):
+    """filter_batch `frames` times; labels / emission index / counts of EVERY cloud and all 11 layers of `layer_slots`
+    against one oracle map per cloud."""
+    import torch
+
+    refs = [oracle.OracleMap(120.0, 0.33) for _ in clouds]
+    out = None
+    for frame in range(frames):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], origins, base_z, first_slot=first_slot, out=out)
+        torch.cuda.synchronize()
+        labels, index, counts = out.labels.cpu().numpy(), out.out_index.cpu().numpy(), out.counts.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, tuple(origins[b]), float(base_z[b]))
+            n = len(c)
+            assert np.array_equal(labels[b, :n], r["label"]), (tag, frame, b)
+            assert np.array_equal(index[b, :n], r["index"]), (tag, frame, b)
+            assert counts[b, 0] == len(r["out_points"]), (tag, frame, b)
+            assert counts[b, 3] == (r["cls"] == oracle.OUTLIER).sum(), (tag, frame, b)
+            if b in layer_slots:
+                assert_same_state(seg.map(first_slot + b), refs[b], f"{tag} frame {frame} cloud {b}")
+
+
+def test_benchmark_launch_geometry_288_slots():
+    """The launch geometry bench.py runs: a context with >= 128 slots (2048-point wave chunks in K1 / scan /
+    scatter / K5), a launch of > 256 clouds (k_sweep with make_params' throughput setting: 2 chain wavefronts per side, one
+    wavefront walking two ring groups) and k_reduce at its floor of 64 work-groups per cloud -- all three at once, 288 DISTINCT
+    clouds on 288 maps, two frames (the second on warm maps: outliers, liveness masks), every cloud's labels / order / counts
+    and all 11 layers of 24 sampled slots against the oracle."""
+    B = 288
+    clouds = _mixed_small_clouds(B, 3000)
+    clouds[7] = synth.empty_cloud(0)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride)
+    assert seg.debug_set_tuning("pw", 0) == 2048
+    pts = _batch_inputs(16, clouds, stride)
+    origins = np.array([[0.05 * (b % 9), -0.03 * (b % 5), 0.01 * (b % 3)] for b in range(B)], dtype=np.float32)
+    base_z = np.array([-1.73 + 0.002 * (b % 11) for b in range(B)])
+    sampled = set(range(0, B, 13)) | {5, 7, B - 1}
+    _check_batch_against_oracle(seg, clouds, pts, origins, base_z, 2, sampled, tag="288 slots")
+    seg.close()
+
+
+@pytest.mark.parametrize("knob", ["pw2048", "sweep_waves1", "sweep_waves2", "sweep_waves3", "k2_per_cloud64", "k2_dense_share4", "all_big_batch"])
+def test_each_launch_geometry_switch_forced_at_small_batch(knob, monkeypatch):
+    """The same three switches one at a time (and together) on a 6-cloud batch, full-size clouds included, so that a failure
+    names the switch: GG_PW=2048 at gg_create; sweep wavefronts per side 1 / 2 / 3; k_reduce with 64 work-groups per cloud and
+    another dense / light split."""
+    if knob in ("pw2048", "all_big_batch"):
+        monkeypatch.setenv("GG_PW", "2048")
+    clouds = [synth.hdl64_cloud(seed=410 + k, n_az=n) for k, n in enumerate([2083, 700, 150, 1200, 90])] + [synth.empty_cloud(0)]
+    B, stride = len(clouds), (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride)
+    if knob in ("pw2048", "all_big_batch"):
+        assert seg.debug_set_tuning("pw", 0) == 2048
+    if knob.startswith("sweep_waves"):
+        seg.debug_set_tuning("sweep_waves", int(knob[-1]))
+    if knob in ("k2_per_cloud64", "all_big_batch"):
+        seg.debug_set_tuning("k2_per_cloud", 64)
+    if knob == "k2_dense_share4":
+        seg.debug_set_tuning("k2_dense_share", 4)
+    if knob == "all_big_batch":
+        seg.debug_set_tuning("sweep_waves", 2)
+    pts = _batch_inputs(16, clouds, stride)
+    origins = np.zeros((B, 3), dtype=np.float32)
+    base_z = np.full(B, -1.73)
+    _check_batch_against_oracle(seg, clouds, pts, origins, base_z, 3, set(range(B)), tag=knob)
+    seg.close()
+
+
+def test_batch_with_a_slot_permutation():
+    """gg_batch.slots (ABI v3): cloud b meets map slots[b]; the maps keep their own histories under changing permutations, and
+    duplicate / out-of-range entries are rejected."""
+    import torch
+
+    clouds = [synth.hdl64_cloud(seed=520 + k, n_az=200 + 31 * k) for k in range(5)]
+    B, stride = len(clouds), (max(len(c) for c in clouds) + 63) // 64 * 64
+    n_slots = 9
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=n_slots, max_points=stride)
+    refs = [oracle.OracleMap(120.0, 0.33) for _ in range(n_slots)]
+    pts = _batch_inputs(16, clouds, stride)
+    out = None
+    for frame, slots in enumerate([[8, 0, 3, 5, 2], [0, 8, 2, 3, 1], [4, 3, 2, 1, 0]]):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73), out=out, slots=slots)
+        torch.cuda.synchronize()
+        labels, index = out.labels.cpu().numpy(), out.out_index.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[slots[b]].filter_cloud(c, ORIGIN0, -1.73)
+            assert np.array_equal(labels[b, : len(c)], r["label"]) and np.array_equal(index[b, : len(c)], r["index"]), (frame, b)
+        for s_ in range(n_slots):
+            assert_same_state(seg.map(s_), refs[s_], f"frame {frame} slot {s_}")
+    for bad in ([0, 1, 2, 3, 3], [0, 1, 2, 3, 9], [0, 1, 2, 3, -1]):
+        with pytest.raises(api.GroundGridError):
+            seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73), slots=bad)
+    seg.close()
+
+
 def test_two_bit_label_masks_from_the_label_kernel():
     """gg_batch.d_label_masks: what a multi-GPU caller all-gathers (groundgrid_amd/dist.py) -- the labels, 2 bits per point."""
     import torch
@@ -432,6 +533,25 @@ def test_map_scroll_edge_cases():
 
 
 # ---------------------------------------------------------------- N3: KITTI-format sequence replay (configs[4] harness)
+
+def test_bench_kitti_dir_leg_on_a_kitti_format_sequence(tmp_path):
+    """bench.py --kitti-dir (BASELINE configs[0] / [4] harness): replays a KITTI-format directory end to end on the device and
+    prints one JSON line with clouds/s, the per-label table and its diff against the published sequence-00 table."""
+    import json
+    import subprocess
+    import sys
+
+    from tests.test_kitti_cpu import _synthetic_sequence
+
+    d, _ = _synthetic_sequence(tmp_path, n_frames=4, n_az=260)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--kitti-dir", str(d), "--kitti-euler-roundtrip"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["clouds"] == 4 and r["value"] > 0 and r["table"]["clouds"] == 4
+    assert "vs_readme_seq00" in r and r["vs_readme_seq00"]["within_tolerance"] is False  # 4 synthetic clouds are not sequence 00
+
 
 @pytest.mark.parametrize("n_frames,n_az", [(5, 260), (70, 1200)])
 def test_kitti_format_sequence_replay_matches_cpu_path(tmp_path, n_frames, n_az):

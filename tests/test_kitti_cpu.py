@@ -116,3 +116,40 @@ def test_config0_cpu_plumbing_sequence_through_the_oracle(tmp_path):
     assert sum(ev.total.values()) > 4 * 10000
     assert s["TP"] > 0 and s["TN"] > 0 and 0.5 < s["accuracy"] <= 1.0   # "road" points are found as ground, "building" as obstacles
     assert "Precision" in ev.table() and set(LABELS.values()) >= {k for k, v in ev.total.items() if v}
+
+
+def test_compare_with_the_published_table():
+    """bench.py --kitti-dir diffs the replay's table against README.md:57-94: identical counts -> zero deltas, within tolerance;
+    a shifted label falls out of it."""
+    g = json.load(open(GOLDEN))
+    ev = GroundEvaluator.from_counts({k: v["nonground"] for k, v in g["labels"].items()}, {k: v["total"] for k, v in g["labels"].items()})
+    ev.cloud_count = g["clouds"]
+    d = ev.compare_with(g, tolerance_pct=0.01)
+    assert d["within_tolerance"] and all(abs(v["delta"]) <= 0.005 for v in d["summary"].values())
+    assert all(abs(v["nonground_pct_delta"]) <= 0.005 and v["total_rel_pct"] == 0 for v in d["labels"].values())
+    ev.non_ground["car"] -= 2_000_000
+    ev.false_positive["car"] += 2_000_000
+    d = ev.compare_with(g, tolerance_pct=1.0)
+    assert not d["within_tolerance"] and d["labels"]["car"]["nonground_pct_delta"] < -4
+
+
+def test_player_euler_round_trip_of_the_broadcast_quaternion():
+    """kitti_data_publisher.py:208-214 broadcasts quaternion_from_euler(*euler_from_quaternion(q)): the same rotation up to
+    rounding (and never far from q), identity for the identity, and frames built with the flag differ in the last ulps only."""
+    rng = np.random.default_rng(5)
+    assert np.array_equal(kitti.euler_roundtrip_quaternion([0, 0, 0, 1.0]), [0, 0, 0, 1.0])
+    for _ in range(200):
+        ang = rng.uniform(-3.1, 3.1)
+        tilt = rng.normal(0, 0.05, 2)
+        q = np.array([tilt[0], tilt[1], np.sin(ang / 2), np.cos(ang / 2)])
+        q /= np.linalg.norm(q)
+        q2 = kitti.euler_roundtrip_quaternion(q)
+        assert np.max(np.abs(q2 - q)) < 1e-14 or np.max(np.abs(q2 + q)) < 1e-14
+    cloud = synth.hdl64_cloud(seed=3, n_az=64)
+    pose = np.eye(4)
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    pose[:2, :2] = [[c, -s_], [s_, c]]
+    pose[:3, 3] = [10.0, -4.0, 0.2]
+    f0 = kitti.make_frame(0, cloud, pose)
+    f1 = kitti.make_frame(0, cloud, pose, euler_roundtrip=True)
+    assert np.max(np.abs(f0.cloud_map["x"] - f1.cloud_map["x"])) < 1e-4
