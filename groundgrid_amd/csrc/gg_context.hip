@@ -705,16 +705,9 @@ int gg_get_config(const gg_context *ctx, gg_config *cfg)
 int gg_set_flags(gg_context *ctx, unsigned flags)
 {
     if (!ctx) return GG_ERR_INVALID;
-    const bool back_to_all_layers = (ctx->flags & GG_FLAG_MINIMAL_LAYERS) && !(flags & GG_FLAG_MINIMAL_LAYERS);
+    // (leaving GG_FLAG_MINIMAL_LAYERS needs no repair: the next cloud writes all nine layers in the columns it marks live, and
+    // every other column logically holds the reset values anyway -- gg_internal.h tile_live)
     ctx->flags = flags;
-    if (back_to_all_layers) {
-        // three layers were not maintained meanwhile: the next cloud rewrites every column of every tile
-        HIPCHK(ctx, hipSetDevice(ctx->device));
-        if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
-        launch_fill_bytes((uint8_t *)ctx->arena.tile_live, (size_t)ctx->n_slots * ctx->arena.tile_live_stride * 2, 0xFF, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
-        return own_stream_mutated_map(ctx);
-    }
     return GG_OK;
 }
 
@@ -894,9 +887,11 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
         launch_plane_insert(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_image, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
     } else {
+        // the per-call layers are stored sparsely behind ONE set of liveness masks (gg_internal.h tile_live): make all nine dense
+        // (reset values into the dead columns, every column live), then overwrite this one with the host's matrix
+        launch_materialise_layers(ctx->arena, slot, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
-        // the host wrote a per-call layer: it may hold anything now, the next cloud rewrites every tile
-        launch_fill_bytes((uint8_t *)(ctx->arena.tile_live + (size_t)slot * ctx->arena.tile_live_stride), (size_t)ctx->arena.g.T * 2, 0xFF, ctx->stream);
     }
     if (const int rc = own_stream_mutated_map(ctx)) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -909,12 +904,13 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     if (!dst || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
-    const float *plane = layer_ptr(ctx->arena, slot, layer);
-    if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) {
+    // both kinds of layer have a device representation of their own (sheared pairs / sparse columns): extract the dense plane
+    if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH)
         launch_plane_extract(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_image, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
-        plane = ctx->d_image;
-    }
+    else
+        launch_layer_extract(ctx->arena, slot, layer, ctx->d_image, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    const float *plane = ctx->d_image;
     HIPCHK(ctx, hipMemcpyAsync(dst, plane, (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
@@ -928,11 +924,11 @@ int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, fl
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const Geometry &g = ctx->arena.g;
     uint8_t *d_img = reinterpret_cast<uint8_t *>(ctx->d_image);
-    const float *plane = layer_ptr(ctx->arena, slot, layer);
-    if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH) {
+    if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH)
         launch_plane_extract(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_scroll_scratch, ctx->stream);
-        plane = ctx->d_scroll_scratch;
-    }
+    else
+        launch_layer_extract(ctx->arena, slot, layer, ctx->d_scroll_scratch, ctx->stream);
+    const float *plane = ctx->d_scroll_scratch;
     launch_layer_to_u8(plane, g.rows, g.cols, ctx->d_bounds, d_img, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     float b[2];

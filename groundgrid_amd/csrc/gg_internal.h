@@ -100,12 +100,16 @@ struct Arena {
     uint32_t *totals;      // [slot][4]  (emitted kept, emitted ignored, outliers, in-map)
     uint32_t *tile_start;  size_t tile_start_stride; // T + 1
     uint16_t *tile_live;   size_t tile_live_stride;  // [slot][T] by Morton rank: bit k = column k of the tile (16 cells, one 64-byte row
-                                                     // segment per layer) may hold something else than the per-call reset values
-                                                     // (:61-75) in the nine per-call layers, i.e. K2 has to rewrite it even if this
-                                                     // cloud leaves it empty.  0: the tile needs no visit unless it receives records
+                                                     // segment per layer) physically HOLDS its values in the nine per-call layers.  A
+                                                     // column whose bit is clear holds stale bytes and logically has the per-call reset
+                                                     // values (:61-75) -- the per-call layers are stored SPARSELY: K2 writes (and marks)
+                                                     // exactly the columns that hold an in-map record of this cloud, k_scan clears the
+                                                     // masks of tiles without records, and every reader (K3's staging, gg_get_layer,
+                                                     // the image kernels) substitutes the reset values through cell_is_live().  Nothing
+                                                     // ever has to "clean" the cells a previous cloud left behind.
     uint4 *tile_list;      size_t tile_list_stride;  // [slot][T] K2's work lists (k_scan): light tiles from the front, dense tiles from the back; an
                                                      // entry is everything K2 needs to know about the tile without another dependent
-                                                     // lookup: x = Morton rank | tile_live (before this cloud) << 16, y / z = first / end
+                                                     // lookup: x = Morton rank, y / z = first / end
                                                      // of its records in `sorted`, w = first row | first col << 16
     uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
     int PW;    // points per wave-chunk
@@ -134,6 +138,18 @@ __host__ __device__ inline float *layer_ptr(const Arena &a, int slot, int layer)
 // request instead of two 4-byte ones everywhere, in the sheared element order of gp_layout.h (the terrain sweep's
 // wavefronts then read and write 512 contiguous bytes per access); the plane slots GG_LAYER_GROUND / GG_LAYER_GROUNDPATCH
 // of `layers` are unused.  gg_get_layer / gg_set_layer convert at the host boundary.
+// the per-call reset value of a layer (:61-75, :147): what a cell outside the live columns logically holds
+__host__ __device__ inline float layer_reset_value(int layer)
+{
+    return layer == GG_LAYER_MINGROUNDHEIGHT ? 3.402823466e+38f /* FLT_MAX, :72 */ : layer == GG_LAYER_MAXGROUNDHEIGHT ? 1.175494351e-38f /* FLT_MIN (sic), :73 */ : 0.0f;
+}
+// does cell (row, col) of `slot` physically hold its per-call layer values (Arena::tile_live)?
+__device__ inline bool cell_is_live(const Arena &a, int slot, int row, int col)
+{
+    const int rank = a.tile_rank[(row / TILE) + (col / TILE) * a.g.tiles_r];
+    return ((a.tile_live[(size_t)slot * a.tile_live_stride + rank] >> (col % TILE)) & 1u) != 0u;
+}
+
 __host__ __device__ inline float2 *gp2_ptr(const Arena &a, int slot) { return a.gp2 + (size_t)slot * a.gp2_stride; }
 __host__ __device__ inline int gp_idx(const Arena &a, int row, int col) { return gp_index(a.gpl, row, col); }
 
@@ -182,6 +198,8 @@ void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
 void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s); // sheared layer -> column-major plane
 void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, hipStream_t s);
+void launch_layer_extract(const Arena &a, int slot, int layer, float *dst, hipStream_t s); // per-call layer -> dense column-major plane (reset values outside the live columns)
+void launch_materialise_layers(const Arena &a, int slot, hipStream_t s);                  // write the reset values into every dead column of the slot's per-call layers, mark all live
 void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds, uint8_t *d_img, hipStream_t s);
 void launch_terrain_image(const Arena &a, int slot, float *d_img, hipStream_t s);
 void launch_scroll(const Arena &a, int slot, float2 *scratch, int s0, int s1, double pos_x, double pos_y, const double plane[4], hipStream_t s);

@@ -356,9 +356,8 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
         const uint4 ent_after = tile_list[min(j + 2 * stride, n_light - 1)];
         const int rank = (int)(ent.x & 0xFFFFu);
         const int row0 = (int)(ent.w & 0xFFFFu), col0 = (int)(ent.w >> 16);
-        // columns that the previous clouds left with something else than the reset values; only those and the ones that hold
-        // records now are written (a light tile has records in ~60 % of its columns: a third of the layer bytes stay unwritten)
-        const uint32_t cols_before = ent.x >> 16;
+        // only the columns that hold a record now are written (and marked live: the per-call layers are sparse, gg_internal.h
+        // tile_live) -- a light tile has records in ~60 % of its columns
         uint32_t cols_now = 0u;
         uint32_t lane_base = 0u;
         if (start != end) {
@@ -455,19 +454,12 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                 const int cell = lane + 64 * k;
                 const uint32_t cb = column_bits(__ballot((wv >> 16) != 0u)); // (pointsRaw > 0: the cell holds an in-map record)
                 cols_now |= cb << (4 * k);
-                if (((cb | (cols_before >> (4 * k))) >> (lane >> 4)) & 1u)
+                if ((cb >> (lane >> 4)) & 1u)
                     write_cell<FULL>(a, L, row0 + (cell & 15), col0 + (cell >> 4), (float)np, (float)(wv >> 16), st);
                 seg = seg_end;
             }
             lds_order(); // (the next tile reuses the memory)
             if (timing && lane == 0) dbg_add(a, 28, __builtin_readcyclecounter() - t_p1); // chains + writes
-        } else { // only the per-call reset (:61-75) of the columns that held points before
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int cell = lane + 64 * k;
-                if ((cols_before >> (4 * k + (lane >> 4))) & 1u)
-                    write_cell<FULL>(a, L, row0 + (cell & 15), col0 + (cell >> 4), 0.0f, 0.0f, reset);
-            }
         }
         if (lane == 0) tile_live[rank] = (uint16_t)cols_now;
         if (timing && lane == 0) {
@@ -678,10 +670,9 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     __syncthreads();
     if (timing) tmark[4] = __builtin_readcyclecounter();
     // (columns: see reduce_light_tiles; thread = cell, a wavefront holds four columns)
-    const uint32_t cols_before = ent.x >> 16;
     const uint32_t cb = column_bits(__ballot(ex[3 * TILE_CELLS + tid] != 0.0f));
     if (lane == 0) lds.wave_full[wave] = cb; // (the split flags were read before the recurrences; combined after the caller's barrier)
-    const bool column_written = (((cb | (cols_before >> (4 * wave))) >> (lane >> 4)) & 1u) != 0u;
+    const bool column_written = ((cb >> (lane >> 4)) & 1u) != 0u;
     CellState st;
     st.mn = ex[1 * TILE_CELLS + tid];
     st.m2 = ex[2 * TILE_CELLS + tid];
@@ -701,11 +692,11 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
 }
 
 // grid = (GD + GL, clouds): per cloud, GD work-groups walk the dense list (one tile per work-group at a time) and GL
-// work-groups the light list (one tile per wavefront at a time).  k_scan wrote both lists.  More than half of the tiles of
-// a sensor cloud receive no point at all; a tile that received none in the previous cloud either already holds the
-// per-call reset values (:61-75: they were written when it last went empty) and is on neither list.  tile_live[rank] =
-// "the tile's per-call layers may hold something else" (set by the cloud that put points there, by gg_reset_map and by
-// host writes).  Exact: every layer in HBM holds at all times what the reference's would.
+// work-groups the light list (one tile per wavefront at a time).  k_scan wrote both lists: the tiles that hold records of this
+// cloud.  More than half of the tiles of a sensor cloud receive no point at all and are visited by nobody: the per-call layers
+// are stored sparsely -- tile_live[rank] says which columns of a tile physically hold values (the ones with in-map records of
+// this cloud), every other cell logically holds the per-call reset values (:61-75), and the readers substitute them
+// (gg_internal.h tile_live).  Exact: gg_get_layer returns at all times what the reference's layers would hold.
 template <bool FULL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
 {

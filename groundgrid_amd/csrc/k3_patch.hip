@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
 {
     __shared__ float pts[SLOTS][LR], var[SLOTS][LR], mnl[SLOTS][LR];
     __shared__ uint32_t col_has_points[MAXTC]; // per tile column: records in the band's tile rows
+    __shared__ uint16_t live_cols[3][MAXTC];   // tile_live of the band's (up to three) tile rows: which columns physically hold values
     // XCD-aware (gg_device.h): the bands of one cloud run on one XCD.  A launch with few clouds cuts every band into segments
     // of blocks_per_segment blocks (one work-group each) so that the chip is still covered.
     const uint32_t item = xcd_contiguous_item(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
@@ -177,10 +178,14 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
         const int tr_lo = (r0 - HALO) / TILE, tr_hi = min((r0 + PR + HALO - 1) / TILE, a.g.tiles_r - 1);
         const int ntr = tr_hi - tr_lo + 1;
+        const uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+        for (int k = tid; k < 3 * tiles_c; k += 256) live_cols[k / tiles_c][k % tiles_c] = 0;
+        __syncthreads();
         for (int k = tid; k < ntr * tiles_c; k += 256) {
             const int tc = k / ntr, tile = (tr_lo + k % ntr) + tc * a.g.tiles_r;
             const int rank = a.tile_rank[tile];
             if (tile_start[rank + 1] != tile_start[rank]) col_has_points[tc] = 1u;
+            live_cols[k % ntr][tc] = tile_live[rank]; // (PR + 2 HALO rows starting at a multiple of TILE: at most three tile rows)
         }
     }
     __syncthreads();
@@ -229,9 +234,12 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             const bool ok = lc < n_cols && gr < rows && gcol < cols;
             const size_t idx = ok ? (size_t)gr + (size_t)gcol * rows : (size_t)0;
             const float p = gp_pts[idx], v = gp_var[idx], m = gp_min[idx];
-            sp[h] = ok ? p : 0.0f;
-            sv[h] = ok ? v : 0.0f;
-            sm[h] = ok ? m : 0.0f;
+            // the per-call layers are sparse (gg_internal.h tile_live): a column that holds no record of this cloud has stale
+            // bytes and logically the reset values of :61-75 -- points 0, variance 0 / (0 + FLT_MIN) = 0, minGroundHeight FLT_MAX
+            const bool live = ok && ((live_cols[ok ? (gr - (r0 - HALO)) / TILE : 0][ok ? gcol / TILE : 0] >> (gcol % TILE)) & 1u) != 0u;
+            sp[h] = live ? p : 0.0f;
+            sv[h] = live ? v : 0.0f;
+            sm[h] = live ? m : (ok ? FLT_MAX : 0.0f);
         }
     };
     auto deposit = [&](int first_col, int n_cols) {

@@ -70,16 +70,53 @@ __global__ __launch_bounds__(256) void k_terrain_image(const Arena a, int slot, 
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= rows || j >= cols) return;
     float flag = 0.0f;
+    // (pointsRaw is a sparse per-call layer: 0 outside the live columns, gg_internal.h tile_live)
+    auto raw_at = [&](int r, int c) { return cell_is_live(a, slot, r, c) ? raw[(size_t)r + (size_t)c * rows] : 0.0f; };
     if (i >= 1 && j >= 1 && i + 1 < rows && j + 1 < cols) {
         float e[9];
 #pragma unroll
-        for (int s = 0; s < 9; ++s) e[s] = raw[(size_t)(i - 1 + s % 3) + (size_t)(j - 1 + s / 3) * rows];
+        for (int s = 0; s < 9; ++s) e[s] = raw_at(i - 1 + s % 3, j - 1 + s / 3);
         flag = tree9(e) >= 27.0f ? 1.0f : 0.0f;
     }
     float *px = img + ((size_t)i * cols + j) * 3;
     px[0] = gp2[gp_idx(a, i, j)].x;
     px[1] = flag;
-    px[2] = raw[(size_t)i + (size_t)j * rows];
+    px[2] = raw_at(i, j);
+}
+
+// One per-call layer as the dense column-major matrix the reference holds: stored values in the live columns, the per-call reset
+// value (:61-75) everywhere else (gg_internal.h tile_live).  The host boundary of the sparse layers (gg_get_layer, image getters).
+__global__ __launch_bounds__(256) void k_layer_extract(const Arena a, int slot, int layer, float *__restrict__ dst)
+{
+    const float *src = layer_ptr(a, slot, layer);
+    const int rows = a.g.rows;
+    const float dead = layer_reset_value(layer);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.g.C; i += gridDim.x * blockDim.x)
+        dst[i] = cell_is_live(a, slot, i % rows, i / rows) ? src[i] : dead;
+}
+void launch_layer_extract(const Arena &a, int slot, int layer, float *dst, hipStream_t s)
+{
+    const int blocks = (a.g.C + 255) / 256 < 2048 ? (a.g.C + 255) / 256 : 2048;
+    hipLaunchKernelGGL(k_layer_extract, dim3(blocks), dim3(256), 0, s, a, slot, layer, dst);
+}
+
+// Make a slot's per-call layers dense in place: every dead column receives the reset values, then every column is marked live.
+// Needed before the host overwrites ONE per-call layer (gg_set_layer): the liveness masks are shared by the nine layers.
+__global__ __launch_bounds__(256) void k_materialise(const Arena a, int slot)
+{
+    const int rows = a.g.rows;
+    float *L = a.layers + (size_t)slot * a.slot_layer_stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.g.C; i += gridDim.x * blockDim.x) {
+        if (cell_is_live(a, slot, i % rows, i / rows)) continue;
+        for (int l = 0; l < GG_NUM_LAYERS; ++l)
+            if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH) L[(size_t)l * a.layer_stride + i] = layer_reset_value(l);
+    }
+}
+void launch_materialise_layers(const Arena &a, int slot, hipStream_t s)
+{
+    const int blocks = (a.g.C + 255) / 256 < 2048 ? (a.g.C + 255) / 256 : 2048;
+    hipLaunchKernelGGL(k_materialise, dim3(blocks), dim3(256), 0, s, a, slot);
+    launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)slot * a.tile_live_stride), (size_t)a.g.T * 2, 0xFF, s); // (after the kernel, same stream)
 }
 
 void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds, uint8_t *d_img, hipStream_t s)

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
     uint32_t *hist = a.hist + (size_t)cp.slot * a.hist_stride;
     uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
 
-    const uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
     uint32_t carry = 0, lcarry = 0, dcarry = 0;
     for (int t0 = 0; t0 < T; t0 += 1024) {
@@ -68,14 +68,15 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
         const uint32_t excl = block_exclusive_scan(s, lds, total);
         {
             // K2's work lists (k2_reduce.hip): tiles with more than K2_LIGHT_MAX records from the back of tile_list, the
-            // other tiles that need a visit (records, or per-call layers that do not hold the reset values) from the front
-            const uint32_t live = t < T ? (uint32_t)tile_live[t] : 0u;
+            // other tiles with records from the front.  A tile without records is on neither list: its columns simply stop
+            // being live (the per-call layers are sparse, gg_internal.h tile_live) -- nothing is cleaned.
             const bool dense = t < T && s > (uint32_t)K2_LIGHT_MAX;
-            const bool light = t < T && !dense && (s > 0u || live != 0u);
+            const bool light = t < T && !dense && s > 0u;
+            if (t < T && s == 0u) tile_live[t] = 0;
             uint32_t ltotal;
             const uint32_t lexcl = block_exclusive_scan((light ? 1u : 0u) | (dense ? 0x10000u : 0u), lds, ltotal);
-            // (rank | live columns, the tile's records, its first cell: K2 starts on a tile after ONE lookup)
-            const uint4 entry = make_uint4((uint32_t)t | (live << 16), carry + excl, carry + excl + s, t < T ? a.rank_cell0[t] : 0u);
+            // (rank, the tile's records, its first cell: K2 starts on a tile after ONE lookup)
+            const uint4 entry = make_uint4((uint32_t)t, carry + excl, carry + excl + s, t < T ? a.rank_cell0[t] : 0u);
             if (light) tile_list[lcarry + (lexcl & 0xFFFFu)] = entry;
             if (dense) tile_list[(uint32_t)T - 1u - (dcarry + (lexcl >> 16))] = entry;
             lcarry += ltotal & 0xFFFFu;

@@ -378,6 +378,38 @@ def test_minimal_layers_flag_keeps_labels_and_terrain():
     assert_same_state(seg.map(0), ref, "after leaving minimal layers")
 
 
+def test_sparse_per_call_layers_at_the_host_boundary():
+    """The nine per-call layers are stored sparsely (only the columns with records of the last cloud hold values): gg_get_layer,
+    the 8-bit images and the terrain image must still show the reference's dense matrices, a host write of ONE per-call layer
+    (gg_set_layer) must not disturb the other eight, and clouds that move across the map must never leave stale cells behind."""
+    a = synth.hdl64_cloud(seed=31, n_az=500)
+    b = synth.clone_cloud(a)
+    b["x"] += np.float32(17.0)   # the second cloud covers other tiles: what the first one wrote there goes stale
+    b["y"] -= np.float32(9.0)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(a))
+    ref = oracle.OracleMap(120.0, 0.33)
+    for k, cloud in enumerate([a, b, a, synth.empty_cloud(0), b]):
+        origin = (17.0, -9.0, 0.0) if cloud is b else ORIGIN0
+        seg.filter_cloud(cloud, origin, -1.73)
+        ref.filter_cloud(cloud, origin, -1.73)
+        assert_same_state(seg.map(0), ref, f"cloud {k}")
+    img, lo, hi = seg.map(0).image_u8("pointsRaw")
+    raw = ref.layer("pointsRaw")
+    assert lo == raw.min() and hi == raw.max() and img.shape == raw.shape and (img > 0).sum() == (raw > raw.min()).sum()
+    assert np.array_equal(seg.map(0).terrain_image()[:, :, 2], raw)
+    # the host overwrites one per-call layer: the other ten read back unchanged, and the next cloud starts from the per-call
+    # reset values again (:61-75) whatever the host wrote
+    mine = np.full(raw.shape, 7.5, dtype=np.float32)
+    before = {n: seg.map(0)[n] for n in oracle.LAYERS}
+    seg.map(0).set("planeDist", mine)
+    for n in oracle.LAYERS:
+        assert nan_equal(seg.map(0)[n], mine if n == "planeDist" else before[n]), n
+    seg.filter_cloud(a, ORIGIN0, -1.73)
+    ref.filter_cloud(a, ORIGIN0, -1.73)
+    assert_same_state(seg.map(0), ref, "after a host write")
+    seg.close()
+
+
 def test_largest_supported_grid_and_ring_group_counts():
     """The sweep's wavefronts own groups of 64 rings: 1000 x 1000 (498 rings, 8 groups on 3 wavefronts per side, 147 KB of LDS
     hand-over tables) down to grids with fewer rings than lanes; a sparse cloud keeps the oracle fast."""
