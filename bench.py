@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only (no warm / config3 / config4 / host_api / CPU legs)")
     ap.add_argument("--no-rotate", action="store_true", help="every step applies cloud b to slot b (round 2's workload)")
     ap.add_argument("--config4-batch", type=int, default=128, help="clouds per launch of the configs[3] leg (GPU-filling)")
+    ap.add_argument("--abi-collective", action="store_true", help="all-gather through the C ABI (gg_allgather_label_masks, RCCL bound by the "
+                    "library itself) instead of torch.distributed")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the N ranks only (gloo when no GPU is visible): launch-path check")
     ap.add_argument("--kitti-dir", default=None, help="SemanticKITTI sequence directory: replay it instead of the synthetic bench")
     ap.add_argument("--kitti-max-frames", type=int, default=0)
@@ -200,7 +202,25 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from groundgrid_amd import api
-    from groundgrid_amd.dist import common_stride, shard_range, unpack_label_masks
+    from groundgrid_amd.dist import AbiLabelGather, common_stride, shard_range, unpack_label_masks
+
+    class StreamGather:
+        """gg_allgather_label_masks on a side stream (the library orders it after the batch that wrote the masks); wait() makes
+        the compute stream wait for it -- the same contract as the torch.distributed work handle it replaces."""
+
+        def __init__(self, gatherer):
+            self.g, self.stream = gatherer, torch.cuda.Stream(device=dev)
+
+        def __call__(self, out, masks):
+            self.g.gather(masks, out=out, stream=self.stream.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+
+            class Handle:
+                def wait(self_inner):
+                    torch.cuda.current_stream(dev).wait_event(ev)
+
+            return Handle()
 
     B = args.batch
     clouds = make_clouds(B, rank)
@@ -233,6 +253,7 @@ def main():
             self.shifts = []
             self.ids = np.arange(nb, dtype=np.int64)
             self.gathered = [torch.empty((world * nb, pts.shape[1] // 4), dtype=torch.uint8, device=dev) for _ in range(2)] if dist else None
+            self.abi = StreamGather(AbiLabelGather(seg_, rank, world)) if (dist and args.abi_collective) else None
 
         def slots_of(self, shift):
             return ((self.ids + shift) % self.nb).astype(np.int32)
@@ -250,7 +271,9 @@ def main():
             self.outs[k] = self.seg.filter_batch(self.pts, self.npts, self.org, self.bz, out=self.outs[k], want_masks=dist is not None,
                                                  slots=self.slots_of(self.shift) if (self.rotate or self.shift) else None)
             self.out = self.outs[k]
-            if dist:
+            if self.abi:
+                self.pending[k] = self.abi(self.gathered[k], self.outs[k].label_masks)
+            elif dist:
                 self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.outs[k].label_masks, async_op=True)
             self.step_no += 1
 
@@ -350,6 +373,7 @@ def main():
     }
     if dist:
         result["collective"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                                "issued_by": "gg_allgather_label_masks (C ABI, RCCL bound by the library)" if args.abi_collective else "torch.distributed",
                                 "bytes_per_rank_per_step": int(B * stride // 4)}
 
     rows, C = seg.rows, seg.rows * seg.rows

@@ -40,6 +40,7 @@ SYMBOLS = [
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
     "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep",
+    "gg_collective_available", "gg_comm_unique_id", "gg_comm_init_rank", "gg_comm_destroy", "gg_allgather_label_masks",
 ]
 
 GG_EIGEN_33, GG_EIGEN_34_SSE = 0, 1
@@ -163,5 +164,10 @@ def load():
     L.gg_transform_from_pose.argtypes = [C.c_int, P(C.c_double), P(C.c_double)]
     L.gg_filter_cloud_async.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, P(C.c_int)]
     L.gg_filter_cloud_wait.argtypes = [vp, C.c_int, vp, P(C.c_size_t), vp, vp]
+    L.gg_collective_available.argtypes = []
+    L.gg_comm_unique_id.argtypes = [vp]
+    L.gg_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, P(vp)]
+    L.gg_comm_destroy.argtypes = [vp]
+    L.gg_allgather_label_masks.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     _lib = L
     return L

@@ -15,6 +15,8 @@
 #include <vector>
 #include <chrono>
 
+#include <dlfcn.h>
+
 #include "gg_internal.h"
 #include "sweep_core.h"
 
@@ -1189,6 +1191,92 @@ int gg_filter_cloud_tf(gg_context *ctx, int slot, const gg_point32 *cloud, size_
 {
     if (!map_from_cloud) return GG_ERR_INVALID;
     return filter_cloud_impl(ctx, slot, cloud, n, map_from_cloud, origin, base_z, out_cloud, out_n, out_label, out_index);
+}
+
+// ---- RCCL, bound at run time (include/groundgrid_hip.h "the one collective of the path") --------------------------------
+extern "C++" {
+namespace {
+struct Rccl {
+    // the NCCL API as RCCL exports it (rccl.h): ncclResult_t == int, ncclSuccess == 0, ncclUint8 == 1, ncclComm_t / hipStream_t opaque
+    struct UniqueId {
+        char internal[128];
+    };
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    Rccl()
+    {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(h, "ncclAllGather"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        ok = GetUniqueId && CommInitRank && CommDestroy && AllGather;
+    }
+};
+Rccl &rccl()
+{
+    static Rccl r; // (dlopen once, on first use)
+    return r;
+}
+} // namespace
+} // extern "C++"
+
+int gg_collective_available(void) { return rccl().ok ? 1 : 0; }
+
+int gg_comm_unique_id(uint8_t id_out[128])
+{
+    if (!id_out) return GG_ERR_INVALID;
+    if (!rccl().ok) return GG_ERR_NO_DEVICE;
+    Rccl::UniqueId id;
+    if (rccl().GetUniqueId(&id) != 0) return GG_ERR_HIP;
+    memcpy(id_out, id.internal, 128);
+    return GG_OK;
+}
+
+int gg_comm_init_rank(const uint8_t id_in[128], int n_ranks, int rank, void **comm_out)
+{
+    if (!id_in || !comm_out || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return GG_ERR_INVALID;
+    *comm_out = nullptr;
+    if (!rccl().ok) return GG_ERR_NO_DEVICE;
+    Rccl::UniqueId id;
+    memcpy(id.internal, id_in, 128);
+    if (rccl().CommInitRank(comm_out, n_ranks, id, rank) != 0) return GG_ERR_HIP;
+    return GG_OK;
+}
+
+int gg_comm_destroy(void *comm)
+{
+    if (!comm) return GG_ERR_INVALID;
+    if (!rccl().ok) return GG_ERR_NO_DEVICE;
+    return rccl().CommDestroy(comm) == 0 ? GG_OK : GG_ERR_HIP;
+}
+
+int gg_allgather_label_masks(gg_context *ctx, void *comm, const uint8_t *d_send, uint8_t *d_recv, size_t bytes_per_rank, void *stream)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    if (!comm) return fail(ctx, GG_ERR_INVALID, "gg_allgather_label_masks: null communicator");
+    if (!d_send || !d_recv || bytes_per_rank == 0) return fail(ctx, GG_ERR_INVALID, "gg_allgather_label_masks: null buffer / zero size");
+    if (!rccl().ok) return fail(ctx, GG_ERR_NO_DEVICE, "librccl.so could not be loaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const hipStream_t s = pick_stream(ctx, stream);
+    // the masks are written by the last batch: order the gather after it when it runs on another stream
+    if (ctx->have_batch_event && ctx->last_batch_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->batch_event, 0));
+    const int rc = rccl().AllGather(d_send, d_recv, bytes_per_rank, /* ncclUint8 */ 1, comm, s);
+    if (rc != 0) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "ncclAllGather: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "error");
+        ctx->last_error = buf;
+        return GG_ERR_HIP;
+    }
+    return GG_OK;
 }
 
 int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class, int32_t *out_cell)

@@ -79,3 +79,61 @@ def common_stride(local_max_points: int, group=None, device=None, multiple: int 
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         stride = int(t.item())
     return stride
+
+
+class AbiLabelGather:
+    """The all-gather of the label masks through the library's own C entry point (gg_allgather_label_masks: RCCL bound with
+    dlopen, no torch in the data path) -- what a C++ host of BASELINE configs[2] would call.  torch.distributed is used ONCE,
+    to hand rank 0's 128-byte RCCL id to the other ranks (any transport would do); with world size 1 not at all."""
+
+    def __init__(self, seg, rank: int = 0, world: int = 1, group=None):
+        import ctypes as C
+
+        from . import _lib
+
+        self._L, self._seg, self.world, self.rank = _lib.load(), seg, world, rank
+        if not self._L.gg_collective_available():
+            raise _lib.GroundGridError("librccl.so could not be loaded")
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            rc = self._L.gg_comm_unique_id(ident)
+            if rc != _lib.GG_OK:
+                raise _lib.GroundGridError(f"gg_comm_unique_id: {_lib.STATUS.get(rc, rc)}")
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+
+            t = torch.tensor(list(ident), dtype=torch.uint8)
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        comm = C.c_void_p()
+        rc = self._L.gg_comm_init_rank(ident, world, rank, C.byref(comm))
+        if rc != _lib.GG_OK:
+            raise _lib.GroundGridError(f"gg_comm_init_rank: {_lib.STATUS.get(rc, rc)}")
+        self._comm = comm
+
+    def gather(self, masks, out=None, stream=None):
+        """masks: contiguous CUDA uint8 tensor of this rank; returns [world * masks.shape[0], ...] on every rank.  Enqueued on
+        the current torch stream (or `stream`), ordered after the context's last batch by the library."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+
+        assert masks.is_cuda and masks.is_contiguous() and masks.dtype == torch.uint8
+        if out is None:
+            out = torch.empty((self.world * masks.shape[0],) + tuple(masks.shape[1:]), dtype=torch.uint8, device=masks.device)
+        s = stream if stream is not None else torch.cuda.current_stream(masks.device).cuda_stream
+        rc = self._L.gg_allgather_label_masks(self._seg._ctx, self._comm, masks.data_ptr(), out.data_ptr(), masks.numel(),
+                                              C.c_void_p(s if s else _lib.GG_STREAM_DEFAULT))
+        if rc != _lib.GG_OK:
+            raise _lib.GroundGridError(f"gg_allgather_label_masks: {_lib.STATUS.get(rc, rc)} {self._L.gg_last_error(self._seg._ctx).decode()}")
+        return out
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._L.gg_comm_destroy(self._comm)
+            self._comm = None

@@ -33,6 +33,48 @@ namespace {
 gg_context *g_ctx = nullptr;
 bool g_have_position = false;
 double g_pos_x = 0.0, g_pos_y = 0.0;
+gg_geometry g_geometry;
+gg_config g_config;
+bool g_have_config = false;
+size_t g_capacity = 0; // points per cloud the context was created for; grows on demand (ensure_capacity)
+
+size_t initial_capacity()
+{
+    // GROUNDGRID_HIP_MAX_POINTS: expected cloud size (default 400 000: three times an HDL-64E revolution).  Only a starting point:
+    // a larger cloud makes the binding re-create the context with room for it.
+    const char *e = std::getenv("GROUNDGRID_HIP_MAX_POINTS");
+    const long v = e ? std::atol(e) : 0;
+    return v > 0 ? static_cast<size_t>(v) : 400000;
+}
+
+// (re)create the device context for clouds of up to `points` points; the map state is uploaded again by the next filter_cloud
+bool create_context(size_t points)
+{
+    if (g_ctx) gg_destroy(g_ctx);
+    g_ctx = nullptr;
+    g_have_position = false;
+    g_capacity = 0;
+    const int rc = gg_create(&g_geometry, 1, points, 0, &g_ctx);
+    if (rc != GG_OK) {
+        ROS_FATAL("groundgrid_hip: gg_create failed with status %d (no gfx950 device, out of memory, or grid_map and init() disagree on the cell count)", rc);
+        g_ctx = nullptr;
+        return false;
+    }
+    g_capacity = points;
+    if (g_have_config) {
+        const int rc2 = gg_set_config(g_ctx, &g_config);
+        if (rc2 != GG_OK) ROS_ERROR("groundgrid_hip: gg_set_config failed with status %d", rc2);
+    }
+    return true;
+}
+
+bool ensure_capacity(size_t points)
+{
+    if (g_ctx && points <= g_capacity) return true;
+    const size_t want = points + points / 2; // headroom: sensor clouds vary by a few percent from revolution to revolution
+    ROS_WARN("groundgrid_hip: a cloud of %zu points exceeds the context's capacity of %zu: re-creating it for %zu", points, g_capacity, want);
+    return create_context(want);
+}
 
 static_assert(sizeof(velodyne_pointcloud::PointXYZIR) == sizeof(gg_point32), "PointXYZIR must be the 32-byte record of point_types.h:27-33");
 
@@ -52,20 +94,12 @@ bool download_all_layers()
 void GroundSegmentation::init(ros::NodeHandle &nodeHandle, const size_t dimension, const float &resolution)
 {
     (void)nodeHandle; // unused by the reference as well
-    gg_geometry g;
-    gg_default_geometry(&g);
-    g.length = static_cast<float>(dimension); // the nodelet passes 120.0f into the size_t parameter (Nodelet.cpp:95)
-    g.resolution = resolution;
-    g.vertical_point_ang_dist = verticalPointAngDist;
-    g.min_dist_squared = minDistSquared;
-    if (g_ctx) gg_destroy(g_ctx);
-    g_ctx = nullptr;
-    g_have_position = false;
-    const int rc = gg_create(&g, 1, 400000, 0, &g_ctx);
-    if (rc != GG_OK) {
-        ROS_FATAL("groundgrid_hip: gg_create failed with status %d (no gfx950 device, or grid_map and init() disagree on the cell count)", rc);
-        return;
-    }
+    gg_default_geometry(&g_geometry);
+    g_geometry.length = static_cast<float>(dimension); // the nodelet passes 120.0f into the size_t parameter (Nodelet.cpp:95)
+    g_geometry.resolution = resolution;
+    g_geometry.vertical_point_ang_dist = verticalPointAngDist;
+    g_geometry.min_dist_squared = minDistSquared;
+    if (!create_context(initial_capacity())) return;
     int rows = 0, cols = 0;
     gg_get_size(g_ctx, &rows, &cols);
     expectedPoints.resize(rows, cols); // :40-46, kept for callers that inspect the member
@@ -76,7 +110,6 @@ void GroundSegmentation::init(ros::NodeHandle &nodeHandle, const size_t dimensio
 void GroundSegmentation::setConfig(const groundgrid::GroundGridConfig &config)
 {
     mConfig = config;
-    if (!g_ctx) return;
     gg_config k;
     gg_default_config(&k);
     k.point_count_cell_variance_threshold = config.point_count_cell_variance_threshold;
@@ -93,7 +126,11 @@ void GroundSegmentation::setConfig(const groundgrid::GroundGridConfig &config)
     k.occupied_cells_point_count_factor = config.occupied_cells_point_count_factor;
     k.min_outlier_detection_ground_confidence = config.min_outlier_detection_ground_confidence;
     k.thread_count = config.thread_count; // accepted, ignored: results are those of thread_count = 1
-    gg_set_config(g_ctx, &k);
+    g_config = k; // (kept: a context re-created for a larger cloud gets the same configuration)
+    g_have_config = true;
+    if (!g_ctx) return;
+    const int rc = gg_set_config(g_ctx, &k);
+    if (rc != GG_OK) ROS_ERROR("groundgrid_hip: gg_set_config failed with status %d", rc);
 }
 
 // src/GroundSegmentation.cpp:50-197
@@ -112,18 +149,26 @@ pcl::PointCloud<GroundSegmentation::PCLPoint>::Ptr GroundSegmentation::filter_cl
     for (int l = 0; l < GG_NUM_LAYERS; ++l)
         if (!map.exists(kLayerNames[l])) map.add(kLayerNames[l], 0.0);
 
+    const size_t n = cloud->points.size();
+    if (!ensure_capacity(n)) return filtered_cloud; // (a re-created context forgets the map: uploaded again just below)
+
     // state the host may have edited since the last cloud: GroundGrid::update moves the map and seeds the exposed cells
     const double px = map.getPosition().x(), py = map.getPosition().y();
     if (!g_have_position || px != g_pos_x || py != g_pos_y) {
-        gg_set_map_position(g_ctx, 0, px, py);
-        gg_set_layer(g_ctx, 0, GG_LAYER_GROUND, map["ground"].data()); // Eigen::MatrixXf is column-major: as is
-        gg_set_layer(g_ctx, 0, GG_LAYER_GROUNDPATCH, map["groundpatch"].data());
+        int rc_up = gg_set_map_position(g_ctx, 0, px, py);
+        if (rc_up == GG_OK) rc_up = gg_set_layer(g_ctx, 0, GG_LAYER_GROUND, map["ground"].data()); // Eigen::MatrixXf is column-major: as is
+        if (rc_up == GG_OK) rc_up = gg_set_layer(g_ctx, 0, GG_LAYER_GROUNDPATCH, map["groundpatch"].data());
+        if (rc_up != GG_OK) {
+            // the device would keep filtering against a stale terrain: report, return nothing, and try the upload again next time
+            ROS_ERROR("groundgrid_hip: uploading the map state failed with status %d (%s)", rc_up, gg_last_error(g_ctx));
+            g_have_position = false;
+            return filtered_cloud;
+        }
         g_have_position = true;
         g_pos_x = px;
         g_pos_y = py;
     }
 
-    const size_t n = cloud->points.size();
     filtered_cloud->points.resize(n);
     const float origin[3] = {cloudOrigin.x, cloudOrigin.y, cloudOrigin.z};
     size_t n_out = 0;
@@ -139,7 +184,9 @@ pcl::PointCloud<GroundSegmentation::PCLPoint>::Ptr GroundSegmentation::filter_cl
     const bool all = download_all_layers();
     for (int l = 0; l < GG_NUM_LAYERS; ++l) {
         const bool state = l == GG_LAYER_GROUND || l == GG_LAYER_GROUNDPATCH || l == GG_LAYER_POINTS || l == GG_LAYER_POINTSRAW;
-        if (all || state) gg_get_layer(g_ctx, 0, l, map[kLayerNames[l]].data());
+        if (!(all || state)) continue;
+        const int rc_down = gg_get_layer(g_ctx, 0, l, map[kLayerNames[l]].data());
+        if (rc_down != GG_OK) ROS_ERROR("groundgrid_hip: downloading layer %s failed with status %d (%s)", kLayerNames[l], rc_down, gg_last_error(g_ctx));
     }
     return filtered_cloud;
 }

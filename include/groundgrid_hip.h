@@ -273,6 +273,28 @@ typedef struct gg_batch {
 int gg_filter_batch(gg_context *ctx, const gg_batch *batch, void *stream);
 int gg_synchronize(gg_context *ctx);
 
+/* ---- the one collective of the path: the all-gather of the per-cloud label masks (BASELINE configs[2]) ----
+ * The reference has no distributed code; clouds shard as independent (cloud, map) pairs and the only exchange is that every
+ * rank ends up with every cloud's labels.  These entry points let a C / C++ host run that configuration without Python:
+ * they bind RCCL (librccl.so, the ROCm build of the NCCL API) at run time with dlopen, so the library has no link-time
+ * dependency on it and a single-GPU user never loads it.
+ *
+ *   gg_comm_unique_id       rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by whatever means
+ *                           the host has (MPI, a socket, torch.distributed ...)
+ *   gg_comm_init_rank       every rank: ncclCommInitRank on the CURRENT HIP device -> an opaque communicator (ncclComm_t)
+ *   gg_allgather_label_masks  ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8) on `stream` (same convention as
+ *                           gg_filter_batch: NULL = the context's stream, GG_STREAM_DEFAULT = the legacy default stream); d_send =
+ *                           this rank's gg_batch.d_label_masks (or d_labels), d_recv = [world][bytes_per_rank].  The call is
+ *                           ordered after the context's last batch (event wait when the streams differ) and returns without
+ *                           waiting; `comm` may be any ncclComm_t, also one the host created itself
+ *   gg_comm_destroy
+ * GG_ERR_NO_DEVICE when librccl.so cannot be loaded, GG_ERR_HIP for RCCL errors (text in gg_last_error). */
+int gg_collective_available(void);
+int gg_comm_unique_id(uint8_t id_out[128]);
+int gg_comm_init_rank(const uint8_t id[128], int n_ranks, int rank, void **comm_out);
+int gg_comm_destroy(void *comm);
+int gg_allgather_label_masks(gg_context *ctx, void *comm, const uint8_t *d_send, uint8_t *d_recv, size_t bytes_per_rank, void *stream);
+
 /* ---- wire formats around the path (src/GroundGridNodelet.cpp:120, :211-291) -------------------------------------- */
 
 /* filter_cloud straight from a sensor_msgs/PointCloud2 payload (e.g. the KITTI player's 18-byte records,

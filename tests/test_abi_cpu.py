@@ -117,6 +117,18 @@ def test_bad_arguments_are_rejected_before_touching_the_device(lib):
     assert lib.gg_rotation_from_quaternion(7, q, R) == -1 and lib.gg_rotation_from_quaternion(0, None, R) == -1
 
 
+def test_collective_entry_points_reject_bad_arguments(lib):
+    """gg_allgather_label_masks & co (the C-ABI face of BASELINE configs[2]'s all-gather): exported, and null communicators /
+    contexts / buffers are refused before RCCL or the device is touched."""
+    assert lib.gg_collective_available() in (0, 1)   # librccl.so ships with ROCm; it is bound with dlopen on first use
+    assert lib.gg_allgather_label_masks(None, None, None, None, 16, None) == -1
+    assert lib.gg_comm_unique_id(None) == -1
+    comm = C.c_void_p()
+    ident = (C.c_uint8 * 128)()
+    assert lib.gg_comm_init_rank(ident, 0, 0, C.byref(comm)) == -1 and lib.gg_comm_init_rank(ident, 2, 2, C.byref(comm)) == -1
+    assert lib.gg_comm_init_rank(None, 1, 0, C.byref(comm)) == -1 and lib.gg_comm_destroy(None) == -1
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under groundgrid_amd/ or include/ may reference it."""
     for base in ("groundgrid_amd", "include"):

@@ -88,3 +88,35 @@ def test_64_clouds_on_two_ranks_all_gather_of_masks_matches_the_oracle():
             r = ref.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
         assert np.array_equal(labels[b, : len(c)], r["label"]), f"cloud {b}: gathered mask differs from the oracle's labels"
         assert not labels[b, len(c):].any()
+
+
+def test_allgather_through_the_c_abi_single_rank():
+    """gg_comm_unique_id -> gg_comm_init_rank -> gg_allgather_label_masks on a one-rank RCCL communicator (all this box has):
+    the gathered buffer equals the masks k_label wrote, on the torch stream and on the context's own stream."""
+    import numpy as np
+    import torch
+
+    from groundgrid_amd import api, synth
+    from groundgrid_amd.dist import AbiLabelGather, unpack_label_masks
+
+    clouds = [synth.hdl64_cloud(seed=700 + k, n_az=180 + 20 * k) for k in range(3)]
+    B, stride = len(clouds), (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride)
+    host = np.zeros((B, stride), dtype=api.POINT16_DTYPE)
+    for b, c in enumerate(clouds):
+        host[b, : len(c)] = api.pack16(c)
+    pts = torch.from_numpy(host.view(np.uint8).reshape(B, stride, 16)).cuda()
+    gather = AbiLabelGather(seg, rank=0, world=1)
+    out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73), want_masks=True)
+    got = gather.gather(out.label_masks)
+    torch.cuda.synchronize()
+    assert torch.equal(got, out.label_masks)
+    lab = unpack_label_masks(got, stride)
+    for b, c in enumerate(clouds):
+        assert torch.equal(lab[b, : len(c)], out.labels[b, : len(c)])
+    side = torch.cuda.Stream()
+    got2 = gather.gather(out.label_masks, stream=side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(got2, out.label_masks)
+    gather.close()
+    seg.close()

@@ -71,3 +71,22 @@ def test_probe_source_is_present_and_cites_the_reference():
     src = open(os.path.join(PIN, "probe.cpp")).read()
     for needle in ("tf2::doTransform(ps, ps, base_to_map)", "convertToDefaultStartIndex", "block<S, S>", "std::hypot", "GroundSegmentation.cpp:", "GroundGrid.cpp:"):
         assert needle in src
+
+
+NOETIC_VECTORS = os.path.join(ROOT, "tests", "golden", "pin_vectors_noetic.json")
+
+
+@pytest.mark.skipif(not os.path.exists(NOETIC_VECTORS), reason="tests/golden/pin_vectors_noetic.json absent: nobody has run "
+                    "tools/pin/run_in_docker.sh on a machine with network + docker yet (the oracle stays PARITY UNPINNED)")
+def test_oracle_reproduces_pin_vectors(capsys):
+    """The day the probe's output of a real ROS Noetic environment (Eigen, grid_map_core, tf2 / KDL, glibc) is committed, this
+    test holds the oracle to it: every section must be reproduced bit for bit by one of the oracle's variants, and the
+    variants the library DEFAULTS to (gg_conventions.eigen_reduction = GG_EIGEN_33, kitti.ROTATION_CONVENTION) must be the
+    ones selected -- no code change needed for "parity" to go from unpinned to pinned."""
+    from groundgrid_amd import kitti
+
+    cmp_ = load_compare()
+    assert cmp_.compare(json.load(open(NOETIC_VECTORS))) == 0
+    chosen = capsys.readouterr().out.split("Select:")[1]
+    assert "eigen_reduction=0" in chosen, "the reference's Eigen uses the 3.4 SSE order: make GG_EIGEN_34_SSE the default"
+    assert f'rotation="{kitti.ROTATION_CONVENTION}"' in chosen
