@@ -443,6 +443,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         return GG_ERR_INVALID;
     }
     a.tune_sweep_waves = getenv("GG_SWEEP_WAVES") ? atoi(getenv("GG_SWEEP_WAVES")) : 0;
+    a.tune_sweep_gpw = getenv("GG_SWEEP_GPW") ? atoi(getenv("GG_SWEEP_GPW")) : 0;
     a.tune_k2_per_cloud = getenv("GG_K2_PER_CLOUD") ? atoi(getenv("GG_K2_PER_CLOUD")) : 0;
     a.tune_k2_dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 0;
     a.NCH = (int)((max_points + a.PW - 1) / a.PW);
@@ -459,7 +460,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->sweep_params = gg::sweep::make_params(n, res, geom.min_dist_squared, ctx->cfg.occupied_cells_decrease_factor);
     if (gg::sweep_lds_bytes(ctx->sweep_params) > 158 * 1024) {
         gg_destroy(ctx);
-        return GG_ERR_GEOMETRY; // the sweep's hand-over tables no longer fit in LDS (n > ~1030)
+        return GG_ERR_GEOMETRY; // the sweep's hand-over tables no longer fit in LDS even with one ring group per work-group (n > ~1500)
     }
     std::vector<uint16_t> tile_rank(g.T), rank_tile(g.T);
     {
@@ -508,6 +509,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_list_stride = align_up((size_t)g.T * 16, A) / 16;
     const size_t o_tlist = carve((size_t)n_slots * a.tile_list_stride * 16);
     const size_t o_tlcnt = carve((size_t)n_slots * 2 * 4);
+    a.sweep_xchg_stride = align_up(std::max<size_t>(gg::sweep_xchg_entries(ctx->sweep_params), 1) * 16, A) / 8;
+    const size_t o_xchg = carve((size_t)n_slots * a.sweep_xchg_stride * 8);
     const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
     const size_t o_spts = carve(max_points * sizeof(gg_point16));
     const size_t o_slab = carve(max_points);
@@ -554,6 +557,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_live = (uint16_t *)(base + o_tlive);
     a.tile_list = (uint4 *)(base + o_tlist);
     a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
+    a.sweep_xchg = (unsigned long long *)(base + o_xchg);
     a.flags = 0;
     a.k2_debug = getenv("GG_K2_DEBUG") ? atoi(getenv("GG_K2_DEBUG")) : 0;
     a.k2_dbg = (unsigned long long *)(base + o_k2dbg);
@@ -1302,6 +1306,7 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     if (!ctx || !key || value < 0) return GG_ERR_INVALID;
     if (!strcmp(key, "pw")) return ctx->arena.PW;
     if (!strcmp(key, "sweep_waves")) ctx->arena.tune_sweep_waves = value;
+    else if (!strcmp(key, "sweep_gpw")) ctx->arena.tune_sweep_gpw = value;
     else if (!strcmp(key, "k2_per_cloud")) ctx->arena.tune_k2_per_cloud = value;
     else if (!strcmp(key, "k2_dense_share")) ctx->arena.tune_k2_dense_share = std::min(value, 15);
     else return GG_ERR_INVALID;

@@ -26,8 +26,9 @@ constexpr uint32_t KEY_OUTSIDE = 0xFFFFFFFFu;
 constexpr int K2_DBG_WGS = 32768;  // slots of k_reduce's phase counters (GG_K2_DEBUG=9)
 // Launch geometry that changes with the batch size -- named here because docs and tests refer to it:
 constexpr int PW_BIG_CONTEXT_SLOTS = 128;      // contexts with at least this many slots use 2048-point wave chunks (else 1024)
-constexpr int SWEEP_LATENCY_MAX_CLOUDS = 256;  // launches of at most this many clouds give every 64-ring group of a side its own
-                                               // wavefront (up to 3 per side); bigger ones use make_params' throughput setting
+constexpr int SWEEP_LATENCY_MAX_CLOUDS = 256;  // (= CUs) k_sweep: launches of at most this many work-groups give every 64-ring group of a side
+                                               // its own wavefront (up to 3 per side), and clouds are cut into as many work-groups
+                                               // ("parts") as keep the launch within it; bigger launches use make_params' throughput setting
 constexpr int K2_MIN_GROUPS_PER_CLOUD = 64;    // k_reduce: work-groups per cloud = max(4096 / clouds, this)
 constexpr int K2_LIGHT_MAX = 512; // tiles with at most this many records are reduced by a single wavefront (k2_reduce.hip)
 // key = tile_rank << 12 | emit << 10 | class << 8 | cell_in_tile (row_in_tile | col_in_tile << 4)
@@ -112,12 +113,14 @@ struct Arena {
                                                      // lookup: x = Morton rank, y / z = first / end
                                                      // of its records in `sorted`, w = first row | first col << 16
     uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
+    unsigned long long *sweep_xchg; size_t sweep_xchg_stride; // [slot] exchange region between the work-groups of one sweep (sweep_core.h "Parts"), in 64-bit words
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)
     // launch geometry overrides (0 = the launchers' defaults).  Set at gg_create from the environment (GG_SWEEP_WAVES,
     // GG_K2_PER_CLOUD, GG_K2_DENSE_SHARE; GG_PW above) or per context by gg_debug_set_tuning: tools measure with them, and the
     // parity tests force every geometry the launchers can pick (tests/test_gpu_parity.py) at small batch sizes.
     int tune_sweep_waves;   // chain wavefronts per side of k_sweep
+    int tune_sweep_gpw;     // ring groups per work-group of k_sweep (sweep_core.h "Parts"); default min(groups, 3)
     int tune_k2_per_cloud;  // minimum work-groups per cloud of k_reduce
     int tune_k2_dense_share; // sixteenths of them that walk the dense list
     unsigned flags;
@@ -190,6 +193,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
 void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s,
                   unsigned long long *dbg = nullptr); // k4_sweep.hip; dbg: 16 x 4 cycle counters of cloud 0's wavefronts (tools)
 size_t sweep_lds_bytes(const sweep::Params &P);
+size_t sweep_xchg_entries(const sweep::Params &P);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
 void launch_fill_bytes(uint8_t *dst, size_t n, uint8_t v, hipStream_t s);

@@ -54,6 +54,30 @@ template <bool DBG> struct DevMemT {
             for (int k = 0; k < 6; ++k) marks[k] = acc[k];
     }
     static constexpr uint32_t OOR = 0x80000000u; // beyond the buffer: loads return 0, stores are dropped, no traffic
+    // exchange region of this cloud (sweep_core.h "Parts"): one WP = two 64-bit words (value | launch sequence number << 32), each
+    // written and read as ONE relaxed agent-scope atomic: a reader that finds both tags current has the value, whatever the
+    // caches and whichever XCD the two work-groups run on -- no fence, no separate flag, nothing to reset between launches
+    unsigned long long *xchg = nullptr;
+    uint32_t seq = 0;
+    GG_DEV void export_wp_if(bool c, int entry, WP v) const
+    {
+        if (c) {
+            const unsigned long long tag = (unsigned long long)seq << 32;
+            __hip_atomic_store(xchg + 2 * (size_t)entry, tag | __float_as_uint(v.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(xchg + 2 * (size_t)entry + 1, tag | __float_as_uint(v.p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    GG_DEV bool import_wp(int entry, WP &v) const
+    {
+        const unsigned long long a = __hip_atomic_load(xchg + 2 * (size_t)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(xchg + 2 * (size_t)entry + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = WP{__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)b)};
+        return (uint32_t)(a >> 32) == seq && (uint32_t)(b >> 32) == seq;
+    }
+    GG_DEV void set_counter(int word, int value) const
+    {
+        __hip_atomic_store(lds + word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 
     GG_DEV Cell load_issue(bool valid, int cell) const
     {
@@ -156,10 +180,11 @@ template <bool DBG> struct WaveClockT {
 #endif
 constexpr int SLEEP_LONG = GG_SWEEP_SLEEP_LONG;
 
-template <int SIDE, bool DBG> GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int wave_of_side, int lane, WaveClockT<DBG> &clk)
+template <int SIDE, bool DBG>
+GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int wave_of_side, int lane, WaveClockT<DBG> &clk, int g0, int g1)
 {
     ChainLane<SIDE> st;
-    for (int group = wave_of_side; group < P.groups; group += P.waves_per_side) {
+    for (int group = g0 + wave_of_side; group < g1; group += P.waves_per_side) {
         const int r0 = LANES * group + 1;
         const int nl = min(P.rings - (r0 - 1), (int)LANES);
         st.init(lane, r0, nl, group, P, L);
@@ -207,16 +232,20 @@ template <int SIDE, bool DBG> GG_DEV void run_chain(const Params &P, const LdsMa
     }
 }
 
-template <int CD, bool DBG> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, WaveClockT<DBG> &clk)
+template <int CD, bool DBG> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, WaveClockT<DBG> &clk, int g0, int g1)
 {
     (void)clk;
     CornerRing<CD> st;
-    for (int group = 0; group < P.groups; ++group) {
+    for (int group = g0; group < g1; ++group) {
         const int r0 = LANES * group + 1;
         const int nl = min(P.rings - (r0 - 1), (int)LANES);
         // prepare: 64 rings at once
         st.issue(r0 + lane, P, mem);
         st.finish(P, mem);
+        // a part that does not start at the centre: the ring before its first one comes from another work-group (the importer
+        // wavefront sets the counter once the two corner values of that ring are in this work-group's table)
+        if (group == g0 && g0 > 0)
+            while (mem.counter(L.corner_done + CD) < r0 - 1) __builtin_amdgcn_s_sleep(SLEEP_LONG);
         const int prev = L.corner + 2 * ((CD * P.c + r0 - 1) * 2);
         WP in_corner = mem.get(prev + 2); // Y_0 of the ring before the group (ring 0: the centre) -- written by this wavefront
         WP in_x1 = r0 > 1 ? mem.get(prev) : WP{0.f, 0.f};
@@ -235,14 +264,136 @@ template <int CD, bool DBG> GG_DEV void run_corner(const Params &P, const LdsMap
     mem.flush_marks();
 }
 
+// The importer wavefront of a part p > 0 (sweep_core.h "Parts"): polls the exchange region for what the part inside publishes about
+// its last ring (ring 64 g0) -- the two corner values of either diagonal, C_last and D_last, and the four boundary chains as they
+// grow -- and republishes it in this work-group's LDS tables, data first, then the progress counter the consumers poll.
+template <bool DBG> GG_DEV void run_import(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, int g0)
+{
+    const int gb = g0, rb = LANES * g0; // boundary index in the exchange region, the ring it is about
+    {   // the four corner values of ring rb (lanes 0..3): the first thing this part's wavefronts need, and the first thing the
+        // part inside produces about that ring (its corner wavefronts run ahead of the chains)
+        WP v{0.f, 0.f};
+        bool ok = lane >= 4;
+        for (;;) {
+            if (!ok) ok = mem.import_wp(xchg_misc(gb, lane), v);
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(SLEEP_LONG);
+        }
+        if (lane < 4) mem.put(L.corner + 2 * (((lane >> 1) * P.c + rb) * 2) + 2 * (lane & 1), v); // AB / CD: x1, then y0
+        // (the LDS operations of one wavefront execute in issue order: values first, then the counters)
+        if (lane == 0) {
+            mem.set_counter(L.corner_done + 0, rb);
+            mem.set_counter(L.corner_done + 1, rb);
+        }
+    }
+    bool joins = false; // C_last / D_last of ring rb: the LAST values the part inside produces, needed by the ends of A / B of ring rb + 1
+    // the boundary chains of ring rb: side s has chain_len<s>(rb) values; 64 consecutive entries per poll
+    int done[4] = {0, 0, 0, 0};
+    const int len[4] = {chain_len<SIDE_A>(rb), chain_len<SIDE_B>(rb), chain_len<SIDE_C>(rb), chain_len<SIDE_D>(rb)};
+    for (;;) {
+        bool all_done = joins, progress = false;
+        if (!joins) {
+            WP v{0.f, 0.f};
+            const bool ok = lane >= 2 || mem.import_wp(xchg_misc(gb, X_JOIN_C + lane), v);
+            if (__all(ok)) {
+                if (lane < 2) mem.put(L.join + 2 * ((lane == 0 ? (int)SIDE_C : (int)SIDE_D) * P.c + rb), v);
+                if (lane == 0) {
+                    mem.set_counter(L.join_done + SIDE_C, rb);
+                    mem.set_counter(L.join_done + SIDE_D, rb);
+                }
+                joins = true;
+                progress = true;
+            }
+        }
+#pragma unroll
+        for (int side = 0; side < 4; ++side) {
+            if (done[side] >= len[side]) continue; // (uniform)
+            all_done = false;
+            const int e = done[side] + lane;
+            WP v{0.f, 0.f};
+            const bool ok = e < len[side] && mem.import_wp(xchg_chain(gb, side, e), v);
+            const unsigned long long m = __ballot(ok);
+            const int nv = (~m == 0ull) ? 64 : __builtin_ctzll(~m); // the values arrive in order: take the leading run
+            if (nv == 0) continue;
+            if (lane < nv) mem.put(L.bnd + 2 * (side * L.bnd_stride + bnd_offset(g0 - 1) - L.bnd_base + e), v);
+            done[side] += nv;
+            if (lane == 0) mem.set_counter(L.bnd_done + side * P.groups + (g0 - 1), done[side]);
+            progress = true;
+        }
+        if (all_done) break;
+        if (!progress) __builtin_amdgcn_s_sleep(SLEEP_LONG);
+    }
+}
+
+// The exporter wavefront of a part that has a successor: copies what the chain and corner wavefronts of this work-group publish
+// about the part's last ring (ring 64 g1) from LDS into the exchange region, as it appears.
+template <bool DBG> GG_DEV void run_export(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, int g1)
+{
+    const int gb = g1, rb = LANES * g1;
+    int sent[4] = {0, 0, 0, 0};
+    const int len[4] = {chain_len<SIDE_A>(rb), chain_len<SIDE_B>(rb), chain_len<SIDE_C>(rb), chain_len<SIDE_D>(rb)};
+    bool head = false, corners = false;
+    for (;;) {
+        bool all_done = head && corners, progress = false;
+#pragma unroll
+        for (int side = 0; side < 4; ++side) {
+            if (sent[side] >= len[side]) continue; // (uniform)
+            all_done = false;
+            const int avail = mem.counter(L.bnd_done + side * P.groups + (g1 - 1));
+            while (sent[side] < avail) { // (uniform)
+                const int e = sent[side] + lane;
+                if (e < avail) mem.export_wp_if(true, xchg_chain(gb, side, e), mem.get(L.bnd + 2 * (side * L.bnd_stride + bnd_offset(g1 - 1) - L.bnd_base + e)));
+                sent[side] = min(sent[side] + (int)LANES, avail);
+                progress = true;
+            }
+        }
+        if (!corners) {
+            int c0, c1, unused;
+            mem.counters3(L.corner_done + 0, L.corner_done + 1, L.join_done + SIDE_C, c0, c1, unused);
+            if (c0 >= rb && c1 >= rb) { // (uniform) AB x1, AB y0, CD x1, CD y0 of ring rb: lanes 0..3
+                if (lane < 4) mem.export_wp_if(true, xchg_misc(gb, lane), mem.get(L.corner + 2 * (((lane >> 1) * P.c + rb) * 2) + 2 * (lane & 1)));
+                corners = true;
+                progress = true;
+            }
+        }
+        if (!head) {
+            const int jc = mem.counter(L.join_done + SIDE_C), jd = mem.counter(L.join_done + SIDE_D);
+            if (jc >= rb && jd >= rb) { // (uniform) C_last, D_last of ring rb: lanes 0..1
+                if (lane < 2) mem.export_wp_if(true, xchg_misc(gb, X_JOIN_C + lane), mem.get(L.join + 2 * ((lane == 0 ? (int)SIDE_C : (int)SIDE_D) * P.c + rb)));
+                head = true;
+                progress = true;
+            }
+        }
+        if (all_done) break;
+        if (!progress) __builtin_amdgcn_s_sleep(SLEEP_LONG);
+    }
+}
+
 // 5 waves per SIMD (<= 96 registers, nothing spilled): two clouds share a CU.  (Measured: forcing 64 registers for three clouds
 // per CU spills and is 1.6x slower at 1024 clouds per launch.)
 template <bool DBG>
-__global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const LdsMap L, const CloudParams *__restrict__ params,
-                                                   unsigned long long *dbg)
+__global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const CloudParams *__restrict__ params, int n_clouds, int n_parts,
+                                                   uint32_t seq, unsigned long long *dbg)
 {
     extern __shared__ int lds[];
-    const int cloud = blockIdx.x;
+    // work-group -> (cloud, part).  The parts of a cloud follow each other in dispatch order (a consumer is never dispatched
+    // before its producer) and, in bundles of eight clouds, differ by multiples of 8 in the index: work-groups go to the 8 XCDs
+    // round-robin, so the parts of a cloud meet in ONE L2 (the hand-over is correct on any placement: agent-scope atomics).
+    int cloud, part;
+    {
+        const int id = (int)blockIdx.x, full = n_clouds & ~7, tail = n_clouds - full;
+        if (id < full * n_parts) {
+            const int rem = id % (8 * n_parts);
+            part = rem >> 3;
+            cloud = (id / (8 * n_parts)) * 8 + (rem & 7);
+        } else {
+            const int rem = id - full * n_parts;
+            part = rem / tail;
+            cloud = full + rem % tail;
+        }
+    }
+    const int g0 = part * P.gpw, g1 = min(g0 + P.gpw, P.groups);
+    const LdsMap L = lds_layout(P.c, P.groups, g0, g1);
     const CloudParams &cp = params[cloud];
     float2 *gp2 = gp2_ptr(a, cp.slot);
     float *points = a.layers + (size_t)cp.slot * a.slot_layer_stride + GG_LAYER_POINTS * a.layer_stride;
@@ -252,7 +403,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     for (int k = threadIdx.x; k < L.corner; k += nthreads) lds[k] = 0;
     const WP centre{1.0f, 1.0f * cp.base_z}; // :405 groundpatch(centre) = 1, :406-411 ground(centre) = translation.z
     if (threadIdx.x == 0) {
-        gp2[gp_index(P.gl, P.c, P.c)] = make_float2(cp.base_z, 1.0f);
+        if (part == 0) gp2[gp_index(P.gl, P.c, P.c)] = make_float2(cp.base_z, 1.0f);
         float *f = reinterpret_cast<float *>(lds);
         for (int side = 0; side < 2; ++side) {
             f[L.corner + 2 * ((side * P.c + 0) * 2) + 2] = centre.w;
@@ -268,7 +419,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     // per lane
     {
         const uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
-        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6, nwaves = nthreads >> 6;
+        const int lane_ = threadIdx.x & 63, wave_ = (int)(threadIdx.x >> 6) + part * (nthreads >> 6), nwaves = (nthreads >> 6) * n_parts; // (shared by the parts)
         for (int rank = wave_; rank < a.g.T; rank += nwaves) {
             const uint32_t cols_live = tile_live[rank];
             if (!cols_live) continue; // (uniform)
@@ -287,6 +438,8 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     DevMemT<DBG> mem;
     mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, P.gl.elems * 8, 0x00020000);
     mem.lds = (lds_int *)lds;
+    mem.xchg = a.sweep_xchg + (size_t)cp.slot * a.sweep_xchg_stride;
+    mem.seq = seq;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const int W = P.waves_per_side;
     WaveClockT<DBG> clk;
@@ -299,43 +452,72 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     // wavefronts numbered consecutively, A_w and C_w shared one SIMD and B_w and D_w another while two SIMDs idled)
     const int side = wave & 3, w_of_side = wave >> 2;
     if (wave < 4 * W && side == SIDE_A)
-        run_chain<SIDE_A, DBG>(P, L, mem, w_of_side, lane, clk);
+        run_chain<SIDE_A, DBG>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W && side == SIDE_B)
-        run_chain<SIDE_B, DBG>(P, L, mem, w_of_side, lane, clk);
+        run_chain<SIDE_B, DBG>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W && side == SIDE_C)
-        run_chain<SIDE_C, DBG>(P, L, mem, w_of_side, lane, clk);
+        run_chain<SIDE_C, DBG>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W)
-        run_chain<SIDE_D, DBG>(P, L, mem, w_of_side, lane, clk);
+        run_chain<SIDE_D, DBG>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave == 4 * W)
-        run_corner<0, DBG>(P, L, mem, lane, clk);
-    else
-        run_corner<1, DBG>(P, L, mem, lane, clk);
+        run_corner<0, DBG>(P, L, mem, lane, clk, g0, g1);
+    else if (wave == 4 * W + 1)
+        run_corner<1, DBG>(P, L, mem, lane, clk, g0, g1);
+    else if (wave == 4 * W + 2) {
+        if (part > 0) run_import<DBG>(P, L, mem, lane, g0);
+    } else if (g1 < P.groups)
+        run_export<DBG>(P, L, mem, lane, g1);
     clk.end(wave, lane);
 }
 
-size_t sweep_lds_bytes(const Params &P) { return (size_t)lds_layout(P.c, P.groups).words * 4; }
+// the largest LDS table any part of a sweep with `gpw` groups per work-group needs
+static size_t parts_lds_bytes(const Params &P, int gpw)
+{
+    size_t words = 0;
+    for (int g0 = 0; g0 < std::max(P.groups, 1); g0 += gpw) words = std::max(words, (size_t)lds_layout(P.c, P.groups, g0, std::min(g0 + gpw, P.groups)).words);
+    return words * 4;
+}
+// what gg_create checks: the sweep must fit in LDS at least when every work-group takes a single ring group per side
+size_t sweep_lds_bytes(const Params &P) { return parts_lds_bytes(P, 1); }
+size_t sweep_xchg_entries(const Params &P) { return (size_t)xchg_entries(P.groups); }
 
 void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_params, int n_clouds, hipStream_t s, unsigned long long *dbg)
 {
     if (n_clouds == 0 || P_in.rings <= 0) return;
-    // Latency setting: a launch of at most one cloud per CU gives every 64-ring group of a side its own wavefront (up to 3)
     Params P = P_in;
+    // Work-groups ("parts", sweep_core.h) per cloud.  The sweep of one cloud is a dependency chain, so a launch that leaves CUs idle
+    // spreads every cloud over as many work-groups as there are CUs to take them (measured, k_sweep per launch: n = 1000, 1 / 8
+    // clouds 1.33 -> 0.87 ms with one 64-ring group per work-group; 128 clouds 1.37 -> 1.19 ms with two work-groups per cloud;
+    // n = 364, 1 .. 64 clouds 0.335 -> 0.32 ms); a launch that fills the chip anyway keeps one work-group per cloud -- more only add
+    // importer / exporter wavefronts.  A work-group never takes more than three groups per side and wavefront set (16 wavefronts).
+    const int n_groups = std::max(P.groups, 1);
+    int n_parts = std::max(1, std::min(n_groups, SWEEP_LATENCY_MAX_CLOUDS / std::max(n_clouds, 1)));
+    P.gpw = (n_groups + n_parts - 1) / n_parts;
+    if (a.tune_sweep_gpw > 0) P.gpw = std::min(a.tune_sweep_gpw, n_groups);
+    while (P.gpw > 1 && parts_lds_bytes(P, P.gpw) > 158 * 1024) --P.gpw; // (big maps: the hand-over tables of many groups do not fit in one LDS)
+    n_parts = (n_groups + P.gpw - 1) / P.gpw;
+    const int groups_per_part = std::min(P.gpw, n_groups);
+    // Latency setting: a launch of at most one work-group per CU gives every 64-ring group of a side its own wavefront (up to 3)
     if (a.tune_sweep_waves > 0)
-        P.waves_per_side = std::max(1, std::min(std::min(P.groups, 3), a.tune_sweep_waves));
-    else if (n_clouds <= SWEEP_LATENCY_MAX_CLOUDS)
-        P.waves_per_side = std::max(1, std::min(P.groups, 3));
-    const LdsMap L = lds_layout(P.c, P.groups);
-    const size_t lds = (size_t)L.words * 4;
+        P.waves_per_side = std::max(1, std::min(std::min(groups_per_part, 3), a.tune_sweep_waves));
+    else if (n_clouds * n_parts <= SWEEP_LATENCY_MAX_CLOUDS)
+        P.waves_per_side = std::max(1, std::min(groups_per_part, 3));
+    else
+        P.waves_per_side = std::min(P.waves_per_side, std::max(1, std::min(groups_per_part, 3)));
+    const size_t lds = parts_lds_bytes(P, P.gpw);
     static std::atomic<uint64_t> big_lds_devices{0};
     if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices)) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    const int threads = (4 * P.waves_per_side + 2) * 64;
+    static std::atomic<uint32_t> launch_seq{0}; // tags the values of this launch in the exchange region (never 0: the arena starts zeroed)
+    uint32_t seq = launch_seq.fetch_add(1, std::memory_order_relaxed) + 1u;
+    if (seq == 0u) seq = launch_seq.fetch_add(1, std::memory_order_relaxed) + 1u;
+    const int threads = (4 * P.waves_per_side + 2 + (n_parts > 1 ? 2 : 0)) * 64; // (+ importer and exporter)
     if (dbg) // (GG_SWEEP_TIMING: the instrumented twin)
-        hipLaunchKernelGGL(k_sweep<true>, dim3(n_clouds), dim3(threads), lds, s, a, P, L, d_params, dbg);
+        hipLaunchKernelGGL(k_sweep<true>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, seq, dbg);
     else
-        hipLaunchKernelGGL(k_sweep<false>, dim3(n_clouds), dim3(threads), lds, s, a, P, L, d_params, dbg);
+        hipLaunchKernelGGL(k_sweep<false>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, seq, dbg);
 }
 
 } // namespace gg

@@ -74,6 +74,7 @@ struct Params {
     int rings;  // c - 1
     int groups; // ceil(rings / LANES)
     int waves_per_side;
+    int gpw;    // ring groups per work-group ("part"); >= groups: one work-group sweeps the whole map (see "Parts" below)
     int r2min;  // the confidence decay (:463-464) applies to cell (x, y) iff (x-c)^2 + (y-c)^2 >= r2min (host-computed, exact)
     double decrease, inv_decrease;
     int decay_fast;
@@ -216,14 +217,45 @@ struct LdsMap {
     int join;        // WP[4][c]      last chain value per side and ring
     int bnd;         // WP[4][bnd_words / 2]   full chains of the group-boundary rings
     int bnd_stride;  // WP entries per side
+    int bnd_base;    // bnd_offset() of the first boundary this work-group's table holds (a part keeps only its own boundaries)
     int scratch;     // per-lane dummy targets of conditional publishes (2 data words + 1 counter word per lane, 8-byte aligned)
     int words;       // total size
 };
 
 SW_HD int bnd_offset(int b) { return 64 * b * (b + 1) + 2 * b; } // boundary b = ring 64 (b + 1): chains of <= 128 (b + 1) + 2 steps before it
 
-SW_HD LdsMap lds_layout(int c, int groups)
+// ---------------------------------------------------------------------------------------------------------------------
+// Parts.  A map with more ring groups than a work-group has wavefronts for (n = 1000: 8 groups per side, 16 wavefronts per
+// work-group) is swept by several work-groups: part p owns the consecutive groups [p gpw, (p + 1) gpw).  Everything a part
+// needs from the part inside it is FEED-FORWARD -- the chains of its innermost ring read the boundary chains, corner values
+// and two joins of the ring before, nothing flows back -- so the hand-over may take its time: the producing work-group's chain
+// and corner wavefronts publish into their LDS tables as if the next group lived next door, an EXPORTER wavefront copies what
+// appears there, tagged with the launch's sequence number, into an exchange region in global memory (the chain wavefronts
+// themselves must not: loads and stores share one in-order counter, and a store that has to reach memory before it is
+// acknowledged would hold up every later wait of the wavefront -- measured: 2x slower), and an IMPORTER wavefront of the
+// consuming work-group polls the region and feeds the values and their progress counters into its own work-group's LDS tables,
+// where the chain and corner wavefronts find them as if a wavefront next door had published them.  Work-groups are dispatched in index order and a part's index is higher than its producer's:
+// a consumer never waits for a work-group that has not been dispatched.
+//
+// Exchange region of one cloud, in entries of one WP: per boundary gb = 1 .. groups - 1 (between ring 64 gb and 64 gb + 1)
+//   4 sides x xchg_len(gb) chain values of ring 64 gb,  then  AB x1, AB y0, CD x1, CD y0,  then  C_last, D_last of ring 64 gb.
+// ---------------------------------------------------------------------------------------------------------------------
+SW_HD int xchg_len(int gb) { return 2 * LANES * gb + 2; }
+SW_HD int xchg_base(int gb)
 {
+    int o = 0;
+    for (int g = 1; g < gb; ++g) o += 4 * xchg_len(g) + 6;
+    return o;
+}
+SW_HD int xchg_entries(int groups) { return xchg_base(groups > 1 ? groups : 1); }
+enum { X_CORNER = 0, X_JOIN_C = 4, X_JOIN_D = 5 };
+SW_HD int xchg_chain(int gb, int side, int e) { return xchg_base(gb) + side * xchg_len(gb) + e; }
+SW_HD int xchg_misc(int gb, int k) { return xchg_base(gb) + 4 * xchg_len(gb) + k; }
+
+// g0, g1: the groups of the work-group (default: all of them)
+SW_HD LdsMap lds_layout(int c, int groups, int g0 = 0, int g1 = -1)
+{
+    if (g1 < 0) g1 = groups;
     LdsMap m;
     int o = 0;
     m.corner_done = o;
@@ -237,7 +269,11 @@ SW_HD LdsMap lds_layout(int c, int groups)
     o += 2 * c * 2 * 2;
     m.join = o;
     o += 4 * c * 2;
-    m.bnd_stride = bnd_offset(groups > 0 ? groups - 1 : 0);
+    // boundaries b = g0 - 1 (imported from the part inside) .. g1 - 1 (the last one is read by the exporter wavefront when another
+    // part follows; the last ring of the map has no boundary chain)
+    const int b_first = g0 > 0 ? g0 - 1 : 0, b_end = g1 < groups ? g1 : (g1 > 0 ? g1 - 1 : 0);
+    m.bnd_base = bnd_offset(b_first);
+    m.bnd_stride = bnd_offset(b_end > b_first ? b_end : b_first) - m.bnd_base;
     m.bnd = o;
     o += 4 * m.bnd_stride * 2;
     m.scratch = o; // [64][3]: where the lanes that have nothing to publish write (publish_if, device)
@@ -389,7 +425,7 @@ template <int SIDE> struct ChainLane {
             a_s1 = in_second;
             a_pred = own_second;
         }
-        a_bnd = group > 0 ? L.bnd + 2 * (SIDE * L.bnd_stride + bnd_offset(group - 1)) : L.bnd;
+        a_bnd = group > 0 ? L.bnd + 2 * (SIDE * L.bnd_stride + bnd_offset(group - 1) - L.bnd_base) : L.bnd;
         // decay test of the visited cell (along-position k0 + s, s = t - l3): offset from the centre line = (k0 + s) - r (sides
         // A, B) or r - (k0 + s) (C, D); its square is the same
         r2c = k0 - r - l3;
@@ -510,7 +546,7 @@ template <int SIDE> struct ChainLane {
         // ---- publish what other wavefronts wait for (data first, then the counter)
         mem.publish_if(t + 1 == lend && len > 0, l, L, a_pub, res, L.join_done + SIDE, r);
         if (has_next_group && t >= u_l3_last && t < u_lend_last) // (uniform: only while the last lane runs)
-            mem.publish_if(l == LANES - 1 && active, l, L, L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) + (t - l3)), res,
+            mem.publish_if(l == LANES - 1 && active, l, L, L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) - L.bnd_base + (t - l3)), res,
                            L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
     }
 };

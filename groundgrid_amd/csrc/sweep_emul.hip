@@ -18,11 +18,31 @@ namespace {
 
 using namespace gg::sweep;
 
-struct HostMem {
+struct HostMem { // one per emulated work-group ("part"): its own LDS, the layer and the exchange region shared with the others
     Cell *gp2;
     std::vector<int32_t> lds;
     bool late;
     long loads = 0, stores = 0, lds_ops = 0;
+    std::vector<uint64_t> *xchg = nullptr; // sweep_core.h "Parts": tagged values between work-groups
+    uint32_t seq = 1;
+    void export_wp_if(bool c, int entry, WP v)
+    {
+        if (!c) return;
+        uint32_t w, p;
+        memcpy(&w, &v.w, 4);
+        memcpy(&p, &v.p, 4);
+        (*xchg)[2 * (size_t)entry] = ((uint64_t)seq << 32) | w;
+        (*xchg)[2 * (size_t)entry + 1] = ((uint64_t)seq << 32) | p;
+    }
+    bool import_wp(int entry, WP &v)
+    {
+        const uint64_t a = (*xchg)[2 * (size_t)entry], b = (*xchg)[2 * (size_t)entry + 1];
+        const uint32_t w = (uint32_t)a, p = (uint32_t)b;
+        memcpy(&v.w, &w, 4);
+        memcpy(&v.p, &p, 4);
+        return (uint32_t)(a >> 32) == seq && (uint32_t)(b >> 32) == seq;
+    }
+    void set_counter(int word, int value) { lds[(size_t)word] = value; }
     Cell load_issue(bool valid, int cell)
     {
         if (!valid) return Cell{0.f, 0.f};
@@ -76,23 +96,25 @@ struct WaveBase {
     virtual ~WaveBase() {}
     virtual bool bad() const { return false; }
     virtual bool done() const = 0;
-    virtual bool try_step(HostMem &mem) = 0; // false: stalled on another wavefront (or done)
+    virtual bool try_step() = 0; // false: stalled on another wavefront (or done)
 };
 
 template <int SIDE> struct ChainWave : WaveBase {
     const Params &P;
     const LdsMap &L;
+    HostMem &mem;
+    int g1; // the part's groups end here
     int wave, group, t, t_last, r0, nl;
     ChainLane<SIDE> lane[LANES];
     ChainSync<SIDE> sync;
     bool advanced = false;
     long steps = 0;
     bool plan_mismatch = false;
-    ChainWave(const Params &p, const LdsMap &l, int w) : P(p), L(l), wave(w), group(w - p.waves_per_side) { next_group(); }
+    ChainWave(const Params &p, const LdsMap &l, HostMem &m, int w, int g0_, int g1_) : P(p), L(l), mem(m), g1(g1_), wave(w), group(g0_ + w - p.waves_per_side) { next_group(); }
     void next_group()
     {
         group += P.waves_per_side;
-        if (group >= P.groups) return;
+        if (group >= g1) return;
         r0 = LANES * group + 1;
         nl = P.rings - (r0 - 1) < LANES ? P.rings - (r0 - 1) : LANES;
         for (int l = 0; l < LANES; ++l) {
@@ -112,10 +134,10 @@ template <int SIDE> struct ChainWave : WaveBase {
         sync.init(r0, nl, group, P, L);
         advanced = false;
     }
-    bool done() const override { return group >= P.groups; }
+    bool done() const override { return group >= g1; }
     bool bad() const override { return plan_mismatch; }
     bool half = false; // step_a of wave-step t is done, step_b waits for the join
-    bool try_step(HostMem &mem) override
+    bool try_step() override
     {
         if (done()) return false;
         const int tmod = ((t % SKEW) + SKEW) % SKEW;
@@ -161,17 +183,22 @@ template <int SIDE> struct ChainWave : WaveBase {
 template <int CD> struct CornerWave : WaveBase {
     const Params &P;
     const LdsMap &L;
-    int r = 1;            // next ring of the recurrence
+    HostMem &mem;
+    int g0, g1;
+    int r;                 // next ring of the recurrence
+    int r_end;             // last ring of the part
     bool prepared = false; // the current group's lanes have their old cells
     CornerRing<CD> lane[LANES];
     WP in_corner{0.f, 0.f}, in_x1{0.f, 0.f};
-    CornerWave(const Params &p, const LdsMap &l) : P(p), L(l) {}
-    bool done() const override { return r > P.rings; }
-    bool try_step(HostMem &mem) override
+    CornerWave(const Params &p, const LdsMap &l, HostMem &m, int g0_, int g1_)
+        : P(p), L(l), mem(m), g0(g0_), g1(g1_), r(LANES * g0_ + 1), r_end(LANES * g1_ < p.rings ? LANES * g1_ : p.rings) {}
+    bool done() const override { return r > r_end; }
+    bool try_step() override
     {
         if (done() || !CornerRing<CD>::ready(r, L, mem)) return false;
         const int l = (r - 1) % LANES, r0 = r - l;
         if (!prepared) { // like the device: the whole group's old cells, requested and consumed at the start of the group
+            if (g0 > 0 && r0 == LANES * g0 + 1 && mem.counter(L.corner_done + CD) < r0 - 1) return false; // the importer has not delivered the ring before the part yet
             for (int k = 0; k < LANES; ++k) lane[k].issue(r0 + k, P, mem);
             for (int k = 0; k < LANES; ++k) lane[k].finish(P, mem);
             const int prev = L.corner + 2 * ((CD * P.c + r0 - 1) * 2);
@@ -187,6 +214,99 @@ template <int CD> struct CornerWave : WaveBase {
         ++r;
         if (l == LANES - 1) prepared = false;
         return true;
+    }
+};
+
+// the exporter wavefront of a part with a successor (k4_sweep.hip run_export): one try = whatever has been published since
+struct ExportWave : WaveBase {
+    const Params &P;
+    const LdsMap &L;
+    HostMem &mem;
+    int g1;
+    bool head = false, corners = false;
+    int sent[4] = {0, 0, 0, 0}, len[4];
+    ExportWave(const Params &p, const LdsMap &l, HostMem &m, int g1_) : P(p), L(l), mem(m), g1(g1_)
+    {
+        const int rb = LANES * g1;
+        len[0] = chain_len<SIDE_A>(rb), len[1] = chain_len<SIDE_B>(rb), len[2] = chain_len<SIDE_C>(rb), len[3] = chain_len<SIDE_D>(rb);
+    }
+    bool done() const override { return head && corners && sent[0] >= len[0] && sent[1] >= len[1] && sent[2] >= len[2] && sent[3] >= len[3]; }
+    bool try_step() override
+    {
+        const int rb = LANES * g1;
+        bool progress = false;
+        for (int side = 0; side < 4; ++side) {
+            const int avail = mem.counter(L.bnd_done + side * P.groups + (g1 - 1));
+            for (; sent[side] < avail; ++sent[side], progress = true)
+                mem.export_wp_if(true, xchg_chain(g1, side, sent[side]), mem.get(L.bnd + 2 * (side * L.bnd_stride + bnd_offset(g1 - 1) - L.bnd_base + sent[side])));
+        }
+        if (!corners && mem.counter(L.corner_done + 0) >= rb && mem.counter(L.corner_done + 1) >= rb) {
+            for (int k = 0; k < 4; ++k) mem.export_wp_if(true, xchg_misc(g1, k), mem.get(L.corner + 2 * (((k >> 1) * P.c + rb) * 2) + 2 * (k & 1)));
+            corners = true;
+            progress = true;
+        }
+        if (!head && mem.counter(L.join_done + SIDE_C) >= rb && mem.counter(L.join_done + SIDE_D) >= rb) {
+            for (int k = 0; k < 2; ++k) mem.export_wp_if(true, xchg_misc(g1, X_JOIN_C + k), mem.get(L.join + 2 * ((k == 0 ? (int)SIDE_C : (int)SIDE_D) * P.c + rb)));
+            head = true;
+            progress = true;
+        }
+        return progress;
+    }
+};
+
+// the importer wavefront of a part p > 0 (k4_sweep.hip run_import): one try = whatever has arrived
+struct ImportWave : WaveBase {
+    const Params &P;
+    const LdsMap &L;
+    HostMem &mem;
+    int g0;
+    bool head = false, joins = false;
+    int have[4] = {0, 0, 0, 0}, len[4];
+    ImportWave(const Params &p, const LdsMap &l, HostMem &m, int g0_) : P(p), L(l), mem(m), g0(g0_)
+    {
+        const int rb = LANES * g0;
+        len[0] = chain_len<SIDE_A>(rb), len[1] = chain_len<SIDE_B>(rb), len[2] = chain_len<SIDE_C>(rb), len[3] = chain_len<SIDE_D>(rb);
+    }
+    bool done() const override { return head && joins && have[0] >= len[0] && have[1] >= len[1] && have[2] >= len[2] && have[3] >= len[3]; }
+    bool try_step() override
+    {
+        const int rb = LANES * g0;
+        if (!head) { // the corner values first: nothing of this part can start without them
+            WP v[4];
+            for (int k = 0; k < 4; ++k)
+                if (!mem.import_wp(xchg_misc(g0, k), v[k])) return false;
+            for (int k = 0; k < 4; ++k) mem.put(L.corner + 2 * (((k >> 1) * P.c + rb) * 2) + 2 * (k & 1), v[k]);
+            mem.set_counter(L.corner_done + 0, rb);
+            mem.set_counter(L.corner_done + 1, rb);
+            head = true;
+            return true;
+        }
+        bool progress = false;
+        if (!joins) {
+            WP c, d;
+            if (mem.import_wp(xchg_misc(g0, X_JOIN_C), c) && mem.import_wp(xchg_misc(g0, X_JOIN_D), d)) {
+                mem.put(L.join + 2 * (SIDE_C * P.c + rb), c);
+                mem.put(L.join + 2 * (SIDE_D * P.c + rb), d);
+                mem.set_counter(L.join_done + SIDE_C, rb);
+                mem.set_counter(L.join_done + SIDE_D, rb);
+                joins = true;
+                progress = true;
+            }
+        }
+        for (int side = 0; side < 4; ++side) {
+            int nv = 0;
+            WP v;
+            while (nv < LANES && have[side] + nv < len[side] && mem.import_wp(xchg_chain(g0, side, have[side] + nv), v)) {
+                mem.put(L.bnd + 2 * (side * L.bnd_stride + bnd_offset(g0 - 1) - L.bnd_base + have[side] + nv), v);
+                ++nv;
+            }
+            if (nv) {
+                have[side] += nv;
+                mem.set_counter(L.bnd_done + side * P.groups + (g0 - 1), have[side]);
+                progress = true;
+            }
+        }
+        return progress;
     }
 };
 
@@ -206,6 +326,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
     // to one wavefront per group (at most 3 per side: 14 wavefronts) when the launch has fewer clouds than the chip has CUs:
     // with SKEW = 1 group g + 1 starts only 64 steps after group g, and a wavefront that still works on group g - 1 delays it.
     P.waves_per_side = P.groups <= 1 ? 1 : P.groups <= 3 ? 2 : 3;
+    P.gpw = P.groups > 1 ? P.groups : 1; // one work-group unless the launcher (or the emulation's GG_SWEEP_GPW) cuts the map into parts
     if (getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(std::min(P.groups, 3), atoi(getenv("GG_SWEEP_WAVES")))); // (the host emulation: tests/test_sweep_emul_cpu.py)
     // :463 (pow((float)x - center, 2.0) + pow((float)y - center, 2.0)) * pow(resolution, 2.0f) > minDistSquared: the left side is a
     // non-decreasing function of the integer (x-c)^2 + (y-c)^2, so the test is an integer threshold
@@ -226,30 +347,47 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
                                            unsigned seed, int late_loads, long *stats)
 {
     if (n < 8 || !gp2) return GG_ERR_INVALID;
-    const Params P = gg::sweep::make_params(n, resolution, min_dist_squared, decrease);
-    const LdsMap L = lds_layout(P.c, P.groups);
-    HostMem mem;
+    Params P = gg::sweep::make_params(n, resolution, min_dist_squared, decrease);
+    if (getenv("GG_SWEEP_GPW")) { // emulate the multi-work-group sweep (sweep_core.h "Parts")
+        P.gpw = std::max(1, std::min(atoi(getenv("GG_SWEEP_GPW")), std::max(P.groups, 1)));
+        P.waves_per_side = std::max(1, std::min(P.waves_per_side, P.gpw));
+    }
+    const int n_groups = std::max(P.groups, 1), n_parts = (n_groups + P.gpw - 1) / P.gpw;
     // the layer in the device's sheared element order (gp_layout.h); gp2 is Eigen-style column-major on both ends
     std::vector<Cell> sheared((size_t)P.gl.elems, Cell{0.f, 0.f});
     for (int col = 0; col < n; ++col)
         for (int row = 0; row < n; ++row) sheared[(size_t)gp_index(P.gl, row, col)] = Cell{gp2[2 * ((size_t)row + (size_t)col * n)], gp2[2 * ((size_t)row + (size_t)col * n) + 1]};
-    mem.gp2 = sheared.data();
-    mem.lds.assign((size_t)L.words, 0);
-    mem.late = late_loads != 0;
+    std::vector<uint64_t> xchg(2 * (size_t)std::max(xchg_entries(P.groups), 1), 0ull);
+    std::vector<LdsMap> maps((size_t)n_parts);
+    std::vector<HostMem> mems((size_t)n_parts);
     // :405-411 centre cell; ring 0 of every hand-over table is the centre
-    mem.gp2[gp_index(P.gl, P.c, P.c)] = Cell{base_z, 1.0f};
+    sheared[(size_t)gp_index(P.gl, P.c, P.c)] = Cell{base_z, 1.0f};
     const WP centre{1.0f, 1.0f * base_z};
-    for (int side = 0; side < 2; ++side) mem.put(L.corner + 2 * ((side * P.c + 0) * 2) + 2, centre);
-    mem.put(L.join + 2 * (SIDE_C * P.c + 0), centre);
-    mem.put(L.join + 2 * (SIDE_D * P.c + 0), centre);
-
     std::vector<WaveBase *> waves;
-    for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_A>(P, L, w));
-    for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_B>(P, L, w));
-    for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_C>(P, L, w));
-    for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_D>(P, L, w));
-    waves.push_back(new CornerWave<0>(P, L));
-    waves.push_back(new CornerWave<1>(P, L));
+    size_t lds_words = 0;
+    for (int part = 0; part < n_parts; ++part) {
+        const int g0 = part * P.gpw, g1 = std::min(g0 + P.gpw, P.groups);
+        LdsMap &L = maps[(size_t)part];
+        HostMem &mem = mems[(size_t)part];
+        L = lds_layout(P.c, P.groups, g0, g1);
+        lds_words = std::max(lds_words, (size_t)L.words);
+        mem.gp2 = sheared.data();
+        mem.lds.assign((size_t)L.words, 0);
+        mem.late = late_loads != 0;
+        mem.xchg = &xchg;
+        mem.seq = 7;
+        for (int side = 0; side < 2; ++side) mem.put(L.corner + 2 * ((side * P.c + 0) * 2) + 2, centre);
+        mem.put(L.join + 2 * (SIDE_C * P.c + 0), centre);
+        mem.put(L.join + 2 * (SIDE_D * P.c + 0), centre);
+        for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_A>(P, L, mem, w, g0, g1));
+        for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_B>(P, L, mem, w, g0, g1));
+        for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_C>(P, L, mem, w, g0, g1));
+        for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_D>(P, L, mem, w, g0, g1));
+        waves.push_back(new CornerWave<0>(P, L, mem, g0, g1));
+        waves.push_back(new CornerWave<1>(P, L, mem, g0, g1));
+        if (part > 0) waves.push_back(new ImportWave(P, L, mem, g0));
+        if (g1 < P.groups) waves.push_back(new ExportWave(P, L, mem, g1));
+    }
 
     // wave scheduling: seed 0 = round robin; otherwise a seeded random walk in which a chosen wavefront runs a random burst
     // (up to "as far as it can") before the next one is chosen: wavefronts drift apart as far as the dataflow allows
@@ -264,7 +402,7 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
         ++rounds;
         if (seed == 0) {
             for (auto *w : waves)
-                if (w->try_step(mem)) {
+                if (w->try_step()) {
                     progress = true;
                     ++total_steps;
                 } else if (!w->done())
@@ -274,7 +412,7 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
                 WaveBase *w = waves[(rnd() >> 8) % waves.size()];
                 const uint32_t mode = (rnd() >> 8) % 8;
                 int burst = mode == 0 ? 1 << 30 : mode < 4 ? 1 + (int)((rnd() >> 8) % 64) : 1;
-                while (burst-- > 0 && w->try_step(mem)) {
+                while (burst-- > 0 && w->try_step()) {
                     progress = true;
                     ++total_steps;
                 }
@@ -282,7 +420,7 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
             }
             if (!progress) // the random picks were all stalled: look at everybody before calling it a deadlock
                 for (auto *w : waves)
-                    if (w->try_step(mem)) {
+                    if (w->try_step()) {
                         progress = true;
                         ++total_steps;
                         break;
@@ -297,11 +435,14 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
     if (stats) {
         stats[0] = total_steps;
         stats[1] = stalls;
-        stats[2] = mem.loads;
-        stats[3] = mem.stores;
-        stats[4] = mem.lds_ops;
-        stats[5] = L.words * 4;
-        stats[6] = P.waves_per_side * 4 + 2;
+        stats[2] = stats[3] = stats[4] = 0;
+        for (const HostMem &m : mems) {
+            stats[2] += m.loads;
+            stats[3] += m.stores;
+            stats[4] += m.lds_ops;
+        }
+        stats[5] = (long)lds_words * 4;
+        stats[6] = (P.waves_per_side * 4 + 2) * n_parts + 2 * (n_parts - 1);
         stats[7] = P.r2min;
     }
     for (auto *w : waves) {

@@ -332,6 +332,43 @@ def test_batch_with_a_slot_permutation():
     seg.close()
 
 
+@pytest.mark.parametrize("length,resolution,gpw,batch", [(120.0, 0.33, 1, 3), (120.0, 0.33, 2, 11), (120.0, 0.33, 1, 17), (240.0, 0.33, 0, 2), (240.0, 0.33, 2, 9),
+                                                         (61.0, 0.25, 1, 8)])
+def test_sweep_cut_into_several_work_groups(length, resolution, gpw, batch):
+    """k_sweep as several cooperating work-groups per cloud (sweep_core.h "Parts": `gpw` ring groups of 64 each, values crossing
+    through the tagged exchange region + importer wavefront): forced at the bench grid (3 groups -> 3 or 2 parts) and at a
+    727-cell map (6 groups: the default cut, 3 + 3), with batch sizes on both sides of the 8-cloud bundles the work-group
+    index is laid out in.  Two frames, every layer against the oracle."""
+    base = synth.hdl64_cloud(seed=61, n_az=400)
+    k = np.float32(length / 120.0)
+    clouds = []
+    for b in range(batch):
+        c = synth.clone_cloud(base)
+        ang = np.float32(0.31 * b)
+        c["x"] = ((np.cos(ang) * base["x"] - np.sin(ang) * base["y"]) * k).astype(np.float32)
+        c["y"] = ((np.sin(ang) * base["x"] + np.cos(ang) * base["y"]) * k).astype(np.float32)
+        clouds.append(c)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
+    if gpw:
+        seg.debug_set_tuning("sweep_gpw", gpw)
+    import torch
+
+    refs = [oracle.OracleMap(length, resolution) for _ in clouds]
+    pts = _batch_inputs(16, clouds, stride)
+    out = None
+    for frame in range(2):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((batch, 3), np.float32), np.full(batch, -1.73), out=out)
+        torch.cuda.synchronize()
+        labels = out.labels.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, ORIGIN0, -1.73)
+            assert np.array_equal(labels[b, : len(c)], r["label"]), (frame, b)
+            if b in (0, 1, batch // 2, batch - 1):
+                assert_same_state(seg.map(b), refs[b], f"frame {frame} cloud {b}")
+    seg.close()
+
+
 def test_two_bit_label_masks_from_the_label_kernel():
     """gg_batch.d_label_masks: what a multi-GPU caller all-gathers (groundgrid_amd/dist.py) -- the labels, 2 bits per point."""
     import torch
@@ -411,10 +448,14 @@ def test_sparse_per_call_layers_at_the_host_boundary():
 
 
 def test_largest_supported_grid_and_ring_group_counts():
-    """The sweep's wavefronts own groups of 64 rings: 1000 x 1000 (498 rings, 8 groups on 3 wavefronts per side, 147 KB of LDS
-    hand-over tables) down to grids with fewer rings than lanes; a sparse cloud keeps the oracle fast."""
-    for length, res in ((200.0, 0.2), (43.0, 0.33), (22.0, 0.33)):
+    """The sweep's wavefronts own groups of 64 rings: 1400 x 1400 (698 rings, 11 groups: only possible as several work-groups per
+    cloud), 1000 x 1000 (498 rings, 8 groups -- one work-group per group by default in a one-cloud launch, and forced onto ONE
+    work-group: 3 wavefronts per side, 147 KB of LDS hand-over tables) down to grids with fewer rings than lanes; a sparse cloud
+    keeps the oracle fast."""
+    for length, res, gpw in ((280.0, 0.2, 0), (200.0, 0.2, 0), (200.0, 0.2, 8), (200.0, 0.2, 5), (43.0, 0.33, 0), (22.0, 0.33, 0)):
         seg = api.GroundSegmentation().init(length, res, n_slots=1, max_points=1000)
+        if gpw:
+            seg.debug_set_tuning("sweep_gpw", gpw)
         ref = oracle.OracleMap(length, res)
         c = synth.random_cloud(1000, seed=2, extent=0.45 * length)
         for _ in range(2):

@@ -95,3 +95,26 @@ def test_special_values_travel_unchanged(lib):
     ref.stage_spiral(-1.0)
     g, w, _ = emulate(lib, n, ref.resolution, ground, conf, -1.0, 5.0, 4, True)
     assert np.array_equal(g, ref.layer("ground"), equal_nan=True) and np.array_equal(w, ref.layer("groundpatch"), equal_nan=True)
+
+
+@pytest.mark.parametrize("length,resolution,gpw", [(61.0, 0.25, 1), (120.0, 0.33, 1), (120.0, 0.33, 2), (150.0, 0.25, 2), (240.0, 0.33, 3), (240.0, 0.33, 1)])
+def test_sweep_cut_into_several_work_groups(lib, monkeypatch, length, resolution, gpw):
+    """sweep_core.h "Parts": a map with more ring groups than one work-group has wavefronts for is swept by several work-groups,
+    each owning `gpw` consecutive groups of 64 rings; what crosses between them (boundary chains, corner values, two joins) is
+    feed-forward and travels through a tagged exchange region that an importer wavefront republishes in the consumer's LDS.
+    Same bar as the single work-group: bit-identical to the serial sweep under every interleaving, no deadlock."""
+    monkeypatch.setenv("GG_SWEEP_GPW", str(gpw))
+    ref = oracle.OracleMap(length, resolution)
+    n = ref.layer("ground").shape[0]
+    ground, conf = random_state(n, 3 * n + gpw)
+    ref.set_layer("ground", ground)
+    ref.set_layer("groundpatch", conf)
+    ref.stage_spiral(-1.73)
+    groups = (n // 2 - 2 + 63) // 64
+    for seed in ((0, 1, 2, 3, 4) if n <= 400 else (0, 6)):
+        for late in (False, True):
+            g, w, stats = emulate(lib, n, ref.resolution, ground, conf, -1.73, 5.0, seed, late)
+            assert np.array_equal(g, ref.layer("ground")), (seed, late, np.argwhere(g != ref.layer("ground"))[:5].tolist())
+            assert np.array_equal(w, ref.layer("groundpatch")), (seed, late)
+    parts = (groups + gpw - 1) // gpw
+    assert parts >= 2 and stats[6] >= parts * 6 + (parts - 1)  # at least 4 chain + 2 corner wavefronts per part, an importer per hand-over

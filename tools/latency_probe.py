@@ -32,10 +32,11 @@ def run(length, res, cloud, batch, steps=12, cold=True):
 if __name__ == "__main__":
     res = {"lib": os.environ.get("GROUNDGRID_HIP_LIB", "default")}
     c2 = synth.hdl64_cloud(seed=20240113)
-    for b in (1, 8, 64):
-        res[f"n364_b{b}"] = run(120.0, 0.33, c2, b)
+    if not os.environ.get("SKIP_SMALL"):
+        for b in [int(v) for v in os.environ.get("BATCHES_SMALL", "1,8,64").split(",")]:
+            res[f"n364_b{b}"] = run(120.0, 0.33, c2, b)
     if not os.environ.get("SKIP_BIG"):
         c4 = synth.os128_cloud_fast(seed=20240113)
-        for b in (1, 8):
+        for b in [int(v) for v in os.environ.get("BATCHES_BIG", "1,8").split(",")]:
             res[f"n1000_b{b}"] = run(200.0, 0.2, c4, b, steps=6)
     print(json.dumps(res))
