@@ -36,7 +36,7 @@ LAYERS = [
 SYMBOLS = [
     "gg_abi_version", "gg_kernel_name", "gg_default_config", "gg_default_geometry", "gg_create", "gg_destroy",
     "gg_set_config", "gg_get_config", "gg_set_flags", "gg_get_size", "gg_get_geometry", "gg_last_error",
-    "gg_reset_map", "gg_reset_maps", "gg_set_map_position", "gg_move_map", "gg_get_map_position", "gg_set_layer", "gg_get_layer", "gg_get_expected_points",
+    "gg_reset_map", "gg_reset_maps", "gg_set_map_position", "gg_move_map", "gg_get_map_position", "gg_set_layer", "gg_get_layer", "gg_get_layers", "gg_get_expected_points",
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
     "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep",
@@ -152,6 +152,7 @@ def load():
     L.gg_filter_cloud.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_float), C.c_double, vp, P(C.c_size_t), vp, vp]
     L.gg_filter_cloud_tf.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, vp, P(C.c_size_t), vp, vp]
     L.gg_filter_cloud_pc2.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, vp, vp, P(C.c_size_t)]
+    L.gg_get_layers.argtypes = [vp, C.c_int, P(vp)]
     L.gg_get_layer_image_u8.argtypes = [vp, C.c_int, C.c_int, vp, P(C.c_float), P(C.c_float)]
     L.gg_get_terrain_image.argtypes = [vp, C.c_int, vp]
     L.gg_filter_batch.argtypes = [vp, P(GGBatch), vp]

@@ -121,8 +121,15 @@ class GridMap:
         flat = np.ascontiguousarray(a.reshape(-1, order="F"))
         _check(L, ctx, L.gg_set_layer(ctx, self.slot, LAYERS.index(layer), flat.ctypes.data), "gg_set_layer")
 
-    def layers(self) -> dict:
-        return {n: self.get(n) for n in LAYERS}
+    def layers(self, names=None) -> dict:
+        """All (or the named) layers with one synchronisation (gg_get_layers): what a publisher loop reads after a cloud."""
+        L, ctx = self._seg._L, self._seg._ctx
+        names = list(LAYERS) if names is None else list(names)
+        n = self._seg.rows * self._seg.cols
+        bufs = {k: np.empty(n, dtype=np.float32) for k in names}
+        ptrs = (C.c_void_p * len(LAYERS))(*[bufs[k].ctypes.data if k in bufs else None for k in LAYERS])
+        _check(L, ctx, L.gg_get_layers(ctx, self.slot, ptrs), "gg_get_layers")
+        return {k: v.reshape((self._seg.rows, self._seg.cols), order="F") for k, v in bufs.items()}
 
     def image_u8(self, layer: str):
         """GridMapCvConverter::toImage<unsigned char,1> (Nodelet.cpp:239): (rows x cols uint8 image, lower, upper)."""
@@ -232,26 +239,39 @@ class GroundSegmentation:
         return buf.reshape((self.rows, self.cols), order="F")
 
     # -- GroundSegmentation::filter_cloud (include/groundgrid/GroundSegmentation.h:54)
+    def _host_buffers(self, n: int, reuse: bool):
+        """Output arrays of one host-buffer call: fresh ones, or (reuse=True) this object's own, grown on demand -- a caller that
+        looks at one result before asking for the next (a sensor loop) then pays no allocation and no first-touch page faults
+        per cloud (3.8 MB per HDL-64E revolution); the returned arrays are views that the next reuse=True call overwrites."""
+        m = max(n, 1)
+        if not reuse:
+            return np.empty(m * 32, dtype=np.uint8).view(POINT_DTYPE), np.empty(m, dtype=np.uint8), np.empty(m, dtype=np.int32)
+        if getattr(self, "_hb_cap", 0) < m:
+            self._hb_cap = m + m // 8
+            self._hb = (np.zeros(self._hb_cap * 32, dtype=np.uint8).view(POINT_DTYPE), np.zeros(self._hb_cap, dtype=np.uint8),
+                        np.zeros(self._hb_cap, dtype=np.int32))
+        return self._hb
+
     def filter_cloud(self, cloud: np.ndarray, cloudOrigin: Sequence[float], mapToBase_z: float, map: Optional[GridMap] = None,
-                     return_details: bool = False, map_from_cloud=None):
+                     return_details: bool = False, map_from_cloud=None, reuse_buffers: bool = False):
         """cloud: POINT_DTYPE array in the map frame.  Returns the segmented cloud (intensity = 49 ground /
         99 non-ground; order kept, ignored, outliers).  With return_details also (labels, out_index)."""
         assert cloud.dtype == POINT_DTYPE, "cloud must use groundgrid_amd.synth.POINT_DTYPE (PointXYZIR, 32 B)"
         gm = map if map is not None else self._maps[0]
         cloud = np.ascontiguousarray(cloud)
         n = cloud.shape[0]
-        out = np.zeros(max(n, 1) * 32, dtype=np.uint8).view(POINT_DTYPE)
-        labels = np.zeros(max(n, 1), dtype=np.uint8)
-        index = np.zeros(max(n, 1), dtype=np.int32)
+        out, labels, index = self._host_buffers(n, reuse_buffers)
         out_n = C.c_size_t(0)
         org = (C.c_float * 3)(*[float(v) for v in cloudOrigin])
+        # (the per-point labels / positions are copied out only when asked for: the reference's call returns the cloud alone)
+        lab_p, idx_p = (labels.ctypes.data, index.ctypes.data) if return_details else (None, None)
         if map_from_cloud is None:
             rc = self._L.gg_filter_cloud(self._ctx, gm.slot, cloud.ctypes.data, n, org, float(mapToBase_z),
-                                         out.ctypes.data, C.byref(out_n), labels.ctypes.data, index.ctypes.data)
+                                         out.ctypes.data, C.byref(out_n), lab_p, idx_p)
         else:  # cloud still in the sensor frame: 3x4 (R | t) of map <- cloud frame, transformed on the device
             tf = (C.c_double * 12)(*[float(v) for v in np.asarray(map_from_cloud, dtype=np.float64).reshape(-1)[:12]])
             rc = self._L.gg_filter_cloud_tf(self._ctx, gm.slot, cloud.ctypes.data, n, tf, org, float(mapToBase_z),
-                                            out.ctypes.data, C.byref(out_n), labels.ctypes.data, index.ctypes.data)
+                                            out.ctypes.data, C.byref(out_n), lab_p, idx_p)
         _check(self._L, self._ctx, rc, "gg_filter_cloud")
         seg = out[: out_n.value]
         if return_details:
@@ -366,15 +386,15 @@ class GroundSegmentation:
         self._async[t.value] = cloud  # keeps the input alive until the wait
         return t.value
 
-    def filter_cloud_wait(self, ticket: int, return_details: bool = False, want_cloud: bool = True):
+    def filter_cloud_wait(self, ticket: int, return_details: bool = False, want_cloud: bool = True, reuse_buffers: bool = False):
         cloud = self._async.pop(ticket)
         n = cloud.shape[0]
-        out = np.zeros(max(n, 1) * 32, dtype=np.uint8).view(POINT_DTYPE) if want_cloud else None
-        labels = np.zeros(max(n, 1), dtype=np.uint8)
-        index = np.zeros(max(n, 1), dtype=np.int32)
+        out, labels, index = self._host_buffers(n, reuse_buffers)
+        if not want_cloud:
+            out = None
         out_n = C.c_size_t(0)
         rc = self._L.gg_filter_cloud_wait(self._ctx, ticket, out.ctypes.data if want_cloud else None, C.byref(out_n),
-                                          labels.ctypes.data, index.ctypes.data)
+                                          labels.ctypes.data if return_details else None, index.ctypes.data if return_details else None)
         _check(self._L, self._ctx, rc, "gg_filter_cloud_wait")
         seg = out[: out_n.value] if want_cloud else None
         if return_details:

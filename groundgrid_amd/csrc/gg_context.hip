@@ -99,6 +99,7 @@ struct gg_context {
     int32_t *d_stage_cell = nullptr;
     float *d_scroll_scratch = nullptr; // 2 layers
     float *d_image = nullptr;          // 3 * C floats (wire-format images)
+    float *d_planes = nullptr;         // GG_NUM_LAYERS * Cpad floats: dense planes of gg_get_layers (allocated on first use)
     float *d_bounds = nullptr;         // 2 floats
     unsigned long long *d_sweep_dbg = nullptr; // GG_SWEEP_TIMING=1: cycle counters of the sweep's wavefronts (cloud 0 of a batch)
 
@@ -688,6 +689,7 @@ void gg_destroy(gg_context *ctx)
     if (ctx->h_stage_labels) hipHostFree(ctx->h_stage_labels);
     if (ctx->h_stage_index) hipHostFree(ctx->h_stage_index);
     if (ctx->h_stage_counts) hipHostFree(ctx->h_stage_counts);
+    if (ctx->d_planes) hipFree(ctx->d_planes);
     if (ctx->d_arena) hipFree(ctx->d_arena);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -918,6 +920,28 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     HIPCHK(ctx, hipGetLastError());
     const float *plane = ctx->d_image;
     HIPCHK(ctx, hipMemcpyAsync(dst, plane, (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!dst) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
+    const size_t plane = ctx->arena.layer_stride;
+    if (!ctx->d_planes) HIPCHK(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)GG_NUM_LAYERS * plane * sizeof(float)));
+    for (int l = 0; l < GG_NUM_LAYERS; ++l) {
+        if (!dst[l]) continue;
+        float *d = ctx->d_planes + (size_t)l * plane;
+        if (l == GG_LAYER_GROUND || l == GG_LAYER_GROUNDPATCH)
+            launch_plane_extract(ctx->arena, slot, l == GG_LAYER_GROUNDPATCH, d, ctx->stream);
+        else
+            launch_layer_extract(ctx->arena, slot, l, d, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(dst[l], d, (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }

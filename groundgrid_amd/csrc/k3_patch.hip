@@ -232,11 +232,12 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             const int lr = k % LR, lc = k / LR;
             const int gr = r0 - HALO + lr, gcol = first_col + lc;
             const bool ok = lc < n_cols && gr < rows && gcol < cols;
-            const size_t idx = ok ? (size_t)gr + (size_t)gcol * rows : (size_t)0;
-            const float p = gp_pts[idx], v = gp_var[idx], m = gp_min[idx];
             // the per-call layers are sparse (gg_internal.h tile_live): a column that holds no record of this cloud has stale
-            // bytes and logically the reset values of :61-75 -- points 0, variance 0 / (0 + FLT_MIN) = 0, minGroundHeight FLT_MAX
+            // bytes and logically the reset values of :61-75 -- points 0, variance 0 / (0 + FLT_MIN) = 0, minGroundHeight FLT_MAX.
+            // Its lanes fetch element 0 like the out-of-range ones (still unconditional loads): no HBM traffic for dead columns
             const bool live = ok && ((live_cols[ok ? (gr - (r0 - HALO)) / TILE : 0][ok ? gcol / TILE : 0] >> (gcol % TILE)) & 1u) != 0u;
+            const size_t idx = live ? (size_t)gr + (size_t)gcol * rows : (size_t)0;
+            const float p = gp_pts[idx], v = gp_var[idx], m = gp_min[idx];
             sp[h] = live ? p : 0.0f;
             sv[h] = live ? v : 0.0f;
             sm[h] = live ? m : (ok ? FLT_MAX : 0.0f);

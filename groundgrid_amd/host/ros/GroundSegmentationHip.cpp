@@ -181,13 +181,16 @@ pcl::PointCloud<GroundSegmentation::PCLPoint>::Ptr GroundSegmentation::filter_cl
     }
     filtered_cloud->points.resize(n_out);
 
+    // the layers the publishers (and GroundGrid::update) read, in one go: the extraction kernels and the downloads are enqueued
+    // back to back and waited for once (gg_get_layers)
     const bool all = download_all_layers();
+    float *dst[GG_NUM_LAYERS];
     for (int l = 0; l < GG_NUM_LAYERS; ++l) {
         const bool state = l == GG_LAYER_GROUND || l == GG_LAYER_GROUNDPATCH || l == GG_LAYER_POINTS || l == GG_LAYER_POINTSRAW;
-        if (!(all || state)) continue;
-        const int rc_down = gg_get_layer(g_ctx, 0, l, map[kLayerNames[l]].data());
-        if (rc_down != GG_OK) ROS_ERROR("groundgrid_hip: downloading layer %s failed with status %d (%s)", kLayerNames[l], rc_down, gg_last_error(g_ctx));
+        dst[l] = (all || state) ? map[kLayerNames[l]].data() : nullptr;
     }
+    const int rc_down = gg_get_layers(g_ctx, 0, dst);
+    if (rc_down != GG_OK) ROS_ERROR("groundgrid_hip: downloading the layers failed with status %d (%s)", rc_down, gg_last_error(g_ctx));
     return filtered_cloud;
 }
 

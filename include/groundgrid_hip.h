@@ -197,6 +197,10 @@ int gg_get_map_position(const gg_context *ctx, int slot, double *pos_x, double *
 /* any of the 11 layers, column-major rows x cols float32 (Eigen::MatrixXf), host memory */
 int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src);
 int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst);
+/* several layers in one go: dst[l] (nullable) receives layer l.  What the nodelet's publishers need after a cloud
+ * (src/GroundGridNodelet.cpp:211-224 publishes every layer that has a subscriber): the extraction kernels and the downloads of
+ * all requested layers are enqueued back to back and waited for once, instead of one synchronisation per layer. */
+int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS]);
 /* GroundSegmentation::expectedPoints (src/GroundSegmentation.cpp:40-46), host copy */
 int gg_get_expected_points(const gg_context *ctx, float *dst);
 
