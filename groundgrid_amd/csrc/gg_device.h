@@ -74,13 +74,17 @@ GG_DEV void index_from_position(const Geometry &g, double pos_x, double pos_y, d
     col = index_of((py - g.half1) - pos_y, g.resolution, g.inv_resolution);
 }
 
-// grid_map_core checkIfPositionWithinMap: t = -I * ((p - mapPos) - L/2); 0 <= t < L per axis
+// grid_map_core checkIfPositionWithinMap: t = M ((p - mapPos) - L/2) with M = [[-1, 0], [0, -1]] (the buffer-order transform);
+// 0 <= t < L per axis.  t_x = -1.0 * a_x + 0.0 * a_y equals -a_x whenever a_y is finite (the products are exact, adding a signed
+// zero changes at most the sign of a zero, which no comparison sees), and when a_y is NaN or infinite t_y = 0.0 * a_x - a_y fails
+// its own range test -- so "inside" is exactly the four comparisons on -a_x, -a_y (the same holds with x and y exchanged); the
+// oracle keeps the matrix form (oracle/gg_oracle.c ggo_get_index), the parity tests hold the two together (NaN / inf points in
+// test_edge_cases and the fuzz scenes).
 GG_DEV bool position_inside(const Geometry &g, double pos_x, double pos_y, double px, double py)
 {
     const double ax = (px - pos_x) - g.half0;
     const double ay = (py - pos_y) - g.half1;
-    const double tx = -1.0 * ax + 0.0 * ay;
-    const double ty = 0.0 * ax + -1.0 * ay;
+    const double tx = -ax, ty = -ay;
     return tx >= 0.0 && ty >= 0.0 && tx < g.length0 && ty < g.length1;
 }
 

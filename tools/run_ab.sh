@@ -1,4 +1,7 @@
-mkdir -p gpurun_out/r03i; O=gpurun_out/r03i
-(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4) > $O/pytest.log; cat $O/pytest.log
-GG_HOST_TIMING=1 python tools/host_path_rate.py > $O/host_path.txt 2>&1; cat $O/host_path.txt | tail -6
-python tools/ab_kernels.py 1024 8 k3dead > $O/ab.json 2>>$O/err.log; cat $O/ab.json
+mkdir -p gpurun_out/r03j; O=gpurun_out/r03j
+V=$PWD/groundgrid_amd/variants
+(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -12) > $O/pytest.log; grep -E "passed|failed|Error|error" $O/pytest.log
+for i in 1 2; do
+GROUNDGRID_HIP_LIB=$V/lib_head.so python tools/ab_kernels.py 1024 8 head > $O/ab_head$i.json 2>>$O/err.log; cat $O/ab_head$i.json
+python tools/ab_kernels.py 1024 8 new > $O/ab_new$i.json 2>>$O/err.log; cat $O/ab_new$i.json
+done
