@@ -710,7 +710,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
     const uint32_t *list_cnt = a.tile_list_cnt + (size_t)cp.slot * 2;
     if (a.k2_debug == 1) return;
-    const unsigned long long t_wg = a.k2_debug == 9 ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long t_wg = (a.k2_debug == 9 || a.k2_debug == 5) ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long *census = nullptr; // (GG_K2_DEBUG=5, tools/k2_census.py: which CU runs how many work-groups at a time)
+    if (a.k2_debug == 5 && threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_ID, XCC_ID
+        census = a.k2_dbg + (size_t)(((xcc & 7u) << 7) | ((hw >> 8) & 0x7Fu)) * 8;
+        atomicAdd(&census[0], 1ull);
+        const unsigned long long r = atomicAdd(&census[1], 1ull) + 1ull;
+        atomicMax(&census[2], r);
+        atomicMin(&census[4], t_wg);
+    }
     if (group < n_dense_groups) {
         const int n_dense = (int)list_cnt[1];
         for (int j = group; j < n_dense; j += n_dense_groups) {
@@ -731,6 +740,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const int n_waves = ((int)gridDim.x - n_dense_groups) * 4;
         const int wave = threadIdx.x >> 6;
         reduce_light_tiles<FULL>(a, cp, tile_list, n_light, (group - n_dense_groups) * 4 + wave, n_waves, lds.light[wave]);
+    }
+    if (census) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        atomicAdd(&census[1], ~0ull); // (-1)
+        atomicAdd(&census[3], t_end - t_wg);
+        atomicMax(&census[5], t_end);
     }
     if (a.k2_debug == 9 && threadIdx.x == 0) {
         const int k = group < n_dense_groups ? 24 : 26;
