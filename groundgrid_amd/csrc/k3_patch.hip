@@ -82,15 +82,8 @@ template <class F> GG_DEV float stream_tree25_eigen34(F get)
     return res;
 }
 
-// first half, in two pieces around the (unconditional) load of the old cell: the block's point count and the test of
-// :364-365, then the two weighted sums (:372-375).  Everything that needs the LDS window.
-template <int S, class Win> GG_DEV float patch_point_count(const Arena &a, const Win &pts, int lr, int lc)
-{
-    constexpr int ci = S / 2; // :352
-    const bool e34 = a.eigen_reduction == GG_EIGEN_34_SSE; // (uniform) which Eigen the reference was built against
-    auto P = [&](int s) { return pts[lc - ci + s / S][lr - ci + s % S]; }; // element s of a block, column-major (:355)
-    return (S == 3) ? stream_tree9(P) : e34 ? stream_tree25_eigen34(P) : stream_tree25(P); // :359
-}
+// first half: the two weighted sums (:372-375) of a cell that passed the point-count test of :364-365 (k_patch computes the
+// count itself, as a box filter).  Everything that needs the LDS window.
 template <int S>
 GG_DEV void patch_sums(const Arena &a, const float (*pts)[LR], const float (*var)[LR], const float (*mnl)[LR], int lr, int lc, PatchCarry &pc)
 {
@@ -157,6 +150,12 @@ constexpr int RING = 16, SLOTS = RING + 4, MAXTC = 256;
 __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams *__restrict__ params, int n_bands, int blocks_per_segment)
 {
     __shared__ float pts[SLOTS][LR], var[SLOTS][LR], mnl[SLOTS][LR];
+    // vertical partial sums of `points` over the window's 12 columns and the block's 32 rows: 5 rows (v5) and the middle 3 (v3).
+    // `points` holds COUNTS -- integer-valued floats far below 2^24 -- so the S x S block sum of :359 is an exact integer in ANY
+    // order of addition: the one float sum of the path that may be taken as a separable box filter (5 + 5 taps instead of 25,
+    // the vertical half shared by the cells of a column) and still equals Eigen's tree sum bit for bit.  It is the sum EVERY
+    // visited cell pays for (:364 decides on it); the two weighted sums (:374-375) keep Eigen's order.
+    __shared__ float v5[LC][PR], v3[LC][PR];
     __shared__ uint32_t col_has_points[MAXTC]; // per tile column: records in the band's tile rows
     __shared__ uint16_t live_cols[3][MAXTC];   // tile_live of the band's (up to three) tile rows: which columns physically hold values
     // XCD-aware (gg_device.h): the bands of one cloud run on one XCD.  A launch with few clouds cuts every band into segments
@@ -290,8 +289,19 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
         const float sqdist = (float)((di * di + dj * dj) * ((double)a.g.resolution_f * (double)a.g.resolution_f));
         const bool visited = cell_visited(j), near = (double)sqdist <= a.cfg.patch_size_change_distance_sq; // :334
+        // :359 the block's point count from the vertical partial sums (exact: integers, see v5 / v3)
+        for (int e = tid; e < LC * PR; e += 256) {
+            const int c = e / PR, r = e % PR;
+            const float *col = pts[base + c] + r; // rows r .. r + 4 of the window = output row r - 2 .. r + 2
+            const float mid = (col[1] + col[2]) + col[3];
+            v3[c][r] = mid;
+            v5[c][r] = (col[0] + col[4]) + mid;
+        }
+        __syncthreads();
         float pointsblockSum = 0.0f;
-        if (visited) pointsblockSum = near ? patch_point_count<3>(a, pts + base, lr, lc) : patch_point_count<5>(a, pts + base, lr, lc);
+        if (visited)
+            pointsblockSum = near ? (v3[tcl + 1][tr] + v3[tcl + 2][tr]) + v3[tcl + 3][tr]
+                                  : ((v5[tcl][tr] + v5[tcl + 1][tr]) + (v5[tcl + 2][tr] + v5[tcl + 3][tr])) + v5[tcl + 4][tr];
         const int S = near ? 3 : 5;
         // :364-365
         const bool pass = visited && !((double)pointsblockSum < std_max(floor(a.cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) &&

@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r03j; O=gpurun_out/r03j
+mkdir -p gpurun_out/r03k; O=gpurun_out/r03k
 V=$PWD/groundgrid_amd/variants
 (timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -12) > $O/pytest.log; grep -E "passed|failed|Error|error" $O/pytest.log
 for i in 1 2; do
