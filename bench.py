@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--config4-batch", type=int, default=128, help="clouds per launch of the configs[3] leg (GPU-filling)")
     ap.add_argument("--abi-collective", action="store_true", help="all-gather through the C ABI (gg_allgather_label_masks, RCCL bound by the "
                     "library itself) instead of torch.distributed")
+    ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (RCCL process group, all-gather per step) even with one rank")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the N ranks only (gloo when no GPU is visible): launch-path check")
     ap.add_argument("--kitti-dir", default=None, help="SemanticKITTI sequence directory: replay it instead of the synthetic bench")
     ap.add_argument("--kitti-max-frames", type=int, default=0)
@@ -194,10 +195,11 @@ def main():
         return kitti_leg(args, local_rank)
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:  # (--force-dist: the multi-GPU code path -- RCCL process group, async gathers -- with ONE rank)
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist = dist_mod
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 

@@ -120,3 +120,27 @@ def test_allgather_through_the_c_abi_single_rank():
     assert torch.equal(got2, out.label_masks)
     gather.close()
     seg.close()
+
+
+@pytest.mark.parametrize("abi", [False, True])
+def test_bench_multi_gpu_code_path_with_one_rank(abi):
+    """bench.py's N > 1 code path on the one GPU this box has (--force-dist: an RCCL process group of one rank): the per-step
+    all-gather of the label masks overlapped with the next step (torch.distributed, or the library's own C entry point with
+    --abi-collective), the configs[2] leg with the gathered masks held against the labels, and the timed batch's oracle check --
+    everything the 8-GPU run executes except a second rank."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--batch", "48", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1",
+           "--config4-batch", "2"] + (["--abi-collective"] if abi else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["collective"]["rccl_ranks"] == 1 and r["collective"]["backend"] == "nccl"
+    assert ("C ABI" in r["collective"]["issued_by"]) == abi
+    assert r["parity_checked_in_run"] is True and r["warm_map"]["parity_checked_in_run"] is True
+    assert r["config3"]["gathered_masks_match_labels"] is True and r["config3"]["parity_checked_in_run"] is True
+    assert r["config4"]["parity_checked_in_run"] is True and r["config4"]["single_cloud"]["parity_checked_in_run"] is True
