@@ -195,6 +195,8 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
         // a join makes the compiler copy freshly loaded registers, i.e. wait for the loads it has just issued
         ChainSync<SIDE> sync;
         sync.init(r0, nl, group, P, L);
+        // which third of the steps can end a chain: t = tb + u with tb = t_first (mod TRIP), TRIP = 0 (mod 3)
+        const int turn = (((join_turn_residue<SIDE>(r0) - t_first) % 3) + 3) % 3; // u = turn (mod 3)
         for (int tb = t_first; tb <= t_last; tb += TRIP) {
 #pragma unroll
             for (int u = 0; u < TRIP; ++u) {
@@ -226,7 +228,7 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
                 const int tmod = (t_first_mod + u) % (int)SKEW;
                 st.step_a(t, u % (int)PF, tmod, x_in, P, L, group > 0, mem);
                 if (!sync.ok_b()) wait_for([&]() { return sync.ok_b(); });
-                st.step_b(t, tmod, P, L, has_next, group, mem);
+                st.step_b(t, tmod, P, L, has_next, group, mem, SKEW != 1 || (u % 3) == turn);
             }
         }
     }

@@ -38,6 +38,7 @@
 
 #include <float.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "gp_layout.h"
 
@@ -153,10 +154,22 @@ SW_HD float decayed_confidence(float occupied, bool decay, const Params &P)
     const float floor_f = (float)0.001;
     const double x = (double)occupied;
     const double t = x - x * P.inv_decrease;
-    const float lo = sw_maxf((float)(t * (1.0 - 0x1p-48)), floor_f);
-    const float hi = sw_maxf((float)(t * (1.0 + 0x1p-48)), floor_f);
-    float d = lo;
-    const bool exact = !(P.decay_fast && lo == hi) && decay;
+    // t is within a relative 2^-49 of the reference's x - x / decrease (decrease >= 1.25), i.e. within 32 of its own ulps, so the
+    // two convert to the same float unless t's significand lies that close to a binary32 rounding boundary -- the midpoint of two
+    // floats: low 29 bits of the significand = 2^28.  Integer test on the low word (64 ulps of margin) instead of converting both
+    // ends of the interval: the sweep is bound by instruction issue, and this is three integer instructions for two binary64
+    // multiplies, a conversion and a max.  (Results below the floor or not finite need no care: 0.001, inf and NaN come out of
+    // either form alike.)
+    uint64_t bits;
+#if defined(__HIP_DEVICE_COMPILE__)
+    bits = (uint64_t)__double_as_longlong(t);
+#else
+    memcpy(&bits, &t, 8);
+#endif
+    const uint32_t low = (uint32_t)bits & 0x1FFFFFFFu;
+    const bool near_boundary = (low - (0x10000000u - 64u)) <= 128u;
+    float d = sw_maxf((float)t, floor_f);
+    const bool exact = (!P.decay_fast || near_boundary) && decay;
     if (sw_any(exact)) {
         SW_KEEP_BRANCH();
         const float de = (float)sw_max(x - x / P.decrease, 0.001);
@@ -505,8 +518,10 @@ template <int SIDE> struct ChainLane {
         xa = t + 1 == lend ? xold : xa; // s + 2 == len + 1
     }
 
+    // join_turn: (wave-uniform) some lane of the group can end its chain at this step -- lane l ends at t + 1 = 3 l + lend of
+    // lane 0 (SKEW = 1), i.e. in every third step only; see join_turn_of
     template <class Mem>
-    SW_HD void step_b(int t, int tmod, const Params &P, const LdsMap &L, bool has_next_group, int group, Mem &mem)
+    SW_HD void step_b(int t, int tmod, const Params &P, const LdsMap &L, bool has_next_group, int group, Mem &mem, bool join_turn = true)
     {
         WP x = xa;
         if (t >= u_join_first && t <= u_join_last) {
@@ -544,12 +559,18 @@ template <int SIDE> struct ChainLane {
         h2 = h1;
         h1 = res;
         // ---- publish what other wavefronts wait for (data first, then the counter)
-        mem.publish_if(t + 1 == lend && len > 0, l, L, a_pub, res, L.join_done + SIDE, r);
+        if (join_turn) mem.publish_if(t + 1 == lend && len > 0, l, L, a_pub, res, L.join_done + SIDE, r);
         if (has_next_group && t >= u_l3_last && t < u_lend_last) // (uniform: only while the last lane runs)
             mem.publish_if(l == LANES - 1 && active, l, L, L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) - L.bnd_base + (t - l3)), res,
                            L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
     }
 };
+
+// Lane l of a group ends its chain at wave-step t with t + 1 = lend_l = (SKEW + 2) l + lend_0: with SKEW = 1 only every third step
+// has a lane that publishes its last value.  Residue of those steps modulo 3 (wave-uniform per group); the device's unrolled loop
+// compares it with a compile-time constant and skips the publish's address selects and LDS writes in the other two thirds.
+template <int SIDE> SW_HD int join_turn_residue(int r0) { return (((chain_len<SIDE>(r0) - 1) % 3) + 3) % 3; } // t = lend_0 - 1 (mod 3)
+SW_HD bool join_turn_of(int t, int residue) { return SKEW != 1 || ((t % 3) + 3) % 3 == residue; }
 
 // first / last wave-step of a group (lane 0 starts its warm-up columns at step -2, loads are requested PF steps earlier)
 SW_HD int group_first_step() { return -2 - PF; }

@@ -171,7 +171,7 @@ template <int SIDE> struct ChainWave : WaveBase {
             const int s_ = t - c.l3;
             if (c.len > 0 && s_ == c.len - 2 && s_ >= -1 && mem.counter(sync.w_join) < ((SIDE == SIDE_A || SIDE == SIDE_B) ? c.r - 1 : c.r)) plan_mismatch = true;
         }
-        for (int l = 0; l < LANES; ++l) lane[l].step_b(t, tmod, P, L, group + 1 < P.groups, group, mem);
+        for (int l = 0; l < LANES; ++l) lane[l].step_b(t, tmod, P, L, group + 1 < P.groups, group, mem, join_turn_of(t, join_turn_residue<SIDE>(r0)));
         half = false;
         ++steps;
         advanced = false;

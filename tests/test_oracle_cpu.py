@@ -321,17 +321,30 @@ def test_map_update_semantics():
 
 
 def test_decay_multiply_guard_is_exact():
-    """k4_spiral.hip computes (float)max(x - x/d, 0.001) (GroundSegmentation.cpp:463-464, double arithmetic) as
-    x - x*(1/d) when both ends of the +-2^-48 interval around that value convert to the same float.  Whenever the guard
-    accepts, the result must equal the divide form bit for bit."""
+    """sweep_core.h decayed_confidence computes (float)max(x - x/d, 0.001) (GroundSegmentation.cpp:463-464, double arithmetic) as
+    x - x*(1/d) unless the low 29 bits of that double's significand lie within 64 ulps of 2^28 (a binary32 rounding boundary) --
+    then, or for d < 1.25, the division decides.  Whenever the guard accepts, the result must equal the divide form bit for bit;
+    the guard must be at least as strict as round 2's interval test (both ends of +-2^-48 convert alike)."""
     rng = np.random.default_rng(5)
     for d in (1.25, 1.3, 2.0, 3.0, 5.0, 7.3, 1e6):
         x = np.concatenate([rng.random(2_000_000, dtype=np.float32), np.float32(10.0) ** rng.uniform(-30, 3, 500_000).astype(np.float32),
                             np.array([0.0, 1.0, 0.5, 1e-7, 0.001, 0.00125, 0.0012500001], dtype=np.float32)]).astype(np.float64)
         exact = np.maximum(x - x / d, 0.001).astype(np.float32)
         t = x - x * (1.0 / d)
+        low = t.view(np.uint64).astype(np.uint64) & np.uint64(0x1FFFFFFF)
+        near = ((low - np.uint64(0x10000000 - 64)) & np.uint64(0xFFFFFFFF)) <= np.uint64(128)
+        fast = np.maximum(t, 0.001).astype(np.float32)
+        ok = ~near
+        assert ok.mean() > 0.999
+        assert np.array_equal(fast[ok], exact[ok])
+        # wherever the interval test of round 2 could not decide and the value is above the floor, the new guard refuses as well
         lo = np.maximum(t * (1.0 - 2.0 ** -48), 0.001).astype(np.float32)
         hi = np.maximum(t * (1.0 + 2.0 ** -48), 0.001).astype(np.float32)
-        ok = lo == hi
-        assert ok.mean() > 0.999
-        assert np.array_equal(lo[ok], exact[ok])
+        assert not np.any((lo != hi) & ok)
+    # adversarial: doubles constructed right next to binary32 midpoints, pushed through the guard as `t`
+    m = (np.arange(1 << 12, dtype=np.uint64) << np.uint64(41)) | np.uint64(0x10000000)  # significands with low 29 bits = 2^28
+    for delta in range(-80, 81, 8):
+        bits = (np.uint64(0x3FB) << np.uint64(52)) | ((m + np.uint64(delta % (1 << 64))) & np.uint64((1 << 52) - 1))
+        low = bits & np.uint64(0x1FFFFFFF)
+        near = ((low - np.uint64(0x10000000 - 64)) & np.uint64(0xFFFFFFFF)) <= np.uint64(128)
+        assert near.all() == (abs(delta) <= 64), delta
