@@ -9,9 +9,14 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstdio>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <chrono>
 
@@ -33,8 +38,81 @@ struct EventPair {
 
 } // namespace
 
+// One helper thread per context for the host-buffer entry points: packing the input cloud and assembling the returned cloud are
+// two memory-bound loops of ~0.07 and ~0.12 ms per HDL-64E cloud on one core, a third of what a synchronous gg_filter_cloud
+// costs beyond its kernels.  The caller's thread takes the first half of a range, the helper the second.  GG_HOST_THREADS=1
+// keeps everything on the caller's thread.
+class HostHelper {
+  public:
+    HostHelper() = default;
+    HostHelper(const HostHelper &) = delete;
+    ~HostHelper() { stop(); }
+    void start()
+    {
+        if (running_) return;
+        running_ = true;
+        thread_ = std::thread([this] { loop(); });
+    }
+    void stop()
+    {
+        if (!running_) return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_one();
+        thread_.join();
+        running_ = false;
+    }
+    // fn(lo, hi) over [0, n): second half on the helper, first half here; returns when both are done
+    template <class F> void split(size_t n, F fn)
+    {
+        if (!running_ || n < 4096) {
+            fn((size_t)0, n);
+            return;
+        }
+        const size_t mid = n / 2;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = [&fn, mid, n] { fn(mid, n); };
+            done_.store(false, std::memory_order_relaxed);
+            have_job_ = true;
+        }
+        cv_.notify_one();
+        fn((size_t)0, mid);
+        while (!done_.load(std::memory_order_acquire)) { // (the halves are equal: a short spin, not a sleep)
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+
+  private:
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [this] { return have_job_ || quit_; });
+            if (quit_) return;
+            std::function<void()> job = std::move(job_);
+            have_job_ = false;
+            lk.unlock();
+            job();
+            done_.store(true, std::memory_order_release);
+            lk.lock();
+        }
+    }
+    std::thread thread_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    std::atomic<bool> done_{true};
+    bool have_job_ = false, quit_ = false, running_ = false;
+};
+
 struct gg_context {
     int device = 0;
+    HostHelper helper;
     hipStream_t stream = nullptr;
     Arena arena{};
     gg_config cfg{};
@@ -522,9 +600,10 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     size_t o_apts[GG_ASYNC_DEPTH], o_alab[GG_ASYNC_DEPTH], o_aidx[GG_ASYNC_DEPTH], o_acnt[GG_ASYNC_DEPTH];
     for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
         o_apts[k] = carve(max_points * sizeof(gg_point16));
-        o_alab[k] = carve(max_points);
-        o_aidx[k] = carve(max_points * 4);
-        o_acnt[k] = carve(64);
+        // results of one ticket as ONE block -- counts (64 B), then the index (4 n B), then the labels (n B) -- so that they come back
+        // with a single copy; where index and labels start inside it depends on the ticket's n
+        o_acnt[k] = carve(64 + max_points * 5 + 64);
+        o_aidx[k] = o_alab[k] = 0;
     }
     const size_t o_scroll = carve(a.gp2_stride * 8); // one layer in its device element order (map scroll) / two planes (images)
     const size_t o_image = carve(3 * Cpad * 4);
@@ -573,9 +652,9 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
         gg_context::AsyncSlot &as = ctx->async_slot[k];
         as.d_pts = (gg_point16 *)(base + o_apts[k]);
-        as.d_labels = (uint8_t *)(base + o_alab[k]);
-        as.d_index = (int32_t *)(base + o_aidx[k]);
         as.d_counts = (int32_t *)(base + o_acnt[k]);
+        as.d_index = (int32_t *)(base + o_acnt[k] + 64);
+        as.d_labels = nullptr; // (placed per ticket: behind the n index entries)
     }
     ctx->d_scroll_scratch = (float *)(base + o_scroll);
     ctx->d_image = (float *)(base + o_image);
@@ -631,14 +710,15 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
         gg_context::AsyncSlot &as = ctx->async_slot[k];
         CREATE_CHK(hipHostMalloc((void **)&as.h_pts, max_points * sizeof(gg_point16), hipHostMallocDefault));
-        CREATE_CHK(hipHostMalloc((void **)&as.h_labels, max_points, hipHostMallocDefault));
-        CREATE_CHK(hipHostMalloc((void **)&as.h_index, max_points * 4, hipHostMallocDefault));
-        CREATE_CHK(hipHostMalloc((void **)&as.h_counts, 64, hipHostMallocDefault));
+        CREATE_CHK(hipHostMalloc((void **)&as.h_counts, 64 + max_points * 5 + 64, hipHostMallocDefault)); // (the same block on the host)
+        as.h_index = as.h_counts + 16;
+        as.h_labels = nullptr;
         CREATE_CHK(hipEventCreateWithFlags(&as.uploaded, hipEventDisableTiming));
         CREATE_CHK(hipEventCreateWithFlags(&as.computed, hipEventDisableTiming));
         CREATE_CHK(hipEventCreateWithFlags(&as.downloaded, hipEventDisableTiming));
     }
 
+    if (!(getenv("GG_HOST_THREADS") && atoi(getenv("GG_HOST_THREADS")) <= 1)) ctx->helper.start();
     {
         const int rc = gg_reset_maps(ctx, 0, n_slots, 0.0, 0.0, 0.0f, 0, nullptr); // (one strided fill per layer for all slots)
         if (rc != GG_OK) {
@@ -655,6 +735,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 void gg_destroy(gg_context *ctx)
 {
     if (!ctx) return;
+    ctx->helper.stop();
     hipSetDevice(ctx->device);
     if (ctx->have_batch_event) hipEventSynchronize(ctx->batch_event);
     if (ctx->h2d_stream) hipStreamSynchronize(ctx->h2d_stream);
@@ -673,9 +754,7 @@ void gg_destroy(gg_context *ctx)
     for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
         gg_context::AsyncSlot &as = ctx->async_slot[k];
         if (as.h_pts) hipHostFree(as.h_pts);
-        if (as.h_labels) hipHostFree(as.h_labels);
-        if (as.h_index) hipHostFree(as.h_index);
-        if (as.h_counts) hipHostFree(as.h_counts);
+        if (as.h_counts) hipHostFree(as.h_counts); // (index and labels live in the same block)
         if (as.uploaded) hipEventDestroy(as.uploaded);
         if (as.computed) hipEventDestroy(as.computed);
         if (as.downloaded) hipEventDestroy(as.downloaded);
@@ -1106,7 +1185,7 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
     for (int c = 0; c < 4; ++c) {
         const size_t lo = n * c / 4, hi = n * (c + 1) / 4;
         if (hi == lo) continue;
-        pack_points(cloud + lo, as.h_pts + lo, hi - lo);
+        ctx->helper.split(hi - lo, [&](size_t a0, size_t a1) { pack_points(cloud + lo + a0, as.h_pts + lo + a0, a1 - a0); });
         HIPCHK(ctx, hipMemcpyAsync(as.d_pts + lo, as.h_pts + lo, (hi - lo) * sizeof(gg_point16), hipMemcpyHostToDevice, ctx->h2d_stream));
     }
     if (host_timing) ctx->host_t[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack0).count();
@@ -1124,6 +1203,8 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
     b.origins = origin;
     b.base_z = &base_z;
     b.transforms = tf;
+    as.d_labels = reinterpret_cast<uint8_t *>(as.d_index + n); // [counts][index: n][labels: n]
+    as.h_labels = reinterpret_cast<uint8_t *>(as.h_index + n);
     b.d_labels = as.d_labels;
     b.d_out_index = as.d_index;
     b.d_out_clouds = nullptr;
@@ -1134,11 +1215,7 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
 
     // results come back on their own stream, so that the next ticket's kernels do not queue behind this download
     HIPCHK(ctx, hipStreamWaitEvent(ctx->d2h_stream, as.computed, 0));
-    if (n) {
-        HIPCHK(ctx, hipMemcpyAsync(as.h_labels, as.d_labels, n, hipMemcpyDeviceToHost, ctx->d2h_stream));
-        HIPCHK(ctx, hipMemcpyAsync(as.h_index, as.d_index, n * 4, hipMemcpyDeviceToHost, ctx->d2h_stream));
-    }
-    HIPCHK(ctx, hipMemcpyAsync(as.h_counts, as.d_counts, 16, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    HIPCHK(ctx, hipMemcpyAsync(as.h_counts, as.d_counts, 64 + n * 5, hipMemcpyDeviceToHost, ctx->d2h_stream)); // counts + index + labels: one copy
     HIPCHK(ctx, hipEventRecord(as.downloaded, ctx->d2h_stream));
 
     as.cloud = cloud;
@@ -1170,18 +1247,23 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
         // the returned cloud (:173-189): the host owns the input, so it assembles the output from index + label
         const gg_point32 *cloud = as.cloud;
         const double *tf = as.has_tf ? as.tf : nullptr;
-        for (size_t i = 0; i < n; ++i) {
-            const int32_t k = as.h_index[i];
-            if (k < 0) continue;
-            out_cloud[k] = cloud[i];
-            if (tf) { // map-frame coordinates, same arithmetic as the device (this file is built with -ffp-contract=off)
-                const double dx = (double)cloud[i].x, dy = (double)cloud[i].y, dz = (double)cloud[i].z;
-                out_cloud[k].x = (float)(((tf[0] * dx + tf[1] * dy) + tf[2] * dz) + tf[3]);
-                out_cloud[k].y = (float)(((tf[4] * dx + tf[5] * dy) + tf[6] * dz) + tf[7]);
-                out_cloud[k].z = (float)(((tf[8] * dx + tf[9] * dy) + tf[10] * dz) + tf[11]);
+        const int32_t *h_index = as.h_index;
+        const uint8_t *h_labels = as.h_labels;
+        // (every input point has its own position in the returned cloud: the two halves of the input write disjoint records)
+        ctx->helper.split(n, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; ++i) {
+                const int32_t k = h_index[i];
+                if (k < 0) continue;
+                out_cloud[k] = cloud[i];
+                if (tf) { // map-frame coordinates, same arithmetic as the device (this file is built with -ffp-contract=off)
+                    const double dx = (double)cloud[i].x, dy = (double)cloud[i].y, dz = (double)cloud[i].z;
+                    out_cloud[k].x = (float)(((tf[0] * dx + tf[1] * dy) + tf[2] * dz) + tf[3]);
+                    out_cloud[k].y = (float)(((tf[4] * dx + tf[5] * dy) + tf[6] * dz) + tf[7]);
+                    out_cloud[k].z = (float)(((tf[8] * dx + tf[9] * dy) + tf[10] * dz) + tf[11]);
+                }
+                out_cloud[k].intensity = (float)h_labels[i];
             }
-            out_cloud[k].intensity = (float)as.h_labels[i];
-        }
+        });
     }
     if (host_timing) {
         ctx->host_t[2] += std::chrono::duration<double>(t_w1 - t_w0).count();

@@ -47,6 +47,15 @@ class GridMap {
         check(gg_get_layer(ctx_, slot_, id, v.data()), "gg_get_layer");
         return v;
     }
+    // all 11 layers with one synchronisation (what a publisher loop reads after a cloud, src/GroundGridNodelet.cpp:211-224)
+    std::vector<std::vector<float>> layers() const
+    {
+        std::vector<std::vector<float>> all((size_t)GG_NUM_LAYERS, std::vector<float>((size_t)rows_ * cols_));
+        float *dst[GG_NUM_LAYERS];
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) dst[l] = all[(size_t)l].data();
+        check(gg_get_layers(ctx_, slot_, dst), "gg_get_layers");
+        return all;
+    }
     void setLayer(gg_layer id, const std::vector<float> &v)
     {
         if (v.size() != (size_t)rows_ * cols_) throw std::runtime_error("setLayer: size mismatch");

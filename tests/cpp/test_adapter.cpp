@@ -64,9 +64,11 @@ int main()
         ok &= out.size() == rn && std::memcmp(out.data(), rout.data(), rn * sizeof(gg_point32)) == 0;
         ok &= std::memcmp(seg.labels().data(), rlabel.data(), cloud.size()) == 0;
         ok &= std::memcmp(seg.out_index().data(), rindex.data(), cloud.size() * 4) == 0;
+        const std::vector<std::vector<float>> all = seg.map().layers(); // one synchronisation for the eleven (gg_get_layers)
         for (int l = 0; l < GG_NUM_LAYERS && ok; ++l) {
             const std::vector<float> a = seg.map().layer((gg_layer)l);
             ok &= same_floats(a.data(), ref->layer[l], a.size());
+            ok &= same_floats(all[(size_t)l].data(), ref->layer[l], a.size());
         }
         std::vector<std::pair<size_t, groundgrid_hip::GroundSegmentation::Index>> pi, ig;
         std::vector<size_t> outl;
