@@ -38,49 +38,50 @@ struct EventPair {
 
 } // namespace
 
-// One helper thread per context for the host-buffer entry points: packing the input cloud and assembling the returned cloud are
-// two memory-bound loops of ~0.07 and ~0.12 ms per HDL-64E cloud on one core, a third of what a synchronous gg_filter_cloud
-// costs beyond its kernels.  The caller's thread takes the first half of a range, the helper the second.  GG_HOST_THREADS=1
-// keeps everything on the caller's thread.
+// Helper threads of a context for the host-buffer entry points: packing the input cloud and assembling the returned cloud are two
+// memory-bound loops of ~0.07 and ~0.12 ms per HDL-64E cloud on one core, a third of what a synchronous gg_filter_cloud costs
+// beyond its kernels.  A range is cut into equal parts, the caller's thread takes the first, the helpers the others.
+// GG_HOST_THREADS = threads per context including the caller's (default 4; 1 = everything on the caller's thread).
 class HostHelper {
   public:
     HostHelper() = default;
     HostHelper(const HostHelper &) = delete;
     ~HostHelper() { stop(); }
-    void start()
+    void start(int helpers)
     {
-        if (running_) return;
-        running_ = true;
-        thread_ = std::thread([this] { loop(); });
+        if (!threads_.empty() || helpers <= 0) return;
+        quit_ = false;
+        for (int k = 0; k < helpers; ++k) threads_.emplace_back([this, k] { loop(k); });
     }
     void stop()
     {
-        if (!running_) return;
+        if (threads_.empty()) return;
         {
             std::lock_guard<std::mutex> g(m_);
             quit_ = true;
+            ++epoch_;
         }
-        cv_.notify_one();
-        thread_.join();
-        running_ = false;
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+        threads_.clear();
     }
-    // fn(lo, hi) over [0, n): second half on the helper, first half here; returns when both are done
+    // fn(lo, hi) over [0, n) in parts() pieces; returns when all of them are done
     template <class F> void split(size_t n, F fn)
     {
-        if (!running_ || n < 4096) {
+        const size_t parts = threads_.size() + 1;
+        if (parts == 1 || n < 4096) {
             fn((size_t)0, n);
             return;
         }
-        const size_t mid = n / 2;
         {
             std::lock_guard<std::mutex> g(m_);
-            job_ = [&fn, mid, n] { fn(mid, n); };
-            done_.store(false, std::memory_order_relaxed);
-            have_job_ = true;
+            job_ = [&fn, n, parts](int k) { fn(n * (size_t)(k + 1) / parts, n * (size_t)(k + 2) / parts); };
+            pending_.store((int)threads_.size(), std::memory_order_relaxed);
+            ++epoch_;
         }
-        cv_.notify_one();
-        fn((size_t)0, mid);
-        while (!done_.load(std::memory_order_acquire)) { // (the halves are equal: a short spin, not a sleep)
+        cv_.notify_all();
+        fn((size_t)0, n / parts);
+        while (pending_.load(std::memory_order_acquire) != 0) { // (the parts are equal: a short spin, not a sleep)
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
@@ -88,26 +89,27 @@ class HostHelper {
     }
 
   private:
-    void loop()
+    void loop(int k)
     {
+        unsigned long seen = 0;
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            cv_.wait(lk, [this] { return have_job_ || quit_; });
+            cv_.wait(lk, [&] { return epoch_ != seen; });
+            seen = epoch_;
             if (quit_) return;
-            std::function<void()> job = std::move(job_);
-            have_job_ = false;
             lk.unlock();
-            job();
-            done_.store(true, std::memory_order_release);
+            job_(k); // (job_ stays valid until pending_ reaches 0: split() does not return before)
+            pending_.fetch_sub(1, std::memory_order_release);
             lk.lock();
         }
     }
-    std::thread thread_;
+    std::vector<std::thread> threads_;
     std::mutex m_;
     std::condition_variable cv_;
-    std::function<void()> job_;
-    std::atomic<bool> done_{true};
-    bool have_job_ = false, quit_ = false, running_ = false;
+    std::function<void(int)> job_;
+    std::atomic<int> pending_{0};
+    unsigned long epoch_ = 0;
+    bool quit_ = false;
 };
 
 struct gg_context {
@@ -718,7 +720,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         CREATE_CHK(hipEventCreateWithFlags(&as.downloaded, hipEventDisableTiming));
     }
 
-    if (!(getenv("GG_HOST_THREADS") && atoi(getenv("GG_HOST_THREADS")) <= 1)) ctx->helper.start();
+    ctx->helper.start((getenv("GG_HOST_THREADS") ? std::max(1, std::min(atoi(getenv("GG_HOST_THREADS")), 16)) : 4) - 1);
     {
         const int rc = gg_reset_maps(ctx, 0, n_slots, 0.0, 0.0, 0.0f, 0, nullptr); // (one strided fill per layer for all slots)
         if (rc != GG_OK) {
@@ -1168,8 +1170,11 @@ static void pack_points(const gg_point32 *__restrict__ cloud, gg_point16 *__rest
     }
 }
 
-int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *tf, const float origin[3],
-                          double base_z, int *ticket)
+// one ticket: pack + upload, the seven kernels, the download.  `pipelined`: uploads and downloads on their own streams so that
+// they overlap the neighbouring tickets' kernels (gg_filter_cloud_async); a synchronous call has nothing to overlap with and puts
+// everything on the context's stream instead -- no cross-stream events (four API calls, ~15 us per cloud)
+static int enqueue_ticket(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *tf, const float origin[3], double base_z,
+                          int *ticket, bool pipelined)
 {
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if ((!cloud && n) || !origin || !ticket) return fail(ctx, GG_ERR_INVALID, "null cloud / origin / ticket");
@@ -1180,17 +1185,19 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
 
     static const bool host_timing = getenv("GG_HOST_TIMING") != nullptr; // (tools: where does the host call spend its time)
     const auto t_pack0 = std::chrono::steady_clock::now();
-    // pack and upload in four pieces: the copy of a piece travels while the next one is packed (and all of it overlaps the
-    // device work of the previous ticket)
-    for (int c = 0; c < 4; ++c) {
-        const size_t lo = n * c / 4, hi = n * (c + 1) / 4;
+    // pack and upload in two pieces (each packed by all of the context's host threads): the copy of the first travels while the
+    // second is packed (and all of it overlaps the device work of the previous ticket)
+    for (int c = 0; c < 2; ++c) {
+        const size_t lo = n * c / 2, hi = n * (c + 1) / 2;
         if (hi == lo) continue;
         ctx->helper.split(hi - lo, [&](size_t a0, size_t a1) { pack_points(cloud + lo + a0, as.h_pts + lo + a0, a1 - a0); });
-        HIPCHK(ctx, hipMemcpyAsync(as.d_pts + lo, as.h_pts + lo, (hi - lo) * sizeof(gg_point16), hipMemcpyHostToDevice, ctx->h2d_stream));
+        HIPCHK(ctx, hipMemcpyAsync(as.d_pts + lo, as.h_pts + lo, (hi - lo) * sizeof(gg_point16), hipMemcpyHostToDevice, pipelined ? ctx->h2d_stream : ctx->stream));
     }
     if (host_timing) ctx->host_t[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack0).count();
-    HIPCHK(ctx, hipEventRecord(as.uploaded, ctx->h2d_stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, as.uploaded, 0));
+    if (pipelined) {
+        HIPCHK(ctx, hipEventRecord(as.uploaded, ctx->h2d_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, as.uploaded, 0));
+    }
 
     const int32_t n32 = (int32_t)n;
     gg_batch b{};
@@ -1211,12 +1218,14 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
     b.d_out_counts = as.d_counts;
     const int rc = enqueue_batch(ctx, &b, ctx->stream);
     if (rc != GG_OK) return rc;
-    HIPCHK(ctx, hipEventRecord(as.computed, ctx->stream));
-
     // results come back on their own stream, so that the next ticket's kernels do not queue behind this download
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->d2h_stream, as.computed, 0));
-    HIPCHK(ctx, hipMemcpyAsync(as.h_counts, as.d_counts, 64 + n * 5, hipMemcpyDeviceToHost, ctx->d2h_stream)); // counts + index + labels: one copy
-    HIPCHK(ctx, hipEventRecord(as.downloaded, ctx->d2h_stream));
+    const hipStream_t down = pipelined ? ctx->d2h_stream : ctx->stream;
+    if (pipelined) {
+        HIPCHK(ctx, hipEventRecord(as.computed, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(down, as.computed, 0));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(as.h_counts, as.d_counts, 64 + n * 5, hipMemcpyDeviceToHost, down)); // counts + index + labels: one copy
+    HIPCHK(ctx, hipEventRecord(as.downloaded, down));
 
     as.cloud = cloud;
     as.n = n;
@@ -1226,6 +1235,12 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
     *ticket = ctx->next_ticket++;
     if (host_timing) ctx->host_t[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack0).count();
     return GG_OK;
+}
+
+int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *tf, const float origin[3],
+                          double base_z, int *ticket)
+{
+    return enqueue_ticket(ctx, slot, cloud, n, tf, origin, base_z, ticket, true);
 }
 
 int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index)
@@ -1284,7 +1299,7 @@ static int filter_cloud_impl(gg_context *ctx, int slot, const gg_point32 *cloud,
     if (!ctx) return GG_ERR_INVALID;
     if (ctx->next_ticket != ctx->oldest_ticket) return fail(ctx, GG_ERR_INVALID, "gg_filter_cloud while async tickets are outstanding");
     int ticket = -1;
-    const int rc = gg_filter_cloud_async(ctx, slot, cloud, n, tf, origin, base_z, &ticket);
+    const int rc = enqueue_ticket(ctx, slot, cloud, n, tf, origin, base_z, &ticket, false);
     if (rc != GG_OK) return rc;
     return gg_filter_cloud_wait(ctx, ticket, out_cloud, out_n, out_label, out_index);
 }
