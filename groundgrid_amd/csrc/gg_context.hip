@@ -525,6 +525,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     }
     a.tune_sweep_waves = getenv("GG_SWEEP_WAVES") ? atoi(getenv("GG_SWEEP_WAVES")) : 0;
     a.tune_sweep_gpw = getenv("GG_SWEEP_GPW") ? atoi(getenv("GG_SWEEP_GPW")) : 0;
+    a.tune_sweep_split = getenv("GG_SWEEP_SPLIT") ? atoi(getenv("GG_SWEEP_SPLIT")) : 0;
     a.tune_k2_per_cloud = getenv("GG_K2_PER_CLOUD") ? atoi(getenv("GG_K2_PER_CLOUD")) : 0;
     a.tune_k2_dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 0;
     a.NCH = (int)((max_points + a.PW - 1) / a.PW);
@@ -1428,6 +1429,7 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     if (!strcmp(key, "pw")) return ctx->arena.PW;
     if (!strcmp(key, "sweep_waves")) ctx->arena.tune_sweep_waves = value;
     else if (!strcmp(key, "sweep_gpw")) ctx->arena.tune_sweep_gpw = value;
+    else if (!strcmp(key, "sweep_split")) ctx->arena.tune_sweep_split = value;
     else if (!strcmp(key, "k2_per_cloud")) ctx->arena.tune_k2_per_cloud = value;
     else if (!strcmp(key, "k2_dense_share")) ctx->arena.tune_k2_dense_share = std::min(value, 15);
     else return GG_ERR_INVALID;

@@ -121,6 +121,7 @@ struct Arena {
     // parity tests force every geometry the launchers can pick (tests/test_gpu_parity.py) at small batch sizes.
     int tune_sweep_waves;   // chain wavefronts per side of k_sweep
     int tune_sweep_gpw;     // ring groups per work-group of k_sweep (sweep_core.h "Parts"); default min(groups, 3)
+    int tune_sweep_split;   // k_sweep "split steps": 0 = when a launch has one ring group per work-group and at most 256 work-groups, 1 = whenever gpw == 1, 2 = never
     int tune_k2_per_cloud;  // minimum work-groups per cloud of k_reduce
     int tune_k2_dense_share; // sixteenths of them that walk the dense list
     unsigned flags;

@@ -74,6 +74,26 @@ template <bool DBG> struct DevMemT {
         v = WP{__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)b)};
         return (uint32_t)(a >> 32) == seq && (uint32_t)(b >> 32) == seq;
     }
+    // one PrepRec = three 64-bit LDS words (split steps); written by the preparing wavefront, read by the chain wavefront
+    GG_DEV void ring_put(int word, const PrepRec &r) const
+    {
+        lds_u64 *p = (lds_u64 *)(lds + word);
+        __hip_atomic_store(p + 0, (uint64_t)__float_as_uint(r.w_new) | ((uint64_t)__float_as_uint(r.own_g) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(p + 1, (uint64_t)__float_as_uint(r.own_w) | ((uint64_t)__float_as_uint(r.own_p) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(p + 2, (uint64_t)__float_as_uint(r.out_w) | ((uint64_t)__float_as_uint(r.out_p) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    GG_DEV PrepRec ring_get(int word) const
+    {
+        lds_u64 *p = (lds_u64 *)(lds + word);
+        const uint64_t a = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t c = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PrepRec r;
+        r.w_new = __uint_as_float((uint32_t)a), r.own_g = __uint_as_float((uint32_t)(a >> 32));
+        r.own_w = __uint_as_float((uint32_t)b), r.own_p = __uint_as_float((uint32_t)(b >> 32));
+        r.out_w = __uint_as_float((uint32_t)c), r.out_p = __uint_as_float((uint32_t)(c >> 32));
+        return r;
+    }
     GG_DEV void set_counter(int word, int value) const
     {
         __hip_atomic_store(lds + word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -180,10 +200,12 @@ template <bool DBG> struct WaveClockT {
 #endif
 constexpr int SLEEP_LONG = GG_SWEEP_SLEEP_LONG;
 
-template <int SIDE, bool DBG>
+// SPLIT: a preparing wavefront (run_prep) does the layer half of every step (sweep_core.h "Split steps")
+template <int SIDE, bool DBG, bool SPLIT>
 GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int wave_of_side, int lane, WaveClockT<DBG> &clk, int g0, int g1)
 {
     ChainLane<SIDE> st;
+    int have_prep = 0; // (split steps) cached count of prepared wave-steps
     for (int group = g0 + wave_of_side; group < g1; group += P.waves_per_side) {
         const int r0 = LANES * group + 1;
         const int nl = min(P.rings - (r0 - 1), (int)LANES);
@@ -226,10 +248,53 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
                 const WP x_in{wave_shr1(ho.w), wave_shr1(ho.p)};
                 constexpr int t_first_mod = ((-2 - (int)PF) % (int)SKEW + (int)SKEW) % (int)SKEW; // tb = t_first (mod TRIP), TRIP = 0 (mod SKEW)
                 const int tmod = (t_first_mod + u) % (int)SKEW;
-                st.step_a(t, u % (int)PF, tmod, x_in, P, L, group > 0, mem);
+                if (SPLIT) {
+                    const int step_no = t - t_first;
+                    if (have_prep <= step_no) { // (rare) the preparing wavefront is not a step ahead
+                        have_prep = mem.counter(L.prep_done + SIDE);
+                        while (have_prep <= step_no) {
+                            __builtin_amdgcn_s_sleep(1);
+                            have_prep = mem.counter(L.prep_done + SIDE);
+                        }
+                    }
+                    const PrepRec rec = mem.ring_get(L.prep + ((SIDE * (int)PREP_DEPTH + (step_no & ((int)PREP_DEPTH - 1))) * (int)LANES + lane) * (int)PREP_WORDS);
+                    st.take(t, tmod, rec, x_in, group > 0, mem);
+                    if (lane == 0) mem.set_counter(L.take_done + SIDE, step_no + 1); // (after the read above: the DS queue is in order)
+                } else {
+                    st.step_a(t, u % (int)PF, tmod, x_in, P, L, group > 0, mem);
+                }
                 if (!sync.ok_b()) wait_for([&]() { return sync.ok_b(); });
                 st.step_b(t, tmod, P, L, has_next, group, mem, SKEW != 1 || (u % 3) == turn);
             }
+        }
+    }
+}
+
+// The preparing wavefront of one side (split steps): the layer half of every wave-step of the work-group's ring group, a few
+// steps ahead of the chain wavefront, into the side's LDS ring.
+template <int SIDE, bool DBG> GG_DEV void run_prep(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, int group)
+{
+    static_assert((PREP_DEPTH & (PREP_DEPTH - 1)) == 0, "ring slots are addressed with a mask");
+    PrepLane<SIDE> st;
+    const int r0 = LANES * group + 1;
+    const int nl = min(P.rings - (r0 - 1), (int)LANES);
+    st.init(lane, r0, nl, P);
+    const int t_first = group_first_step(), t_last = group_last_step<SIDE>(r0, nl);
+    int have_taken = 0;
+    for (int tb = t_first; tb <= t_last; tb += TRIP) {
+#pragma unroll
+        for (int u = 0; u < TRIP; ++u) {
+            const int t = tb + u, step_no = t - t_first;
+            if (step_no - have_taken >= (int)PREP_DEPTH) { // the ring is full: wait for the chain wavefront
+                have_taken = mem.counter(L.take_done + SIDE);
+                while (step_no - have_taken >= (int)PREP_DEPTH) {
+                    __builtin_amdgcn_s_sleep(2);
+                    have_taken = mem.counter(L.take_done + SIDE);
+                }
+            }
+            const PrepRec rec = st.step(t, u % (int)PF, P, mem);
+            mem.ring_put(L.prep + ((SIDE * (int)PREP_DEPTH + (step_no & ((int)PREP_DEPTH - 1))) * (int)LANES + lane) * (int)PREP_WORDS, rec);
+            if (lane == 0) mem.set_counter(L.prep_done + SIDE, step_no + 1); // (the records first: in-order DS queue)
         }
     }
 }
@@ -395,7 +460,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
         }
     }
     const int g0 = part * P.gpw, g1 = min(g0 + P.gpw, P.groups);
-    const LdsMap L = lds_layout(P.c, P.groups, g0, g1);
+    const LdsMap L = lds_layout(P.c, P.groups, g0, g1, P.split_steps != 0);
     const CloudParams &cp = params[cloud];
     float2 *gp2 = gp2_ptr(a, cp.slot);
     float *points = a.layers + (size_t)cp.slot * a.slot_layer_stride + GG_LAYER_POINTS * a.layer_stride;
@@ -453,14 +518,33 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     // a work-group go to the CU's four SIMDs round-robin, so ids 4 w + side put them on four different SIMDs (with the sides'
     // wavefronts numbered consecutively, A_w and C_w shared one SIMD and B_w and D_w another while two SIMDs idled)
     const int side = wave & 3, w_of_side = wave >> 2;
-    if (wave < 4 * W && side == SIDE_A)
-        run_chain<SIDE_A, DBG>(P, L, mem, w_of_side, lane, clk, g0, g1);
+    if (P.split_steps) { // one ring group per work-group: wavefronts 0..3 chains, 4..7 their preparing wavefronts, 8 / 9 corners, 10 importer, 11 exporter
+        if (wave < 4) {
+            if (side == SIDE_A) run_chain<SIDE_A, DBG, true>(P, L, mem, 0, lane, clk, g0, g1);
+            else if (side == SIDE_B) run_chain<SIDE_B, DBG, true>(P, L, mem, 0, lane, clk, g0, g1);
+            else if (side == SIDE_C) run_chain<SIDE_C, DBG, true>(P, L, mem, 0, lane, clk, g0, g1);
+            else run_chain<SIDE_D, DBG, true>(P, L, mem, 0, lane, clk, g0, g1);
+        } else if (wave < 8) {
+            if (side == SIDE_A) run_prep<SIDE_A, DBG>(P, L, mem, lane, g0);
+            else if (side == SIDE_B) run_prep<SIDE_B, DBG>(P, L, mem, lane, g0);
+            else if (side == SIDE_C) run_prep<SIDE_C, DBG>(P, L, mem, lane, g0);
+            else run_prep<SIDE_D, DBG>(P, L, mem, lane, g0);
+        } else if (wave == 8)
+            run_corner<0, DBG>(P, L, mem, lane, clk, g0, g1);
+        else if (wave == 9)
+            run_corner<1, DBG>(P, L, mem, lane, clk, g0, g1);
+        else if (wave == 10) {
+            if (part > 0) run_import<DBG>(P, L, mem, lane, g0);
+        } else if (g1 < P.groups)
+            run_export<DBG>(P, L, mem, lane, g1);
+    } else if (wave < 4 * W && side == SIDE_A)
+        run_chain<SIDE_A, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W && side == SIDE_B)
-        run_chain<SIDE_B, DBG>(P, L, mem, w_of_side, lane, clk, g0, g1);
+        run_chain<SIDE_B, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W && side == SIDE_C)
-        run_chain<SIDE_C, DBG>(P, L, mem, w_of_side, lane, clk, g0, g1);
+        run_chain<SIDE_C, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W)
-        run_chain<SIDE_D, DBG>(P, L, mem, w_of_side, lane, clk, g0, g1);
+        run_chain<SIDE_D, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave == 4 * W)
         run_corner<0, DBG>(P, L, mem, lane, clk, g0, g1);
     else if (wave == 4 * W + 1)
@@ -473,10 +557,11 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
 }
 
 // the largest LDS table any part of a sweep with `gpw` groups per work-group needs
-static size_t parts_lds_bytes(const Params &P, int gpw)
+static size_t parts_lds_bytes(const Params &P, int gpw, bool split = false)
 {
     size_t words = 0;
-    for (int g0 = 0; g0 < std::max(P.groups, 1); g0 += gpw) words = std::max(words, (size_t)lds_layout(P.c, P.groups, g0, std::min(g0 + gpw, P.groups)).words);
+    for (int g0 = 0; g0 < std::max(P.groups, 1); g0 += gpw)
+        words = std::max(words, (size_t)lds_layout(P.c, P.groups, g0, std::min(g0 + gpw, P.groups), split).words);
     return words * 4;
 }
 // what gg_create checks: the sweep must fit in LDS at least when every work-group takes a single ring group per side
@@ -506,7 +591,14 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
         P.waves_per_side = std::max(1, std::min(groups_per_part, 3));
     else
         P.waves_per_side = std::min(P.waves_per_side, std::max(1, std::min(groups_per_part, 3)));
-    const size_t lds = parts_lds_bytes(P, P.gpw);
+    // Split steps (sweep_core.h): with one ring group per work-group there are wavefront slots left; a preparing wavefront per side
+    // takes the layer half of every step off the chain wavefront (tune_sweep_split: 0 auto, 1 on where possible, 2 off)
+    P.split_steps = (P.gpw == 1 && a.tune_sweep_split != 2 && (a.tune_sweep_split == 1 || n_clouds * n_parts <= SWEEP_LATENCY_MAX_CLOUDS) &&
+                     parts_lds_bytes(P, 1, true) <= 158 * 1024)
+                        ? 1
+                        : 0;
+    if (P.split_steps) P.waves_per_side = 1;
+    const size_t lds = parts_lds_bytes(P, P.gpw, P.split_steps != 0);
     static std::atomic<uint64_t> big_lds_devices{0};
     if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices)) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -515,7 +607,7 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
     static std::atomic<uint32_t> launch_seq{0}; // tags the values of this launch in the exchange region (never 0: the arena starts zeroed)
     uint32_t seq = launch_seq.fetch_add(1, std::memory_order_relaxed) + 1u;
     if (seq == 0u) seq = launch_seq.fetch_add(1, std::memory_order_relaxed) + 1u;
-    const int threads = (4 * P.waves_per_side + 2 + (n_parts > 1 ? 2 : 0)) * 64; // (+ importer and exporter)
+    const int threads = P.split_steps ? 12 * 64 : (4 * P.waves_per_side + 2 + (n_parts > 1 ? 2 : 0)) * 64; // (+ importer and exporter)
     if (dbg) // (GG_SWEEP_TIMING: the instrumented twin)
         hipLaunchKernelGGL(k_sweep<true>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, seq, dbg);
     else

@@ -67,6 +67,12 @@ struct WP {
 struct Cell {
     float g, w; // ground, confidence (the interleaved layer's element)
 };
+// what a preparing wavefront leaves for its chain wavefront per lane and wave-step ("Split steps" below)
+struct PrepRec {
+    float w_new;               // the visited cell's new confidence (decayed_confidence of its old one)
+    float own_g, own_w, own_p; // the arriving own-line cell (the next successor): height, confidence, product
+    float out_w, out_p;        // the arriving outer-line cell: confidence, product
+};
 
 // uniform parameters of one sweep
 struct Params {
@@ -76,6 +82,7 @@ struct Params {
     int groups; // ceil(rings / LANES)
     int waves_per_side;
     int gpw;    // ring groups per work-group ("part"); >= groups: one work-group sweeps the whole map (see "Parts" below)
+    int split_steps; // 1: every chain wavefront has a PREPARING wavefront next to it (see "Split steps"; needs gpw == 1)
     int r2min;  // the confidence decay (:463-464) applies to cell (x, y) iff (x-c)^2 + (y-c)^2 >= r2min (host-computed, exact)
     double decrease, inv_decrease;
     int decay_fast;
@@ -226,12 +233,15 @@ struct LdsMap {
     int corner_done; // [2]   rings finished by the AB / CD corner lane
     int join_done;   // [4]   highest ring whose chain of that side has published its last value
     int bnd_done;    // [4][groups]   steps published by the last lane of a group (consumed by lane 0 of the next group)
+    int prep_done;   // [4]   "split steps" (below): wave-steps the side's preparing wavefront has put into the ring
+    int take_done;   // [4]   ... and wave-steps the side's chain wavefront has taken out of it
     int corner;      // WP[2][c][2]   AB: (A_1, B_0), CD: (C_1, D_0) per ring; ring 0 = the centre cell
     int join;        // WP[4][c]      last chain value per side and ring
     int bnd;         // WP[4][bnd_words / 2]   full chains of the group-boundary rings
     int bnd_stride;  // WP entries per side
     int bnd_base;    // bnd_offset() of the first boundary this work-group's table holds (a part keeps only its own boundaries)
     int scratch;     // per-lane dummy targets of conditional publishes (2 data words + 1 counter word per lane, 8-byte aligned)
+    int prep;        // PrepRec[4][PREP_DEPTH][LANES]   ring of prepared wave-steps per side (split steps only; else 0 words)
     int words;       // total size
 };
 
@@ -266,7 +276,8 @@ SW_HD int xchg_chain(int gb, int side, int e) { return xchg_base(gb) + side * xc
 SW_HD int xchg_misc(int gb, int k) { return xchg_base(gb) + 4 * xchg_len(gb) + k; }
 
 // g0, g1: the groups of the work-group (default: all of them)
-SW_HD LdsMap lds_layout(int c, int groups, int g0 = 0, int g1 = -1)
+enum { PREP_DEPTH = 8, PREP_WORDS = 6 }; // ring slots per side; words of one PrepRec
+SW_HD LdsMap lds_layout(int c, int groups, int g0 = 0, int g1 = -1, bool split_steps = false)
 {
     if (g1 < 0) g1 = groups;
     LdsMap m;
@@ -277,6 +288,10 @@ SW_HD LdsMap lds_layout(int c, int groups, int g0 = 0, int g1 = -1)
     o += 4;
     m.bnd_done = o;
     o += 4 * groups;
+    m.prep_done = o;
+    o += 4;
+    m.take_done = o;
+    o += 4;
     o = (o + 1) & ~1;
     m.corner = o;
     o += 2 * c * 2 * 2;
@@ -291,6 +306,9 @@ SW_HD LdsMap lds_layout(int c, int groups, int g0 = 0, int g1 = -1)
     o += 4 * m.bnd_stride * 2;
     m.scratch = o; // [64][3]: where the lanes that have nothing to publish write (publish_if, device)
     o += LANES * 3 + 1;
+    o = (o + 1) & ~1;
+    m.prep = o;
+    if (split_steps) o += 4 * PREP_DEPTH * LANES * PREP_WORDS;
     m.words = o;
     return m;
 }
@@ -518,6 +536,33 @@ template <int SIDE> struct ChainLane {
         xa = t + 1 == lend ? xold : xa; // s + 2 == len + 1
     }
 
+    // step_a when a preparing wavefront did the layer half (split steps): `rec` is its record of this wave-step
+    template <class Mem>
+    SW_HD void take(int t, int tmod, const PrepRec &rec, WP x_in, bool has_prev_group, Mem &mem)
+    {
+        w_new_ = rec.w_new;
+        WP c_bnd{0.f, 0.f};
+        if (has_prev_group && t >= 0 && t < u_len0) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
+        if (tmod == 0 && t >= 0 && t <= u_start_last) {
+            cs0 = mem.get(a_s0);
+            cs1 = mem.get(a_s1);
+            cpred = mem.get(a_pred);
+        }
+        const unsigned ua = (unsigned)(t + 2 - l3); // s + 2
+        Sg = Ng;
+        Sw = Nw;
+        Sp = Np;
+        Ng = rec.own_g;
+        Nw = rec.own_w;
+        Np = rec.own_p;
+        xold = (tmod == (2 * SKEW - 2) % SKEW && ua == 0u) ? WP{rec.own_w, rec.own_p} : xold;
+        U[0] = U[1];
+        U[1] = U[2];
+        U[2] = WP{rec.out_w, rec.out_p};
+        xa = l == 0 ? c_bnd : x_in;
+        xa = t + 1 == lend ? xold : xa;
+    }
+
     // join_turn: (wave-uniform) some lane of the group can end its chain at this step -- lane l ends at t + 1 = 3 l + lend of
     // lane 0 (SKEW = 1), i.e. in every third step only; see join_turn_of
     template <class Mem>
@@ -563,6 +608,64 @@ template <int SIDE> struct ChainLane {
         if (has_next_group && t >= u_l3_last && t < u_lend_last) // (uniform: only while the last lane runs)
             mem.publish_if(l == LANES - 1 && active, l, L, L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) - L.bnd_base + (t - l3)), res,
                            L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Split steps (latency launches: one ring group per work-group).  A lone wavefront issues one instruction per 4-8 cycles
+// whatever its kind, and the sweep of one cloud is as long as its ~540 dependent wave-steps: whatever a chain wavefront does
+// per step that does NOT depend on the values handed to it -- the layer loads, the decay of the visited cell's confidence, the
+// products of the arriving own-line and outer-line cells -- is done by a second, PREPARING wavefront of the same side, which
+// runs a few steps ahead and leaves one PrepRec per lane and step in an LDS ring (PREP_DEPTH steps).  The chain wavefront
+// takes the record instead of executing step_a's first half: about half of its instructions per step are gone.  Two
+// monotonic counters per side guard the ring (prepared / taken steps, counted from the group's first step).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int SIDE> struct PrepLane {
+    int l3, len, lim, ownA, outA, xold_cell, own_end, r2c, r2r;
+    float Nw;                 // confidence of the cell that arrived last (= the cell visited in the next step)
+    Cell q_own[PF], q_out[PF];
+    SW_HD void init(int lane, int r0, int nl, const Params &P)
+    {
+        const bool live = lane < nl;
+        const int r = live ? r0 + lane : r0;
+        len = live ? chain_len<SIDE>(r) : 0;
+        const int k0 = chain_k0<SIDE>();
+        l3 = SKEW * lane;
+        lim = len > 0 ? len + 2 : 0;
+        ownA = side_cell<SIDE>(P, r, 0, 1) + 64 * (k0 - 1 - l3);
+        outA = side_cell<SIDE>(P, r, 1, 1) + 64 * (k0 - 1 - l3);
+        xold_cell = side_cell<SIDE>(P, r, -1, k0 + len);
+        own_end = side_cell<SIDE>(P, r, 0, k0 + len);
+        r2c = k0 - r - l3;
+        r2r = r * r;
+        Nw = 0.f;
+        for (int k = 0; k < PF; ++k) q_own[k] = q_out[k] = Cell{0.f, 0.f};
+    }
+    // the layer half of ChainLane::step_a, for wave-step t (slot = wave-step mod PF)
+    template <class Mem> SW_HD PrepRec step(int t, int slot, const Params &P, Mem &mem)
+    {
+        PrepRec rec;
+        const int ao = t + r2c;
+        rec.w_new = decayed_confidence(Nw, r2r + ao * ao >= P.r2min, P);
+        const unsigned ua = (unsigned)(t + 2 - l3);
+        const bool col = ua < (unsigned)lim;
+        int own_now = (int)ua == len + 1 ? own_end : ownA + 64 * (t + 1);
+        own_now = ua == 0u ? xold_cell : own_now;
+        const Cell own = mem.fresh(mem.load_value(q_own[slot], col, own_now));
+        const Cell out = mem.fresh(mem.load_value(q_out[slot], col, outA + 64 * (t + 1)));
+        const unsigned uq = ua + (unsigned)PF;
+        const bool colq = uq < (unsigned)lim;
+        int own_req = (int)uq == len + 1 ? own_end : ownA + 64 * (t + 1 + PF);
+        own_req = uq == 0u ? xold_cell : own_req;
+        q_own[slot] = mem.load_issue(colq, own_req);
+        q_out[slot] = mem.load_issue(colq, outA + 64 * (t + 1 + PF));
+        Nw = own.w;
+        rec.own_g = own.g;
+        rec.own_w = own.w;
+        rec.own_p = own.w * own.g;
+        rec.out_w = out.w;
+        rec.out_p = out.w * out.g;
+        return rec;
     }
 };
 

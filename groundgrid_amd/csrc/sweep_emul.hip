@@ -43,6 +43,18 @@ struct HostMem { // one per emulated work-group ("part"): its own LDS, the layer
         return (uint32_t)(a >> 32) == seq && (uint32_t)(b >> 32) == seq;
     }
     void set_counter(int word, int value) { lds[(size_t)word] = value; }
+    void ring_put(int word, const PrepRec &r)
+    {
+        ++lds_ops;
+        memcpy(&lds[(size_t)word], &r, sizeof r);
+    }
+    PrepRec ring_get(int word)
+    {
+        ++lds_ops;
+        PrepRec r;
+        memcpy(&r, &lds[(size_t)word], sizeof r);
+        return r;
+    }
     Cell load_issue(bool valid, int cell)
     {
         if (!valid) return Cell{0.f, 0.f};
@@ -156,10 +168,18 @@ template <int SIDE> struct ChainWave : WaveBase {
                 if (c.len > 0 && t - c.l3 == 0 && mem.counter(sync.w_corner) < c.r) plan_mismatch = true;
             }
             if (group > 0 && t >= 0 && t + 2 < lane[0].len && mem.counter(sync.w_bnd) < t + 1) plan_mismatch = true;
+            const int step_no = t - group_first_step(); // (split steps: position in the ring's step count)
+            if (P.split_steps && mem.counter(L.prep_done + SIDE) <= step_no) return false; // the preparing wavefront has not got there yet
             WP x_in[LANES];
             for (int l = 0; l < LANES; ++l) x_in[l] = l ? lane[l - 1].handed_over() : WP{0.f, 0.f}; // wave shift right by one, before anybody moves
             const int slot = ((t % PF) + PF) % PF;
-            for (int l = 0; l < LANES; ++l) lane[l].step_a(t, slot, tmod, x_in[l], P, L, group > 0, mem);
+            if (P.split_steps) {
+                for (int l = 0; l < LANES; ++l)
+                    lane[l].take(t, tmod, mem.ring_get(L.prep + ((SIDE * PREP_DEPTH + (step_no % PREP_DEPTH)) * LANES + l) * PREP_WORDS), x_in[l], group > 0, mem);
+                mem.set_counter(L.take_done + SIDE, step_no + 1);
+            } else {
+                for (int l = 0; l < LANES; ++l) lane[l].step_a(t, slot, tmod, x_in[l], P, L, group > 0, mem);
+            }
             half = true;
         }
         if (!sync.ok_b()) {
@@ -213,6 +233,37 @@ template <int CD> struct CornerWave : WaveBase {
         in_x1 = x1;
         ++r;
         if (l == LANES - 1) prepared = false;
+        return true;
+    }
+};
+
+// the preparing wavefront of one side (split steps, k4_sweep.hip run_prep): one try = one wave-step, if the ring has room
+template <int SIDE> struct PrepWave : WaveBase {
+    const Params &P;
+    const LdsMap &L;
+    HostMem &mem;
+    int group, r0, nl, t, t_last;
+    PrepLane<SIDE> lane[LANES];
+    PrepWave(const Params &p, const LdsMap &l, HostMem &m, int g) : P(p), L(l), mem(m), group(g)
+    {
+        r0 = LANES * group + 1;
+        nl = P.rings - (r0 - 1) < LANES ? P.rings - (r0 - 1) : LANES;
+        for (int k = 0; k < LANES; ++k) lane[k].init(k, r0, nl, P);
+        t = group_first_step();
+        t_last = group_last_step<SIDE>(r0, nl);
+        t_last += (TRIP - (t_last - t + 1) % TRIP) % TRIP; // (whole trips, like the chain wavefront)
+    }
+    bool done() const override { return t > t_last; }
+    bool try_step() override
+    {
+        if (done()) return false;
+        const int step_no = t - group_first_step();
+        if (step_no - mem.counter(L.take_done + SIDE) >= PREP_DEPTH) return false; // the ring is full
+        const int slot = ((t % PF) + PF) % PF;
+        for (int k = 0; k < LANES; ++k)
+            mem.ring_put(L.prep + ((SIDE * PREP_DEPTH + (step_no % PREP_DEPTH)) * LANES + k) * PREP_WORDS, lane[k].step(t, slot, P, mem));
+        mem.set_counter(L.prep_done + SIDE, step_no + 1);
+        ++t;
         return true;
     }
 };
@@ -326,6 +377,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
     // to one wavefront per group (at most 3 per side: 14 wavefronts) when the launch has fewer clouds than the chip has CUs:
     // with SKEW = 1 group g + 1 starts only 64 steps after group g, and a wavefront that still works on group g - 1 delays it.
     P.waves_per_side = P.groups <= 1 ? 1 : P.groups <= 3 ? 2 : 3;
+    P.split_steps = 0;
     P.gpw = P.groups > 1 ? P.groups : 1; // one work-group unless the launcher (or the emulation's GG_SWEEP_GPW) cuts the map into parts
     if (getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(std::min(P.groups, 3), atoi(getenv("GG_SWEEP_WAVES")))); // (the host emulation: tests/test_sweep_emul_cpu.py)
     // :463 (pow((float)x - center, 2.0) + pow((float)y - center, 2.0)) * pow(resolution, 2.0f) > minDistSquared: the left side is a
@@ -351,6 +403,7 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
     if (getenv("GG_SWEEP_GPW")) { // emulate the multi-work-group sweep (sweep_core.h "Parts")
         P.gpw = std::max(1, std::min(atoi(getenv("GG_SWEEP_GPW")), std::max(P.groups, 1)));
         P.waves_per_side = std::max(1, std::min(P.waves_per_side, P.gpw));
+        if (getenv("GG_SWEEP_SPLIT") && atoi(getenv("GG_SWEEP_SPLIT")) && P.gpw == 1) P.split_steps = 1; // + a preparing wavefront per side
     }
     const int n_groups = std::max(P.groups, 1), n_parts = (n_groups + P.gpw - 1) / P.gpw;
     // the layer in the device's sheared element order (gp_layout.h); gp2 is Eigen-style column-major on both ends
@@ -369,7 +422,7 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
         const int g0 = part * P.gpw, g1 = std::min(g0 + P.gpw, P.groups);
         LdsMap &L = maps[(size_t)part];
         HostMem &mem = mems[(size_t)part];
-        L = lds_layout(P.c, P.groups, g0, g1);
+        L = lds_layout(P.c, P.groups, g0, g1, P.split_steps != 0);
         lds_words = std::max(lds_words, (size_t)L.words);
         mem.gp2 = sheared.data();
         mem.lds.assign((size_t)L.words, 0);
@@ -383,6 +436,12 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
         for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_B>(P, L, mem, w, g0, g1));
         for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_C>(P, L, mem, w, g0, g1));
         for (int w = 0; w < P.waves_per_side; ++w) waves.push_back(new ChainWave<SIDE_D>(P, L, mem, w, g0, g1));
+        if (P.split_steps) {
+            waves.push_back(new PrepWave<SIDE_A>(P, L, mem, g0));
+            waves.push_back(new PrepWave<SIDE_B>(P, L, mem, g0));
+            waves.push_back(new PrepWave<SIDE_C>(P, L, mem, g0));
+            waves.push_back(new PrepWave<SIDE_D>(P, L, mem, g0));
+        }
         waves.push_back(new CornerWave<0>(P, L, mem, g0, g1));
         waves.push_back(new CornerWave<1>(P, L, mem, g0, g1));
         if (part > 0) waves.push_back(new ImportWave(P, L, mem, g0));

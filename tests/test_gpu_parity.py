@@ -332,13 +332,16 @@ def test_batch_with_a_slot_permutation():
     seg.close()
 
 
-@pytest.mark.parametrize("length,resolution,gpw,batch", [(120.0, 0.33, 1, 3), (120.0, 0.33, 2, 11), (120.0, 0.33, 1, 17), (240.0, 0.33, 0, 2), (240.0, 0.33, 2, 9),
-                                                         (61.0, 0.25, 1, 8)])
-def test_sweep_cut_into_several_work_groups(length, resolution, gpw, batch):
+@pytest.mark.parametrize("length,resolution,gpw,batch,split", [(120.0, 0.33, 1, 3, 0), (120.0, 0.33, 2, 11, 0), (120.0, 0.33, 1, 17, 2), (240.0, 0.33, 0, 2, 0),
+                                                               (240.0, 0.33, 2, 9, 0), (61.0, 0.25, 1, 8, 0), (120.0, 0.33, 1, 9, 1), (240.0, 0.33, 1, 3, 2),
+                                                               (200.0, 0.2, 1, 1, 1), (22.0, 0.33, 1, 2, 1)])
+def test_sweep_cut_into_several_work_groups(length, resolution, gpw, batch, split):
     """k_sweep as several cooperating work-groups per cloud (sweep_core.h "Parts": `gpw` ring groups of 64 each, values crossing
     through the tagged exchange region + importer wavefront): forced at the bench grid (3 groups -> 3 or 2 parts) and at a
     727-cell map (6 groups: the default cut, 3 + 3), with batch sizes on both sides of the 8-cloud bundles the work-group
-    index is laid out in.  Two frames, every layer against the oracle."""
+    index is laid out in.  `split`: the "split steps" of launches with one ring group per work-group (a preparing wavefront per
+    side does the layer half of every step; sweep_core.h) forced on (1) / off (2) / left to the launcher (0: on for these small
+    launches whenever gpw == 1).  Two frames, every layer against the oracle."""
     base = synth.hdl64_cloud(seed=61, n_az=400)
     k = np.float32(length / 120.0)
     clouds = []
@@ -352,6 +355,8 @@ def test_sweep_cut_into_several_work_groups(length, resolution, gpw, batch):
     seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
     if gpw:
         seg.debug_set_tuning("sweep_gpw", gpw)
+    if split:
+        seg.debug_set_tuning("sweep_split", split)
     import torch
 
     refs = [oracle.OracleMap(length, resolution) for _ in clouds]

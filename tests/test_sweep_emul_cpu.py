@@ -118,3 +118,24 @@ def test_sweep_cut_into_several_work_groups(lib, monkeypatch, length, resolution
             assert np.array_equal(w, ref.layer("groundpatch")), (seed, late)
     parts = (groups + gpw - 1) // gpw
     assert parts >= 2 and stats[6] >= parts * 6 + (parts - 1)  # at least 4 chain + 2 corner wavefronts per part, an importer per hand-over
+
+
+@pytest.mark.parametrize("length,resolution", [(22.0, 0.33), (61.0, 0.25), (120.0, 0.33), (240.0, 0.33)])
+def test_split_steps_with_a_preparing_wavefront_per_side(lib, monkeypatch, length, resolution):
+    """sweep_core.h "Split steps" (latency launches, one ring group per work-group): the layer half of every wave-step -- loads,
+    confidence decay, products -- runs on a PREPARING wavefront a few steps ahead and reaches the chain wavefront through an LDS
+    ring guarded by two counters.  The preparing wavefront loads cells up to PREP_DEPTH + PF steps before they are used: with
+    `late` loads off that is the earliest a value can be read, with the adversarial schedule the ring runs full and empty."""
+    monkeypatch.setenv("GG_SWEEP_GPW", "1")
+    monkeypatch.setenv("GG_SWEEP_SPLIT", "1")
+    ref = oracle.OracleMap(length, resolution)
+    n = ref.layer("ground").shape[0]
+    ground, conf = random_state(n, 5 * n + 1)
+    ref.set_layer("ground", ground)
+    ref.set_layer("groundpatch", conf)
+    ref.stage_spiral(-1.73)
+    for seed in ((0, 1, 2, 3, 4, 5) if n <= 400 else (0, 7)):
+        for late in (False, True):
+            g, w, stats = emulate(lib, n, ref.resolution, ground, conf, -1.73, 5.0, seed, late)
+            assert np.array_equal(g, ref.layer("ground")), (seed, late, np.argwhere(g != ref.layer("ground"))[:5].tolist())
+            assert np.array_equal(w, ref.layer("groundpatch")), (seed, late)
