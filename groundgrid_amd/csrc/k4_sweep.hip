@@ -231,6 +231,10 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
                     while (!ready()) {
                         // a waiting wavefront's polls take issue slots from the working wavefronts of its SIMD: back off after
                         // the first few (the hand-over it waits for is then several steps away)
+#if defined(GG_SWEEP_TIGHT_POLL)
+                        if (spins < GG_SWEEP_TIGHT_POLL) {
+                        } else
+#endif
                         if (spins < 4)
                             __builtin_amdgcn_s_sleep(1);
                         else

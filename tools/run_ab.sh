@@ -1,4 +1,6 @@
-mkdir -p gpurun_out/r03s; O=gpurun_out/r03s
-(timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "sweep_cut" 2>&1 | tail -12) > $O/pytest_sweep.log; grep -E "passed|failed|Error|error" $O/pytest_sweep.log
-for sp in 2 0; do GG_SWEEP_SPLIT=$sp BATCHES_SMALL=1,8,64 BATCHES_BIG=1,8 timeout 300 python tools/latency_probe.py > $O/lat_split$sp.json 2>>$O/err.log; cat $O/lat_split$sp.json; done
-(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -12) > $O/pytest_all.log; grep -E "passed|failed|Error|error" $O/pytest_all.log
+mkdir -p gpurun_out/r03t; O=gpurun_out/r03t
+V=$PWD/groundgrid_amd/variants
+for lib in default tight2 tight4; do
+  if [ $lib = default ]; then unset GROUNDGRID_HIP_LIB; else export GROUNDGRID_HIP_LIB=$V/lib_$lib.so; fi
+  BATCHES_SMALL=1,64 BATCHES_BIG=1 timeout 300 python tools/latency_probe.py > $O/lat_$lib.json 2>>$O/err.log; cat $O/lat_$lib.json
+done
