@@ -528,6 +528,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tune_sweep_split = getenv("GG_SWEEP_SPLIT") ? atoi(getenv("GG_SWEEP_SPLIT")) : 0;
     a.tune_k2_per_cloud = getenv("GG_K2_PER_CLOUD") ? atoi(getenv("GG_K2_PER_CLOUD")) : 0;
     a.tune_k2_dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 0;
+    a.k2_skip = getenv("GG_K2_SKIP") ? atoi(getenv("GG_K2_SKIP")) : 0;
     a.NCH = (int)((max_points + a.PW - 1) / a.PW);
     make_dev_config(ctx->cfg, a.cfg);
 
@@ -614,7 +615,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t gp_valid_words = ((size_t)a.gpl.elems + 31) / 32;
     const size_t o_gpvalid = carve(gp_valid_words * 4);
     const size_t o_dbg = carve(64 * 8); // sweep timing
-    const bool k2_timing = getenv("GG_K2_DEBUG") && (atoi(getenv("GG_K2_DEBUG")) == 9 || atoi(getenv("GG_K2_DEBUG")) == 5);
+    const bool k2_timing = getenv("GG_K2_DEBUG") && (atoi(getenv("GG_K2_DEBUG")) == 9 || atoi(getenv("GG_K2_DEBUG")) == 5 || atoi(getenv("GG_K2_DEBUG")) == 6);
     const size_t o_k2dbg = carve(k2_timing ? (size_t)K2_DBG_WGS * 32 * 8 : 64);
     ctx->arena_bytes = off;
     CREATE_CHK(hipMalloc(&ctx->d_arena, ctx->arena_bytes));
@@ -1455,6 +1456,15 @@ extern "C" int gg_debug_k2_census(gg_context *ctx, unsigned long long *out, int 
         for (int k = 0; k < 1024; ++k) z[(size_t)k * 8 + 4] = ~0ull; // (first start: a minimum)
         if (hipMemcpy(ctx->arena.k2_dbg, z.data(), z.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return GG_ERR_HIP;
     }
+    return GG_OK;
+}
+
+// tools only: k_reduce's per-work-group records (GG_K2_DEBUG=6): n x 4 words
+extern "C" int gg_debug_k2_trace(gg_context *ctx, unsigned long long *out, int n)
+{
+    if (!ctx || !out || ctx->arena.k2_debug != 6 || n < 1 || n > 65536) return GG_ERR_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return GG_ERR_HIP;
+    if (hipMemcpy(out, ctx->arena.k2_dbg, (size_t)n * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
     return GG_OK;
 }
 

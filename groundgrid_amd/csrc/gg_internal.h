@@ -124,6 +124,7 @@ struct Arena {
     int tune_sweep_split;   // k_sweep "split steps": 0 = when a launch has one ring group per work-group and at most 256 work-groups, 1 = whenever gpw == 1, 2 = never
     int tune_k2_per_cloud;  // minimum work-groups per cloud of k_reduce
     int tune_k2_dense_share; // sixteenths of them that walk the dense list
+    int k2_skip;             // measurement (GG_K2_SKIP): 1 = k_reduce leaves the light tiles out, 2 = the dense tiles
     unsigned flags;
     int k2_debug;        // env GG_K2_DEBUG (measurement only): 1 = k_reduce stops after the tile lookup, 2 = after step 1, 3 = after step 3,
                          // 9 = per-phase cycle counters into k2_dbg (tools/k2_phases.py)

@@ -366,9 +366,11 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                 lds.cnt64[lane + 64 * k] = 0ull;
                 lds.wmask[lane + 64 * k] = 0ull;
             }
-            // 1. count
+            // 1. count  (only the windows that hold records: a light tile has ~110 on average, two windows of the eight)
+            const int n_win = (int)((end - start + 63u) >> 6);
 #pragma unroll
             for (int w = 0; w < WB; ++w) {
+                if (w >= n_win) break; // (uniform)
                 const bool in = rw[w].y != KEY_OUTSIDE;
                 const unsigned long long km = __ballot(in && ((rw[w].y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT);
                 const LaneRun run = lane_run(in ? (rw[w].y & 255u) : 256u, lane);
@@ -408,6 +410,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             lds_order();
 #pragma unroll
             for (int w = 0; w < WB; ++w) {
+                if (w >= n_win) break; // (uniform)
                 const uint2 r = rw[w];
                 const bool kept = r.y != KEY_OUTSIDE && ((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT;
                 const LaneRun run = lane_run(kept ? (r.y & 255u) : 256u, lane);
@@ -691,38 +694,26 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     }
 }
 
-// grid = (GD + GL, clouds): per cloud, GD work-groups walk the dense list (one tile per work-group at a time) and GL
-// work-groups the light list (one tile per wavefront at a time).  k_scan wrote both lists: the tiles that hold records of this
+// One share of one cloud's work: group < n_dense_groups walks the cloud's dense list (one tile per work-group at a time), the
+// other groups the light list (one tile per wavefront at a time).  k_scan wrote both lists: the tiles that hold records of this
 // cloud.  More than half of the tiles of a sensor cloud receive no point at all and are visited by nobody: the per-call layers
 // are stored sparsely -- tile_live[rank] says which columns of a tile physically hold values (the ones with in-map records of
 // this cloud), every other cell logically holds the per-call reset values (:61-75), and the readers substitute them
 // (gg_internal.h tile_live).  Exact: gg_get_layer returns at all times what the reference's layers would hold.
 template <bool FULL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
+GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params, ReduceLds &lds, int cloud, int group, int n_groups, int n_dense_groups)
 {
-    __shared__ ReduceLds lds;
-    // (cloud, group) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD, in
-    // Morton order, so vertically adjacent tiles complete each other's 128-byte layer lines in the same L2
-    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
-    const int cloud = (int)(item / gridDim.x);
-    const int group = (int)(item % gridDim.x);
     const CloudParams cp = params[cloud];
     const uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
     const uint32_t *list_cnt = a.tile_list_cnt + (size_t)cp.slot * 2;
-    if (a.k2_debug == 1) return;
-    const unsigned long long t_wg = (a.k2_debug == 9 || a.k2_debug == 5) ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long *census = nullptr; // (GG_K2_DEBUG=5, tools/k2_census.py: which CU runs how many work-groups at a time)
-    if (a.k2_debug == 5 && threadIdx.x == 0) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_ID, XCC_ID
-        census = a.k2_dbg + (size_t)(((xcc & 7u) << 7) | ((hw >> 8) & 0x7Fu)) * 8;
-        atomicAdd(&census[0], 1ull);
-        const unsigned long long r = atomicAdd(&census[1], 1ull) + 1ull;
-        atomicMax(&census[2], r);
-        atomicMin(&census[4], t_wg);
-    }
     if (group < n_dense_groups) {
-        const int n_dense = (int)list_cnt[1];
-        for (int j = group; j < n_dense; j += n_dense_groups) {
+        const int n_dense = a.k2_skip == 2 ? 0 : (int)list_cnt[1];
+        // The dispatcher deals work-groups to an XCD's four shader engines in strict rotation and in order (tools/k2_trace.py:
+        // every engine receives exactly a quarter of the work-groups).  Tile j of every cloud holds about the same number of
+        // records (same sensor), so which group takes which tile changes with the cloud -- otherwise one engine gets the fullest
+        // tile of every cloud.
+        const int first = (group + cloud * 5) % n_dense_groups;
+        for (int j = first; j < n_dense; j += n_dense_groups) {
             // (the thread index is made opaque per tile: otherwise every address derived from it is computed once, before
             // the loop, and kept in registers across the whole tile -- 30 VGPRs more)
             int tid = threadIdx.x;
@@ -736,10 +727,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                                                                                          (lds.dense.wave_full[2] << 8) | (lds.dense.wave_full[3] << 12));
         }
     } else {
-        const int n_light = (int)list_cnt[0];
-        const int n_waves = ((int)gridDim.x - n_dense_groups) * 4;
+        const int n_light = a.k2_skip == 1 ? 0 : (int)list_cnt[0];
+        const int n_waves = (n_groups - n_dense_groups) * 4;
         const int wave = threadIdx.x >> 6;
         reduce_light_tiles<FULL>(a, cp, tile_list, n_light, (group - n_dense_groups) * 4 + wave, n_waves, lds.light[wave]);
+    }
+}
+
+// grid = (GD + GL, clouds): one work-group per share.
+template <bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
+{
+    __shared__ ReduceLds lds;
+    // (cloud, group) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD, in
+    // Morton order, so vertically adjacent tiles complete each other's 128-byte layer lines in the same L2
+    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int cloud = (int)(item / gridDim.x);
+    const int group = (int)(item % gridDim.x);
+    if (a.k2_debug == 1) return;
+    const unsigned long long t_wg = (a.k2_debug == 9 || a.k2_debug == 5) ? __builtin_readcyclecounter() : a.k2_debug == 6 ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long *census = nullptr; // (GG_K2_DEBUG=5, tools/k2_census.py: which CU runs how many work-groups at a time)
+    if (a.k2_debug == 5 && threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_ID, XCC_ID
+        census = a.k2_dbg + (size_t)(((xcc & 7u) << 7) | ((hw >> 8) & 0x7Fu)) * 8;
+        atomicAdd(&census[0], 1ull);
+        const unsigned long long r = atomicAdd(&census[1], 1ull) + 1ull;
+        atomicMax(&census[2], r);
+        atomicMin(&census[4], t_wg);
+    }
+    reduce_share<FULL>(a, params, lds, cloud, group, (int)gridDim.x, n_dense_groups);
+    if (a.k2_debug == 6 && threadIdx.x == 0 && item < 65536u) { // (tools/k2_trace.py: one record per work-group)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        unsigned long long *rec = a.k2_dbg + (size_t)item * 4;
+        rec[0] = t_wg;
+        rec[1] = __builtin_amdgcn_s_memrealtime(); // (100 MHz, the same counter on every XCD)
+        rec[2] = ((xcc & 7u) << 7) | ((hw >> 8) & 0x7Fu);
+        rec[3] = (unsigned long long)(group < n_dense_groups);
     }
     if (census) {
         const unsigned long long t_end = __builtin_readcyclecounter();

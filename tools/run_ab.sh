@@ -1,6 +1,10 @@
-mkdir -p gpurun_out/r03t; O=gpurun_out/r03t
+# scratch: ABAB of library variants on the headline workload; usage: LIBS="base default" REPS=3 bash tools/run_ab.sh
 V=$PWD/groundgrid_amd/variants
-for lib in default tight2 tight4; do
-  if [ $lib = default ]; then unset GROUNDGRID_HIP_LIB; else export GROUNDGRID_HIP_LIB=$V/lib_$lib.so; fi
-  BATCHES_SMALL=1,64 BATCHES_BIG=1 timeout 300 python tools/latency_probe.py > $O/lat_$lib.json 2>>$O/err.log; cat $O/lat_$lib.json
+for r in $(seq 1 ${REPS:-3}); do
+  for lib in ${LIBS:-base default}; do
+    if [ $lib = default ]; then unset GROUNDGRID_HIP_LIB; else export GROUNDGRID_HIP_LIB=$V/lib_$lib.so; fi
+    timeout 150 python tools/ab_kernels.py 1024 8 $lib 2>/dev/null | tail -1 | python -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); c=j['cold']; print(j['tag'], c['ms_per_step'], 'reduce', c['k_reduce'], 'classify', c['k_classify'], 'patch', c['k_patch'], 'sweep', c['k_sweep'], 'label', c['k_label'], 'scatter', c['k_scatter'])"
+  done
 done
