@@ -572,7 +572,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_trank = carve((size_t)g.T * 2);
     const size_t o_rtile = carve((size_t)g.T * 2);
     const size_t o_rcell0 = carve((size_t)g.T * 4);
-    const size_t o_layers = carve((size_t)n_slots * GG_NUM_LAYERS * Cpad * 4);
+    const size_t percall_slot_floats = align_up((size_t)g.T * PERCALL_BLOCK * 4, A) / 4;
+    const size_t o_layers = carve((size_t)n_slots * percall_slot_floats * 4);
     a.gpl = make_gp_layout(n);
     a.gp2_stride = align_up((size_t)a.gpl.elems * 8, A) / 8;
     const size_t o_gp2 = carve((size_t)n_slots * a.gp2_stride * 8);
@@ -628,8 +629,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.rank_cell0 = (const uint32_t *)(base + o_rcell0);
     a.layers = (float *)(base + o_layers);
     a.gp2 = (float2 *)(base + o_gp2);
-    a.layer_stride = Cpad;
-    a.slot_layer_stride = Cpad * GG_NUM_LAYERS;
+    a.slot_layer_stride = percall_slot_floats;
     a.rec = (uint2 *)(base + o_rec);
     a.sorted = (uint2 *)(base + o_sorted);
     a.zcell = (float *)(base + o_zcell);
@@ -891,7 +891,6 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
         if (ctx->have_batch_event && ctx->last_batch_stream != st) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->batch_event, 0));
     }
     const Arena &a = ctx->arena;
-    const size_t C = (size_t)a.g.C;
     for (int s = first_slot; s < first_slot + n; ++s) {
         ctx->no_confidence[s] = 1; // groundpatch := 1e-7 everywhere (scrolling keeps that: exposed cells get 0)
         ctx->pos_x[s] = pos_x;
@@ -901,9 +900,7 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
     // spaced, so one strided fill per layer covers all n slots.
     const float init[GG_NUM_LAYERS] = {0.0f, odom_z, (float)0.0000001, (float)100.0, (float)-100.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!persistent_only) {
-        for (int l = 0; l < GG_NUM_LAYERS; ++l)
-            if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH)
-                launch_fill_strided(layer_ptr(a, first_slot, l), C, a.slot_layer_stride, n, init[l], st);
+        launch_fill_percall(a, first_slot, n, init, st);
         // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
         launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)first_slot * a.tile_live_stride), (size_t)n * a.tile_live_stride * 2, 0xFF, st);
     }
@@ -982,7 +979,9 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
         // (reset values into the dead columns, every column live), then overwrite this one with the host's matrix
         launch_materialise_layers(ctx->arena, slot, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(layer_ptr(ctx->arena, slot, layer), src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
+        launch_layer_insert(ctx->arena, slot, layer, ctx->d_image, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
     }
     if (const int rc = own_stream_mutated_map(ctx)) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1013,7 +1012,7 @@ int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
     if (!dst) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
-    const size_t plane = ctx->arena.layer_stride;
+    const size_t plane = align_up((size_t)ctx->arena.g.C * 4, 256) / 4;
     if (!ctx->d_planes) HIPCHK(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)GG_NUM_LAYERS * plane * sizeof(float)));
     for (int l = 0; l < GG_NUM_LAYERS; ++l) {
         if (!dst[l]) continue;

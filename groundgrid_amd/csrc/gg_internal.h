@@ -91,7 +91,7 @@ struct Arena {
     const uint16_t *rank_tile;    // [T] Morton rank -> tile
     const uint32_t *rank_cell0;   // [T] Morton rank -> first row | first col << 16 of the tile (per-point lookups: no division)
     // per slot (slot s at base + s * stride)
-    float *layers;  size_t layer_stride;  size_t slot_layer_stride;  // layer l of slot s: layers + s*slot_layer_stride + l*layer_stride
+    float *layers;  size_t slot_layer_stride;  // the nine per-call layers of slot s, TILE BY TILE (percall_block below): layers + s*slot_layer_stride
     const uint32_t *gp_valid;     // one bit per element of the gp2 order: does gg_reset_maps fill it (the 128-byte lines that hold cells; the rest is padding)
     float2 *gp2;    size_t gp2_stride;    GpLayout gpl;              // (ground, confidence) of slot s: gp2 + s*gp2_stride, element order gp_layout.h
     uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
@@ -133,9 +133,40 @@ struct Arena {
     int eigen_reduction; // gg_conventions::eigen_reduction (GG_EIGEN_33 / GG_EIGEN_34_SSE): order of the 5x5 block sums in K3
 };
 
-__host__ __device__ inline float *layer_ptr(const Arena &a, int slot, int layer)
+// The nine per-call layers (everything but ground / groundpatch) are stored tile by tile: the 16x16 tile of Morton rank r owns the
+// block [r * PERCALL_BLOCK, (r + 1) * PERCALL_BLOCK) of its slot, laid out [layer position][column in tile][row in tile] -- 9 x 256
+// floats, 9 KiB, every (layer, column) a 64-byte line segment.  K2 writes a tile's nine layers as ONE contiguous region instead of
+// 144 segments 1456 bytes apart in nine planes (measured: k_reduce 1.47 -> 1.31 ms per 1024 clouds with the same bytes), K5
+// addresses a point's cell straight from its key (tile rank, cell in tile) without the tile's origin, and K3's block of 8 columns
+// is 512 contiguous bytes per layer.  The order of the layers inside a block puts the three K3 reads first and the three that
+// GG_FLAG_MINIMAL_LAYERS leaves out last.  The dense column-major matrices of the reference exist at the host boundary only
+// (gg_get_layer / gg_set_layer, k6_wire.hip).
+constexpr int PERCALL_LAYERS = 9;
+constexpr int PERCALL_BLOCK = PERCALL_LAYERS * TILE * TILE;
+enum : int { PL_POINTS = 0, PL_VARIANCE = 1, PL_MINGROUNDHEIGHT = 2, PL_M2 = 3, PL_POINTSRAW = 4, PL_MEANVARIANCE = 5, PL_MAXGROUNDHEIGHT = 6,
+             PL_GROUNDCANDIDATES = 7, PL_PLANEDIST = 8 };
+__host__ __device__ inline int percall_position(int layer) // gg_layer -> position in a block (-1: ground / groundpatch live elsewhere)
 {
-    return a.layers + (size_t)slot * a.slot_layer_stride + (size_t)layer * a.layer_stride;
+    switch (layer) {
+    case GG_LAYER_POINTS: return PL_POINTS;
+    case GG_LAYER_VARIANCE: return PL_VARIANCE;
+    case GG_LAYER_MINGROUNDHEIGHT: return PL_MINGROUNDHEIGHT;
+    case GG_LAYER_M2: return PL_M2;
+    case GG_LAYER_POINTSRAW: return PL_POINTSRAW;
+    case GG_LAYER_MEANVARIANCE: return PL_MEANVARIANCE;
+    case GG_LAYER_MAXGROUNDHEIGHT: return PL_MAXGROUNDHEIGHT;
+    case GG_LAYER_GROUNDCANDIDATES: return PL_GROUNDCANDIDATES;
+    case GG_LAYER_PLANEDIST: return PL_PLANEDIST;
+    default: return -1;
+    }
+}
+__host__ __device__ inline float *percall_ptr(const Arena &a, int slot) { return a.layers + (size_t)slot * a.slot_layer_stride; }
+// element of (tile rank, layer position, cell in tile = row in tile + 16 * column in tile)
+__host__ __device__ inline size_t percall_index(int rank, int position, int cell) { return (size_t)rank * PERCALL_BLOCK + (size_t)position * (TILE * TILE) + (size_t)cell; }
+// ... of map cell (row, col)
+__device__ inline size_t percall_index_of(const Arena &a, int position, int row, int col)
+{
+    return percall_index(a.tile_rank[(row / TILE) + (col / TILE) * a.g.tiles_r], position, (row % TILE) + (col % TILE) * TILE);
 }
 
 // `ground` and `groundpatch` (confidence) are always used together -- confidence-weighted height -- and are the only
@@ -200,6 +231,8 @@ void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io
 void launch_fill(float *dst, size_t n, float v, hipStream_t s);
 void launch_fill_bytes(uint8_t *dst, size_t n, uint8_t v, hipStream_t s);
 void launch_fill_strided(float *dst, size_t n, size_t stride, int count, float v, hipStream_t s);   // count regions of n floats, `stride` apart
+void launch_fill_percall(const Arena &a, int first_slot, int n_slots, const float init[GG_NUM_LAYERS], hipStream_t s); // every per-call layer of the slots := init[layer]
+void launch_layer_insert(const Arena &a, int slot, int layer, const float *src, hipStream_t s);    // dense column-major plane -> per-call layer (all columns live)
 void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float x, float y, const uint32_t *valid, hipStream_t s);
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
 void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s); // sheared layer -> column-major plane

@@ -284,24 +284,23 @@ union ReduceLds {
     LightLds light[4];
 };
 
-// the 9 per-call layers of one cell (minimal layers: the three that nothing in the path reads are not maintained)
+// the 9 per-call layers of one cell (minimal layers: the three that nothing in the path reads are not maintained); B = the tile's
+// block of the per-call layers (gg_internal.h percall_index: [layer position][cell]), `cell` = row in tile + 16 * column in tile.
+// (Cells of a border tile beyond the map's last row / column exist in the block and are written like the others: nobody reads them.)
 template <bool FULL>
-GG_DEV void write_cell(const Arena &a, float *L, int row, int col, float c, float raw, const CellState &st)
+GG_DEV void write_cell(float *B, int cell, float c, float raw, const CellState &st)
 {
-    if (row < a.g.rows && col < a.g.cols) {
-        const size_t idx = (size_t)row + (size_t)col * a.g.rows;
-        const size_t ls = a.layer_stride;
-        L[GG_LAYER_POINTS * ls + idx] = c;
-        L[GG_LAYER_MINGROUNDHEIGHT * ls + idx] = st.mn;
-        L[GG_LAYER_M2 * ls + idx] = st.m2;
-        L[GG_LAYER_VARIANCE * ls + idx] = st.m2 / (c + FLT_MIN); // :323
-        L[GG_LAYER_POINTSRAW * ls + idx] = raw;
-        L[GG_LAYER_MEANVARIANCE * ls + idx] = st.mean;
-        if (FULL) {
-            L[GG_LAYER_MAXGROUNDHEIGHT * ls + idx] = st.mx;
-            L[GG_LAYER_GROUNDCANDIDATES * ls + idx] = st.gc;
-            L[GG_LAYER_PLANEDIST * ls + idx] = st.pdm;
-        }
+    constexpr int P = TILE * TILE;
+    B[PL_POINTS * P + cell] = c;
+    B[PL_MINGROUNDHEIGHT * P + cell] = st.mn;
+    B[PL_M2 * P + cell] = st.m2;
+    B[PL_VARIANCE * P + cell] = st.m2 / (c + FLT_MIN); // :323
+    B[PL_POINTSRAW * P + cell] = raw;
+    B[PL_MEANVARIANCE * P + cell] = st.mean;
+    if (FULL) {
+        B[PL_MAXGROUNDHEIGHT * P + cell] = st.mx;
+        B[PL_GROUNDCANDIDATES * P + cell] = st.gc;
+        B[PL_PLANEDIST * P + cell] = st.pdm;
     }
 }
 
@@ -333,7 +332,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
 {
     if (first >= n_light) return;
     const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
-    float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
+    float *L = percall_ptr(a, cp.slot);
     uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX};
     const float oz = cp.oz;
@@ -355,7 +354,6 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
         const uint32_t next_start = has_next ? ent_next.y : 0u, next_end = has_next ? ent_next.z : 0u;
         const uint4 ent_after = tile_list[min(j + 2 * stride, n_light - 1)];
         const int rank = (int)(ent.x & 0xFFFFu);
-        const int row0 = (int)(ent.w & 0xFFFFu), col0 = (int)(ent.w >> 16);
         // only the columns that hold a record now are written (and marked live: the per-call layers are sparse, gg_internal.h
         // tile_live) -- a light tile has records in ~60 % of its columns
         uint32_t cols_now = 0u;
@@ -458,7 +456,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                 const uint32_t cb = column_bits(__ballot((wv >> 16) != 0u)); // (pointsRaw > 0: the cell holds an in-map record)
                 cols_now |= cb << (4 * k);
                 if ((cb >> (lane >> 4)) & 1u)
-                    write_cell<FULL>(a, L, row0 + (cell & 15), col0 + (cell >> 4), (float)np, (float)(wv >> 16), st);
+                    write_cell<FULL>(L + percall_index(rank, 0, 0), cell, (float)np, (float)(wv >> 16), st);
                 seg = seg_end;
             }
             lds_order(); // (the next tile reuses the memory)
@@ -483,7 +481,6 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int rank = (int)(ent.x & 0xFFFFu);
-    const int row0 = (int)(ent.w & 0xFFFFu), col0 = (int)(ent.w >> 16);
     const uint32_t start = ent.y, end = ent.z;
     const float oz = cp.oz;
     float *ex = reinterpret_cast<float *>(&lds.cnt64[0][0]); // result exchange, [layer value][cell] (8 KiB over the counters of step 1)
@@ -684,8 +681,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     st.gc = ex[6 * TILE_CELLS + tid];
     st.pdm = ex[7 * TILE_CELLS + tid];
     if (column_written)
-        write_cell<FULL>(a, a.layers + (size_t)cp.slot * a.slot_layer_stride, row0 + (tid & 15), col0 + (tid >> 4), ex[0 * TILE_CELLS + tid],
-                   ex[3 * TILE_CELLS + tid], st);
+        write_cell<FULL>(percall_ptr(a, cp.slot) + percall_index(rank, 0, 0), tid, ex[0 * TILE_CELLS + tid], ex[3 * TILE_CELLS + tid], st);
     if (timing && tid == 0) {
         tmark[5] = __builtin_readcyclecounter();
         dbg_add(a, 0, 1ull);                       // dense tiles

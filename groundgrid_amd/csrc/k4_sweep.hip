@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     const LdsMap L = lds_layout(P.c, P.groups, g0, g1, P.split_steps != 0);
     const CloudParams &cp = params[cloud];
     float2 *gp2 = gp2_ptr(a, cp.slot);
-    float *points = a.layers + (size_t)cp.slot * a.slot_layer_stride + GG_LAYER_POINTS * a.layer_stride;
+    float *percall = percall_ptr(a, cp.slot);
     const int nthreads = blockDim.x;
 
     // hand-over tables start empty: counters 0 = "ring 0 done", and ring 0 of every table is the centre cell
@@ -494,13 +494,11 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
         for (int rank = wave_; rank < a.g.T; rank += nwaves) {
             const uint32_t cols_live = tile_live[rank];
             if (!cols_live) continue; // (uniform)
-            const int tile = a.rank_tile[rank];
-            const int tr = tile % a.g.tiles_r, tc = tile / a.g.tiles_r;
+            float *points = percall + percall_index(rank, PL_POINTS, 0); // (the tile's 256 counts are contiguous)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int cell = lane_ + 64 * k;
-                const int row = tr * TILE + (cell & 15), col = tc * TILE + (cell >> 4);
-                if (row < a.g.rows && col < a.g.cols && ((cols_live >> (cell >> 4)) & 1u)) points[(size_t)row + (size_t)col * a.g.rows] = 0.0f;
+                if ((cols_live >> (cell >> 4)) & 1u) points[cell] = 0.0f;
             }
         }
     }

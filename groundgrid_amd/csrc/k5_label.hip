@@ -55,11 +55,11 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
     }
     if (chunk >= nch) return;
 
-    const int rows = a.g.rows;
-    const float *L = a.layers + (size_t)cp.slot * a.slot_layer_stride;
+    const float *L = percall_ptr(a, cp.slot);
     const float2 *gp2 = gp2_ptr(a, cp.slot);
-    const float *variance = L + GG_LAYER_VARIANCE * a.layer_stride;
-    float *points = const_cast<float *>(L) + GG_LAYER_POINTS * a.layer_stride;
+    // (a record's key names its tile and its cell in the tile: the per-call layers are addressed without the tile's origin)
+    const float *variance = L + percall_index(0, PL_VARIANCE, 0);
+    float *points = const_cast<float *>(L) + percall_index(0, PL_POINTS, 0);
     const uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
     const char *pts = reinterpret_cast<const char *>(io.d_points) + (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
     uint8_t *labels = io.d_labels ? io.d_labels + (size_t)cloud * io.cloud_stride : nullptr;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                 row = (int)(c0 & 0xFFFFu) + (int)(key & 15u);
                 col = (int)(c0 >> 16) + (int)((key >> 4) & 15u);
             }
-            cidx[j] = (uint32_t)row + (uint32_t)col * (uint32_t)rows;
+            cidx[j] = lab[j] ? (key >> KEY_TILE_SHIFT) * (uint32_t)PERCALL_BLOCK + (key & 255u) : 0u;
             gh[j] = gp2[gp_idx(a, row, col)].x; // :162
             var[j] = variance[cidx[j]]; // :165
             const float cx = cell0_x - ((float)row + 0.5f) * res_f, cy = cell0_y - ((float)col + 0.5f) * res_f;

@@ -8,6 +8,7 @@
 #include "gg_device.h"
 
 #include <float.h>
+#include <algorithm>
 
 namespace gg {
 
@@ -64,14 +65,14 @@ __global__ __launch_bounds__(256) void k_layer_to_u8(const float *__restrict__ l
 __global__ __launch_bounds__(256) void k_terrain_image(const Arena a, int slot, float *__restrict__ img)
 {
     const float2 *gp2 = gp2_ptr(a, slot);
-    const float *raw = layer_ptr(a, slot, GG_LAYER_POINTSRAW);
+    const float *percall = percall_ptr(a, slot);
     const int rows = a.g.rows, cols = a.g.cols;
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= rows || j >= cols) return;
     float flag = 0.0f;
     // (pointsRaw is a sparse per-call layer: 0 outside the live columns, gg_internal.h tile_live)
-    auto raw_at = [&](int r, int c) { return cell_is_live(a, slot, r, c) ? raw[(size_t)r + (size_t)c * rows] : 0.0f; };
+    auto raw_at = [&](int r, int c) { return cell_is_live(a, slot, r, c) ? percall[percall_index_of(a, PL_POINTSRAW, r, c)] : 0.0f; };
     if (i >= 1 && j >= 1 && i + 1 < rows && j + 1 < cols) {
         float e[9];
 #pragma unroll
@@ -88,11 +89,11 @@ __global__ __launch_bounds__(256) void k_terrain_image(const Arena a, int slot, 
 // value (:61-75) everywhere else (gg_internal.h tile_live).  The host boundary of the sparse layers (gg_get_layer, image getters).
 __global__ __launch_bounds__(256) void k_layer_extract(const Arena a, int slot, int layer, float *__restrict__ dst)
 {
-    const float *src = layer_ptr(a, slot, layer);
-    const int rows = a.g.rows;
+    const float *src = percall_ptr(a, slot);
+    const int rows = a.g.rows, position = percall_position(layer);
     const float dead = layer_reset_value(layer);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.g.C; i += gridDim.x * blockDim.x)
-        dst[i] = cell_is_live(a, slot, i % rows, i / rows) ? src[i] : dead;
+        dst[i] = cell_is_live(a, slot, i % rows, i / rows) ? src[percall_index_of(a, position, i % rows, i / rows)] : dead;
 }
 void launch_layer_extract(const Arena &a, int slot, int layer, float *dst, hipStream_t s)
 {
@@ -105,11 +106,12 @@ void launch_layer_extract(const Arena &a, int slot, int layer, float *dst, hipSt
 __global__ __launch_bounds__(256) void k_materialise(const Arena a, int slot)
 {
     const int rows = a.g.rows;
-    float *L = a.layers + (size_t)slot * a.slot_layer_stride;
+    float *L = percall_ptr(a, slot);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.g.C; i += gridDim.x * blockDim.x) {
         if (cell_is_live(a, slot, i % rows, i / rows)) continue;
+        const size_t at = percall_index_of(a, 0, i % rows, i / rows);
         for (int l = 0; l < GG_NUM_LAYERS; ++l)
-            if (l != GG_LAYER_GROUND && l != GG_LAYER_GROUNDPATCH) L[(size_t)l * a.layer_stride + i] = layer_reset_value(l);
+            if (percall_position(l) >= 0) L[at + (size_t)percall_position(l) * (TILE * TILE)] = layer_reset_value(l);
     }
 }
 void launch_materialise_layers(const Arena &a, int slot, hipStream_t s)
@@ -117,6 +119,40 @@ void launch_materialise_layers(const Arena &a, int slot, hipStream_t s)
     const int blocks = (a.g.C + 255) / 256 < 2048 ? (a.g.C + 255) / 256 : 2048;
     hipLaunchKernelGGL(k_materialise, dim3(blocks), dim3(256), 0, s, a, slot);
     launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)slot * a.tile_live_stride), (size_t)a.g.T * 2, 0xFF, s); // (after the kernel, same stream)
+}
+
+// The host's dense column-major matrix into one per-call layer (gg_set_layer, after launch_materialise_layers: every column live).
+__global__ __launch_bounds__(256) void k_layer_insert(const Arena a, int slot, int layer, const float *__restrict__ src)
+{
+    float *dst = percall_ptr(a, slot);
+    const int rows = a.g.rows, position = percall_position(layer);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.g.C; i += gridDim.x * blockDim.x) dst[percall_index_of(a, position, i % rows, i / rows)] = src[i];
+}
+void launch_layer_insert(const Arena &a, int slot, int layer, const float *src, hipStream_t s)
+{
+    const int blocks = (a.g.C + 255) / 256 < 2048 ? (a.g.C + 255) / 256 : 2048;
+    hipLaunchKernelGGL(k_layer_insert, dim3(blocks), dim3(256), 0, s, a, slot, layer, src);
+}
+
+// GroundGrid's initial values (src/GroundGrid.cpp:71-75) into every per-call layer of n slots: element e of a slot's region belongs
+// to layer position (e / 256) % 9
+struct PercallInit {
+    float v[PERCALL_LAYERS];
+};
+__global__ __launch_bounds__(256) void k_fill_percall(float *__restrict__ dst, size_t n, size_t stride, const PercallInit init)
+{
+    float *d = dst + (size_t)blockIdx.y * stride;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = init.v[(i / (TILE * TILE)) % PERCALL_LAYERS];
+}
+void launch_fill_percall(const Arena &a, int first_slot, int n_slots, const float init[GG_NUM_LAYERS], hipStream_t s)
+{
+    if (n_slots <= 0) return;
+    PercallInit pi;
+    for (int l = 0; l < GG_NUM_LAYERS; ++l)
+        if (percall_position(l) >= 0) pi.v[percall_position(l)] = init[l];
+    const size_t n = (size_t)a.g.T * PERCALL_BLOCK;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, n_slots >= 64 ? (size_t)64 : (size_t)1024);
+    hipLaunchKernelGGL(k_fill_percall, dim3(blocks, n_slots), dim3(256), 0, s, percall_ptr(a, first_slot), n, a.slot_layer_stride, pi);
 }
 
 void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds, uint8_t *d_img, hipStream_t s)
