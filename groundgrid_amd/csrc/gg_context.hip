@@ -589,7 +589,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_start_stride = align_up((size_t)(g.T + 1) * 4, A) / 4;
     const size_t o_tstart = carve((size_t)n_slots * a.tile_start_stride * 4);
     a.tile_live_stride = align_up((size_t)g.T, A);
-    const size_t o_tlive = carve((size_t)n_slots * a.tile_live_stride * 2);
+    const size_t o_tlive = carve((size_t)n_slots * a.tile_live_stride * 4);
     a.tile_list_stride = align_up((size_t)g.T * 16, A) / 16;
     const size_t o_tlist = carve((size_t)n_slots * a.tile_list_stride * 16);
     const size_t o_tlcnt = carve((size_t)n_slots * 2 * 4);
@@ -638,7 +638,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.chunk_emit = (uint32_t *)(base + o_emit);
     a.totals = (uint32_t *)(base + o_totals);
     a.tile_start = (uint32_t *)(base + o_tstart);
-    a.tile_live = (uint16_t *)(base + o_tlive);
+    a.tile_live = (uint32_t *)(base + o_tlive);
     a.tile_list = (uint4 *)(base + o_tlist);
     a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
     a.sweep_xchg = (unsigned long long *)(base + o_xchg);
@@ -902,7 +902,7 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
     if (!persistent_only) {
         launch_fill_percall(a, first_slot, n, init, st);
         // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
-        launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)first_slot * a.tile_live_stride), (size_t)n * a.tile_live_stride * 2, 0xFF, st);
+        launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)first_slot * a.tile_live_stride), (size_t)n * a.tile_live_stride * 4, 0xFF, st);
     }
     launch_fill2_strided(gp2_ptr(a, first_slot), (size_t)a.gpl.elems, a.gp2_stride, n, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], a.gp_valid, st);
     HIPCHK(ctx, hipGetLastError());

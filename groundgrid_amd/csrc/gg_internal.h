@@ -100,14 +100,17 @@ struct Arena {
     uint32_t *chunk_emit;  size_t emit_stride;   // NCH * 4
     uint32_t *totals;      // [slot][4]  (emitted kept, emitted ignored, outliers, in-map)
     uint32_t *tile_start;  size_t tile_start_stride; // T + 1
-    uint16_t *tile_live;   size_t tile_live_stride;  // [slot][T] by Morton rank: bit k = column k of the tile (16 cells, one 64-byte row
-                                                     // segment per layer) physically HOLDS its values in the nine per-call layers.  A
-                                                     // column whose bit is clear holds stale bytes and logically has the per-call reset
-                                                     // values (:61-75) -- the per-call layers are stored SPARSELY: K2 writes (and marks)
-                                                     // exactly the columns that hold an in-map record of this cloud, k_scan clears the
-                                                     // masks of tiles without records, and every reader (K3's staging, gg_get_layer,
-                                                     // the image kernels) substitutes the reset values through cell_is_live().  Nothing
-                                                     // ever has to "clean" the cells a previous cloud left behind.
+    uint32_t *tile_live;   size_t tile_live_stride;  // [slot][T] by Morton rank: bit k = HALF COLUMN k of the tile (cells 8k .. 8k + 7 of the
+                                                     // tile's cell order row + 16 col: 8 cells, one 32-byte sector per layer) physically
+                                                     // HOLDS its values in the nine per-call layers.  A half column whose bit is clear
+                                                     // holds stale bytes and logically has the per-call reset values (:61-75) -- the
+                                                     // per-call layers are stored SPARSELY: K2 writes (and marks) exactly the half columns
+                                                     // that hold an in-map record of this cloud, k_scan clears the masks of tiles without
+                                                     // records, and every reader (K3's staging, gg_get_layer, the image kernels)
+                                                     // substitutes the reset values through cell_is_live().  Nothing ever has to "clean"
+                                                     // the cells a previous cloud left behind.  (Half columns: a scan line crosses a
+                                                     // tile as an arc that touches most columns in one or two cells -- 27 % fewer layer
+                                                     // bytes than with whole columns on a street scene.)
     uint4 *tile_list;      size_t tile_list_stride;  // [slot][T] K2's work lists (k_scan): light tiles from the front, dense tiles from the back; an
                                                      // entry is everything K2 needs to know about the tile without another dependent
                                                      // lookup: x = Morton rank, y / z = first / end
@@ -179,11 +182,13 @@ __host__ __device__ inline float layer_reset_value(int layer)
 {
     return layer == GG_LAYER_MINGROUNDHEIGHT ? 3.402823466e+38f /* FLT_MAX, :72 */ : layer == GG_LAYER_MAXGROUNDHEIGHT ? 1.175494351e-38f /* FLT_MIN (sic), :73 */ : 0.0f;
 }
+// the bit of tile_live that covers `cell` = row in tile + 16 * column in tile
+__host__ __device__ inline int live_bit(int cell) { return cell >> 3; }
 // does cell (row, col) of `slot` physically hold its per-call layer values (Arena::tile_live)?
 __device__ inline bool cell_is_live(const Arena &a, int slot, int row, int col)
 {
     const int rank = a.tile_rank[(row / TILE) + (col / TILE) * a.g.tiles_r];
-    return ((a.tile_live[(size_t)slot * a.tile_live_stride + rank] >> (col % TILE)) & 1u) != 0u;
+    return ((a.tile_live[(size_t)slot * a.tile_live_stride + rank] >> live_bit((row % TILE) + (col % TILE) * TILE)) & 1u) != 0u;
 }
 
 __host__ __device__ inline float2 *gp2_ptr(const Arena &a, int slot) { return a.gp2 + (size_t)slot * a.gp2_stride; }

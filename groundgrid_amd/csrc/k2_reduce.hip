@@ -304,12 +304,14 @@ GG_DEV void write_cell(float *B, int cell, float c, float raw, const CellState &
     }
 }
 
-// Which of a tile's 16 columns hold records: `held` = ballot of "my cell holds an in-map record" over a wavefront whose lanes
-// 16 j .. 16 j + 15 are the cells of one column (four columns per wavefront / per k).  Returns the four column bits.
-GG_DEV uint32_t column_bits(unsigned long long held)
+// Which of a tile's 32 half columns hold records: `held` = ballot of "my cell holds an in-map record" over a wavefront whose lanes
+// 8 j .. 8 j + 7 are the cells of one half column (eight half columns per wavefront / per k).  Returns the eight bits.
+GG_DEV uint32_t half_column_bits(unsigned long long held)
 {
-    return ((held & 0xFFFFull) ? 1u : 0u) | ((held & 0xFFFF0000ull) ? 2u : 0u) | ((held & 0xFFFF00000000ull) ? 4u : 0u) |
-           ((held & 0xFFFF000000000000ull) ? 8u : 0u);
+    uint32_t b = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b |= ((held >> (8 * j)) & 0xFFull) ? (1u << j) : 0u;
+    return b;
 }
 
 // ---- light tiles: one wavefront per tile, no barrier, nothing leaves LDS but the layers --------------------------------------
@@ -333,7 +335,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
     if (first >= n_light) return;
     const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
     float *L = percall_ptr(a, cp.slot);
-    uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX};
     const float oz = cp.oz;
     const bool timing = a.k2_debug == 9;
@@ -453,16 +455,16 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                     four_points<RL>(zz, i, np, rr, oz, st);
                 }
                 const int cell = lane + 64 * k;
-                const uint32_t cb = column_bits(__ballot((wv >> 16) != 0u)); // (pointsRaw > 0: the cell holds an in-map record)
-                cols_now |= cb << (4 * k);
-                if ((cb >> (lane >> 4)) & 1u)
+                const uint32_t cb = half_column_bits(__ballot((wv >> 16) != 0u)); // (pointsRaw > 0: the cell holds an in-map record)
+                cols_now |= cb << (8 * k);
+                if ((cb >> (lane >> 3)) & 1u)
                     write_cell<FULL>(L + percall_index(rank, 0, 0), cell, (float)np, (float)(wv >> 16), st);
                 seg = seg_end;
             }
             lds_order(); // (the next tile reuses the memory)
             if (timing && lane == 0) dbg_add(a, 28, __builtin_readcyclecounter() - t_p1); // chains + writes
         }
-        if (lane == 0) tile_live[rank] = (uint16_t)cols_now;
+        if (lane == 0) tile_live[rank] = cols_now;
         if (timing && lane == 0) {
             dbg_add(a, had_points ? 8 : 12, 1ull);
             dbg_add(a, had_points ? 9 : 14, (unsigned long long)(end - start));
@@ -670,9 +672,9 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     __syncthreads();
     if (timing) tmark[4] = __builtin_readcyclecounter();
     // (columns: see reduce_light_tiles; thread = cell, a wavefront holds four columns)
-    const uint32_t cb = column_bits(__ballot(ex[3 * TILE_CELLS + tid] != 0.0f));
+    const uint32_t cb = half_column_bits(__ballot(ex[3 * TILE_CELLS + tid] != 0.0f));
     if (lane == 0) lds.wave_full[wave] = cb; // (the split flags were read before the recurrences; combined after the caller's barrier)
-    const bool column_written = ((cb >> (lane >> 4)) & 1u) != 0u;
+    const bool column_written = ((cb >> (lane >> 3)) & 1u) != 0u;
     CellState st;
     st.mn = ex[1 * TILE_CELLS + tid];
     st.m2 = ex[2 * TILE_CELLS + tid];
@@ -718,9 +720,9 @@ GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params,
             const int rank = (int)(ent.x & 0xFFFFu);
             reduce_dense_tile<FULL>(a, cp, ent, lds.dense, tid);
             __syncthreads(); // (the next tile reuses the shared memory)
-            if (tid == 0) // the tile's columns that hold records now (every wavefront left its four bits)
-                (a.tile_live + (size_t)cp.slot * a.tile_live_stride)[rank] = (uint16_t)(lds.dense.wave_full[0] | (lds.dense.wave_full[1] << 4) |
-                                                                                         (lds.dense.wave_full[2] << 8) | (lds.dense.wave_full[3] << 12));
+            if (tid == 0) // the tile's columns that hold records now (every wavefront left its eight bits)
+                (a.tile_live + (size_t)cp.slot * a.tile_live_stride)[rank] =
+                    lds.dense.wave_full[0] | (lds.dense.wave_full[1] << 8) | (lds.dense.wave_full[2] << 16) | (lds.dense.wave_full[3] << 24);
         }
     } else {
         const int n_light = a.k2_skip == 1 ? 0 : (int)list_cnt[0];

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     // visited cell pays for (:364 decides on it); the two weighted sums (:374-375) keep Eigen's order.
     __shared__ float v5[LC][PR], v3[LC][PR];
     __shared__ uint32_t col_has_points[MAXTC]; // per tile column: records in the band's tile rows
-    __shared__ uint32_t live_cols[3][MAXTC];   // the band's (up to three) tile rows: tile_live (which columns physically hold values) | Morton rank << 16
+    __shared__ uint32_t live_cols[3][MAXTC];   // the band's (up to three) tile rows: tile_live (which half columns physically hold values)
+    __shared__ uint16_t band_rank[3][MAXTC];   // ... and the tiles' Morton ranks (where their blocks of the per-call layers are)
     // XCD-aware (gg_device.h): the bands of one cloud run on one XCD.  A launch with few clouds cuts every band into segments
     // of blocks_per_segment blocks (one work-group each) so that the chip is still covered.
     const uint32_t item = xcd_contiguous_item(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
@@ -177,14 +178,15 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
         const int tr_lo = (r0 - HALO) / TILE, tr_hi = min((r0 + PR + HALO - 1) / TILE, a.g.tiles_r - 1);
         const int ntr = tr_hi - tr_lo + 1;
-        const uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+        const uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
         for (int k = tid; k < 3 * tiles_c; k += 256) live_cols[k / tiles_c][k % tiles_c] = 0u;
         __syncthreads();
         for (int k = tid; k < ntr * tiles_c; k += 256) {
             const int tc = k / ntr, tile = (tr_lo + k % ntr) + tc * a.g.tiles_r;
             const int rank = a.tile_rank[tile];
             if (tile_start[rank + 1] != tile_start[rank]) col_has_points[tc] = 1u;
-            live_cols[k % ntr][tc] = (uint32_t)tile_live[rank] | ((uint32_t)rank << 16); // (PR + 2 HALO rows starting at a multiple of TILE: at most three tile rows)
+            band_rank[k % ntr][tc] = (uint16_t)rank;
+            live_cols[k % ntr][tc] = tile_live[rank]; // (PR + 2 HALO rows starting at a multiple of TILE: at most three tile rows)
         }
     }
     __syncthreads();
@@ -232,12 +234,13 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             const int lr = k % LR, lc = k / LR;
             const int gr = r0 - HALO + lr, gcol = first_col + lc;
             const bool ok = lc < n_cols && gr < rows && gcol < cols;
-            // the per-call layers are sparse (gg_internal.h tile_live): a column that holds no record of this cloud has stale
+            // the per-call layers are sparse (gg_internal.h tile_live): a half column that holds no record of this cloud has stale
             // bytes and logically the reset values of :61-75 -- points 0, variance 0 / (0 + FLT_MIN) = 0, minGroundHeight FLT_MAX.
             // Its lanes fetch element 0 like the out-of-range ones (still unconditional loads): no HBM traffic for dead columns
-            const uint32_t lr_tile = live_cols[ok ? (gr - (r0 - HALO)) / TILE : 0][ok ? gcol / TILE : 0];
-            const bool live = ok && ((lr_tile >> (gcol % TILE)) & 1u) != 0u;
-            const size_t idx = live ? percall_index((int)(lr_tile >> 16), 0, (gr % TILE) + (gcol % TILE) * TILE) : (size_t)0;
+            const int btr = ok ? (gr - (r0 - HALO)) / TILE : 0, btc = ok ? gcol / TILE : 0;
+            const int cell_in_tile = (gr % TILE) + (gcol % TILE) * TILE;
+            const bool live = ok && ((live_cols[btr][btc] >> live_bit(cell_in_tile)) & 1u) != 0u;
+            const size_t idx = live ? percall_index((int)band_rank[btr][btc], 0, cell_in_tile) : (size_t)0;
             const float p = gp_pts[idx], v = gp_var[idx], m = gp_min[idx];
             sp[h] = live ? p : 0.0f;
             sv[h] = live ? v : 0.0f;

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     // columns of tiles that received records hold anything but 0 (K2's tile_live invariant): one wavefront per such tile, 4 cells
     // per lane
     {
-        const uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+        const uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
         const int lane_ = threadIdx.x & 63, wave_ = (int)(threadIdx.x >> 6) + part * (nthreads >> 6), nwaves = (nthreads >> 6) * n_parts; // (shared by the parts)
         for (int rank = wave_; rank < a.g.T; rank += nwaves) {
             const uint32_t cols_live = tile_live[rank];
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int cell = lane_ + 64 * k;
-                if ((cols_live >> (cell >> 4)) & 1u) points[cell] = 0.0f;
+                if ((cols_live >> live_bit(cell)) & 1u) points[cell] = 0.0f;
             }
         }
     }

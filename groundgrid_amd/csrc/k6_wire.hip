@@ -118,7 +118,7 @@ void launch_materialise_layers(const Arena &a, int slot, hipStream_t s)
 {
     const int blocks = (a.g.C + 255) / 256 < 2048 ? (a.g.C + 255) / 256 : 2048;
     hipLaunchKernelGGL(k_materialise, dim3(blocks), dim3(256), 0, s, a, slot);
-    launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)slot * a.tile_live_stride), (size_t)a.g.T * 2, 0xFF, s); // (after the kernel, same stream)
+    launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)slot * a.tile_live_stride), (size_t)a.g.T * 4, 0xFF, s); // (after the kernel, same stream)
 }
 
 // The host's dense column-major matrix into one per-call layer (gg_set_layer, after launch_materialise_layers: every column live).

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
     uint32_t *hist = a.hist + (size_t)cp.slot * a.hist_stride;
     uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
 
-    uint16_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
     uint32_t carry = 0, lcarry = 0, dcarry = 0;
     for (int t0 = 0; t0 < T; t0 += 1024) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
             // being live (the per-call layers are sparse, gg_internal.h tile_live) -- nothing is cleaned.
             const bool dense = t < T && s > (uint32_t)K2_LIGHT_MAX;
             const bool light = t < T && !dense && s > 0u;
-            if (t < T && s == 0u) tile_live[t] = 0;
+            if (t < T && s == 0u) tile_live[t] = 0u;
             uint32_t ltotal;
             const uint32_t lexcl = block_exclusive_scan((light ? 1u : 0u) | (dense ? 0x10000u : 0u), lds, ltotal);
             // (rank, the tile's records, its first cell: K2 starts on a tile after ONE lookup)
