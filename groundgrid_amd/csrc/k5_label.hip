@@ -91,14 +91,18 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
     const float cell0_x = (float)((cp.pos_x + a.g.half0) - (double)cp.ox), cell0_y = (float)((cp.pos_y + a.g.half1) - (double)cp.oy);
 
     constexpr int ITEMS = 4;
-    for (int p0 = base; p0 < end; p0 += 64 * ITEMS) {
-        uint2 r[ITEMS];
+    // The records of the NEXT 256 points are requested while this iteration's gathers are in flight (two buffers that take turns:
+    // a copy at the loop's back edge would wait for the load): an iteration is two dependent round trips -- records, then the
+    // cell's ground and variance -- and the first of them now overlaps the previous iteration's second.
+    auto request_records = [&](uint2 (&r)[ITEMS], int p0) { // (unconditional loads at clamped indices)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) r[j] = rec[min(p0 + j * 64 + lane, end - 1)];
+    };
+    auto iteration = [&](uint2 (&r)[ITEMS], uint2 (&r_next)[ITEMS], int p0) {
         bool valid[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const int p = p0 + j * 64 + lane;
-            valid[j] = p < end;
-            r[j] = rec[valid[j] ? p : base];
+            valid[j] = p0 + j * 64 + lane < end;
             if (!valid[j]) r[j].y = KEY_OUTSIDE;
         }
         uint32_t cidx[ITEMS]; // (C < 2^32)
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             const float cx = cell0_x - ((float)row + 0.5f) * res_f, cy = cell0_y - ((float)col + 0.5f) * res_f;
             dc[j] = __builtin_amdgcn_sqrtf(cx * cx + cy * cy); // distance of the cell's centre from the origin (1 ulp: it is a bound)
         }
+        request_records(r_next, min(p0 + 64 * ITEMS, end - 1));
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int p = p0 + j * 64 + lane;
@@ -204,6 +209,14 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
             ign_base += (uint32_t)__popcll(mi);
             outl_base += (uint32_t)__popcll(mo);
         }
+    };
+    if (base >= end) return;
+    uint2 ra[ITEMS], rb[ITEMS];
+    request_records(ra, base);
+    for (int p0 = base; p0 < end; p0 += 2 * 64 * ITEMS) {
+        iteration(ra, rb, p0);
+        if (p0 + 64 * ITEMS >= end) break;
+        iteration(rb, ra, p0 + 64 * ITEMS);
     }
 }
 
