@@ -106,6 +106,34 @@ GG_DEV LaneRun lane_run(uint32_t id, int lane)
     return r;
 }
 
+// single-instruction forms where the compiler emits two or three (compare + select for std::min / std::max, a canonicalising
+// v_max before every fminf operand, a separate instruction per |x|); NaN operands are ignored by all of them as by the
+// expressions they replace
+GG_DEV float v_max(float a, float b)
+{
+    float r;
+    __asm__("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+GG_DEV float v_min(float a, float b)
+{
+    float r;
+    __asm__("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+GG_DEV float min_abs(float a, float m) // min(|a|, m)
+{
+    float r;
+    __asm__("v_min_f32 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(m));
+    return r;
+}
+GG_DEV float min3_abs(float a, float b, float m) // min(|a|, |b|, m)
+{
+    float r;
+    __asm__("v_min3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
+
 enum : int { R_MEAN = 1 /* meanVariance, m2 */, R_GC = 2 /* groundCandidates, maxGroundHeight */, R_PDM = 4 /* planeDist */, R_MN = 8 /* minGroundHeight */ };
 
 struct CellState {
@@ -141,13 +169,21 @@ GG_DEV void one_point_fast(float z, float c, double r, float oz, CellState &s, f
         }
     }
     if (R & R_PDM) q_pdm = quot(planeDist + c * s.pdm, r); // :303
-    if (!FIRST && (R & (R_GC | R_MEAN | R_PDM))) {
-        const float m = fminf(fminf(fabsf(q_gc), fabsf(mean_was)), fminf(fabsf(q_mean), fabsf(q_pdm)));
-        smallest = fminf(smallest, m);
+    if (!FIRST) { // (one instruction per two magnitudes; the chains a wavefront does not run contribute nothing)
+        if ((R & R_GC) && (R & R_MEAN)) {
+            smallest = min3_abs(q_gc, mean_was, smallest);
+            smallest = (R & R_PDM) ? min3_abs(q_mean, q_pdm, smallest) : min_abs(q_mean, smallest);
+        } else if (R & R_MEAN) {
+            smallest = min3_abs(q_mean, mean_was, smallest);
+            if (R & R_PDM) smallest = min_abs(q_pdm, smallest);
+        } else {
+            if (R & R_GC) smallest = min_abs(q_gc, smallest);
+            if (R & R_PDM) smallest = min_abs(q_pdm, smallest);
+        }
     }
     if (R & R_GC) {
-        s.gc = q_gc;             // :296
-        s.mx = std_max(s.mx, z); // :307
+        s.gc = q_gc;            // :296
+        s.mx = v_max(s.mx, z);  // :307 (std::max(mx, z): mx > 0 always, so no signed-zero case; a NaN z leaves mx alone in both)
     }
     if (R & R_MEAN) {
         const float mean_new = mean_base + q_mean;          // :302
@@ -155,7 +191,7 @@ GG_DEV void one_point_fast(float z, float c, double r, float oz, CellState &s, f
         s.mean = mean_new;
     }
     if (R & R_PDM) s.pdm = q_pdm; // :303
-    if (R & R_MN) s.mn = std_min(s.mn, z - 0.0001f); // :308
+    if (R & R_MN) s.mn = v_min(s.mn, z - 0.0001f); // :308 (std::min: a difference is never -0, a NaN leaves mn alone in both)
 }
 
 // the same point with the reference's expressions as they stand (IEEE divisions)
