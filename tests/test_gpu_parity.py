@@ -421,7 +421,7 @@ def test_minimal_layers_flag_keeps_labels_and_terrain():
 
 
 def test_sparse_per_call_layers_at_the_host_boundary():
-    """The nine per-call layers are stored sparsely (only the columns with records of the last cloud hold values): gg_get_layer,
+    """The nine per-call layers are stored sparsely (only the half columns with records of the last cloud hold values): gg_get_layer,
     the 8-bit images and the terrain image must still show the reference's dense matrices, a host write of ONE per-call layer
     (gg_set_layer) must not disturb the other eight, and clouds that move across the map must never leave stale cells behind."""
     a = synth.hdl64_cloud(seed=31, n_az=500)
@@ -450,6 +450,39 @@ def test_sparse_per_call_layers_at_the_host_boundary():
     ref.filter_cloud(a, ORIGIN0, -1.73)
     assert_same_state(seg.map(0), ref, "after a host write")
     seg.close()
+
+
+def test_per_call_layers_round_trip_through_their_tile_blocks():
+    """The per-call layers live tile by tile on the device (9 KiB blocks by Morton rank, half-column liveness masks); the host sees
+    column-major matrices.  Every layer written and read back, on grids whose last tile row / column is partial (130, 364 cells)
+    and on a small one (66 cells); after a cloud (sparse state), after a reset (dense state), several slots, all layers at once."""
+    rng = np.random.default_rng(5)
+    for length, res, slots in ((43.0, 0.33, 3), (120.0, 0.33, 2), (22.0, 0.33, 1)):
+        seg = api.GroundSegmentation().init(length, res, n_slots=slots, max_points=4096)
+        n = seg.map(0).getSize()[0]
+        cloud = synth.random_cloud(3000, seed=9, extent=0.4 * length)
+        for slot in range(slots):
+            m = seg.map(slot)
+            if slot % 2 == 0:
+                seg.filter_cloud(cloud, ORIGIN0, -1.7, map=m)  # (sparse: only some half columns hold values)
+            want = {name: rng.standard_normal((n, n)).astype(np.float32) for name in oracle.LAYERS}
+            want["points"][0, 0] = np.float32("nan")
+            want["variance"][n - 1, n - 1] = np.float32("inf")
+            for name in oracle.LAYERS:
+                m.set(name, want[name])
+            for name in oracle.LAYERS:  # one at a time ...
+                assert nan_equal(m[name], want[name]), (length, slot, name)
+            got = m.layers()            # ... and all with one synchronisation
+            for name in oracle.LAYERS:
+                assert nan_equal(got[name], want[name]), (length, slot, name)
+        # the other slots were not touched by the writes to this one
+        if slots > 1:
+            a = seg.map(0).layers()
+            seg.map(1).set("m2", np.zeros((n, n), dtype=np.float32))
+            b = seg.map(0).layers()
+            for name in oracle.LAYERS:
+                assert nan_equal(a[name], b[name]), name
+        seg.close()
 
 
 def test_largest_supported_grid_and_ring_group_counts():
