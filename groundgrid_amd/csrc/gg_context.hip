@@ -796,7 +796,7 @@ int gg_get_config(const gg_context *ctx, gg_config *cfg)
 int gg_set_flags(gg_context *ctx, unsigned flags)
 {
     if (!ctx) return GG_ERR_INVALID;
-    // (leaving GG_FLAG_MINIMAL_LAYERS needs no repair: the next cloud writes all nine layers in the columns it marks live, and
+    // (leaving GG_FLAG_MINIMAL_LAYERS needs no repair: the next cloud writes all nine layers in the half columns it marks live, and
     // every other column logically holds the reset values anyway -- gg_internal.h tile_live)
     ctx->flags = flags;
     return GG_OK;
@@ -976,7 +976,7 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
         HIPCHK(ctx, hipGetLastError());
     } else {
         // the per-call layers are stored sparsely behind ONE set of liveness masks (gg_internal.h tile_live): make all nine dense
-        // (reset values into the dead columns, every column live), then overwrite this one with the host's matrix
+        // (reset values into the dead half columns, every half column live), then overwrite this one with the host's matrix
         launch_materialise_layers(ctx->arena, slot, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -994,7 +994,7 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     if (!dst || layer < 0 || layer >= GG_NUM_LAYERS) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
-    // both kinds of layer have a device representation of their own (sheared pairs / sparse columns): extract the dense plane
+    // both kinds of layer have a device representation of their own (sheared pairs / sparse tile blocks): extract the dense plane
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH)
         launch_plane_extract(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_image, ctx->stream);
     else

@@ -352,7 +352,7 @@ GG_DEV uint32_t half_column_bits(unsigned long long held)
 
 // ---- light tiles: one wavefront per tile, no barrier, nothing leaves LDS but the layers --------------------------------------
 // At most K2_LIGHT_MAX = 8 x 64 records: the wave holds them all in registers.  Lane l owns cells l, l + 64, l + 128, l + 192
-// (4 columns x 16 rows per store instruction: 64-byte row segments, as in the dense path).  A wave walks its share of the
+// (4 columns x 16 rows = 256 contiguous bytes of the tile's block per layer and store instruction, as in the dense path).  A wave walks its share of the
 // cloud's light list and keeps the next tile's loads in flight: its rank two tiles ahead, its record range one tile ahead,
 // its records while the current tile's recurrences run.
 GG_DEV void load_light_records(uint2 (&rw)[WB], const uint2 *sorted, uint32_t start, uint32_t end, int lane)
@@ -392,8 +392,8 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
         const uint32_t next_start = has_next ? ent_next.y : 0u, next_end = has_next ? ent_next.z : 0u;
         const uint4 ent_after = tile_list[min(j + 2 * stride, n_light - 1)];
         const int rank = (int)(ent.x & 0xFFFFu);
-        // only the columns that hold a record now are written (and marked live: the per-call layers are sparse, gg_internal.h
-        // tile_live) -- a light tile has records in ~60 % of its columns
+        // only the half columns (8 cells, a 32-byte sector per layer) that hold a record now are written and marked live: the
+        // per-call layers are sparse, gg_internal.h tile_live -- a light tile has records in ~40 % of its half columns
         uint32_t cols_now = 0u;
         uint32_t lane_base = 0u;
         if (start != end) {
@@ -707,10 +707,10 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     }
     __syncthreads();
     if (timing) tmark[4] = __builtin_readcyclecounter();
-    // (columns: see reduce_light_tiles; thread = cell, a wavefront holds four columns)
+    // (half columns: see reduce_light_tiles; thread = cell, a wavefront holds four columns)
     const uint32_t cb = half_column_bits(__ballot(ex[3 * TILE_CELLS + tid] != 0.0f));
     if (lane == 0) lds.wave_full[wave] = cb; // (the split flags were read before the recurrences; combined after the caller's barrier)
-    const bool column_written = ((cb >> (lane >> 3)) & 1u) != 0u;
+    const bool half_column_written = ((cb >> (lane >> 3)) & 1u) != 0u;
     CellState st;
     st.mn = ex[1 * TILE_CELLS + tid];
     st.m2 = ex[2 * TILE_CELLS + tid];
@@ -718,7 +718,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     st.mx = ex[5 * TILE_CELLS + tid];
     st.gc = ex[6 * TILE_CELLS + tid];
     st.pdm = ex[7 * TILE_CELLS + tid];
-    if (column_written)
+    if (half_column_written)
         write_cell<FULL>(percall_ptr(a, cp.slot) + percall_index(rank, 0, 0), tid, ex[0 * TILE_CELLS + tid], ex[3 * TILE_CELLS + tid], st);
     if (timing && tid == 0) {
         tmark[5] = __builtin_readcyclecounter();
@@ -731,7 +731,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
 // One share of one cloud's work: group < n_dense_groups walks the cloud's dense list (one tile per work-group at a time), the
 // other groups the light list (one tile per wavefront at a time).  k_scan wrote both lists: the tiles that hold records of this
 // cloud.  More than half of the tiles of a sensor cloud receive no point at all and are visited by nobody: the per-call layers
-// are stored sparsely -- tile_live[rank] says which columns of a tile physically hold values (the ones with in-map records of
+// are stored sparsely -- tile_live[rank] says which half columns of a tile physically hold values (the ones with in-map records of
 // this cloud), every other cell logically holds the per-call reset values (:61-75), and the readers substitute them
 // (gg_internal.h tile_live).  Exact: gg_get_layer returns at all times what the reference's layers would hold.
 template <bool FULL>
@@ -756,7 +756,7 @@ GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params,
             const int rank = (int)(ent.x & 0xFFFFu);
             reduce_dense_tile<FULL>(a, cp, ent, lds.dense, tid);
             __syncthreads(); // (the next tile reuses the shared memory)
-            if (tid == 0) // the tile's columns that hold records now (every wavefront left its eight bits)
+            if (tid == 0) // the tile's half columns that hold records now (every wavefront left its eight bits)
                 (a.tile_live + (size_t)cp.slot * a.tile_live_stride)[rank] =
                     lds.dense.wave_full[0] | (lds.dense.wave_full[1] << 8) | (lds.dense.wave_full[2] << 16) | (lds.dense.wave_full[3] << 24);
         }

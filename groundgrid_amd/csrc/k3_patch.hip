@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             const bool ok = lc < n_cols && gr < rows && gcol < cols;
             // the per-call layers are sparse (gg_internal.h tile_live): a half column that holds no record of this cloud has stale
             // bytes and logically the reset values of :61-75 -- points 0, variance 0 / (0 + FLT_MIN) = 0, minGroundHeight FLT_MAX.
-            // Its lanes fetch element 0 like the out-of-range ones (still unconditional loads): no HBM traffic for dead columns
+            // Its lanes fetch element 0 like the out-of-range ones (still unconditional loads): no HBM traffic for dead half columns
             const int btr = ok ? (gr - (r0 - HALO)) / TILE : 0, btc = ok ? gcol / TILE : 0;
             const int cell_in_tile = (gr % TILE) + (gcol % TILE) * TILE;
             const bool live = ok && ((live_cols[btr][btc] >> live_bit(cell_in_tile)) & 1u) != 0u;

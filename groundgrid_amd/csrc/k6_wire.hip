@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_terrain_image(const Arena a, int slot, 
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= rows || j >= cols) return;
     float flag = 0.0f;
-    // (pointsRaw is a sparse per-call layer: 0 outside the live columns, gg_internal.h tile_live)
+    // (pointsRaw is a sparse per-call layer: 0 outside the live half columns, gg_internal.h tile_live)
     auto raw_at = [&](int r, int c) { return cell_is_live(a, slot, r, c) ? percall[percall_index_of(a, PL_POINTSRAW, r, c)] : 0.0f; };
     if (i >= 1 && j >= 1 && i + 1 < rows && j + 1 < cols) {
         float e[9];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_terrain_image(const Arena a, int slot, 
     px[2] = raw_at(i, j);
 }
 
-// One per-call layer as the dense column-major matrix the reference holds: stored values in the live columns, the per-call reset
+// One per-call layer as the dense column-major matrix the reference holds: stored values in the live half columns, the per-call reset
 // value (:61-75) everywhere else (gg_internal.h tile_live).  The host boundary of the sparse layers (gg_get_layer, image getters).
 __global__ __launch_bounds__(256) void k_layer_extract(const Arena a, int slot, int layer, float *__restrict__ dst)
 {

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
         const uint32_t excl = block_exclusive_scan(s, lds, total);
         {
             // K2's work lists (k2_reduce.hip): tiles with more than K2_LIGHT_MAX records from the back of tile_list, the
-            // other tiles with records from the front.  A tile without records is on neither list: its columns simply stop
+            // other tiles with records from the front.  A tile without records is on neither list: its half columns simply stop
             // being live (the per-call layers are sparse, gg_internal.h tile_live) -- nothing is cleaned.
             const bool dense = t < T && s > (uint32_t)K2_LIGHT_MAX;
             const bool light = t < T && !dense && s > 0u;
