@@ -139,13 +139,13 @@ GG_DEV void detect_ground_patch_b(const Arena &a, const PatchCarry &pc, float2 *
 }
 
 // One work-group per (cloud, band of PR rows); it walks the band's blocks of PC columns from left to right with a rolling
-// window of LC = PC + 4 columns in LDS (a ring of 16 column slots; slots 0..3 are mirrored at 16..19 so that both block
-// parities read 12 CONSECUTIVE slots), keeps the next block's columns in flight in registers while it computes the current
+// window of LC = PC + 4 columns in LDS (a ring of 32 column slots; slots 0..3 are mirrored at 32..35 so that every
+// window is 12 CONSECUTIVE slots), keeps the next block's columns in flight in registers while it computes the current
 // one, and skips the blocks that no KEPT point can reach: a cell only changes if its block of `points` sums to at least 3
 // (:364), and `points` is zero in every 16x16 tile without records (K2 reset it, :61-75) -- the record counts of the band's
 // three tile rows are folded into one flag per tile column when the work-group starts.  (540 blocks per cloud as separate
 // work-groups spent 0.6 ms of 1.6 on launching work-groups and another 0.4 on their first loads.)
-constexpr int RING = 16, SLOTS = RING + 4, MAXTC = 256;
+constexpr int RING = 32, SLOTS = RING + 4, MAXTC = 256;
 
 __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams *__restrict__ params, int n_bands, int blocks_per_segment)
 {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         consume.live = false;
 
         const int j = HALO + PC * b + tcl;
-        const int base = (PC * b) & (RING - 1); // 0 or 8: the window is slots base .. base + LC - 1
+        const int base = (PC * b) & (RING - 1); // 0, 8, 16 or 24: the window is slots base .. base + LC - 1
         const int lr = tr + HALO, lc = tcl + HALO;
         // :332
         const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
@@ -325,7 +325,11 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             else
                 patch_sums<5>(a, pts + base, var + base, mnl + base, lr, lc, produce);
         }
-        __syncthreads(); // (the window is overwritten next)
+        // The next block's deposit overwrites column slots.  When it is the neighbour, its 8 new columns go to the slots BEHIND this
+        // window (the ring holds 32: 12 of this window + 8 new ones never meet), so wavefronts without cells in the weighted sums go
+        // on -- deposit, request the block after -- while the others finish; v5 / v3 are rewritten only after the next step's
+        // first barrier, which everybody reaches after its reads here.  A block further away lands on any slots: barrier.
+        if (nb != b + 1) __syncthreads();
         b = nb;
     };
     PatchCarry c0, c1;
