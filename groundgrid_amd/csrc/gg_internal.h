@@ -2,7 +2,7 @@
 //
 // HBM layout of one context (see DESIGN.md "Data layout"):
 //   shared   : expectedPoints[C]  spiral schedule  tile rank tables
-//   per slot : 11 layers [C] f32 (column-major, i + j*rows, as Eigen::MatrixXf)
+//   per slot : the nine per-call layers tile by tile (percall_index below; ground / groundpatch: gp2, gp_layout.h)
 //              rec[Nmax]    (z, key)     cloud order     written by K1
 //              sorted[Nmax] (z, key)     Morton-tile order, cloud order inside a tile (stable)
 //              hist[NCH][T] per-wave-chunk tile histogram -> exclusive offsets after the scan
