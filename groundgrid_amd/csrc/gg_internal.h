@@ -30,6 +30,8 @@ constexpr int SWEEP_LATENCY_MAX_CLOUDS = 256;  // (= CUs) k_sweep: launches of a
                                                // its own wavefront (up to 3 per side), and clouds are cut into as many work-groups
                                                // ("parts") as keep the launch within it; bigger launches use make_params' throughput setting
 constexpr int K2_MIN_GROUPS_PER_CLOUD = 64;    // k_reduce: work-groups per cloud = max(4096 / clouds, this)
+constexpr int PACKED_TILE_COUNTERS_MIN_T = 1024; // maps with more tiles keep K1's / k_scatter's per-wavefront tile counters as 16-bit halves
+                                                 // (a chunk has fewer than 65536 points): 71 -> 40 KB of LDS per work-group at 3969 tiles
 constexpr int K2_LIGHT_MAX = 512; // tiles with at most this many records are reduced by a single wavefront (k2_reduce.hip)
 // key = tile_rank << 12 | emit << 10 | class << 8 | cell_in_tile (row_in_tile | col_in_tile << 4)
 constexpr int KEY_TILE_SHIFT = 12;

@@ -172,13 +172,17 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
     const int nch = (n + a.PW - 1) / a.PW;
     const int T = a.g.T;
     // tile -> Morton rank, staged once per work-group (behind the four histograms): a point's key waits for this lookup
-    uint16_t *lds_tile_rank = reinterpret_cast<uint16_t *>(lds_hist + 4 * T);
+    // (big maps: two 16-bit counters per word -- a chunk has fewer than 65536 points -- so that four work-groups fit a CU's LDS
+    // where two did: this kernel lives on wavefronts in flight)
+    const bool packed = T > PACKED_TILE_COUNTERS_MIN_T && a.PW < 65536;
+    const int words = packed ? (T + 1) / 2 : T; // per wavefront
+    uint16_t *lds_tile_rank = reinterpret_cast<uint16_t *>(lds_hist + 4 * words);
     for (int t = threadIdx.x; t < T; t += 256) lds_tile_rank[t] = a.tile_rank[t];
     __syncthreads();
     if (chunk >= nch) return;
 
-    uint32_t *hist = lds_hist + wave * T;
-    for (int t = lane; t < T; t += 64) hist[t] = 0u;
+    uint32_t *hist = lds_hist + wave * words;
+    for (int t = lane; t < words; t += 64) hist[t] = 0u;
 
     const float2 *gp2 = gp2_ptr(a, cp.slot);
     const char *pts = reinterpret_cast<const char *>(io.d_points) +
@@ -232,7 +236,13 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
             if (inmap_[j]) key = make_key(a, lds_tile_rank, gi0[j], gi1[j], cls);
             if (valid[j]) rec[p] = make_uint2(__float_as_uint(pt[j].z), key);
             const bool inmap = key != KEY_OUTSIDE;
-            if (inmap) atomicAdd(&hist[key >> KEY_TILE_SHIFT], 1u);
+            if (inmap) {
+                const uint32_t tr = key >> KEY_TILE_SHIFT;
+                if (packed) // (uniform)
+                    atomicAdd(&hist[tr >> 1], 1u << ((tr & 1u) * 16u));
+                else
+                    atomicAdd(&hist[tr], 1u);
+            }
             const bool emit = inmap && (key & KEY_EMIT_BIT);
             n_inmap += (uint32_t)__popcll(__ballot(inmap));
             n_kept += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_KEPT));
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
     }
 
     uint32_t *ghist = a.hist + (size_t)cp.slot * a.hist_stride + (size_t)chunk * T;
-    for (int t = lane; t < T; t += 64) ghist[t] = hist[t];
+    for (int t = lane; t < T; t += 64) ghist[t] = packed ? (hist[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu : hist[t];
     if (lane == 0) {
         uint32_t *ce = a.chunk_emit + (size_t)cp.slot * a.emit_stride + (size_t)chunk * 4;
         ce[0] = n_kept;
@@ -257,7 +267,8 @@ void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO 
     const int nch = (max_n + a.PW - 1) / a.PW;
     if (nch == 0 || n_clouds == 0) return;
     dim3 grid((nch + 3) / 4, n_clouds);
-    const size_t lds = (size_t)4 * a.g.T * sizeof(uint32_t) + (((size_t)a.g.T * 2 + 3) & ~(size_t)3);
+    const bool packed = a.g.T > PACKED_TILE_COUNTERS_MIN_T && a.PW < 65536;
+    const size_t lds = (size_t)4 * (packed ? (a.g.T + 1) / 2 : a.g.T) * sizeof(uint32_t) + (((size_t)a.g.T * 2 + 3) & ~(size_t)3);
     // per-wave tile histograms beyond the 64 KiB default (grids above ~1024 cells per side) need the explicit opt-in
     static std::atomic<uint64_t> big_lds_devices{0};
     if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices)) {

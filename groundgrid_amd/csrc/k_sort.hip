@@ -138,9 +138,17 @@ __global__ __launch_bounds__(256) void k_scatter(const Arena a, const CloudParam
     if (chunk >= nch) return;
 
     const int T = a.g.T;
-    uint32_t *offs = lds_offs + wave * T;
+    // Small maps: the wavefront's running offset per tile, absolute, in LDS.  Big maps (PACKED_TILE_COUNTERS_MIN_T): only the
+    // number of records already placed per tile, two 16-bit counters per word; the chunk's start per tile stays in its row of
+    // `hist`, and every lane fetches its own record's (a gather, once per window, outside the serial loop over the window's tiles).
+    const bool packed = T > PACKED_TILE_COUNTERS_MIN_T && a.PW < 65536;
+    const int words = packed ? (T + 1) / 2 : T;
+    uint32_t *offs = lds_offs + wave * words;
     const uint32_t *ghist = a.hist + (size_t)cp.slot * a.hist_stride + (size_t)chunk * T;
-    for (int t = lane; t < T; t += 64) offs[t] = ghist[t];
+    if (packed)
+        for (int t = lane; t < words; t += 64) offs[t] = 0u;
+    else
+        for (int t = lane; t < T; t += 64) offs[t] = ghist[t];
 
     const uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
     uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
@@ -154,15 +162,21 @@ __global__ __launch_bounds__(256) void k_scatter(const Arena a, const CloudParam
         const bool inmap = r.y != KEY_OUTSIDE;
         const uint32_t t = r.y >> KEY_TILE_SHIFT;
         unsigned long long todo = __ballot(inmap);
-        uint32_t dst = 0;
+        uint32_t dst = (packed && inmap) ? ghist[t] : 0u; // (packed: the chunk's first position in the record's tile)
         while (todo) { // one iteration per distinct tile in the window (wave-uniform loop)
             const int leader = __ffsll((long long)todo) - 1;
             const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
             const bool mine = inmap && t == t0;
             const unsigned long long same = __ballot(mine);
-            const uint32_t b = offs[t0];
-            if (mine) dst = b + (uint32_t)rank_below(same);
-            if (lane == leader) offs[t0] = b + (uint32_t)__popcll(same);
+            if (packed) { // (uniform)
+                const uint32_t sh = (t0 & 1u) * 16u, w = offs[t0 >> 1];
+                if (mine) dst += ((w >> sh) & 0xFFFFu) + (uint32_t)rank_below(same);
+                if (lane == leader) offs[t0 >> 1] = w + ((uint32_t)__popcll(same) << sh);
+            } else {
+                const uint32_t b = offs[t0];
+                if (mine) dst = b + (uint32_t)rank_below(same);
+                if (lane == leader) offs[t0] = b + (uint32_t)__popcll(same);
+            }
             todo &= ~same;
         }
         if (inmap) sorted[dst] = r;
@@ -174,7 +188,8 @@ void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, i
     const int nch = (max_n + a.PW - 1) / a.PW;
     if (nch == 0 || n_clouds == 0) return;
     dim3 grid((nch + 3) / 4, n_clouds);
-    const size_t lds = (size_t)4 * a.g.T * sizeof(uint32_t);
+    const bool packed = a.g.T > PACKED_TILE_COUNTERS_MIN_T && a.PW < 65536;
+    const size_t lds = (size_t)4 * (packed ? (a.g.T + 1) / 2 : a.g.T) * sizeof(uint32_t);
     static std::atomic<uint64_t> big_lds_devices{0}; // (see launch_classify)
     if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices))
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
