@@ -180,6 +180,7 @@ struct gg_context {
     float *d_scroll_scratch = nullptr; // 2 layers
     float *d_image = nullptr;          // 3 * C floats (wire-format images)
     float *d_planes = nullptr;         // GG_NUM_LAYERS * Cpad floats: dense planes of gg_get_layers (allocated on first use)
+    float *h_planes = nullptr;         // ... and their pinned landing zone on the host (one download for all requested layers)
     float *d_bounds = nullptr;         // 2 floats
     unsigned long long *d_sweep_dbg = nullptr; // GG_SWEEP_TIMING=1: cycle counters of the sweep's wavefronts (cloud 0 of a batch)
 
@@ -773,6 +774,7 @@ void gg_destroy(gg_context *ctx)
     if (ctx->h_stage_index) hipHostFree(ctx->h_stage_index);
     if (ctx->h_stage_counts) hipHostFree(ctx->h_stage_counts);
     if (ctx->d_planes) hipFree(ctx->d_planes);
+    if (ctx->h_planes) hipHostFree(ctx->h_planes);
     if (ctx->d_arena) hipFree(ctx->d_arena);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1014,17 +1016,31 @@ int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const size_t plane = align_up((size_t)ctx->arena.g.C * 4, 256) / 4;
     if (!ctx->d_planes) HIPCHK(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)GG_NUM_LAYERS * plane * sizeof(float)));
+    if (!ctx->h_planes) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_planes, (size_t)GG_NUM_LAYERS * plane * sizeof(float), hipHostMallocDefault));
+    // The requested planes are extracted side by side, come down in ONE copy into pinned memory (a copy into the caller's
+    // pageable matrices is staged by the runtime in small pieces: 0.7 ms for eleven 364 x 364 layers, against 0.15 ms), and the
+    // context's host threads move them on to where the caller wants them.
+    int want[GG_NUM_LAYERS], n_want = 0;
     for (int l = 0; l < GG_NUM_LAYERS; ++l) {
         if (!dst[l]) continue;
-        float *d = ctx->d_planes + (size_t)l * plane;
+        float *d = ctx->d_planes + (size_t)n_want * plane;
         if (l == GG_LAYER_GROUND || l == GG_LAYER_GROUNDPATCH)
             launch_plane_extract(ctx->arena, slot, l == GG_LAYER_GROUNDPATCH, d, ctx->stream);
         else
             launch_layer_extract(ctx->arena, slot, l, d, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(dst[l], d, (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
+        want[n_want++] = l;
     }
+    if (n_want == 0) return GG_OK;
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_planes, ctx->d_planes, (size_t)n_want * plane * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t C = (size_t)ctx->arena.g.C;
+    ctx->helper.split((size_t)n_want * C, [&](size_t lo, size_t hi) {
+        for (size_t k = lo / C; k < (size_t)n_want && k * C < hi; ++k) {
+            const size_t a0 = std::max(lo, k * C) - k * C, a1 = std::min(hi, (k + 1) * C) - k * C;
+            memcpy(dst[want[k]] + a0, ctx->h_planes + k * plane + a0, (a1 - a0) * sizeof(float));
+        }
+    });
     return GG_OK;
 }
 
