@@ -182,6 +182,7 @@ struct gg_context {
     float *d_planes = nullptr;         // GG_NUM_LAYERS * Cpad floats: dense planes of gg_get_layers (allocated on first use)
     float *h_planes = nullptr;         // ... and their pinned landing zone on the host (one download for all requested layers)
     float *d_bounds = nullptr;         // 2 floats
+    volatile uint32_t *h_dev_error = nullptr;  // host view of Arena::dev_error (mapped pinned memory)
     unsigned long long *d_sweep_dbg = nullptr; // GG_SWEEP_TIMING=1: cycle counters of the sweep's wavefronts (cloud 0 of a batch)
 
     // profiling
@@ -210,6 +211,23 @@ int fail(gg_context *ctx, int code, const char *what, hipError_t e = hipSuccess)
     do {                                                                       \
         hipError_t e__ = (call);                                               \
         if (e__ != hipSuccess) return fail((ctx), GG_ERR_HIP, #call, e__);     \
+    } while (0)
+
+// After a synchronisation: did a kernel give up a bounded wait (Arena::dev_error)?  The reference has no error path at all
+// (SURVEY 5); a library that spins inside kernels must at least say so instead of hanging or returning garbage silently.
+int device_error(gg_context *ctx)
+{
+    const uint32_t code = ctx->h_dev_error ? *ctx->h_dev_error : 0u;
+    if (code == GG_DEVERR_NONE) return GG_OK;
+    return fail(ctx, GG_ERR_HIP, code == GG_DEVERR_FRONT_WAIT ? "k_classify: a cloud's tile scan never completed (bounded wait ran out); the outputs of that batch are void"
+                                 : code == GG_DEVERR_SWEEP_WAIT ? "k_sweep: a hand-over between work-groups never arrived (bounded wait ran out); the outputs of that batch are void"
+                                                                : "a kernel reported an unknown device-side error");
+}
+#define SYNCCHK(ctx, call)                                   \
+    do {                                                     \
+        HIPCHK(ctx, call);                                   \
+        const int rc__ = device_error(ctx);                  \
+        if (rc__ != GG_OK) return rc__;                      \
     } while (0)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -269,6 +287,46 @@ int own_stream_mutated_map(gg_context *ctx)
     ctx->map_event_pending = true;
     return GG_OK;
 }
+
+// rocTX ranges named after the reference's four stage timers (src/GroundSegmentation.cpp:124 "rasterization", :138 "patch
+// detection", :144 "interpolation", :194 "segmentation") around the launch groups of a batch, so that a rocprofv3
+// --marker-trace reads in the reference's terms.  The library is looked up at run time (no link-time dependency, nothing happens
+// when no profiler is attached); GG_ROCTX=0 turns it off.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = getenv("GG_ROCTX");
+        if (e && atoi(e) == 0) return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+struct StageRange {
+    static Roctx &lib()
+    {
+        static Roctx r;
+        return r;
+    }
+    bool on;
+    explicit StageRange(const char *stage) : on(lib().push != nullptr)
+    {
+        if (on) lib().push(stage);
+    }
+    ~StageRange()
+    {
+        if (on) lib().pop();
+    }
+    StageRange(const StageRange &) = delete;
+};
 
 struct Profiler {
     gg_context *ctx;
@@ -360,23 +418,35 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     a.eigen_reduction = ctx->conv.eigen_reduction;
     Profiler prof{ctx, s, (ctx->flags & GG_FLAG_PROFILE) != 0};
 
-    prof.begin(GG_K_CLASSIFY);
-    launch_classify(a, dp, io, nb, max_n, s);
-    prof.end();
-    prof.begin(GG_K_SCAN);
-    launch_scan(a, dp, nb, s);
-    prof.end();
-    prof.begin(GG_K_SCATTER);
-    launch_scatter(a, dp, nb, max_n, s);
-    prof.end();
-    prof.begin(GG_K_REDUCE);
-    launch_reduce(a, dp, nb, s);
-    prof.end();
-    prof.begin(GG_K_PATCH);
-    launch_patch(a, dp, nb, s);
-    prof.end();
+    {
+        StageRange stage("rasterization"); // insert_cloud, :98-124
+        // the front end in one, two or three launches (k1_classify.hip): what launch_classify did not do itself follows here
+        prof.begin(GG_K_CLASSIFY);
+        const int front = launch_classify(a, dp, io, nb, max_n, s);
+        prof.end();
+        if (front == FRONT_THREE_LAUNCHES) {
+            prof.begin(GG_K_SCAN);
+            launch_scan(a, dp, nb, s);
+            prof.end();
+        }
+        if (front != FRONT_ONE_LAUNCH) {
+            prof.begin(GG_K_SCATTER);
+            launch_scatter(a, dp, nb, max_n, s);
+            prof.end();
+        }
+        prof.begin(GG_K_REDUCE);
+        launch_reduce(a, dp, nb, s);
+        prof.end();
+    }
+    {
+        StageRange stage("patch detection"); // detect_ground_patches, :126-138
+        prof.begin(GG_K_PATCH);
+        launch_patch(a, dp, nb, s);
+        prof.end();
+    }
     prof.begin(GG_K_SPIRAL);
     {
+        StageRange stage("interpolation"); // spiral_ground_interpolation, :141-144
         sweep::Params sp = ctx->sweep_params;
         sp.decrease = ctx->cfg.occupied_cells_decrease_factor;
         sp.inv_decrease = 1.0 / sp.decrease;
@@ -384,9 +454,12 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
         launch_sweep(a, sp, dp, nb, s, ctx->d_sweep_dbg);
     }
     prof.end();
-    prof.begin(GG_K_LABEL);
-    launch_label(a, dp, io, nb, max_n, s);
-    prof.end();
+    {
+        StageRange stage("segmentation"); // the label loop, :146-194
+        prof.begin(GG_K_LABEL);
+        launch_label(a, dp, io, nb, max_n, s);
+        prof.end();
+    }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ring_done[g], s));
     ctx->ring_used[g] = true;
@@ -511,7 +584,9 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     g.resolution_f = (float)res;
     g.min_dist_squared = geom.min_dist_squared;
     g.center = n / 2 - 1;
-    if (g.T > 65535 || (size_t)4 * g.T * sizeof(uint32_t) > 160 * 1024) {
+    a.hist_pitch = (g.T + 3) & ~3;
+    a.n_slots = n_slots;
+    if (g.T > 65535 || (size_t)4 * a.hist_pitch * sizeof(uint32_t) > 150 * 1024) {
         gg_destroy(ctx);
         return GG_ERR_GEOMETRY; // per-wave LDS tile histograms no longer fit
     }
@@ -527,6 +602,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tune_sweep_waves = getenv("GG_SWEEP_WAVES") ? atoi(getenv("GG_SWEEP_WAVES")) : 0;
     a.tune_sweep_gpw = getenv("GG_SWEEP_GPW") ? atoi(getenv("GG_SWEEP_GPW")) : 0;
     a.tune_sweep_split = getenv("GG_SWEEP_SPLIT") ? atoi(getenv("GG_SWEEP_SPLIT")) : 0;
+    a.tune_front = getenv("GG_FRONT") ? atoi(getenv("GG_FRONT")) : 0;
     a.tune_k2_per_cloud = getenv("GG_K2_PER_CLOUD") ? atoi(getenv("GG_K2_PER_CLOUD")) : 0;
     a.tune_k2_dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 0;
     a.k2_skip = getenv("GG_K2_SKIP") ? atoi(getenv("GG_K2_SKIP")) : 0;
@@ -582,7 +658,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_sorted = carve((size_t)n_slots * Npad * 8);
     a.zcell_stride = align_up((Npad + (size_t)32 * g.T + 64) * 4, A) / 4;
     const size_t o_zcell = carve((size_t)n_slots * a.zcell_stride * 4);
-    a.hist_stride = align_up((size_t)a.NCH * g.T * 4, A) / 4;
+    a.hist_stride = align_up((size_t)a.NCH * a.hist_pitch * 4, A) / 4;
     const size_t o_hist = carve((size_t)n_slots * a.hist_stride * 4);
     a.emit_stride = align_up((size_t)a.NCH * 4 * 4, A) / 4;
     const size_t o_emit = carve((size_t)n_slots * a.emit_stride * 4);
@@ -594,6 +670,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_list_stride = align_up((size_t)g.T * 16, A) / 16;
     const size_t o_tlist = carve((size_t)n_slots * a.tile_list_stride * 16);
     const size_t o_tlcnt = carve((size_t)n_slots * 2 * 4);
+    const size_t o_fsync = carve(((size_t)2 * n_slots + 16) * 4);
+    const size_t o_ssync = carve(64);
     a.sweep_xchg_stride = align_up(std::max<size_t>(gg::sweep_xchg_entries(ctx->sweep_params), 1) * 16, A) / 8;
     const size_t o_xchg = carve((size_t)n_slots * a.sweep_xchg_stride * 8);
     const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
@@ -642,6 +720,21 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_live = (uint32_t *)(base + o_tlive);
     a.tile_list = (uint4 *)(base + o_tlist);
     a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
+    a.front_sync = (uint32_t *)(base + o_fsync);
+    a.sweep_sync = (uint32_t *)(base + o_ssync);
+    {
+        const uint32_t first_epoch[4] = {0u, 0u, 1u, 0u}; // (the exchange region starts zeroed: tag 0 is never current)
+        CREATE_CHK(hipMemcpyAsync(a.sweep_sync, first_epoch, sizeof first_epoch, hipMemcpyHostToDevice, ctx->stream));
+        CREATE_CHK(hipStreamSynchronize(ctx->stream));
+    }
+    {
+        // one word the kernels can reach and the host can read without a copy: a bounded wait that ran out reports here
+        CREATE_CHK(hipHostMalloc((void **)&ctx->h_dev_error, 64, hipHostMallocMapped));
+        *ctx->h_dev_error = 0u;
+        void *dptr = nullptr;
+        CREATE_CHK(hipHostGetDevicePointer(&dptr, (void *)ctx->h_dev_error, 0));
+        a.dev_error = (uint32_t *)dptr;
+    }
     a.sweep_xchg = (unsigned long long *)(base + o_xchg);
     a.flags = 0;
     a.k2_debug = getenv("GG_K2_DEBUG") ? atoi(getenv("GG_K2_DEBUG")) : 0;
@@ -768,6 +861,7 @@ void gg_destroy(gg_context *ctx)
     if (ctx->batch_event) hipEventDestroy(ctx->batch_event);
     if (ctx->h2d_stream) hipStreamDestroy(ctx->h2d_stream);
     if (ctx->d2h_stream) hipStreamDestroy(ctx->d2h_stream);
+    if (ctx->h_dev_error) hipHostFree((void *)ctx->h_dev_error);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_stage_pts) hipHostFree(ctx->h_stage_pts);
     if (ctx->h_stage_labels) hipHostFree(ctx->h_stage_labels);
@@ -986,7 +1080,7 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
         HIPCHK(ctx, hipGetLastError());
     }
     if (const int rc = own_stream_mutated_map(ctx)) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNCCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
 
@@ -1004,7 +1098,7 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     HIPCHK(ctx, hipGetLastError());
     const float *plane = ctx->d_image;
     HIPCHK(ctx, hipMemcpyAsync(dst, plane, (size_t)ctx->arena.g.C * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNCCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
 
@@ -1033,7 +1127,7 @@ int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
     if (n_want == 0) return GG_OK;
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_planes, ctx->d_planes, (size_t)n_want * plane * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNCCHK(ctx, hipStreamSynchronize(ctx->stream));
     const size_t C = (size_t)ctx->arena.g.C;
     ctx->helper.split((size_t)n_want * C, [&](size_t lo, size_t hi) {
         for (size_t k = lo / C; k < (size_t)n_want && k * C < hi; ++k) {
@@ -1062,7 +1156,7 @@ int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, fl
     float b[2];
     HIPCHK(ctx, hipMemcpyAsync(dst, d_img, (size_t)g.C, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(b, ctx->d_bounds, sizeof b, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNCCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (lower) *lower = b[0];
     if (upper) *upper = b[1];
     return GG_OK;
@@ -1078,7 +1172,7 @@ int gg_get_terrain_image(gg_context *ctx, int slot, float *dst)
     launch_terrain_image(ctx->arena, slot, ctx->d_image, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(dst, ctx->d_image, (size_t)g.C * 3 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNCCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
 
@@ -1124,7 +1218,7 @@ int gg_filter_cloud_pc2(gg_context *ctx, int slot, const uint8_t *data, size_t n
     if (n && out_label) HIPCHK(ctx, hipMemcpyAsync(out_label, ctx->d_stage_labels, n, hipMemcpyDeviceToHost, s));
     if (n && out_index) HIPCHK(ctx, hipMemcpyAsync(out_index, ctx->d_stage_index, n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage_counts, ctx->d_stage_counts, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
+    SYNCCHK(ctx, hipStreamSynchronize(s));
     if (out_n) *out_n = (size_t)ctx->h_stage_counts[0];
     return GG_OK;
 }
@@ -1168,7 +1262,7 @@ int gg_synchronize(gg_context *ctx)
     if (!ctx) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc; // batches on caller streams included
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNCCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
 
@@ -1269,7 +1363,7 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
     ctx->oldest_ticket = ticket + 1; // (also on error below: the slot is reusable either way)
     static const bool host_timing = getenv("GG_HOST_TIMING") != nullptr;
     const auto t_w0 = std::chrono::steady_clock::now();
-    HIPCHK(ctx, hipEventSynchronize(as.downloaded));
+    SYNCCHK(ctx, hipEventSynchronize(as.downloaded));
     const auto t_w1 = std::chrono::steady_clock::now();
     const size_t n = as.n;
     if (out_n) *out_n = (size_t)as.h_counts[0];
@@ -1432,7 +1526,7 @@ int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class
     HIPCHK(ctx, hipGetLastError());
     if (out_class) HIPCHK(ctx, hipMemcpyAsync(out_class, ctx->d_stage_class, n, hipMemcpyDeviceToHost, ctx->stream));
     if (out_cell) HIPCHK(ctx, hipMemcpyAsync(out_cell, ctx->d_stage_cell, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    SYNCCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
 
@@ -1446,6 +1540,10 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     if (!strcmp(key, "sweep_waves")) ctx->arena.tune_sweep_waves = value;
     else if (!strcmp(key, "sweep_gpw")) ctx->arena.tune_sweep_gpw = value;
     else if (!strcmp(key, "sweep_split")) ctx->arena.tune_sweep_split = value;
+    else if (!strcmp(key, "front")) ctx->arena.tune_front = std::min(value, 3);
+    else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
+    else if (!strcmp(key, "sweep_fault")) ctx->arena.tune_sweep_fault = value;
+    else if (!strcmp(key, "clear_device_error")) *ctx->h_dev_error = 0u;
     else if (!strcmp(key, "k2_per_cloud")) ctx->arena.tune_k2_per_cloud = value;
     else if (!strcmp(key, "k2_dense_share")) ctx->arena.tune_k2_dense_share = std::min(value, 15);
     else return GG_ERR_INVALID;

@@ -118,6 +118,26 @@ GG_DEV int rank_below(unsigned long long mask)
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// Runs.  A scan line crosses a cell several returns at a time, so the records of a 64-record window mostly come as runs of
+// consecutive lanes with the same cell -- and same-address LDS atomics execute one lane at a time.  The first lane of a run
+// speaks for the whole run: `head` and the run's lane mask.  `id` = the lane's cell, or any value the runs of interest never
+// take for lanes that do not take part (they split runs, which is only conservative).
+struct LaneRun {
+    bool head;
+    unsigned long long mask;
+};
+GG_DEV LaneRun lane_run(uint32_t id, int lane)
+{
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)id, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    LaneRun r;
+    r.head = lane == 0 || id != prev;
+    const unsigned long long hm = __ballot(r.head);
+    const unsigned long long above = (hm >> 1) >> lane; // heads after this lane
+    const unsigned long long upto = above & (0ull - above); // the next head, as a bit relative to lane + 1 (0: none)
+    r.mask = ((upto << 1) - 1ull) << lane; // lanes [lane, next head); upto == 0 -> all lanes from this one up
+    return r;
+}
+
 // cell (row, col) of a key
 GG_DEV void key_to_cell(const Arena &a, uint32_t key, int &row, int &col)
 {

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "groundgrid_hip.h"
 #include "gp_layout.h"
@@ -98,7 +99,12 @@ struct Arena {
     float2 *gp2;    size_t gp2_stride;    GpLayout gpl;              // (ground, confidence) of slot s: gp2 + s*gp2_stride, element order gp_layout.h
     uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
     float *zcell;   size_t zcell_stride;  // per slot: the KEPT heights grouped by cell (K2's stable cell sort), Nmax + 32 T + 64
-    uint32_t *hist;        size_t hist_stride;   // NCH * T
+    uint32_t *hist;        size_t hist_stride;   // NCH * hist_pitch
+    int hist_pitch;        // words per chunk row of `hist`: T rounded up to a multiple of 4 (rows are read and written 16 bytes at a time)
+    uint32_t *front_sync;  // [2 n_slots + 16] words the fused front end (k1_classify.hip) synchronises through, zeroed before every launch
+                           // that uses them: arrivals per slot, "scanned" flag per slot, 8 ticket counters (one per XCD)
+    uint32_t *dev_error;   // one word of host-mapped pinned memory: a kernel that gives up a bounded wait leaves a GG_DEVERR_* code
+                           // here and the next gg_* call that synchronises reports GG_ERR_HIP instead of hanging
     uint32_t *chunk_emit;  size_t emit_stride;   // NCH * 4
     uint32_t *totals;      // [slot][4]  (emitted kept, emitted ignored, outliers, in-map)
     uint32_t *tile_start;  size_t tile_start_stride; // T + 1
@@ -118,7 +124,9 @@ struct Arena {
                                                      // lookup: x = Morton rank, y / z = first / end
                                                      // of its records in `sorted`, w = first row | first col << 16
     uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
+    uint32_t *sweep_sync; // [4] ticket counter, finished work-groups, epoch of k_sweep launches with several work-groups per cloud (k4_sweep.hip)
     unsigned long long *sweep_xchg; size_t sweep_xchg_stride; // [slot] exchange region between the work-groups of one sweep (sweep_core.h "Parts"), in 64-bit words
+    int n_slots; // independent map states of the context
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)
     // launch geometry overrides (0 = the launchers' defaults).  Set at gg_create from the environment (GG_SWEEP_WAVES,
@@ -127,6 +135,11 @@ struct Arena {
     int tune_sweep_waves;   // chain wavefronts per side of k_sweep
     int tune_sweep_gpw;     // ring groups per work-group of k_sweep (sweep_core.h "Parts"); default min(groups, 3)
     int tune_sweep_split;   // k_sweep "split steps": 0 = when a launch has one ring group per work-group and at most 256 work-groups, 1 = whenever gpw == 1, 2 = never
+    int tune_sweep_poll_cap; // tests: polls after which k_sweep's waits give up (0 = about a second)
+    int tune_sweep_fault;   // tests: sweep::Params::debug_fault
+    int tune_front;         // the front end (classify + tile sort): 0 = the launcher's choice, 1 = three launches (k_classify, k_scan,
+                            // k_scatter), 2 = the scan inside k_classify (the last work-group of a cloud to finish scans it), 3 = one launch
+                            // (after the scan every work-group scatters its own chunks)
     int tune_k2_per_cloud;  // minimum work-groups per cloud of k_reduce
     int tune_k2_dense_share; // sixteenths of them that walk the dense list
     int k2_skip;             // measurement (GG_K2_SKIP): 1 = k_reduce leaves the light tiles out, 2 = the dense tiles
@@ -209,19 +222,35 @@ struct BatchIO {
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: the launchers that need more than 64 KiB of dynamic
-// LDS opt in once per DEVICE (a process may hold contexts on several GPUs), tracked in a bit mask indexed by the current device.
-inline bool first_use_on_this_device(std::atomic<uint64_t> &seen)
-{
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const uint64_t bit = 1ull << (dev & 63);
-    if (seen.load(std::memory_order_relaxed) & bit) return false;
-    seen.fetch_or(bit, std::memory_order_relaxed);
-    return true;
-}
+// LDS opt in once per DEVICE (a process may hold contexts on several GPUs).  `opt_in` runs under a lock and the device is marked
+// only after it returned, so a second thread launching on the same device either sees the mark (the attribute is set) or waits for
+// the lock; devices beyond the 64 the mask has bits for opt in on every launch (idempotent).
+struct PerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    std::mutex lock;
+    template <class F> void run(F opt_in)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const bool tracked = dev >= 0 && dev < 64;
+        const uint64_t bit = tracked ? 1ull << dev : 0ull;
+        if (tracked && (done.load(std::memory_order_acquire) & bit)) return;
+        std::lock_guard<std::mutex> g(lock);
+        if (tracked && (done.load(std::memory_order_relaxed) & bit)) return;
+        opt_in();
+        if (tracked) done.fetch_or(bit, std::memory_order_release);
+    }
+};
+
+// codes a kernel leaves in Arena::dev_error when it gives up a bounded wait
+enum : uint32_t { GG_DEVERR_NONE = 0, GG_DEVERR_FRONT_WAIT = 1 /* k_classify: a cloud's scan never completed */, GG_DEVERR_SWEEP_WAIT = 2 /* k_sweep: a hand-over never arrived */ };
+// the front end's launch shapes (Arena::tune_front)
+enum : int { FRONT_AUTO = 0, FRONT_THREE_LAUNCHES = 1, FRONT_SCAN_IN_CLASSIFY = 2, FRONT_ONE_LAUNCH = 3 };
+constexpr int FRONT_DEFAULT_SHAPE = FRONT_THREE_LAUNCHES;
 
 // kernel launchers (one per .hip file)
-void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);
+int launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s); // returns the FRONT_* shape it
+                                                                                                                               // ran: the caller adds launch_scan / launch_scatter for what is left
 void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, int max_n, hipStream_t s);
 void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);

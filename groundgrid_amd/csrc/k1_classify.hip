@@ -9,6 +9,7 @@
 //
 // HBM-bound: algorithmic bytes per point = 16 (point) + 4 (old ground gather) read, 8 (z,key) written.
 #include "gg_device.h"
+#include "sort_core.h"
 
 #include <algorithm>
 
@@ -158,127 +159,269 @@ GG_DEV uint32_t make_key(const Arena &a, const uint16_t *tile_rank, int gi0, int
            ((uint32_t)(gi1 % TILE) << 4);
 }
 
-template <int FMT>
-__global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
+// The front end in one, two or three launches (gg_internal.h FRONT_*):
+//   FRONT_THREE_LAUNCHES    this kernel classifies and writes the chunk histograms; k_scan and k_scatter (k_sort.hip) follow.
+//   FRONT_SCAN_IN_CLASSIFY  the work-groups of a cloud count their arrivals; the LAST one to finish scans the cloud's histograms
+//                           (sort_core.h scan_cloud) while the chip classifies other clouds.  Nobody waits for anybody: no
+//                           assumption about dispatch order or residency.  k_scatter follows.
+//   FRONT_ONE_LAUNCH        ... and the others wait for that scan (one lane polls one word, bounded) and scatter their own
+//                           chunks, whose records they wrote a moment ago.  A waiting work-group needs the other work-groups of
+//                           its cloud to START: work is handed out by TICKET (an atomic counter per XCD, taken when a
+//                           work-group starts running, cloud-major), so at most one cloud per counter is ever partly started,
+//                           and the launcher only picks this shape when the device holds more work-groups than that
+//                           (launch_classify) -- whatever order the dispatcher starts work-groups in (MI355X_MICROARCH.md
+//                           Contract [G]).  A wait that still runs out leaves GG_DEVERR_FRONT_WAIT instead of hanging.
+// What crosses work-groups inside the launch (histogram rows, emission counters, the scanned offsets) is written and read with
+// 16-byte agent-scope accesses (sort_core.h), the arrival counter and the flag with agent-scope atomics; the words are zeroed by
+// a memset node in front of every launch.
+constexpr uint32_t FRONT_WAIT_POLLS = 1u << 22; // x ~0.3 us: gives up after about a second
+
+template <int FMT, int SHAPE>
+__global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io, int n_counters)
 {
-    extern __shared__ uint32_t lds_hist[]; // [4][T]
-    // XCD-aware (gg_device.h): the chunks of one cloud run on one XCD, so its layers / records are cached in ONE L2
-    const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
-    const int cloud = (int)(item / gridDim.x), bx = (int)(item % gridDim.x);
-    const CloudParams &cp = params[cloud]; // (a reference: the 12 transform doubles stay in memory unless has_tf)
+    // dynamic LDS only (a static variable would shift its base off 16 bytes): [4][words] histograms, the tile ranks, 16 scratch words
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = bx * 4 + wave;
-    const int n = cp.n_points;
-    const int nch = (n + a.PW - 1) / a.PW;
-    const int T = a.g.T;
+    const int T = a.g.T, TP = a.hist_pitch;
     // tile -> Morton rank, staged once per work-group (behind the four histograms): a point's key waits for this lookup
     // (big maps: two 16-bit counters per word -- a chunk has fewer than 65536 points -- so that four work-groups fit a CU's LDS
     // where two did: this kernel lives on wavefronts in flight)
     const bool packed = T > PACKED_TILE_COUNTERS_MIN_T && a.PW < 65536;
-    const int words = packed ? (T + 1) / 2 : T; // per wavefront
+    const int words = packed ? TP / 2 : TP; // per wavefront
     uint16_t *lds_tile_rank = reinterpret_cast<uint16_t *>(lds_hist + 4 * words);
+    uint32_t *s_scan = lds_hist + 4 * words + (((T * 2 + 15) & ~15) >> 2);
+    uint32_t &s_word = s_scan[8];
+    const uint32_t n_items = gridDim.x * gridDim.y;
+    uint32_t item;
+    if (SHAPE == FRONT_ONE_LAUNCH) {
+        // a ticket from this XCD's counter (its share of the cloud-major work list, as xcd_contiguous_item cuts it), from the next
+        // XCD's when that one is used up: there are as many tickets as work-groups
+        if (threadIdx.x == 0) {
+            uint32_t *tickets = a.front_sync + 2 * (size_t)a.n_slots;
+            const uint32_t nc = (uint32_t)n_counters, q = n_items / nc, r = n_items % nc;
+            const uint32_t home = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) % nc; // XCC_ID
+            uint32_t got = 0xFFFFFFFFu;
+            for (uint32_t k = 0; k < nc && got == 0xFFFFFFFFu; ++k) {
+                const uint32_t x = (home + k) % nc, size = q + (x < r ? 1u : 0u);
+                const uint32_t t = __hip_atomic_fetch_add(&tickets[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t < size) got = x * q + (x < r ? x : r) + t;
+            }
+            s_word = got;
+        }
+        __syncthreads();
+        item = s_word;
+        if (item == 0xFFFFFFFFu) return; // (cannot happen: as many tickets as work-groups)
+    } else {
+        // XCD-aware (gg_device.h): the chunks of one cloud run on one XCD, so its layers / records are cached in ONE L2
+        item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, n_items);
+    }
+    const int cloud = (int)(item / gridDim.x), bx = (int)(item % gridDim.x);
+    const CloudParams &cp = params[cloud]; // (a reference: the 12 transform doubles stay in memory unless has_tf)
+    const int chunk = bx * 4 + wave;
+    const int n = cp.n_points;
+    const int nch = (n + a.PW - 1) / a.PW;
+    const int groups_of_cloud = max(1, (nch + 3) / 4); // work-groups that hold chunks of this cloud (an empty cloud: one, which scans)
+    if (bx >= groups_of_cloud) return; // (uniform; the grid is sized for the batch's largest cloud)
     for (int t = threadIdx.x; t < T; t += 256) lds_tile_rank[t] = a.tile_rank[t];
-    __syncthreads();
-    if (chunk >= nch) return;
-
     uint32_t *hist = lds_hist + wave * words;
     for (int t = lane; t < words; t += 64) hist[t] = 0u;
+    __syncthreads();
+    const bool active = chunk < nch;
 
     const float2 *gp2 = gp2_ptr(a, cp.slot);
     const char *pts = reinterpret_cast<const char *>(io.d_points) +
                       (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
     uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
+    const __amdgpu_buffer_rsrc_t ghist = words_rsrc(a.hist + (size_t)cp.slot * a.hist_stride, a.hist_stride);
+    const uint32_t row = (uint32_t)chunk * (uint32_t)TP; // this chunk's row of `hist`, in words
 
-    uint32_t n_kept = 0, n_ign = 0, n_outl = 0, n_inmap = 0;
     const int base = chunk * a.PW;
     const int end = min(base + a.PW, n);
-    // ITEMS independent 64-point windows per trip: all point loads are issued before the first classification, so
-    // several HBM / L2 round trips (point record, then the old-ground gather) are in flight per lane.
-    constexpr int ITEMS = 4;
-    for (int p0 = base; p0 < end; p0 += 64 * ITEMS) {
-        PointIn pt[ITEMS];
-        bool valid[ITEMS];
+    if (active) {
+        uint32_t n_kept = 0, n_ign = 0, n_outl = 0, n_inmap = 0;
+        // ITEMS independent 64-point windows per trip: all point loads are issued before the first classification, so
+        // several HBM / L2 round trips (point record, then the old-ground gather) are in flight per lane.
+        constexpr int ITEMS = 4;
+        for (int p0 = base; p0 < end; p0 += 64 * ITEMS) {
+            PointIn pt[ITEMS];
+            bool valid[ITEMS];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int p = p0 + j * 64 + lane;
-            valid[j] = p < end;
-            pt[j] = load_point<FMT>(pts, (size_t)(valid[j] ? p : base));
-        }
-        if (cp.has_tf) { // N2: cloud still in the sensor frame (uniform branch)
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) transform_point(cp.tf, pt[j].x, pt[j].y, pt[j].z);
-        }
-        int gi0[ITEMS], gi1[ITEMS];
-        bool inmap_[ITEMS];
-        float og[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { // index math for all windows, then all old-ground gathers in flight together
-            inmap_[j] = locate_point(a, cp, pt[j], gi0[j], gi1[j]) && valid[j];
-            og[j] = gp2[inmap_[j] ? gp_idx(a, gi0[j], gi1[j]) : 0].x; // :243
-        }
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int p = p0 + j * 64 + lane;
-            int cls = GG_CLASS_KEPT;
-            bool walk = false;
-            if (inmap_[j]) cls = classify_point(a, cp, pt[j], og[j], walk);
-            unsigned long long todo = __ballot(walk);
-            if (__popcll(todo) > WALK_COOPERATIVE_MAX) { // (uniform) most lanes are candidates: everybody walks its own ray
-                if (walk && ray_walk_hits_lane(a, cp, gp2, pt[j].x, pt[j].y, pt[j].z)) cls = GG_CLASS_OUTLIER;
-                todo = 0ull;
+            for (int j = 0; j < ITEMS; ++j) {
+                const int p = p0 + j * 64 + lane;
+                valid[j] = p < end;
+                pt[j] = load_point<FMT>(pts, (size_t)(valid[j] ? p : base));
             }
-            for (; todo != 0ull; todo &= todo - 1ull) { // (uniform loop, rarely entered)
-                const int src = __builtin_ctzll(todo);
-                const bool hit = ray_walk_hits(a, cp, gp2, __shfl(pt[j].x, src, 64), __shfl(pt[j].y, src, 64), __shfl(pt[j].z, src, 64), lane);
-                if (lane == src && hit) cls = GG_CLASS_OUTLIER;
+            if (cp.has_tf) { // N2: cloud still in the sensor frame (uniform branch)
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) transform_point(cp.tf, pt[j].x, pt[j].y, pt[j].z);
             }
-            uint32_t key = KEY_OUTSIDE;
-            if (inmap_[j]) key = make_key(a, lds_tile_rank, gi0[j], gi1[j], cls);
-            if (valid[j]) rec[p] = make_uint2(__float_as_uint(pt[j].z), key);
-            const bool inmap = key != KEY_OUTSIDE;
-            if (inmap) {
+            int gi0[ITEMS], gi1[ITEMS];
+            bool inmap_[ITEMS];
+            float og[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) { // index math for all windows, then all old-ground gathers in flight together
+                inmap_[j] = locate_point(a, cp, pt[j], gi0[j], gi1[j]) && valid[j];
+                og[j] = gp2[inmap_[j] ? gp_idx(a, gi0[j], gi1[j]) : 0].x; // :243
+            }
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int p = p0 + j * 64 + lane;
+                int cls = GG_CLASS_KEPT;
+                bool walk = false;
+                if (inmap_[j]) cls = classify_point(a, cp, pt[j], og[j], walk);
+                unsigned long long todo = __ballot(walk);
+                if (__popcll(todo) > WALK_COOPERATIVE_MAX) { // (uniform) most lanes are candidates: everybody walks its own ray
+                    if (walk && ray_walk_hits_lane(a, cp, gp2, pt[j].x, pt[j].y, pt[j].z)) cls = GG_CLASS_OUTLIER;
+                    todo = 0ull;
+                }
+                for (; todo != 0ull; todo &= todo - 1ull) { // (uniform loop, rarely entered)
+                    const int src = __builtin_ctzll(todo);
+                    const bool hit = ray_walk_hits(a, cp, gp2, __shfl(pt[j].x, src, 64), __shfl(pt[j].y, src, 64), __shfl(pt[j].z, src, 64), lane);
+                    if (lane == src && hit) cls = GG_CLASS_OUTLIER;
+                }
+                uint32_t key = KEY_OUTSIDE;
+                if (inmap_[j]) key = make_key(a, lds_tile_rank, gi0[j], gi1[j], cls);
+                if (valid[j]) rec[p] = make_uint2(__float_as_uint(pt[j].z), key);
+                const bool inmap = key != KEY_OUTSIDE;
+                // the tile histogram: consecutive returns of a scan line fall into one tile, and same-address LDS atomics execute a
+                // lane at a time -- the first lane of every run of equal tiles adds the run's length (gg_device.h lane_run)
                 const uint32_t tr = key >> KEY_TILE_SHIFT;
-                if (packed) // (uniform)
-                    atomicAdd(&hist[tr >> 1], 1u << ((tr & 1u) * 16u));
-                else
-                    atomicAdd(&hist[tr], 1u);
+                const LaneRun run = lane_run(inmap ? tr : 0x100000u, lane);
+                if (inmap && run.head) {
+                    const uint32_t len = (uint32_t)__popcll(run.mask);
+                    if (packed) // (uniform)
+                        atomicAdd(&hist[tr >> 1], len << ((tr & 1u) * 16u));
+                    else
+                        atomicAdd(&hist[tr], len);
+                }
+                const bool emit = inmap && (key & KEY_EMIT_BIT);
+                n_inmap += (uint32_t)__popcll(__ballot(inmap));
+                n_kept += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_KEPT));
+                n_ign += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_IGNORED));
+                n_outl += (uint32_t)__popcll(__ballot(inmap && cls == GG_CLASS_OUTLIER));
             }
-            const bool emit = inmap && (key & KEY_EMIT_BIT);
-            n_inmap += (uint32_t)__popcll(__ballot(inmap));
-            n_kept += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_KEPT));
-            n_ign += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_IGNORED));
-            n_outl += (uint32_t)__popcll(__ballot(inmap && cls == GG_CLASS_OUTLIER));
+        }
+
+        // the chunk's row of `hist` (zeros in its padding) and its emission counters, 16 bytes at a time
+        for (int g = lane; g < TP / 4; g += 64) {
+            u32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = 4 * g + k;
+                v[k] = packed ? (hist[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu : hist[t];
+            }
+            store16_agent(ghist, row + 4u * (uint32_t)g, v);
+        }
+        if (lane == 0) {
+            const u32x4 v = {n_kept, n_ign, n_outl, n_inmap};
+            store16_agent(words_rsrc(a.chunk_emit + (size_t)cp.slot * a.emit_stride, a.emit_stride), 4u * (uint32_t)chunk, v);
         }
     }
+    if (SHAPE == FRONT_THREE_LAUNCHES) return;
 
-    uint32_t *ghist = a.hist + (size_t)cp.slot * a.hist_stride + (size_t)chunk * T;
-    for (int t = lane; t < T; t += 64) ghist[t] = packed ? (hist[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu : hist[t];
-    if (lane == 0) {
-        uint32_t *ce = a.chunk_emit + (size_t)cp.slot * a.emit_stride + (size_t)chunk * 4;
-        ce[0] = n_kept;
-        ce[1] = n_ign;
-        ce[2] = n_outl;
-        ce[3] = n_inmap;
+    // ---- the cloud's last work-group scans ----
+    drain_vector_memory(); // (every storing wavefront, before the arrival is counted)
+    __syncthreads();
+    uint32_t *arrivals = a.front_sync + (size_t)cp.slot, *scanned = a.front_sync + (size_t)a.n_slots + (size_t)cp.slot;
+    if (threadIdx.x == 0) s_word = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = s_word == (uint32_t)groups_of_cloud - 1u;
+    if (last) {
+        scan_cloud<4>(a, cp, nch, s_scan);
+        if (SHAPE == FRONT_ONE_LAUNCH) {
+            drain_vector_memory();
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(scanned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (SHAPE != FRONT_ONE_LAUNCH) return;
+
+    // ---- everybody scatters its own chunks ----
+    if (!last) {
+        __syncthreads(); // (s_word is reused)
+        if (threadIdx.x == 0) {
+            uint32_t polls = 0;
+            while (__hip_atomic_load(scanned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && polls < FRONT_WAIT_POLLS) {
+                __builtin_amdgcn_s_sleep(16);
+                ++polls;
+            }
+            s_word = polls < FRONT_WAIT_POLLS ? 1u : 0u;
+            if (polls >= FRONT_WAIT_POLLS) __hip_atomic_store(a.dev_error, (uint32_t)GG_DEVERR_FRONT_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        if (s_word == 0u) return; // (the error word says so; the batch's outputs are void)
+    }
+    if (!active) return;
+    uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
+    if (packed) {
+        for (int t = lane; t < words; t += 64) hist[t] = 0u;
+        scatter_chunk<true>(hist, ghist, row, rec, sorted, base, end, lane);
+    } else {
+        for (int g = lane; g < TP / 4; g += 64) *reinterpret_cast<u32x4 *>(hist + 4 * g) = load16_agent(ghist, row + 4u * (uint32_t)g);
+        scatter_chunk<false>(hist, ghist, row, rec, sorted, base, end, lane);
     }
 }
 
-void launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s)
+size_t classify_lds_bytes(const Arena &a)
+{
+    const bool packed = a.g.T > PACKED_TILE_COUNTERS_MIN_T && a.PW < 65536;
+    return (size_t)4 * (packed ? a.hist_pitch / 2 : a.hist_pitch) * sizeof(uint32_t) + (((size_t)a.g.T * 2 + 15) & ~(size_t)15) + 64;
+}
+
+template <int FMT, int SHAPE>
+static void launch_classify_as(const Arena &a, const CloudParams *d_params, const BatchIO &io, dim3 grid, size_t lds, int n_counters, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_classify<FMT, SHAPE>), grid, dim3(256), lds, s, a, d_params, io, n_counters);
+}
+
+// work-groups of k_classify<.., FRONT_ONE_LAUNCH> the current device holds at a time (0: unknown)
+static int front_resident_groups(size_t lds)
+{
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_classify<GG_POINT16, FRONT_ONE_LAUNCH>), 256, lds) != hipSuccess) return 0;
+    // (the API can overstate what the hardware admits by one work-group per CU, MI355X_MICROARCH.md "Residency": count one less)
+    return std::max(0, per_cu - 1) * cus;
+}
+
+int launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s)
 {
     const int nch = (max_n + a.PW - 1) / a.PW;
-    if (nch == 0 || n_clouds == 0) return;
-    dim3 grid((nch + 3) / 4, n_clouds);
-    const bool packed = a.g.T > PACKED_TILE_COUNTERS_MIN_T && a.PW < 65536;
-    const size_t lds = (size_t)4 * (packed ? (a.g.T + 1) / 2 : a.g.T) * sizeof(uint32_t) + (((size_t)a.g.T * 2 + 3) & ~(size_t)3);
+    if (n_clouds == 0) return FRONT_ONE_LAUNCH; // (nothing to do for anybody)
+    const int groups = std::max(1, (nch + 3) / 4); // (an empty batch still scans: tile lists, counts)
+    dim3 grid(groups, n_clouds);
+    const size_t lds = classify_lds_bytes(a);
     // per-wave tile histograms beyond the 64 KiB default (grids above ~1024 cells per side) need the explicit opt-in
-    static std::atomic<uint64_t> big_lds_devices{0};
-    if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices)) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static PerDeviceOnce big_lds;
+    if (lds > 64 * 1024)
+        big_lds.run([] {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT16, FRONT_THREE_LAUNCHES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT32, FRONT_THREE_LAUNCHES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT16, FRONT_SCAN_IN_CLASSIFY>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT32, FRONT_SCAN_IN_CLASSIFY>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT16, FRONT_ONE_LAUNCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<GG_POINT32, FRONT_ONE_LAUNCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+    int shape = a.tune_front != FRONT_AUTO ? a.tune_front : FRONT_DEFAULT_SHAPE;
+    int n_counters = 8;
+    if (shape == FRONT_ONE_LAUNCH) {
+        // a waiting work-group needs the rest of its cloud to start: with one ticket counter per XCD at most 8 clouds are partly
+        // started, with a single counter one -- the device must hold more work-groups than those can have waiting
+        const int resident = front_resident_groups(lds);
+        if (resident >= 8 * groups + 8) n_counters = 8;
+        else if (resident >= groups + 1) n_counters = 1;
+        else shape = FRONT_SCAN_IN_CLASSIFY;
     }
-    if (io.point_format == GG_POINT16)
-        hipLaunchKernelGGL(k_classify<GG_POINT16>, grid, dim3(256), lds, s, a, d_params, io);
+    if (shape != FRONT_THREE_LAUNCHES) hipMemsetAsync(a.front_sync, 0, ((size_t)2 * a.n_slots + 16) * sizeof(uint32_t), s);
+    const bool p16 = io.point_format == GG_POINT16;
+    if (shape == FRONT_THREE_LAUNCHES)
+        p16 ? launch_classify_as<GG_POINT16, FRONT_THREE_LAUNCHES>(a, d_params, io, grid, lds, n_counters, s) : launch_classify_as<GG_POINT32, FRONT_THREE_LAUNCHES>(a, d_params, io, grid, lds, n_counters, s);
+    else if (shape == FRONT_SCAN_IN_CLASSIFY)
+        p16 ? launch_classify_as<GG_POINT16, FRONT_SCAN_IN_CLASSIFY>(a, d_params, io, grid, lds, n_counters, s) : launch_classify_as<GG_POINT32, FRONT_SCAN_IN_CLASSIFY>(a, d_params, io, grid, lds, n_counters, s);
     else
-        hipLaunchKernelGGL(k_classify<GG_POINT32>, grid, dim3(256), lds, s, a, d_params, io);
+        p16 ? launch_classify_as<GG_POINT16, FRONT_ONE_LAUNCH>(a, d_params, io, grid, lds, n_counters, s) : launch_classify_as<GG_POINT32, FRONT_ONE_LAUNCH>(a, d_params, io, grid, lds, n_counters, s);
+    return shape;
 }
 
 // ---- small utility kernels ----------------------------------------------------------------

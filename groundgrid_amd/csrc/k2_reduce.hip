@@ -86,26 +86,6 @@ GG_DEV void lds_order() { __asm__ volatile("" ::: "memory"); } // LDS operations
 // random, boundary and tie operands) and the GPU parity tests.
 GG_DEV float quot(float a, double r) { return (float)((double)a * r); }
 
-// Runs.  A scan line crosses a cell several returns at a time, so the records of a 64-record window mostly come as runs of
-// consecutive lanes with the same cell -- and same-address LDS atomics execute one lane at a time.  The first lane of a run
-// speaks for the whole run: `head` and the run's lane mask.  `id` = the lane's cell, or any value the runs of interest never
-// take for lanes that do not take part (they split runs, which is only conservative).
-struct LaneRun {
-    bool head;
-    unsigned long long mask;
-};
-GG_DEV LaneRun lane_run(uint32_t id, int lane)
-{
-    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)id, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-    LaneRun r;
-    r.head = lane == 0 || id != prev;
-    const unsigned long long hm = __ballot(r.head);
-    const unsigned long long above = (hm >> 1) >> lane; // heads after this lane
-    const unsigned long long upto = above & (0ull - above); // the next head, as a bit relative to lane + 1 (0: none)
-    r.mask = ((upto << 1) - 1ull) << lane; // lanes [lane, next head); upto == 0 -> all lanes from this one up
-    return r;
-}
-
 // single-instruction forms where the compiler emits two or three (compare + select for std::min / std::max, a canonicalising
 // v_max before every fminf operand, a separate instruction per |x|); NaN operands are ignored by all of them as by the
 // expressions they replace

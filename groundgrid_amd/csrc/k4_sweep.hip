@@ -35,6 +35,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
 
+__shared__ uint32_t sweep_wait_failed; // (work-group: a wavefront gave up a bounded wait, DevMemT::give_up)
+__shared__ uint32_t sweep_pad_;        // (keeps the static LDS -- these two words and k_sweep's s_sync[2] -- a multiple of 16 bytes)
+
 template <bool DBG> struct DevMemT {
     __amdgpu_buffer_rsrc_t rsrc; // the interleaved (ground, confidence) layer of this cloud
     lds_int *lds;
@@ -52,6 +55,20 @@ template <bool DBG> struct DevMemT {
     {
         if (dbg_mode() & 4)
             for (int k = 0; k < 6; ++k) marks[k] = acc[k];
+    }
+    // Bounded waits.  A wavefront of this kernel waits either for another wavefront of its OWN work-group (LDS counters) or -- the
+    // importer wavefront only -- for values of ANOTHER work-group in the exchange region.  Only the second kind can wait for
+    // something that never comes (a producer that is not running, a corrupted region), and everything else waits, directly or
+    // not, for what the importer republishes.  So the importer counts its polls: when a wait outlasts Params::poll_cap polls it
+    // gives up, hands on what it has as if it were complete (its consumers -- and through the exporter the work-groups further out
+    // -- run through their steps instead of waiting in turn) and raises a flag that the work-group's first thread passes to the
+    // context's error word when the kernel ends: the next gg_* call that synchronises returns GG_ERR_HIP, the outputs of the batch
+    // are void, and nothing hangs.
+    GG_DEV bool give_up(int polls, const Params &P) const
+    {
+        if (polls < P.poll_cap) return false;
+        __hip_atomic_store(&sweep_wait_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return true;
     }
     static constexpr uint32_t OOR = 0x80000000u; // beyond the buffer: loads return 0, stores are dropped, no traffic
     // exchange region of this cloud (sweep_core.h "Parts"): one WP = two 64-bit words (value | launch sequence number << 32), each
@@ -345,9 +362,9 @@ template <bool DBG> GG_DEV void run_import(const Params &P, const LdsMap &L, Dev
         // part inside produces about that ring (its corner wavefronts run ahead of the chains)
         WP v{0.f, 0.f};
         bool ok = lane >= 4;
-        for (;;) {
+        for (int polls = 0;; ++polls) {
             if (!ok) ok = mem.import_wp(xchg_misc(gb, lane), v);
-            if (__all(ok)) break;
+            if (__all(ok) || mem.give_up(polls, P)) break;
             __builtin_amdgcn_s_sleep(SLEEP_LONG);
         }
         if (lane < 4) mem.put(L.corner + 2 * (((lane >> 1) * P.c + rb) * 2) + 2 * (lane & 1), v); // AB / CD: x1, then y0
@@ -361,7 +378,7 @@ template <bool DBG> GG_DEV void run_import(const Params &P, const LdsMap &L, Dev
     // the boundary chains of ring rb: side s has chain_len<s>(rb) values; 64 consecutive entries per poll
     int done[4] = {0, 0, 0, 0};
     const int len[4] = {chain_len<SIDE_A>(rb), chain_len<SIDE_B>(rb), chain_len<SIDE_C>(rb), chain_len<SIDE_D>(rb)};
-    for (;;) {
+    for (int idle = 0;;) {
         bool all_done = joins, progress = false;
         if (!joins) {
             WP v{0.f, 0.f};
@@ -392,7 +409,18 @@ template <bool DBG> GG_DEV void run_import(const Params &P, const LdsMap &L, Dev
             progress = true;
         }
         if (all_done) break;
-        if (!progress) __builtin_amdgcn_s_sleep(SLEEP_LONG);
+        idle = progress ? 0 : idle + 1;
+        if (!progress) {
+            if (mem.give_up(idle, P)) { // (what never arrived is handed on as it is: the consumers must not wait for it either)
+                if (lane == 0) {
+                    mem.set_counter(L.join_done + SIDE_C, rb);
+                    mem.set_counter(L.join_done + SIDE_D, rb);
+                    for (int side = 0; side < 4; ++side) mem.set_counter(L.bnd_done + side * P.groups + (g0 - 1), len[side]);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(SLEEP_LONG);
+        }
     }
 }
 
@@ -430,7 +458,7 @@ template <bool DBG> GG_DEV void run_export(const Params &P, const LdsMap &L, Dev
         if (!head) {
             const int jc = mem.counter(L.join_done + SIDE_C), jd = mem.counter(L.join_done + SIDE_D);
             if (jc >= rb && jd >= rb) { // (uniform) C_last, D_last of ring rb: lanes 0..1
-                if (lane < 2) mem.export_wp_if(true, xchg_misc(gb, X_JOIN_C + lane), mem.get(L.join + 2 * ((lane == 0 ? (int)SIDE_C : (int)SIDE_D) * P.c + rb)));
+                if (lane < 2 && P.debug_fault != 2) mem.export_wp_if(true, xchg_misc(gb, X_JOIN_C + lane), mem.get(L.join + 2 * ((lane == 0 ? (int)SIDE_C : (int)SIDE_D) * P.c + rb)));
                 head = true;
                 progress = true;
             }
@@ -444,21 +472,41 @@ template <bool DBG> GG_DEV void run_export(const Params &P, const LdsMap &L, Dev
 // per CU spills and is 1.6x slower at 1024 clouds per launch.)
 template <bool DBG>
 __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const CloudParams *__restrict__ params, int n_clouds, int n_parts,
-                                                   uint32_t seq, unsigned long long *dbg)
+                                                   unsigned long long *dbg)
 {
     extern __shared__ int lds[];
-    // work-group -> (cloud, part).  The parts of a cloud follow each other in dispatch order (a consumer is never dispatched
-    // before its producer) and, in bundles of eight clouds, differ by multiples of 8 in the index: work-groups go to the 8 XCDs
-    // round-robin, so the parts of a cloud meet in ONE L2 (the hand-over is correct on any placement: agent-scope atomics).
+    __shared__ __attribute__((aligned(16))) uint32_t s_sync[2]; // (with sweep_wait_failed: static LDS stays a multiple of 8 bytes, the 64-bit
+                                                                // accesses to the dynamic region behind it keep their alignment)
+    // work-group -> (cloud, part).  A part waits for values of the part inside it (feed-forward only), so a consumer must never
+    // hold a place its producer needs: the work-groups of a launch with several parts per cloud take a TICKET when they start
+    // running (one atomic counter) and the ticket, not blockIdx, names (cloud, part) -- the parts of a cloud follow each other in
+    // ticket order, so a producer has always started before its consumer, in whatever order the dispatcher starts work-groups
+    // (MI355X_MICROARCH.md Contract [G]).  In bundles of eight clouds the parts of a cloud differ by multiples of 8 in the id:
+    // when work-groups do start in index order they go to the 8 XCDs round-robin and the parts of a cloud meet in ONE L2 (speed
+    // only: the hand-over is correct on any placement, agent-scope atomics).  The values in the exchange region are tagged with an
+    // EPOCH that lives in device memory: the last work-group of a launch to finish advances it (and re-arms the ticket counter),
+    // so nothing depends on a per-launch kernel argument (a replayed graph would freeze one).
+    uint32_t *sync_words = a.sweep_sync;
+    uint32_t id = blockIdx.x, epoch = 0u;
+    if (n_parts > 1) {
+        if (threadIdx.x == 0) {
+            s_sync[0] = __hip_atomic_fetch_add(sync_words + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_sync[1] = __hip_atomic_load(sync_words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        id = s_sync[0];
+        epoch = s_sync[1];
+        if (P.debug_fault == 1) id = gridDim.x - 1u - id;
+    }
     int cloud, part;
     {
-        const int id = (int)blockIdx.x, full = n_clouds & ~7, tail = n_clouds - full;
-        if (id < full * n_parts) {
-            const int rem = id % (8 * n_parts);
+        const int full = n_clouds & ~7, tail = n_clouds - full;
+        if ((int)id < full * n_parts) {
+            const int rem = (int)id % (8 * n_parts);
             part = rem >> 3;
-            cloud = (id / (8 * n_parts)) * 8 + (rem & 7);
+            cloud = ((int)id / (8 * n_parts)) * 8 + (rem & 7);
         } else {
-            const int rem = id - full * n_parts;
+            const int rem = (int)id - full * n_parts;
             part = rem / tail;
             cloud = full + rem % tail;
         }
@@ -472,6 +520,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
 
     // hand-over tables start empty: counters 0 = "ring 0 done", and ring 0 of every table is the centre cell
     for (int k = threadIdx.x; k < L.corner; k += nthreads) lds[k] = 0;
+    if (threadIdx.x == 0) sweep_wait_failed = 0u;
     const WP centre{1.0f, 1.0f * cp.base_z}; // :405 groundpatch(centre) = 1, :406-411 ground(centre) = translation.z
     if (threadIdx.x == 0) {
         if (part == 0) gp2[gp_index(P.gl, P.c, P.c)] = make_float2(cp.base_z, 1.0f);
@@ -508,7 +557,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, P.gl.elems * 8, 0x00020000);
     mem.lds = (lds_int *)lds;
     mem.xchg = a.sweep_xchg + (size_t)cp.slot * a.sweep_xchg_stride;
-    mem.seq = seq;
+    mem.seq = epoch;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const int W = P.waves_per_side;
     WaveClockT<DBG> clk;
@@ -556,6 +605,16 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     } else if (g1 < P.groups)
         run_export<DBG>(P, L, mem, lane, g1);
     clk.end(wave, lane);
+    __syncthreads();
+    if (threadIdx.x == 0 && sweep_wait_failed) __hip_atomic_store(a.dev_error, (uint32_t)GG_DEVERR_SWEEP_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (n_parts > 1) { // the last work-group of the launch re-arms the tickets and advances the epoch (never 0: the arena starts zeroed)
+        if (threadIdx.x == 0 && __hip_atomic_fetch_add(sync_words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+            __hip_atomic_store(sync_words + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync_words + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t next = epoch + 1u;
+            __hip_atomic_store(sync_words + 2, next ? next : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // the largest LDS table any part of a sweep with `gpw` groups per work-group needs
@@ -601,19 +660,19 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
                         : 0;
     if (P.split_steps) P.waves_per_side = 1;
     const size_t lds = parts_lds_bytes(P, P.gpw, P.split_steps != 0);
-    static std::atomic<uint64_t> big_lds_devices{0};
-    if (lds > 64 * 1024 && first_use_on_this_device(big_lds_devices)) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    static std::atomic<uint32_t> launch_seq{0}; // tags the values of this launch in the exchange region (never 0: the arena starts zeroed)
-    uint32_t seq = launch_seq.fetch_add(1, std::memory_order_relaxed) + 1u;
-    if (seq == 0u) seq = launch_seq.fetch_add(1, std::memory_order_relaxed) + 1u;
+    static PerDeviceOnce big_lds;
+    if (lds > 64 * 1024)
+        big_lds.run([] {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+    P.poll_cap = a.tune_sweep_poll_cap > 0 ? a.tune_sweep_poll_cap : 1 << 22; // (x ~0.2 us: about a second)
+    P.debug_fault = a.tune_sweep_fault;
     const int threads = P.split_steps ? 12 * 64 : (4 * P.waves_per_side + 2 + (n_parts > 1 ? 2 : 0)) * 64; // (+ importer and exporter)
     if (dbg) // (GG_SWEEP_TIMING: the instrumented twin)
-        hipLaunchKernelGGL(k_sweep<true>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, seq, dbg);
+        hipLaunchKernelGGL(k_sweep<true>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
     else
-        hipLaunchKernelGGL(k_sweep<false>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, seq, dbg);
+        hipLaunchKernelGGL(k_sweep<false>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
 }
 
 } // namespace gg

@@ -1,0 +1,224 @@
+// sort_core.h -- device-side pieces of the stable tile sort between K1 and K2, shared by the stand-alone kernels (k_sort.hip)
+// and the fused front end (k1_classify.hip, Arena::tune_front):
+//
+//   scan_cloud     one work-group: hist[chunk][tile] (one row per wave-chunk, written by K1) -> exclusive offsets in
+//                  (tile-major, chunk-minor) order, tile_start[], K2's two work lists (light / dense tiles), the cleared
+//                  liveness masks of tiles without records, and the exclusive prefixes of the per-chunk emission counters
+//                  (kept / ignored / outliers) that give every point its position in the returned cloud (K5).
+//   scatter_chunk  one wavefront: re-walks its chunk in cloud order and places record p at offset[tile] + (number of earlier
+//                  points of the chunk in that tile).  Ranks inside a 64-point window come from ballots, the running offset
+//                  of a tile from ONE returning LDS add per distinct tile and window (issued by the tile's first lane, handed
+//                  to the others with a lane permute) -- the LDS unit executes a wavefront's operations in order, so the adds
+//                  of several windows are in flight together and the sort is STABLE: inside a tile, and therefore inside every
+//                  cell, records stay in cloud order, which is what makes the float32 Welford recurrence of K2
+//                  bit-reproducible (src/GroundSegmentation.cpp:296-305 is order dependent).
+//
+// Rows of `hist` cross work-groups INSIDE a launch when the scan is fused into K1 (the last work-group of a cloud to finish
+// scans for all of them) and again when the scatter is fused as well (everybody waits for that scan): every access to them is
+// a 16-byte agent-scope (sc1) buffer access -- written through to memory, read past the L1 -- so no fence is needed and nothing
+// depends on which XCD a work-group runs on (MI355X_MICROARCH.md "Inter-workgroup visibility", recipe R1).
+#pragma once
+
+#include "gg_device.h"
+
+namespace gg {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AUX_SC1 = 16; // cache-policy bits of the raw buffer builtins on gfx940+: sc0 = 1, nt = 2, sc1 = 16
+
+GG_DEV __amdgpu_buffer_rsrc_t words_rsrc(const uint32_t *base, size_t words)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(base), 0, (int)(words * 4), 0x00020000);
+}
+GG_DEV u32x4 load16_agent(__amdgpu_buffer_rsrc_t r, uint32_t word) { return __builtin_amdgcn_raw_buffer_load_b128(r, word * 4u, 0, AUX_SC1); }
+GG_DEV void store16_agent(__amdgpu_buffer_rsrc_t r, uint32_t word, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, word * 4u, 0, AUX_SC1); }
+GG_DEV void drain_vector_memory() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // (inline asm: the compiler cannot drop it)
+
+// wave-level inclusive scan (64 lanes)
+GG_DEV uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// block-level exclusive scan of one value per thread (blockDim.x = 64 NW), returns the exclusive prefix; total in `total`
+template <int NW>
+GG_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds /*[NW + 1]*/, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v, lane);
+    __syncthreads(); // protect lds reuse across calls
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t w = (lane < NW) ? lds[lane] : 0u;
+        const uint32_t winc = wave_inclusive_scan(w, lane);
+        if (lane < NW) lds[lane] = winc - w;
+        if (lane == NW - 1) lds[NW] = winc;
+    }
+    __syncthreads();
+    total = lds[NW];
+    return lds[wave] + inc - v;
+}
+
+// The scan of one cloud by one work-group of 64 NW threads.  A thread owns FOUR consecutive tiles (one 16-byte column segment
+// of every chunk's row); `nch` = the cloud's chunks.
+template <int NW>
+GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t *lds /*[NW + 1]*/)
+{
+    constexpr int NT = 64 * NW;
+    const int tid = threadIdx.x;
+    const int T = a.g.T, TP = a.hist_pitch, G = TP / 4;
+    const __amdgpu_buffer_rsrc_t hist = words_rsrc(a.hist + (size_t)cp.slot * a.hist_stride, a.hist_stride);
+    uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
+    uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
+    uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
+
+    uint32_t carry = 0, lcarry = 0, dcarry = 0;
+    for (int g0 = 0; g0 < G; g0 += NT) {
+        const int g = g0 + tid;
+        const bool have = g < G;
+        u32x4 s = {0u, 0u, 0u, 0u};
+        if (have) {
+#pragma unroll 8
+            for (int c = 0; c < nch; ++c) s += load16_agent(hist, (uint32_t)c * (uint32_t)TP + 4u * (uint32_t)g);
+        }
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan<NW>(s.x + s.y + s.z + s.w, lds, total);
+        {
+            // K2's work lists (k2_reduce.hip): tiles with more than K2_LIGHT_MAX records from the back of tile_list, the
+            // other tiles with records from the front, both in rank order.  A tile without records is on neither list: its half
+            // columns simply stop being live (the per-call layers are sparse, gg_internal.h tile_live) -- nothing is cleaned.
+            uint32_t nl = 0, nd = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = have && 4 * g + k < T;
+                nd += (in && s[k] > (uint32_t)K2_LIGHT_MAX) ? 1u : 0u;
+                nl += (in && s[k] > 0u && s[k] <= (uint32_t)K2_LIGHT_MAX) ? 1u : 0u;
+            }
+            uint32_t ltotal;
+            const uint32_t lexcl = block_exclusive_scan<NW>(nl | (nd << 16), lds, ltotal);
+            uint32_t li = lcarry + (lexcl & 0xFFFFu), di = dcarry + (lexcl >> 16), start = carry + excl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = 4 * g + k;
+                if (have && t < T) {
+                    // (rank, the tile's records, its first cell: K2 starts on a tile after ONE lookup)
+                    const uint4 entry = make_uint4((uint32_t)t, start, start + s[k], a.rank_cell0[t]);
+                    if (s[k] == 0u) tile_live[t] = 0u;
+                    else if (s[k] > (uint32_t)K2_LIGHT_MAX) tile_list[(uint32_t)T - 1u - di++] = entry;
+                    else tile_list[li++] = entry;
+                    tile_start[t] = start;
+                    start += s[k];
+                }
+            }
+            lcarry += ltotal & 0xFFFFu;
+            dcarry += ltotal >> 16;
+        }
+        if (have) { // every chunk's count becomes its first position in `sorted`
+            u32x4 run;
+            run.x = carry + excl;
+            run.y = run.x + s.x;
+            run.z = run.y + s.y;
+            run.w = run.z + s.z;
+#pragma unroll 8
+            for (int c = 0; c < nch; ++c) {
+                const uint32_t w = (uint32_t)c * (uint32_t)TP + 4u * (uint32_t)g;
+                const u32x4 h = load16_agent(hist, w);
+                store16_agent(hist, w, run);
+                run += h;
+            }
+        }
+        carry += total;
+    }
+    if (tid == 0) {
+        tile_start[T] = carry;
+        uint32_t *lc = a.tile_list_cnt + (size_t)cp.slot * 2;
+        lc[0] = lcarry;
+        lc[1] = dcarry;
+    }
+
+    // emission counters: exclusive prefix over chunks for each of the 4 categories (read by K5, the next kernel but two)
+    const __amdgpu_buffer_rsrc_t ce = words_rsrc(a.chunk_emit + (size_t)cp.slot * a.emit_stride, a.emit_stride);
+    uint32_t *ce_out = a.chunk_emit + (size_t)cp.slot * a.emit_stride;
+    u32x4 kcarry = {0u, 0u, 0u, 0u};
+    for (int c0 = 0; c0 < nch; c0 += NT) {
+        const int c = c0 + tid;
+        u32x4 v = {0u, 0u, 0u, 0u}, e;
+        if (c < nch) v = load16_agent(ce, 4u * (uint32_t)c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t total;
+            e[k] = kcarry[k] + block_exclusive_scan<NW>(v[k], lds, total);
+            kcarry[k] += total;
+        }
+        if (c < nch) *reinterpret_cast<u32x4 *>(ce_out + 4 * (size_t)c) = e;
+    }
+    if (tid == 0) *reinterpret_cast<u32x4 *>(a.totals + (size_t)cp.slot * 4) = kcarry;
+}
+
+// The stable scatter of one wave-chunk [base, end) of cloud records.  `offs` = the wavefront's LDS row (hist_pitch words, or
+// half as many when PACKED): unpacked it holds the next free position of every tile (the caller loaded the chunk's row of
+// `hist`), packed (maps of more than PACKED_TILE_COUNTERS_MIN_T tiles) only the number of records already placed per tile, two
+// 16-bit counters per word, zeroed by the caller -- the chunk's first position per tile then stays in its row of `hist` and every
+// lane fetches its own record's.
+template <bool PACKED>
+GG_DEV void scatter_chunk(uint32_t *offs, __amdgpu_buffer_rsrc_t hist, uint32_t row_word, const uint2 *__restrict__ rec, uint2 *__restrict__ sorted,
+                          int base, int end, int lane)
+{
+    constexpr int SI = 4; // windows in flight
+    for (int p0 = base; p0 < end; p0 += 64 * SI) {
+        uint2 r[SI];
+#pragma unroll
+        for (int j = 0; j < SI; ++j) {
+            const int p = p0 + 64 * j + lane;
+            r[j] = make_uint2(0u, KEY_OUTSIDE);
+            if (p < end) r[j] = rec[p];
+        }
+        uint32_t dst[SI];
+#pragma unroll
+        for (int j = 0; j < SI; ++j) {
+            const bool inmap = r[j].y != KEY_OUTSIDE;
+            const uint32_t t = r[j].y >> KEY_TILE_SHIFT;
+            uint32_t first_pos = 0u;
+            if (PACKED) first_pos = __builtin_amdgcn_raw_buffer_load_b32(hist, inmap ? (row_word + t) * 4u : 0xFFFFFFFFu, 0, AUX_SC1); // (out of range: 0)
+            // rank among the window's records of the same tile, their number, and the tile's first lane: ballots only
+            uint32_t rank = 0u, cnt = 0u;
+            int first = lane;
+            for (unsigned long long todo = __ballot(inmap); todo != 0ull;) { // one iteration per distinct tile (wave-uniform)
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
+                const bool mine = inmap && t == t0;
+                const unsigned long long same = __ballot(mine);
+                if (mine) {
+                    rank = (uint32_t)rank_below(same);
+                    cnt = (uint32_t)__popcll(same);
+                    first = leader;
+                }
+                todo &= ~same;
+            }
+            // ... one returning LDS add per distinct tile (no two lanes of one instruction meet on an address); the adds of the
+            // SI windows queue up behind each other in the LDS unit, in program order
+            uint32_t old = 0u;
+            if (inmap && lane == first) {
+                if (PACKED) {
+                    const uint32_t sh = (t & 1u) * 16u;
+                    old = (__hip_atomic_fetch_add(&offs[t >> 1], cnt << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> sh) & 0xFFFFu;
+                } else {
+                    old = __hip_atomic_fetch_add(&offs[t], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            dst[j] = first_pos + (uint32_t)__shfl((int)old, first, 64) + rank;
+        }
+#pragma unroll
+        for (int j = 0; j < SI; ++j)
+            if (r[j].y != KEY_OUTSIDE) sorted[dst[j]] = r[j];
+    }
+}
+
+} // namespace gg

@@ -86,6 +86,9 @@ struct Params {
     int r2min;  // the confidence decay (:463-464) applies to cell (x, y) iff (x-c)^2 + (y-c)^2 >= r2min (host-computed, exact)
     double decrease, inv_decrease;
     int decay_fast;
+    int poll_cap;    // polls after which a wait gives up (k4_sweep.hip "Bounded waits"; emulator: unused)
+    int debug_fault; // tests only: 1 = the parts of a cloud take their tickets in REVERSE order (consumers start before their producers),
+                     // 2 = the exporter withholds the joins of its last ring (the next part's wait must run out, not hang)
     GpLayout gl; // where cell (row, col) of the layer lives (gp_layout.h): a wavefront's 64 cells of a step are contiguous
 };
 

@@ -305,6 +305,51 @@ def test_each_launch_geometry_switch_forced_at_small_batch(knob, monkeypatch):
     seg.close()
 
 
+@pytest.mark.parametrize("shape", [1, 2, 3])
+@pytest.mark.parametrize("pw,n_az,geometry", [(8192, 100, (120.0, 0.33)), (2048, 60, (120.0, 0.33)), (2048, 2083, (120.0, 0.33)), (64, 64, (120.0, 0.33)),
+                                               (256, 900, (61.0, 0.25)), (0, 700, (200.0, 0.2)), (1024, 500, (200.0, 0.2))])
+def test_front_end_in_one_two_and_three_launches(shape, pw, n_az, geometry, monkeypatch):
+    """The front end (classify + stable tile sort) as three launches, with the scan inside k_classify (the last work-group of a
+    cloud to finish scans it) and as ONE launch (ticketed work-groups wait for their cloud's scan and scatter their own chunks;
+    k1_classify.hip FRONT_*), forced per context, with chunk sizes that give the largest cloud 1, 2 and ~60 chunks (and 15
+    work-groups of 64-point chunks), on the 16-bit packed tile counters of maps with more than 1024 tiles (200 m / 0.2 m), and
+    with clouds of very different sizes plus an empty one in the same launch (work-groups without chunks, a cloud nobody but
+    its first work-group scans).  Three frames, every cloud's labels / order / counts and all 11 layers against the oracle."""
+    if pw:
+        monkeypatch.setenv("GG_PW", str(pw))
+    length, resolution = geometry
+    k = np.float32(length / 120.0)
+    clouds = []
+    for j, frac in enumerate([1.0, 0.31, 0.07, 0.55]):
+        c = synth.clone_cloud(synth.hdl64_cloud(seed=880 + j, n_az=max(8, int(n_az * frac))))
+        c["x"] *= k
+        c["y"] *= k
+        clouds.append(c)
+    clouds.insert(2, synth.empty_cloud(0))
+    B, stride = len(clouds), (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=B, max_points=stride)
+    if pw:
+        assert seg.debug_set_tuning("pw", 0) == pw
+    seg.debug_set_tuning("front", shape)
+    pts = _batch_inputs(16, clouds, stride)
+    import torch
+
+    refs = [oracle.OracleMap(length, resolution) for _ in clouds]
+    out = None
+    for frame in range(3):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73), out=out)
+        torch.cuda.synchronize()
+        labels, index, counts = out.labels.cpu().numpy(), out.out_index.cpu().numpy(), out.counts.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, ORIGIN0, -1.73)
+            n = len(c)
+            assert np.array_equal(labels[b, :n], r["label"]), (frame, b)
+            assert np.array_equal(index[b, :n], r["index"]), (frame, b)
+            assert counts[b, 0] == len(r["out_points"]) and counts[b, 3] == (r["cls"] == oracle.OUTLIER).sum(), (frame, b)
+            assert_same_state(seg.map(b), refs[b], f"shape {shape} frame {frame} cloud {b}")
+    seg.close()
+
+
 def test_batch_with_a_slot_permutation():
     """gg_batch.slots (ABI v3): cloud b meets map slots[b]; the maps keep their own histories under changing permutations, and
     duplicate / out-of-range entries are rejected."""
@@ -371,6 +416,84 @@ def test_sweep_cut_into_several_work_groups(length, resolution, gpw, batch, spli
             assert np.array_equal(labels[b, : len(c)], r["label"]), (frame, b)
             if b in (0, 1, batch // 2, batch - 1):
                 assert_same_state(seg.map(b), refs[b], f"frame {frame} cloud {b}")
+    seg.close()
+
+
+def _rotated_clouds(count, length, seed=61, n_az=400):
+    base = synth.hdl64_cloud(seed=seed, n_az=n_az)
+    k = np.float32(length / 120.0)
+    clouds = []
+    for b in range(count):
+        c = synth.clone_cloud(base)
+        ang = np.float32(0.31 * b)
+        c["x"] = ((np.cos(ang) * base["x"] - np.sin(ang) * base["y"]) * k).astype(np.float32)
+        c["y"] = ((np.sin(ang) * base["x"] + np.cos(ang) * base["y"]) * k).astype(np.float32)
+        clouds.append(c)
+    return clouds
+
+
+@pytest.mark.parametrize("length,resolution,batch,split", [(120.0, 0.33, 3, 0), (120.0, 0.33, 11, 2), (240.0, 0.33, 5, 0)])
+def test_sweep_parts_started_in_reverse_order_still_match(length, resolution, batch, split):
+    """The work-groups that sweep one cloud take a ticket when they start running, and the ticket names (cloud, part): a part's
+    producer has always started before it, whatever order the dispatcher starts work-groups in (MI355X_MICROARCH.md Contract
+    [G]).  The debug knob hands the tickets out in REVERSE -- every consumer starts before its producer, the worst order an
+    all-resident launch can see -- and the results must not change: labels of every cloud and all layers against the oracle,
+    two frames."""
+    import torch
+
+    clouds = _rotated_clouds(batch, length)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
+    seg.debug_set_tuning("sweep_gpw", 1)
+    if split:
+        seg.debug_set_tuning("sweep_split", split)
+    seg.debug_set_tuning("sweep_fault", 1)
+    refs = [oracle.OracleMap(length, resolution) for _ in clouds]
+    pts = _batch_inputs(16, clouds, stride)
+    out = None
+    for frame in range(2):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((batch, 3), np.float32), np.full(batch, -1.73), out=out)
+        torch.cuda.synchronize()
+        seg.synchronize()
+        labels = out.labels.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, ORIGIN0, -1.73)
+            assert np.array_equal(labels[b, : len(c)], r["label"]), (frame, b)
+            assert_same_state(seg.map(b), refs[b], f"frame {frame} cloud {b}")
+    seg.close()
+
+
+def test_sweep_hand_over_that_never_arrives_is_an_error_not_a_hang():
+    """A part of a multi-work-group sweep whose producer never delivers (here: the exporter withholds the joins of its last
+    ring) must not spin forever: the importer's wait is bounded, the kernel runs to its end, and the next call that
+    synchronises reports GG_ERR_HIP with the reason.  Afterwards the context works again (error cleared, maps reset)."""
+    import torch
+
+    clouds = _rotated_clouds(2, 120.0)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=2, max_points=stride)
+    seg.debug_set_tuning("sweep_gpw", 1)
+    seg.debug_set_tuning("sweep_fault", 2)
+    seg.debug_set_tuning("sweep_poll_cap", 3000)
+    pts = _batch_inputs(16, clouds, stride)
+    n, org, bz = [len(c) for c in clouds], np.zeros((2, 3), np.float32), np.full(2, -1.73)
+    seg.filter_batch(pts, n, org, bz)
+    torch.cuda.synchronize()  # (returns: the kernels ended)
+    with pytest.raises(api.GroundGridError, match="k_sweep: a hand-over"):
+        seg.synchronize()
+    seg.debug_set_tuning("sweep_fault", 0)
+    seg.debug_set_tuning("sweep_poll_cap", 0)
+    seg.debug_set_tuning("clear_device_error", 0)
+    seg.reset_maps(0, 2)
+    refs = [oracle.OracleMap(120.0, 0.33) for _ in clouds]
+    out = seg.filter_batch(pts, n, org, bz)
+    torch.cuda.synchronize()
+    seg.synchronize()
+    labels = out.labels.cpu().numpy()
+    for b, c in enumerate(clouds):
+        r = refs[b].filter_cloud(c, ORIGIN0, -1.73)
+        assert np.array_equal(labels[b, : len(c)], r["label"]), b
+        assert_same_state(seg.map(b), refs[b], f"after the fault, cloud {b}")
     seg.close()
 
 
