@@ -22,6 +22,7 @@ STATUS = {
     -6: "GG_ERR_NO_DEVICE",
 }
 
+GG_ABI_VERSION = 4  # include/groundgrid_hip.h
 GG_POINT32, GG_POINT16 = 0, 1
 GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE = 1, 2
 GG_NUM_KERNELS = 7
@@ -40,7 +41,7 @@ SYMBOLS = [
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
     "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep",
-    "gg_collective_available", "gg_comm_unique_id", "gg_comm_init_rank", "gg_comm_destroy", "gg_allgather_label_masks",
+    "gg_collective_available", "gg_comm_unique_id", "gg_comm_init_rank", "gg_comm_init_rank_for", "gg_comm_destroy", "gg_allgather_label_masks",
 ]
 
 GG_EIGEN_33, GG_EIGEN_34_SSE = 0, 1
@@ -125,6 +126,8 @@ def load():
     P = C.POINTER
     vp = C.c_void_p
     L.gg_abi_version.restype = C.c_int
+    if L.gg_abi_version() != GG_ABI_VERSION:  # (struct layouts below are this version's: a stale .so would read past gg_batch)
+        raise GroundGridError(f"{LIB_PATH} has ABI version {L.gg_abi_version()}, this package expects {GG_ABI_VERSION}: rebuild it")
     L.gg_kernel_name.restype = C.c_char_p
     L.gg_kernel_name.argtypes = [C.c_int]
     L.gg_default_config.argtypes = [P(GGConfig)]
@@ -168,6 +171,7 @@ def load():
     L.gg_collective_available.argtypes = []
     L.gg_comm_unique_id.argtypes = [vp]
     L.gg_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, P(vp)]
+    L.gg_comm_init_rank_for.argtypes = [vp, vp, C.c_int, C.c_int, P(vp)]
     L.gg_comm_destroy.argtypes = [vp]
     L.gg_allgather_label_masks.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     _lib = L

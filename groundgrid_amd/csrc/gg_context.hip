@@ -21,8 +21,11 @@
 #include <chrono>
 
 #include <dlfcn.h>
+#include <sched.h>
+#include <unistd.h>
 
 #include "gg_internal.h"
+#include "host_helper.h"
 #include "sweep_core.h"
 
 using namespace gg;
@@ -37,80 +40,6 @@ struct EventPair {
 };
 
 } // namespace
-
-// Helper threads of a context for the host-buffer entry points: packing the input cloud and assembling the returned cloud are two
-// memory-bound loops of ~0.07 and ~0.12 ms per HDL-64E cloud on one core, a third of what a synchronous gg_filter_cloud costs
-// beyond its kernels.  A range is cut into equal parts, the caller's thread takes the first, the helpers the others.
-// GG_HOST_THREADS = threads per context including the caller's (default 4; 1 = everything on the caller's thread).
-class HostHelper {
-  public:
-    HostHelper() = default;
-    HostHelper(const HostHelper &) = delete;
-    ~HostHelper() { stop(); }
-    void start(int helpers)
-    {
-        if (!threads_.empty() || helpers <= 0) return;
-        quit_ = false;
-        for (int k = 0; k < helpers; ++k) threads_.emplace_back([this, k] { loop(k); });
-    }
-    void stop()
-    {
-        if (threads_.empty()) return;
-        {
-            std::lock_guard<std::mutex> g(m_);
-            quit_ = true;
-            ++epoch_;
-        }
-        cv_.notify_all();
-        for (auto &t : threads_) t.join();
-        threads_.clear();
-    }
-    // fn(lo, hi) over [0, n) in parts() pieces; returns when all of them are done
-    template <class F> void split(size_t n, F fn)
-    {
-        const size_t parts = threads_.size() + 1;
-        if (parts == 1 || n < 4096) {
-            fn((size_t)0, n);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> g(m_);
-            job_ = [&fn, n, parts](int k) { fn(n * (size_t)(k + 1) / parts, n * (size_t)(k + 2) / parts); };
-            pending_.store((int)threads_.size(), std::memory_order_relaxed);
-            ++epoch_;
-        }
-        cv_.notify_all();
-        fn((size_t)0, n / parts);
-        while (pending_.load(std::memory_order_acquire) != 0) { // (the parts are equal: a short spin, not a sleep)
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-    }
-
-  private:
-    void loop(int k)
-    {
-        unsigned long seen = 0;
-        std::unique_lock<std::mutex> lk(m_);
-        for (;;) {
-            cv_.wait(lk, [&] { return epoch_ != seen; });
-            seen = epoch_;
-            if (quit_) return;
-            lk.unlock();
-            job_(k); // (job_ stays valid until pending_ reaches 0: split() does not return before)
-            pending_.fetch_sub(1, std::memory_order_release);
-            lk.lock();
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::function<void(int)> job_;
-    std::atomic<int> pending_{0};
-    unsigned long epoch_ = 0;
-    bool quit_ = false;
-};
 
 struct gg_context {
     int device = 0;
@@ -137,6 +66,9 @@ struct gg_context {
     // cross-stream ordering (include/groundgrid_hip.h, gg_filter_batch): `map_event` is recorded on ctx->stream after every
     // map mutation enqueued there, `batch_event` on the launch stream after every batch
     hipEvent_t map_event = nullptr, batch_event = nullptr;
+    hipEvent_t gather_event = nullptr;       // recorded behind the last gg_allgather_label_masks
+    hipStream_t gather_stream = nullptr;
+    const uint8_t *gather_lo = nullptr, *gather_hi = nullptr; // ... and the send buffer it reads (null: none pending)
     bool map_event_pending = false;          // a mutation was enqueued on ctx->stream since the last batch waited for it
     hipStream_t last_batch_stream = nullptr; // stream batch_event was last recorded on
     bool have_batch_event = false;
@@ -401,6 +333,14 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     // on another stream
     if (s != ctx->stream && ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->map_event, 0));
     if (ctx->have_batch_event && ctx->last_batch_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->batch_event, 0));
+    if (ctx->gather_lo) { // an all-gather still reads label masks: a batch on another stream that rewrites them waits for it
+        auto overlaps = [&](const uint8_t *p, size_t bytes) { return p && p < ctx->gather_hi && p + bytes > ctx->gather_lo; };
+        const size_t per_cloud = b->cloud_stride;
+        if (ctx->gather_stream != s && (overlaps(b->d_label_masks, (size_t)nb * ((per_cloud + 3) / 4)) || overlaps(b->d_labels, (size_t)nb * per_cloud)))
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->gather_event, 0));
+        if (ctx->gather_stream == s || overlaps(b->d_label_masks, (size_t)nb * ((per_cloud + 3) / 4)) || overlaps(b->d_labels, (size_t)nb * per_cloud))
+            ctx->gather_lo = ctx->gather_hi = nullptr; // (ordered now, by the stream or by the event)
+    }
     HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * nb, hipMemcpyHostToDevice, s));
 
     BatchIO io;
@@ -568,6 +508,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->map_event, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->batch_event, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->gather_event, hipEventDisableTiming));
 
     Arena &a = ctx->arena;
     Geometry &g = a.g;
@@ -816,7 +757,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         CREATE_CHK(hipEventCreateWithFlags(&as.downloaded, hipEventDisableTiming));
     }
 
-    ctx->helper.start((getenv("GG_HOST_THREADS") ? std::max(1, std::min(atoi(getenv("GG_HOST_THREADS")), 16)) : 4) - 1);
+    ctx->helper.configure((getenv("GG_HOST_THREADS") ? std::max(1, std::min(atoi(getenv("GG_HOST_THREADS")), 16)) : 4) - 1);
     {
         const int rc = gg_reset_maps(ctx, 0, n_slots, 0.0, 0.0, 0.0f, 0, nullptr); // (one strided fill per layer for all slots)
         if (rc != GG_OK) {
@@ -859,6 +800,7 @@ void gg_destroy(gg_context *ctx)
     }
     if (ctx->map_event) hipEventDestroy(ctx->map_event);
     if (ctx->batch_event) hipEventDestroy(ctx->batch_event);
+    if (ctx->gather_event) hipEventDestroy(ctx->gather_event);
     if (ctx->h2d_stream) hipStreamDestroy(ctx->h2d_stream);
     if (ctx->d2h_stream) hipStreamDestroy(ctx->d2h_stream);
     if (ctx->h_dev_error) hipHostFree((void *)ctx->h_dev_error);
@@ -1266,21 +1208,6 @@ int gg_synchronize(gg_context *ctx)
     return GG_OK;
 }
 
-// pack PointXYZIR -> 16-B records while copying into pinned staging (halves PCIe and HBM traffic; only x, y, z, ring are
-// ever read, :222-250).  One 16-byte load + the ring per point, one 16-byte store: the loop vectorises to SSE moves.
-static void pack_points(const gg_point32 *__restrict__ cloud, gg_point16 *__restrict__ dst, size_t n)
-{
-    for (size_t i = 0; i < n; ++i) {
-        gg_point16 d;
-        d.x = cloud[i].x;
-        d.y = cloud[i].y;
-        d.z = cloud[i].z;
-        d.ring = cloud[i].ring;
-        d.pad = 0;
-        dst[i] = d;
-    }
-}
-
 // one ticket: pack + upload, the seven kernels, the download.  `pipelined`: uploads and downloads on their own streams so that
 // they overlap the neighbouring tickets' kernels (gg_filter_cloud_async); a synchronous call has nothing to overlap with and puts
 // everything on the context's stream instead -- no cross-stream events (four API calls, ~15 us per cloud)
@@ -1376,20 +1303,7 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
         const int32_t *h_index = as.h_index;
         const uint8_t *h_labels = as.h_labels;
         // (every input point has its own position in the returned cloud: the two halves of the input write disjoint records)
-        ctx->helper.split(n, [&](size_t i0, size_t i1) {
-            for (size_t i = i0; i < i1; ++i) {
-                const int32_t k = h_index[i];
-                if (k < 0) continue;
-                out_cloud[k] = cloud[i];
-                if (tf) { // map-frame coordinates, same arithmetic as the device (this file is built with -ffp-contract=off)
-                    const double dx = (double)cloud[i].x, dy = (double)cloud[i].y, dz = (double)cloud[i].z;
-                    out_cloud[k].x = (float)(((tf[0] * dx + tf[1] * dy) + tf[2] * dz) + tf[3]);
-                    out_cloud[k].y = (float)(((tf[4] * dx + tf[5] * dy) + tf[6] * dz) + tf[7]);
-                    out_cloud[k].z = (float)(((tf[8] * dx + tf[9] * dy) + tf[10] * dz) + tf[11]);
-                }
-                out_cloud[k].intensity = (float)h_labels[i];
-            }
-        });
+        ctx->helper.split(n, [&](size_t i0, size_t i1) { assemble_returned_cloud(cloud, h_index, h_labels, tf, out_cloud, i0, i1); });
     }
     if (host_timing) {
         ctx->host_t[2] += std::chrono::duration<double>(t_w1 - t_w0).count();
@@ -1488,6 +1402,15 @@ int gg_comm_init_rank(const uint8_t id_in[128], int n_ranks, int rank, void **co
     return GG_OK;
 }
 
+int gg_comm_init_rank_for(gg_context *ctx, const uint8_t id_in[128], int n_ranks, int rank, void **comm_out)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = gg_comm_init_rank(id_in, n_ranks, rank, comm_out);
+    if (rc != GG_OK) fail(ctx, rc, rc == GG_ERR_NO_DEVICE ? "librccl.so could not be loaded" : "ncclCommInitRank failed");
+    return rc;
+}
+
 int gg_comm_destroy(void *comm)
 {
     if (!comm) return GG_ERR_INVALID;
@@ -1512,6 +1435,11 @@ int gg_allgather_label_masks(gg_context *ctx, void *comm, const uint8_t *d_send,
         ctx->last_error = buf;
         return GG_ERR_HIP;
     }
+    // a later batch on another stream that writes into the buffer this gather still reads must wait for it (enqueue_batch)
+    HIPCHK(ctx, hipEventRecord(ctx->gather_event, s));
+    ctx->gather_stream = s;
+    ctx->gather_lo = d_send;
+    ctx->gather_hi = d_send + bytes_per_rank;
     return GG_OK;
 }
 

@@ -310,11 +310,11 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
                 const int t = 4 * g + k;
                 v[k] = packed ? (hist[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu : hist[t];
             }
-            store16_agent(ghist, row + 4u * (uint32_t)g, v);
+            store16_row<SHAPE != FRONT_THREE_LAUNCHES>(ghist, row + 4u * (uint32_t)g, v); // (agent scope when the scan runs in this launch)
         }
         if (lane == 0) {
             const u32x4 v = {n_kept, n_ign, n_outl, n_inmap};
-            store16_agent(words_rsrc(a.chunk_emit + (size_t)cp.slot * a.emit_stride, a.emit_stride), 4u * (uint32_t)chunk, v);
+            store16_row<SHAPE != FRONT_THREE_LAUNCHES>(words_rsrc(a.chunk_emit + (size_t)cp.slot * a.emit_stride, a.emit_stride), 4u * (uint32_t)chunk, v);
         }
     }
     if (SHAPE == FRONT_THREE_LAUNCHES) return;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
     __syncthreads();
     const bool last = s_word == (uint32_t)groups_of_cloud - 1u;
     if (last) {
-        scan_cloud<4>(a, cp, nch, s_scan);
+        scan_cloud<4, true>(a, cp, nch, s_scan);
         if (SHAPE == FRONT_ONE_LAUNCH) {
             drain_vector_memory();
             __syncthreads();
@@ -355,10 +355,10 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
     uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
     if (packed) {
         for (int t = lane; t < words; t += 64) hist[t] = 0u;
-        scatter_chunk<true>(hist, ghist, row, rec, sorted, base, end, lane);
+        scatter_chunk<true, true>(hist, ghist, row, rec, sorted, base, end, lane);
     } else {
         for (int g = lane; g < TP / 4; g += 64) *reinterpret_cast<u32x4 *>(hist + 4 * g) = load16_agent(ghist, row + 4u * (uint32_t)g);
-        scatter_chunk<false>(hist, ghist, row, rec, sorted, base, end, lane);
+        scatter_chunk<false, true>(hist, ghist, row, rec, sorted, base, end, lane);
     }
 }
 

@@ -220,8 +220,11 @@ GG_DEV void four_points(const float (&z)[4], uint32_t i, uint32_t np, const doub
             if (i + (uint32_t)k < np) one_point_fast<R, false>(z[k], c0 + (float)k, rr[k], oz, s, smallest);
     }
     // a NaN among the heights (:300 skips the mean and planeDist updates): the sum of the four is NaN then (and for inf - inf,
-    // which only costs the detour); heights beyond np are other cells' or padding
-    if (R & (R_MEAN | R_PDM)) {
+    // which only costs the detour); heights beyond np are other cells' or padding.  The maximum's chain takes the detour as well:
+    // std::max(mx, z) of :307 leaves mx alone for ANY NaN, the single-instruction v_max_f32 only for a quiet one -- for a
+    // SIGNALLING NaN (K1 stores the sensor's bits as they come) it returns a quieted NaN (IEEE mode); one_point_exact compares
+    // and selects like the reference (test_edge_cases feeds both kinds).
+    if (R & (R_GC | R_MEAN | R_PDM)) {
         const float chk = ((z[0] + z[1]) + (z[2] + z[3])) - oz;
         smallest = (chk != chk) ? 0.0f : smallest;
     }

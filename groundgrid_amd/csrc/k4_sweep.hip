@@ -35,8 +35,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
 
-__shared__ uint32_t sweep_wait_failed; // (work-group: a wavefront gave up a bounded wait, DevMemT::give_up)
-__shared__ uint32_t sweep_pad_;        // (keeps the static LDS -- these two words and k_sweep's s_sync[2] -- a multiple of 16 bytes)
+// The kernel's only static LDS, 16 bytes and 16-byte aligned, so that the dynamic region behind it (64-bit accesses all over) keeps
+// its alignment: [0] ticket, [1] epoch (k_sweep), [2] a wavefront gave up a bounded wait (DevMemT::give_up).
+__shared__ __attribute__((aligned(16))) uint32_t sweep_static[4];
+#define sweep_wait_failed sweep_static[2]
 
 template <bool DBG> struct DevMemT {
     __amdgpu_buffer_rsrc_t rsrc; // the interleaved (ground, confidence) layer of this cloud
@@ -470,13 +472,15 @@ template <bool DBG> GG_DEV void run_export(const Params &P, const LdsMap &L, Dev
 
 // 5 waves per SIMD (<= 96 registers, nothing spilled): two clouds share a CU.  (Measured: forcing 64 registers for three clouds
 // per CU spills and is 1.6x slower at 1024 clouds per launch.)
-template <bool DBG>
-__global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const CloudParams *__restrict__ params, int n_clouds, int n_parts,
+// PARTS: the launch cuts every cloud into several work-groups (tickets, importer / exporter wavefronts, the exchange region); the
+// throughput launches -- one work-group per cloud -- are compiled without any of that.
+template <bool DBG, bool PARTS>
+__global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const CloudParams *__restrict__ params, int n_clouds, int n_parts_rt,
                                                    unsigned long long *dbg)
 {
-    extern __shared__ int lds[];
-    __shared__ __attribute__((aligned(16))) uint32_t s_sync[2]; // (with sweep_wait_failed: static LDS stays a multiple of 8 bytes, the 64-bit
-                                                                // accesses to the dynamic region behind it keep their alignment)
+    const int n_parts = PARTS ? n_parts_rt : 1;
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    uint32_t *s_sync = sweep_static;
     // work-group -> (cloud, part).  A part waits for values of the part inside it (feed-forward only), so a consumer must never
     // hold a place its producer needs: the work-groups of a launch with several parts per cloud take a TICKET when they start
     // running (one atomic counter) and the ticket, not blockIdx, names (cloud, part) -- the parts of a cloud follow each other in
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     // so nothing depends on a per-launch kernel argument (a replayed graph would freeze one).
     uint32_t *sync_words = a.sweep_sync;
     uint32_t id = blockIdx.x, epoch = 0u;
-    if (n_parts > 1) {
+    if (PARTS) {
         if (threadIdx.x == 0) {
             s_sync[0] = __hip_atomic_fetch_add(sync_words + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_sync[1] = __hip_atomic_load(sync_words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
 
     // hand-over tables start empty: counters 0 = "ring 0 done", and ring 0 of every table is the centre cell
     for (int k = threadIdx.x; k < L.corner; k += nthreads) lds[k] = 0;
-    if (threadIdx.x == 0) sweep_wait_failed = 0u;
+    if (PARTS && threadIdx.x == 0) sweep_wait_failed = 0u;
     const WP centre{1.0f, 1.0f * cp.base_z}; // :405 groundpatch(centre) = 1, :406-411 ground(centre) = translation.z
     if (threadIdx.x == 0) {
         if (part == 0) gp2[gp_index(P.gl, P.c, P.c)] = make_float2(cp.base_z, 1.0f);
@@ -584,9 +588,9 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
             run_corner<0, DBG>(P, L, mem, lane, clk, g0, g1);
         else if (wave == 9)
             run_corner<1, DBG>(P, L, mem, lane, clk, g0, g1);
-        else if (wave == 10) {
+        else if (PARTS && wave == 10) {
             if (part > 0) run_import<DBG>(P, L, mem, lane, g0);
-        } else if (g1 < P.groups)
+        } else if (PARTS && g1 < P.groups)
             run_export<DBG>(P, L, mem, lane, g1);
     } else if (wave < 4 * W && side == SIDE_A)
         run_chain<SIDE_A, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
@@ -600,14 +604,14 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
         run_corner<0, DBG>(P, L, mem, lane, clk, g0, g1);
     else if (wave == 4 * W + 1)
         run_corner<1, DBG>(P, L, mem, lane, clk, g0, g1);
-    else if (wave == 4 * W + 2) {
+    else if (PARTS && wave == 4 * W + 2) {
         if (part > 0) run_import<DBG>(P, L, mem, lane, g0);
-    } else if (g1 < P.groups)
+    } else if (PARTS && g1 < P.groups)
         run_export<DBG>(P, L, mem, lane, g1);
     clk.end(wave, lane);
-    __syncthreads();
-    if (threadIdx.x == 0 && sweep_wait_failed) __hip_atomic_store(a.dev_error, (uint32_t)GG_DEVERR_SWEEP_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (n_parts > 1) { // the last work-group of the launch re-arms the tickets and advances the epoch (never 0: the arena starts zeroed)
+    if (PARTS) { // the last work-group of the launch re-arms the tickets and advances the epoch (never 0: the arena starts zeroed)
+        __syncthreads();
+        if (threadIdx.x == 0 && sweep_wait_failed) __hip_atomic_store(a.dev_error, (uint32_t)GG_DEVERR_SWEEP_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (threadIdx.x == 0 && __hip_atomic_fetch_add(sync_words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
             __hip_atomic_store(sync_words + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sync_words + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -663,16 +667,20 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
     static PerDeviceOnce big_lds;
     if (lds > 64 * 1024)
         big_lds.run([] {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            // (dynamic + the kernel's 16 static bytes must stay within the CU's 160 KiB, or the attribute is refused)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         });
     P.poll_cap = a.tune_sweep_poll_cap > 0 ? a.tune_sweep_poll_cap : 1 << 22; // (x ~0.2 us: about a second)
     P.debug_fault = a.tune_sweep_fault;
     const int threads = P.split_steps ? 12 * 64 : (4 * P.waves_per_side + 2 + (n_parts > 1 ? 2 : 0)) * 64; // (+ importer and exporter)
     if (dbg) // (GG_SWEEP_TIMING: the instrumented twin)
-        hipLaunchKernelGGL(k_sweep<true>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
+        hipLaunchKernelGGL((k_sweep<true, true>), dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
+    else if (n_parts > 1)
+        hipLaunchKernelGGL((k_sweep<false, true>), dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
     else
-        hipLaunchKernelGGL(k_sweep<false>, dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
+        hipLaunchKernelGGL((k_sweep<false, false>), dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
 }
 
 } // namespace gg

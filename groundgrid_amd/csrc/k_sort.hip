@@ -15,17 +15,18 @@
 
 namespace gg {
 
-__global__ __launch_bounds__(256) void k_scan(const Arena a, const CloudParams *__restrict__ params)
+__global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams *__restrict__ params)
 {
-    __shared__ uint32_t lds[8];
+    __shared__ uint32_t lds[32];
+    __shared__ u32x4 part[1024];
     const CloudParams cp = params[blockIdx.x];
-    scan_cloud<4>(a, cp, (cp.n_points + a.PW - 1) / a.PW, lds);
+    scan_cloud<16, false>(a, cp, (cp.n_points + a.PW - 1) / a.PW, lds, part);
 }
 
 void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)
 {
     if (n_clouds == 0) return;
-    hipLaunchKernelGGL(k_scan, dim3(n_clouds), dim3(256), 0, s, a, d_params);
+    hipLaunchKernelGGL(k_scan, dim3(n_clouds), dim3(1024), 0, s, a, d_params);
 }
 
 __global__ __launch_bounds__(256) void k_scatter(const Arena a, const CloudParams *__restrict__ params)
@@ -56,10 +57,10 @@ __global__ __launch_bounds__(256) void k_scatter(const Arena a, const CloudParam
     const int end = min(base + a.PW, n);
     if (packed) {
         for (int t = lane; t < words; t += 64) offs[t] = 0u;
-        scatter_chunk<true>(offs, ghist, row, rec, sorted, base, end, lane);
+        scatter_chunk<true, false>(offs, ghist, row, rec, sorted, base, end, lane);
     } else {
-        for (int g = lane; g < TP / 4; g += 64) *reinterpret_cast<u32x4 *>(offs + 4 * g) = load16_agent(ghist, row + 4u * (uint32_t)g);
-        scatter_chunk<false>(offs, ghist, row, rec, sorted, base, end, lane);
+        for (int g = lane; g < TP / 4; g += 64) *reinterpret_cast<u32x4 *>(offs + 4 * g) = load16_row<false>(ghist, row + 4u * (uint32_t)g);
+        scatter_chunk<false, false>(offs, ghist, row, rec, sorted, base, end, lane);
     }
 }
 

@@ -67,9 +67,23 @@ GG_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds /*[NW + 1]*/, uin
 }
 
 // The scan of one cloud by one work-group of 64 NW threads.  A thread owns FOUR consecutive tiles (one 16-byte column segment
-// of every chunk's row); `nch` = the cloud's chunks.
-template <int NW>
-GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t *lds /*[NW + 1]*/)
+// of every chunk's row); `nch` = the cloud's chunks.  AGENT: the rows were written by other work-groups of THIS launch (fused
+// front end): agent-scope accesses; as a launch of its own the scan uses plain ones (the rows are still in the L2).
+// `part` != nullptr (64 NW entries): when there are fewer tile groups than threads, the threads of a tile group share the cloud's
+// chunks among them -- a thread's loads are one dependent memory round trip per unrolled batch, and the scan of ONE cloud
+// (latency launches) is as long as that chain.
+template <bool AGENT> GG_DEV u32x4 load16_row(__amdgpu_buffer_rsrc_t r, uint32_t word)
+{
+    return AGENT ? load16_agent(r, word) : __builtin_amdgcn_raw_buffer_load_b128(r, word * 4u, 0, 0);
+}
+template <bool AGENT> GG_DEV void store16_row(__amdgpu_buffer_rsrc_t r, uint32_t word, u32x4 v)
+{
+    if (AGENT) store16_agent(r, word, v);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, r, word * 4u, 0, 0);
+}
+
+template <int NW, bool AGENT>
+GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t *lds /*[NW + 1]*/, u32x4 *part = nullptr /*[64 NW]*/)
 {
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x;
@@ -78,18 +92,43 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
     uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
     uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
+    // GS tile groups per round, each shared by Q threads (chunk ranges); thread -> (share q, group gi)
+    const int GS = part ? min(NT, (G + 63) & ~63) : NT, Q = part ? NT / GS : 1;
+    const int gi = tid % GS, q = tid / GS;
+    const int c_lo = q < Q ? (int)((long long)nch * q / Q) : 0, c_hi = q < Q ? (int)((long long)nch * (q + 1) / Q) : 0;
 
     uint32_t carry = 0, lcarry = 0, dcarry = 0;
-    for (int g0 = 0; g0 < G; g0 += NT) {
-        const int g = g0 + tid;
-        const bool have = g < G;
+    for (int g0 = 0; g0 < G; g0 += GS) {
+        const int g = g0 + gi;
+        const bool have = g < G && q < Q;
         u32x4 s = {0u, 0u, 0u, 0u};
         if (have) {
-#pragma unroll 8
-            for (int c = 0; c < nch; ++c) s += load16_agent(hist, (uint32_t)c * (uint32_t)TP + 4u * (uint32_t)g);
+#pragma unroll 16
+            for (int c = c_lo; c < c_hi; ++c) s += load16_row<AGENT>(hist, (uint32_t)c * (uint32_t)TP + 4u * (uint32_t)g);
         }
+        u32x4 before = {0u, 0u, 0u, 0u}; // the records of this group in the chunks before this thread's share
+        if (part && Q > 1) {
+            __syncthreads();
+            part[tid] = s;
+            __syncthreads();
+            u32x4 all = {0u, 0u, 0u, 0u};
+            for (int k = 0; k < Q; ++k) {
+                const u32x4 v = part[k * GS + gi];
+                if (k < q) before += v;
+                all += v;
+            }
+            s = all; // (every thread of the group now holds the group's totals)
+        }
+        const bool lead = have && q == 0; // one thread per group speaks for it in the scans and writes the lists
         uint32_t total;
-        const uint32_t excl = block_exclusive_scan<NW>(s.x + s.y + s.z + s.w, lds, total);
+        const uint32_t excl_lead = block_exclusive_scan<NW>(lead ? s.x + s.y + s.z + s.w : 0u, lds, total);
+        uint32_t excl = excl_lead;
+        if (part && Q > 1) { // the group's prefix reaches its other threads through the same scratch
+            __syncthreads();
+            if (lead) part[gi].x = excl_lead;
+            __syncthreads();
+            excl = part[gi].x;
+        }
         {
             // K2's work lists (k2_reduce.hip): tiles with more than K2_LIGHT_MAX records from the back of tile_list, the
             // other tiles with records from the front, both in rank order.  A tile without records is on neither list: its half
@@ -97,7 +136,7 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
             uint32_t nl = 0, nd = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const bool in = have && 4 * g + k < T;
+                const bool in = lead && 4 * g + k < T;
                 nd += (in && s[k] > (uint32_t)K2_LIGHT_MAX) ? 1u : 0u;
                 nl += (in && s[k] > 0u && s[k] <= (uint32_t)K2_LIGHT_MAX) ? 1u : 0u;
             }
@@ -107,7 +146,7 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int t = 4 * g + k;
-                if (have && t < T) {
+                if (lead && t < T) {
                     // (rank, the tile's records, its first cell: K2 starts on a tile after ONE lookup)
                     const uint4 entry = make_uint4((uint32_t)t, start, start + s[k], a.rank_cell0[t]);
                     if (s[k] == 0u) tile_live[t] = 0u;
@@ -126,11 +165,12 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
             run.y = run.x + s.x;
             run.z = run.y + s.y;
             run.w = run.z + s.z;
-#pragma unroll 8
-            for (int c = 0; c < nch; ++c) {
+            run += before;
+#pragma unroll 16
+            for (int c = c_lo; c < c_hi; ++c) {
                 const uint32_t w = (uint32_t)c * (uint32_t)TP + 4u * (uint32_t)g;
-                const u32x4 h = load16_agent(hist, w);
-                store16_agent(hist, w, run);
+                const u32x4 h = load16_row<AGENT>(hist, w);
+                store16_row<AGENT>(hist, w, run);
                 run += h;
             }
         }
@@ -150,7 +190,7 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
     for (int c0 = 0; c0 < nch; c0 += NT) {
         const int c = c0 + tid;
         u32x4 v = {0u, 0u, 0u, 0u}, e;
-        if (c < nch) v = load16_agent(ce, 4u * (uint32_t)c);
+        if (c < nch) v = load16_row<AGENT>(ce, 4u * (uint32_t)c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t total;
@@ -166,8 +206,8 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
 // half as many when PACKED): unpacked it holds the next free position of every tile (the caller loaded the chunk's row of
 // `hist`), packed (maps of more than PACKED_TILE_COUNTERS_MIN_T tiles) only the number of records already placed per tile, two
 // 16-bit counters per word, zeroed by the caller -- the chunk's first position per tile then stays in its row of `hist` and every
-// lane fetches its own record's.
-template <bool PACKED>
+// lane fetches its own record's.  AGENT: the offsets were written by another work-group of this launch (fused front end).
+template <bool PACKED, bool AGENT>
 GG_DEV void scatter_chunk(uint32_t *offs, __amdgpu_buffer_rsrc_t hist, uint32_t row_word, const uint2 *__restrict__ rec, uint2 *__restrict__ sorted,
                           int base, int end, int lane)
 {
@@ -186,7 +226,7 @@ GG_DEV void scatter_chunk(uint32_t *offs, __amdgpu_buffer_rsrc_t hist, uint32_t 
             const bool inmap = r[j].y != KEY_OUTSIDE;
             const uint32_t t = r[j].y >> KEY_TILE_SHIFT;
             uint32_t first_pos = 0u;
-            if (PACKED) first_pos = __builtin_amdgcn_raw_buffer_load_b32(hist, inmap ? (row_word + t) * 4u : 0xFFFFFFFFu, 0, AUX_SC1); // (out of range: 0)
+            if (PACKED) first_pos = __builtin_amdgcn_raw_buffer_load_b32(hist, inmap ? (row_word + t) * 4u : 0xFFFFFFFFu, 0, AGENT ? AUX_SC1 : 0); // (out of range: 0)
             // rank among the window's records of the same tile, their number, and the tile's first lane: ballots only
             uint32_t rank = 0u, cnt = 0u;
             int first = lane;

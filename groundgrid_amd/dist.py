@@ -109,9 +109,10 @@ class AbiLabelGather:
             dist.broadcast(t, src=0, group=group)
             ident = (C.c_uint8 * 128)(*t.cpu().tolist())
         comm = C.c_void_p()
-        rc = self._L.gg_comm_init_rank(ident, world, rank, C.byref(comm))
+        # (on the CONTEXT's device: with one rank or a gloo group nothing else has selected a HIP device in this process)
+        rc = self._L.gg_comm_init_rank_for(seg._ctx, ident, world, rank, C.byref(comm))
         if rc != _lib.GG_OK:
-            raise _lib.GroundGridError(f"gg_comm_init_rank: {_lib.STATUS.get(rc, rc)}")
+            raise _lib.GroundGridError(f"gg_comm_init_rank_for: {_lib.STATUS.get(rc, rc)}")
         self._comm = comm
 
     def gather(self, masks, out=None, stream=None):

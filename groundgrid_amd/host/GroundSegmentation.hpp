@@ -86,6 +86,11 @@ class GroundSegmentation {
     {
         gg_destroy(ctx_);
         ctx_ = nullptr;
+        // (the structs this header passes by pointer -- gg_batch, gg_config -- are this version's: a library of another version
+        // would read past them)
+        if (gg_abi_version() != GG_ABI_VERSION)
+            throw std::runtime_error("libgroundgrid_hip.so has ABI version " + std::to_string(gg_abi_version()) + ", this header is version " +
+                                     std::to_string(GG_ABI_VERSION));
         gg_geometry g;
         gg_default_geometry(&g);
         g.length = (float)dimension; // the nodelet passes 120.0f (Nodelet.cpp:95)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 3
+#define GG_ABI_VERSION 4
 
 typedef enum gg_status {
     GG_OK = 0,
@@ -286,16 +286,21 @@ int gg_synchronize(gg_context *ctx);
  *   gg_comm_unique_id       rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by whatever means
  *                           the host has (MPI, a socket, torch.distributed ...)
  *   gg_comm_init_rank       every rank: ncclCommInitRank on the CURRENT HIP device -> an opaque communicator (ncclComm_t)
+ *   gg_comm_init_rank_for   the same on the device of `ctx` (selected first): what a caller that holds a context wants -- with one
+ *                           rank, or a transport that never touched HIP, nothing else has selected a device yet (ABI v4)
  *   gg_allgather_label_masks  ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8) on `stream` (same convention as
  *                           gg_filter_batch: NULL = the context's stream, GG_STREAM_DEFAULT = the legacy default stream); d_send =
  *                           this rank's gg_batch.d_label_masks (or d_labels), d_recv = [world][bytes_per_rank].  The call is
  *                           ordered after the context's last batch (event wait when the streams differ) and returns without
- *                           waiting; `comm` may be any ncclComm_t, also one the host created itself
+ *                           waiting; `comm` may be any ncclComm_t, also one the host created itself.  The library remembers the
+ *                           send buffer: a later gg_filter_batch on ANOTHER stream whose d_label_masks / d_labels overlap it is
+ *                           ordered after the gather (event wait) -- batches that write other buffers (double buffering) are not
  *   gg_comm_destroy
  * GG_ERR_NO_DEVICE when librccl.so cannot be loaded, GG_ERR_HIP for RCCL errors (text in gg_last_error). */
 int gg_collective_available(void);
 int gg_comm_unique_id(uint8_t id_out[128]);
 int gg_comm_init_rank(const uint8_t id[128], int n_ranks, int rank, void **comm_out);
+int gg_comm_init_rank_for(gg_context *ctx, const uint8_t id[128], int n_ranks, int rank, void **comm_out);
 int gg_comm_destroy(void *comm);
 int gg_allgather_label_masks(gg_context *ctx, void *comm, const uint8_t *d_send, uint8_t *d_recv, size_t bytes_per_rank, void *stream);
 

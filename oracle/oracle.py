@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgg_oracle.so")
+_LIB_PATH = os.environ.get("GG_ORACLE_LIB") or os.path.join(_HERE, "libgg_oracle.so")  # (override: the sanitizer build of tests/test_sanitizers_cpu.py)
 
 # include/velodyne_pointcloud/point_types.h:27-33 -> 32-byte record
 POINT_DTYPE = np.dtype(

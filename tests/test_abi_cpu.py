@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_kernel_names(lib):
-    assert lib.gg_abi_version() == 3  # v2: gg_move_map takes matrix entries, conventions, async host call; v3: gg_batch.slots
+    assert lib.gg_abi_version() == 4  # v2: gg_move_map takes matrix entries, conventions, async host call; v3: gg_batch.slots; v4: gg_comm_init_rank_for
     names = [lib.gg_kernel_name(k).decode() for k in range(_lib.GG_NUM_KERNELS)]
     assert names == ["k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_sweep", "k_label"]
 

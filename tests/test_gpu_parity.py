@@ -165,6 +165,14 @@ def test_edge_cases():
                    dtype=np.float32)
     cloud = synth.make_cloud(pts, ring=[0, 0, 2000, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5])
     run_pair(cloud, frames=2)
+    # a SIGNALLING NaN height between two ordinary returns of one cell (np.nan is a quiet one): std::max(mx, z) of :307 must leave the
+    # cell's maximum alone (k2_reduce.hip quiet)
+    snan = synth.make_cloud(np.array([[5, 5, -1.2], [5.01, 5.01, 0.0], [5.02, 5.0, -1.1], [7, 7, 0.0], [7.01, 7.0, -1.0]], dtype=np.float32))
+    z = snan["z"].view(np.uint32)
+    z[1] = 0x7FA00000
+    z[3] = 0xFF800001
+    assert np.isnan(snan["z"][1]) and np.isnan(snan["z"][3])
+    run_pair(snan, frames=2)
     run_pair(synth.empty_cloud(0), frames=2)
     run_pair(synth.make_cloud(np.array([[900.0, 900.0, 0.0]], dtype=np.float32)), frames=1)  # everything outside
 
