@@ -4,7 +4,9 @@
 #include <utility>
 #include <vector>
 namespace grid_map {
-struct Position { double x() const; double y() const; };
+struct Position { Position(); Position(double x, double y); double x() const; double y() const; };
+struct Length { Length(double x, double y); double x() const; double y() const; };
+struct Size { int operator()(int k) const; };
 struct Index { Index(int row, int col); int operator()(int k) const; };
 class Matrix { // Eigen::MatrixXf
   public:
@@ -16,6 +18,12 @@ class Matrix { // Eigen::MatrixXf
 };
 class GridMap {
   public:
+    explicit GridMap(const std::vector<std::string> &layers);
+    void setFrameId(const std::string &frameId);
+    void setGeometry(const Length &length, const double resolution, const Position &position);
+    void setPosition(const Position &position);
+    const Length &getLength() const;
+    const Size &getSize() const;
     const Position &getPosition() const;
     bool exists(const std::string &layer) const;
     void add(const std::string &layer, const double value);

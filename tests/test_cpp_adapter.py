@@ -27,6 +27,42 @@ def compile_adapter():
     return EXE
 
 
+BINDING_EXE = os.path.join(ROOT, "tests", "cpp", "test_binding_core")
+
+
+def compile_binding_core():
+    build.build()
+    oracle.build()
+    src = os.path.join(ROOT, "tests", "cpp", "test_binding_core.cpp")
+    hdr = os.path.join(ROOT, "groundgrid_amd", "host", "binding_core.hpp")
+    if not os.path.exists(BINDING_EXE) or os.path.getmtime(BINDING_EXE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call([
+            "g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", src, "-o", BINDING_EXE,
+            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "groundgrid_amd", "host"), "-I", os.path.join(ROOT, "oracle"),
+            "-L", os.path.join(ROOT, "groundgrid_amd"), "-lgroundgrid_hip", "-L", os.path.join(ROOT, "oracle"), "-lgg_oracle",
+            "-Wl,-rpath," + os.path.join(ROOT, "groundgrid_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+            "-Wl,-rpath,/opt/rocm/lib",
+        ])
+    return BINDING_EXE
+
+
+def test_binding_core_compiles_and_links_against_the_c_abi():
+    assert os.path.exists(compile_binding_core())
+
+
+@pytest.mark.gpu
+def test_two_objects_keep_separate_maps_host_managed_and_device_resident():
+    """groundgrid_amd/host/binding_core.hpp -- the logic of both reference-typed bindings below the ROS types: one context per
+    GroundSegmentation object, a host-managed map (uploads on moves, all layers down per cloud) next to a device-resident one
+    (gg_reset_map / gg_move_map, nothing down during the drive, the context re-created for a larger cloud in mid-drive),
+    interleaved, every returned cloud and every layer against the C oracle."""
+    exe = compile_binding_core()
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "binding core OK" in p.stdout
+
+
 STREAMS_EXE = os.path.join(ROOT, "tests", "cpp", "test_streams")
 
 

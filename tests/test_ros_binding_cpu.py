@@ -26,8 +26,24 @@ def test_binding_compiles_against_the_reference_class_declaration(tmp_path):
                  "spiral_ground_interpolation(", "interpolate_cell("):
         assert re.search(r"groundgrid::GroundSegmentation::" + re.escape(name.split("groundgrid::GroundSegmentation::")[-1]), syms), name
     undefined = subprocess.check_output(["nm", "-C", "--undefined-only", obj], text=True)
-    for entry in ("gg_create", "gg_set_config", "gg_filter_cloud", "gg_get_layers", "gg_set_layer", "gg_set_map_position", "gg_get_point_classes"):
+    for entry in ("gg_create", "gg_set_config", "gg_filter_cloud", "gg_get_layers", "gg_set_layer", "gg_set_map_position", "gg_get_point_classes", "gg_abi_version"):
         assert re.search(r"\bU " + entry + r"\b", undefined), entry  # ... and forwards to the C ABI
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INCLUDE), reason="the reference checkout only exists in the build container")
+def test_map_manager_binding_compiles_against_the_reference_class_declaration(tmp_path):
+    """groundgrid_amd/host/ros/GroundGridHip.cpp -- GroundGrid::initGroundGrid / update on the device (gg_reset_map / gg_move_map)
+    -- against the reference's own include/groundgrid/GroundGrid.h:50-85."""
+    obj = str(tmp_path / "groundgrid_binding.o")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c", os.path.join(ROOT, "groundgrid_amd", "host", "ros", "GroundGridHip.cpp"), "-o", obj,
+                           "-I", os.path.join(ROOT, "tests", "cpp", "decl_only"), "-I", REF_INCLUDE, "-I", os.path.join(ROOT, "include")])
+    syms = subprocess.check_output(["nm", "-C", "--defined-only", obj], text=True)
+    for name in ("GroundGrid::GroundGrid()", "GroundGrid::~GroundGrid()", "GroundGrid::setConfig(groundgrid::GroundGridConfig&)",
+                 "GroundGrid::initGroundGrid(", "GroundGrid::update("):
+        assert "groundgrid::" + name in syms, name
+    undefined = subprocess.check_output(["nm", "-C", "--undefined-only", obj], text=True)
+    for entry in ("gg_reset_map", "gg_move_map", "gg_rotation_from_quaternion", "gg_get_map_position"):
+        assert re.search(r"\bU " + entry + r"\b", undefined), entry
 
 
 def test_stand_ins_define_no_functions():
