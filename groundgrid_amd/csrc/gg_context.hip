@@ -543,8 +543,6 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tune_sweep_waves = getenv("GG_SWEEP_WAVES") ? atoi(getenv("GG_SWEEP_WAVES")) : 0;
     a.tune_sweep_gpw = getenv("GG_SWEEP_GPW") ? atoi(getenv("GG_SWEEP_GPW")) : 0;
     a.tune_sweep_split = getenv("GG_SWEEP_SPLIT") ? atoi(getenv("GG_SWEEP_SPLIT")) : 0;
-    a.k2_light_max = g.T > PACKED_TILE_COUNTERS_MIN_T ? K2_LIGHT_MAX_BIG : K2_LIGHT_MAX;
-    if (getenv("GG_K2_LIGHT_MAX")) a.k2_light_max = atoi(getenv("GG_K2_LIGHT_MAX")) > 512 ? K2_LIGHT_MAX_BIG : K2_LIGHT_MAX;
     a.tune_front = getenv("GG_FRONT") ? atoi(getenv("GG_FRONT")) : 0;
     a.tune_k2_per_cloud = getenv("GG_K2_PER_CLOUD") ? atoi(getenv("GG_K2_PER_CLOUD")) : 0;
     a.tune_k2_dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 0;
@@ -1471,7 +1469,6 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     else if (!strcmp(key, "sweep_gpw")) ctx->arena.tune_sweep_gpw = value;
     else if (!strcmp(key, "sweep_split")) ctx->arena.tune_sweep_split = value;
     else if (!strcmp(key, "front")) ctx->arena.tune_front = std::min(value, 3);
-    else if (!strcmp(key, "k2_light_max")) ctx->arena.k2_light_max = value > 512 ? K2_LIGHT_MAX_BIG : K2_LIGHT_MAX;
     else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
     else if (!strcmp(key, "sweep_fault")) ctx->arena.tune_sweep_fault = value;
     else if (!strcmp(key, "clear_device_error")) *ctx->h_dev_error = 0u;

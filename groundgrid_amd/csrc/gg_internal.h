@@ -33,8 +33,7 @@ constexpr int SWEEP_LATENCY_MAX_CLOUDS = 256;  // (= CUs) k_sweep: launches of a
 constexpr int K2_MIN_GROUPS_PER_CLOUD = 64;    // k_reduce: work-groups per cloud = max(4096 / clouds, this)
 constexpr int PACKED_TILE_COUNTERS_MIN_T = 1024; // maps with more tiles keep K1's / k_scatter's per-wavefront tile counters as 16-bit halves
                                                  // (a chunk has fewer than 65536 points): 71 -> 40 KB of LDS per work-group at 3969 tiles
-constexpr int K2_LIGHT_MAX = 512; // tiles with at most this many records are reduced by a single wavefront (k2_reduce.hip); K2_LIGHT_MAX_BIG
-constexpr int K2_LIGHT_MAX_BIG = 1024; // ... on maps of more than PACKED_TILE_COUNTERS_MIN_T tiles (Arena::k2_light_max, tunable "k2_light_max")
+constexpr int K2_LIGHT_MAX = 512; // tiles with at most this many records are reduced by a single wavefront (k2_reduce.hip)
 // key = tile_rank << 12 | emit << 10 | class << 8 | cell_in_tile (row_in_tile | col_in_tile << 4)
 constexpr int KEY_TILE_SHIFT = 12;
 constexpr uint32_t KEY_EMIT_BIT = 1u << 10;
@@ -141,7 +140,6 @@ struct Arena {
     int tune_front;         // the front end (classify + tile sort): 0 = the launcher's choice, 1 = three launches (k_classify, k_scan,
                             // k_scatter), 2 = the scan inside k_classify (the last work-group of a cloud to finish scans it), 3 = one launch
                             // (after the scan every work-group scatters its own chunks)
-    int k2_light_max;       // K2_LIGHT_MAX or K2_LIGHT_MAX_BIG: k_scan's split of the tiles into K2's light / dense lists, and which k_reduce runs
     int tune_k2_per_cloud;  // minimum work-groups per cloud of k_reduce
     int tune_k2_dense_share; // sixteenths of them that walk the dense list
     int k2_skip;             // measurement (GG_K2_SKIP): 1 = k_reduce leaves the light tiles out, 2 = the dense tiles

@@ -36,7 +36,6 @@
 #include "gg_device.h"
 
 #include <float.h>
-#include <stddef.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -294,16 +293,14 @@ struct DenseLds {
     uint32_t bin_cnt[NBIN], bin_start[NBIN];
     uint32_t wave_tot[4], wave_full[4];
 };
-// LW = 64-record windows a light tile may have (gg_internal.h light_tile_windows: 8, or 16 on maps with many tiles)
-template <int LW> struct LightLds {           // per wavefront
-    unsigned long long cnt64[TILE_CELLS];     // 2 KiB  counters of step 1; then the first 512 heights grouped by cell
-    float zs_more[64 * (LW - 8) + 2];         //        ... and the heights beyond them (contiguous with cnt64: one float[64 LW])
+struct LightLds {                             // per wavefront
+    unsigned long long cnt64[TILE_CELLS];     // 2 KiB  counters of step 1; then the heights grouped by cell (float[512])
     unsigned long long wmask[TILE_CELLS];     // 2 KiB
     uint32_t woffs[TILE_CELLS];               // 1 KiB
 };
-template <int LW> union ReduceLds {
+union ReduceLds {
     DenseLds dense;
-    LightLds<LW> light[4];
+    LightLds light[4];
 };
 
 // the 9 per-call layers of one cell (minimal layers: the three that nothing in the path reads are not maintained); B = the tile's
@@ -341,20 +338,19 @@ GG_DEV uint32_t half_column_bits(unsigned long long held)
 // (4 columns x 16 rows = 256 contiguous bytes of the tile's block per layer and store instruction, as in the dense path).  A wave walks its share of the
 // cloud's light list and keeps the next tile's loads in flight: its rank two tiles ahead, its record range one tile ahead,
 // its records while the current tile's recurrences run.
-template <int LW> GG_DEV void load_light_records(uint2 (&rw)[LW], const uint2 *sorted, uint32_t start, uint32_t end, int lane)
+GG_DEV void load_light_records(uint2 (&rw)[WB], const uint2 *sorted, uint32_t start, uint32_t end, int lane)
 {
 #pragma unroll
-    for (int j = 0; j < LW; ++j) {
+    for (int j = 0; j < WB; ++j) {
         const uint32_t p = start + 64u * (uint32_t)j + (uint32_t)lane;
         rw[j] = make_uint2(0u, KEY_OUTSIDE);
         if (p < end) rw[j] = sorted[p];
     }
 }
 
-template <bool FULL, int LW>
-GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint4 *tile_list, int n_light, int first, int stride, LightLds<LW> &lds)
+template <bool FULL>
+GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint4 *tile_list, int n_light, int first, int stride, LightLds &lds)
 {
-    static_assert(offsetof(LightLds<LW>, zs_more) == sizeof(unsigned long long) * TILE_CELLS, "the heights run on from the counters' memory");
     if (first >= n_light) return;
     const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
     float *L = percall_ptr(a, cp.slot);
@@ -369,8 +365,8 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
     uint4 ent = tile_list[first];
     uint4 ent_next = tile_list[min(first + stride, n_light - 1)];
     uint32_t start = ent.y, end = ent.z;
-    uint2 rw[LW];
-    load_light_records<LW>(rw, sorted, start, end, (int)(threadIdx.x & 63));
+    uint2 rw[WB];
+    load_light_records(rw, sorted, start, end, (int)(threadIdx.x & 63));
     for (int j = first; j < n_light; j += stride) {
         int lane = threadIdx.x & 63;
         __asm__ volatile("" : "+v"(lane)); // (per tile: keeps the lane's address arithmetic out of long-lived registers)
@@ -392,8 +388,8 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             // 1. count  (only the windows that hold records: a light tile has ~110 on average, two windows of the eight)
             const int n_win = (int)((end - start + 63u) >> 6);
 #pragma unroll
-            for (int w = 0; w < LW; ++w) {
-                if (w >= n_win) continue; // (uniform; not a break: a loop with an early exit is only unrolled up to 8 trips)
+            for (int w = 0; w < WB; ++w) {
+                if (w >= n_win) break; // (uniform)
                 const bool in = rw[w].y != KEY_OUTSIDE;
                 const unsigned long long km = __ballot(in && ((rw[w].y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT);
                 const LaneRun run = lane_run(in ? (rw[w].y & 255u) : 256u, lane);
@@ -432,8 +428,8 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
             float *zs = reinterpret_cast<float *>(&lds.cnt64[0]);
             lds_order();
 #pragma unroll
-            for (int w = 0; w < LW; ++w) {
-                if (w >= n_win) continue; // (uniform)
+            for (int w = 0; w < WB; ++w) {
+                if (w >= n_win) break; // (uniform)
                 const uint2 r = rw[w];
                 const bool kept = r.y != KEY_OUTSIDE && ((r.y >> KEY_CLASS_SHIFT) & 3u) == (uint32_t)GG_CLASS_KEPT;
                 const LaneRun run = lane_run(kept ? (r.y & 255u) : 256u, lane);
@@ -456,7 +452,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
         if (timing && lane == 0 && start != end) dbg_add(a, 29, t_p1 - t_begin); // prologue + wait for the records + count + place
         // the next tile's records travel while this tile's recurrences run
         const bool had_points = start != end;
-        load_light_records<LW>(rw, sorted, next_start, next_end, lane);
+        load_light_records(rw, sorted, next_start, next_end, lane);
         if (had_points) {
             // 4. + 5. the four cells of the lane, one after the other; point i of every lane's cell has c = i
             const float *zs = reinterpret_cast<const float *>(&lds.cnt64[0]);
@@ -467,13 +463,13 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                 const uint32_t wv = __hip_atomic_load(&lds.woffs[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t seg_end = wv & 0xFFFFu;
                 const uint32_t np = seg_end - seg;
-                for (uint32_t i = 0; __any(i < np); i += 4u) { // (uniform; at most 64 LW < RCAP points)
+                for (uint32_t i = 0; __any(i < np); i += 4u) { // (uniform; at most K2_LIGHT_MAX < RCAP points)
                     double rr[4];
                     float zz[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         rr[q] = recip_table.v[i + (uint32_t)q];
-                        zz[q] = zs[min(seg + i + (uint32_t)q, (uint32_t)(64 * LW) - 1u)];
+                        zz[q] = zs[min(seg + i + (uint32_t)q, (uint32_t)K2_LIGHT_MAX - 1u)];
                     }
                     four_points<RL>(zz, i, np, rr, oz, st);
                 }
@@ -721,8 +717,8 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
 // are stored sparsely -- tile_live[rank] says which half columns of a tile physically hold values (the ones with in-map records of
 // this cloud), every other cell logically holds the per-call reset values (:61-75), and the readers substitute them
 // (gg_internal.h tile_live).  Exact: gg_get_layer returns at all times what the reference's layers would hold.
-template <bool FULL, int LW>
-GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params, ReduceLds<LW> &lds, int cloud, int group, int n_groups, int n_dense_groups)
+template <bool FULL>
+GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params, ReduceLds &lds, int cloud, int group, int n_groups, int n_dense_groups)
 {
     const CloudParams cp = params[cloud];
     const uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
@@ -751,19 +747,15 @@ GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params,
         const int n_light = a.k2_skip == 1 ? 0 : (int)list_cnt[0];
         const int n_waves = (n_groups - n_dense_groups) * 4;
         const int wave = threadIdx.x >> 6;
-        reduce_light_tiles<FULL, LW>(a, cp, tile_list, n_light, (group - n_dense_groups) * 4 + wave, n_waves, lds.light[wave]);
+        reduce_light_tiles<FULL>(a, cp, tile_list, n_light, (group - n_dense_groups) * 4 + wave, n_waves, lds.light[wave]);
     }
 }
 
 // grid = (GD + GL, clouds): one work-group per share.
-// LW = 8: light tiles of up to 512 records, 6 wavefronts per SIMD (the headline map: 196 of 236 tiles with records are light).
-// LW = 16: up to 1024 records, 28 KB of LDS per work-group and 5 wavefronts per SIMD -- for maps with many tiles, where a dense
-// sensor leaves 400 .. 800 records in nearly every tile (BASELINE configs[3]: 2.1 M points over 3969 tiles) and the dense path's
-// four barrier-synchronised passes over a work-group are a poor fit for so few records per wavefront.
-template <bool FULL, int LW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LW == 8 ? 6 : 5, LW == 8 ? 6 : 5))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
+template <bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
 {
-    __shared__ ReduceLds<LW> lds;
+    __shared__ ReduceLds lds;
     // (cloud, group) from the dispatch order, XCD-aware (gg_device.h): the tiles of one cloud are reduced on one XCD, in
     // Morton order, so vertically adjacent tiles complete each other's 128-byte layer lines in the same L2
     const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
@@ -780,7 +772,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LW == 8 ? 6
         atomicMax(&census[2], r);
         atomicMin(&census[4], t_wg);
     }
-    reduce_share<FULL, LW>(a, params, lds, cloud, group, (int)gridDim.x, n_dense_groups);
+    reduce_share<FULL>(a, params, lds, cloud, group, (int)gridDim.x, n_dense_groups);
     if (a.k2_debug == 6 && threadIdx.x == 0 && item < 65536u) { // (tools/k2_trace.py: one record per work-group)
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         unsigned long long *rec = a.k2_dbg + (size_t)item * 4;
@@ -812,14 +804,10 @@ void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hi
     const int dense_share = a.tune_k2_dense_share > 0 ? a.tune_k2_dense_share : 12; // sixteenths of the groups
     const int gd = std::max(1, per_cloud * dense_share / 16), gl = std::max(1, per_cloud - gd);
     dim3 grid(gd + gl, n_clouds);
-    const bool minimal = (a.flags & GG_FLAG_MINIMAL_LAYERS) != 0;
-    if (a.k2_light_max > 512) {
-        if (minimal) hipLaunchKernelGGL((k_reduce<false, 16>), grid, dim3(256), 0, s, a, d_params, gd);
-        else hipLaunchKernelGGL((k_reduce<true, 16>), grid, dim3(256), 0, s, a, d_params, gd);
-    } else {
-        if (minimal) hipLaunchKernelGGL((k_reduce<false, 8>), grid, dim3(256), 0, s, a, d_params, gd);
-        else hipLaunchKernelGGL((k_reduce<true, 8>), grid, dim3(256), 0, s, a, d_params, gd);
-    }
+    if (a.flags & GG_FLAG_MINIMAL_LAYERS)
+        hipLaunchKernelGGL(k_reduce<false>, grid, dim3(256), 0, s, a, d_params, gd);
+    else
+        hipLaunchKernelGGL(k_reduce<true>, grid, dim3(256), 0, s, a, d_params, gd);
 }
 
 } // namespace gg

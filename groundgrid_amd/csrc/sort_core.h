@@ -137,8 +137,8 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bool in = lead && 4 * g + k < T;
-                nd += (in && s[k] > (uint32_t)a.k2_light_max) ? 1u : 0u;
-                nl += (in && s[k] > 0u && s[k] <= (uint32_t)a.k2_light_max) ? 1u : 0u;
+                nd += (in && s[k] > (uint32_t)K2_LIGHT_MAX) ? 1u : 0u;
+                nl += (in && s[k] > 0u && s[k] <= (uint32_t)K2_LIGHT_MAX) ? 1u : 0u;
             }
             uint32_t ltotal;
             const uint32_t lexcl = block_exclusive_scan<NW>(nl | (nd << 16), lds, ltotal);
@@ -150,7 +150,7 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
                     // (rank, the tile's records, its first cell: K2 starts on a tile after ONE lookup)
                     const uint4 entry = make_uint4((uint32_t)t, start, start + s[k], a.rank_cell0[t]);
                     if (s[k] == 0u) tile_live[t] = 0u;
-                    else if (s[k] > (uint32_t)a.k2_light_max) tile_list[(uint32_t)T - 1u - di++] = entry;
+                    else if (s[k] > (uint32_t)K2_LIGHT_MAX) tile_list[(uint32_t)T - 1u - di++] = entry;
                     else tile_list[li++] = entry;
                     tile_start[t] = start;
                     start += s[k];

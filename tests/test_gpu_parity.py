@@ -181,14 +181,12 @@ def test_initial_ground_height_nonzero():
     run_pair(synth.hdl64_cloud(seed=3, n_az=400), frames=2, odom_z=-1.5)
 
 
-def test_config4_geometry_dense_cloud(monkeypatch):
+def test_config4_geometry_dense_cloud():
     # BASELINE configs[3] geometry: 200 m @ 0.2 m -> 1000 x 1000 cells; 128 beams x 2048 azimuths (~260 k points)
     cloud = synth.os128_cloud(seed=1, n_az=2048)
     seg = api.GroundSegmentation().init(200.0, 0.2, n_slots=1, max_points=len(cloud))
     assert (seg.rows, seg.cols) == (1000, 1000)
     seg.close()
-    run_pair(cloud, length=200.0, resolution=0.2, frames=2)  # (k_reduce's light tiles hold up to 1024 records on this map)
-    monkeypatch.setenv("GG_K2_LIGHT_MAX", "512")             # ... and up to 512 like on the small map: more tiles take the dense path
     run_pair(cloud, length=200.0, resolution=0.2, frames=2)
 
 
@@ -288,7 +286,7 @@ def test_benchmark_launch_geometry_288_slots():
     seg.close()
 
 
-@pytest.mark.parametrize("knob", ["pw2048", "sweep_waves1", "sweep_waves2", "sweep_waves3", "k2_per_cloud64", "k2_dense_share4", "all_big_batch", "k2_light_1024"])
+@pytest.mark.parametrize("knob", ["pw2048", "sweep_waves1", "sweep_waves2", "sweep_waves3", "k2_per_cloud64", "k2_dense_share4", "all_big_batch"])
 def test_each_launch_geometry_switch_forced_at_small_batch(knob, monkeypatch):
     """The same three switches one at a time (and together) on a 6-cloud batch, full-size clouds included, so that a failure
     names the switch: GG_PW=2048 at gg_create; sweep wavefronts per side 1 / 2 / 3; k_reduce with 64 work-groups per cloud and
@@ -308,8 +306,6 @@ def test_each_launch_geometry_switch_forced_at_small_batch(knob, monkeypatch):
         seg.debug_set_tuning("k2_dense_share", 4)
     if knob == "all_big_batch":
         seg.debug_set_tuning("sweep_waves", 2)
-    if knob == "k2_light_1024":  # the single-wavefront path of k_reduce for tiles of up to 1024 records (default on maps of > 1024 tiles)
-        seg.debug_set_tuning("k2_light_max", 1024)
     pts = _batch_inputs(16, clouds, stride)
     origins = np.zeros((B, 3), dtype=np.float32)
     base_z = np.full(B, -1.73)

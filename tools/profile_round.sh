@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run on the MI355X box (through gpurun):  bash tools/profile_round.sh r02a
+# (SKIP_CONFIG4=1 leaves the configs[3] passes out.)
 # Produces, under gpurun_out/<rev>/: the rocprofv3 --kernel-trace --stats summary of the default bench (no extras), two separate
 # --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with other trace domains), the derived pmc_raw_per_launch.json /
 # pmc_summary.json, and the bench JSON line of the same revision.  Copy the directory into profiles/<rev>/ afterwards.
@@ -20,8 +21,23 @@ W=$(find "$OUT/write" -name '*counter_collection.csv' | head -1)
 mkdir -p "$OUT/profiles/$REV"
 python "$REPO/tools/pmc_summary.py" "$F" "$W" "$OUT/profiles/$REV" 1024 > "$OUT/pmc_summary.log" 2>&1
 cp "$OUT/profiles/$REV/pmc_raw_per_launch.json" "$OUT/profiles/pmc_summary.json" "$OUT/" 2>/dev/null
-# the bench line proper (with the fresh pmc_summary in place so that roofline.traffic is filled in)
 cp "$OUT/pmc_summary.json" "$REPO/profiles/pmc_summary.json" 2>/dev/null
+# configs[3] (2.1 M points, 1000 x 1000, 128 clouds per launch): kernel stats and the same two counter passes, merged into pmc_summary.json
+C4="python $REPO/bench.py --only-config4 --cpu-seconds 0"
+if [ -z "${SKIP_CONFIG4:-}" ]; then
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt4" -o kt -- $C4 > "$OUT/config4_under_rocprof.json" 2> "$OUT/kt4.err"
+cp "$(find "$OUT/kt4" -name '*kernel_stats.csv' | head -1)" "$OUT/config4_kernel_stats.csv" 2>/dev/null
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch4" -o f -- $C4 > /dev/null 2> "$OUT/fetch4.err"
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write4" -o w -- $C4 > /dev/null 2> "$OUT/write4.err"
+F4=$(find "$OUT/fetch4" -name '*counter_collection.csv' | head -1)
+W4=$(find "$OUT/write4" -name '*counter_collection.csv' | head -1)
+mkdir -p "$REPO/profiles/$REV"
+python "$REPO/tools/pmc_summary.py" "$F4" "$W4" "$REPO/profiles/$REV" 128 config4_kernels > "$OUT/pmc_summary_config4.log" 2>&1
+cp "$REPO/profiles/$REV/pmc_raw_per_launch_config4_kernels.json" "$OUT/" 2>/dev/null
+cp "$REPO/profiles/pmc_summary.json" "$OUT/pmc_summary.json" 2>/dev/null
+rm -rf "$OUT/kt4" "$OUT/fetch4" "$OUT/write4"
+fi
+# the bench line proper (with the fresh pmc_summary in place so that roofline.traffic is filled in)
 cd "$REPO" && timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write" "$OUT/profiles"
 ls -la "$OUT"
