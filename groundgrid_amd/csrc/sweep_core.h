@@ -260,8 +260,9 @@ SW_HD int bnd_offset(int b) { return 64 * b * (b + 1) + 2 * b; } // boundary b =
 // themselves must not: loads and stores share one in-order counter, and a store that has to reach memory before it is
 // acknowledged would hold up every later wait of the wavefront -- measured: 2x slower), and an IMPORTER wavefront of the
 // consuming work-group polls the region and feeds the values and their progress counters into its own work-group's LDS tables,
-// where the chain and corner wavefronts find them as if a wavefront next door had published them.  Work-groups are dispatched in index order and a part's index is higher than its producer's:
-// a consumer never waits for a work-group that has not been dispatched.
+// where the chain and corner wavefronts find them as if a wavefront next door had published them.  Which work-group sweeps which
+// part is decided by a ticket taken when the work-group starts running (k4_sweep.hip), parts of a cloud in increasing order: a
+// consumer never waits for a producer that has not started, in whatever order work-groups are dispatched.
 //
 // Exchange region of one cloud, in entries of one WP: per boundary gb = 1 .. groups - 1 (between ring 64 gb and 64 gb + 1)
 //   4 sides x xchg_len(gb) chain values of ring 64 gb,  then  AB x1, AB y0, CD x1, CD y0,  then  C_last, D_last of ring 64 gb.
