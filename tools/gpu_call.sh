@@ -2,10 +2,15 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-bash tools/profile_round.sh r04a > gpurun_out/r04a_profile.log 2>&1
-tail -5 gpurun_out/r04a_profile.log
-bash tools/sq_pmc.sh > gpurun_out/r04a/sq_counters.txt 2>&1
-tail -c 600 gpurun_out/r04a/sq_counters.txt
-rm -rf gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3
-cp profiles/pmc_summary.json gpurun_out/r04a/pmc_summary_final.json
-ls -la gpurun_out/r04a
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -12 > gpurun_out/t7_tests.log
+cat gpurun_out/t7_tests.log
+{
+for rep in 1 2; do
+GG_K3=1 timeout 200 python tools/ab_kernels.py 1024 8 k3_bands 2>/dev/null | tail -1
+timeout 200 python tools/ab_kernels.py 1024 8 k3_tiles 2>/dev/null | tail -1
+done
+GG_K3=1 SKIP_BIG=1 BATCHES_SMALL=1 timeout 300 python tools/latency_probe.py 2>/dev/null | tail -1
+SKIP_BIG=1 BATCHES_SMALL=1 timeout 300 python tools/latency_probe.py 2>/dev/null | tail -1
+GG_K3=1 SKIP_SMALL=1 BATCHES_BIG=128 timeout 300 python tools/latency_probe.py 2>/dev/null | tail -1
+SKIP_SMALL=1 BATCHES_BIG=128 timeout 300 python tools/latency_probe.py 2>/dev/null | tail -1
+} | tee gpurun_out/t7_ab.log
