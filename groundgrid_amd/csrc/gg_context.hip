@@ -414,6 +414,8 @@ bool slot_ok(const gg_context *ctx, int slot) { return ctx && slot >= 0 && slot 
 
 } // namespace
 
+static int rebuild_patch_table(gg_context *ctx);
+
 extern "C" {
 
 int gg_abi_version(void) { return GG_ABI_VERSION; }
@@ -587,6 +589,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t Cpad = align_up(C * 4, A) / 4;
     const size_t Npad = align_up(max_points * 8, A) / 8;
     const size_t o_expected = carve(C * 4);
+    const size_t o_ptable = carve(C * 16);
     const size_t o_trank = carve((size_t)g.T * 2);
     const size_t o_rtile = carve((size_t)g.T * 2);
     const size_t o_rcell0 = carve((size_t)g.T * 4);
@@ -644,6 +647,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipMemsetAsync(base, 0, ctx->arena_bytes, ctx->stream));
 
     a.expected = (const float *)(base + o_expected);
+    a.patch_table = (const float4 *)(base + o_ptable);
     a.tile_rank = (const uint16_t *)(base + o_trank);
     a.rank_tile = (const uint16_t *)(base + o_rtile);
     a.rank_cell0 = (const uint32_t *)(base + o_rcell0);
@@ -759,6 +763,13 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 
     ctx->helper.configure((getenv("GG_HOST_THREADS") ? std::max(1, std::min(atoi(getenv("GG_HOST_THREADS")), 16)) : 4) - 1);
     {
+        const int rc = rebuild_patch_table(ctx);
+        if (rc != GG_OK) {
+            gg_destroy(ctx);
+            return rc;
+        }
+    }
+    {
         const int rc = gg_reset_maps(ctx, 0, n_slots, 0.0, 0.0, 0.0f, 0, nullptr); // (one strided fill per layer for all slots)
         if (rc != GG_OK) {
             gg_destroy(ctx);
@@ -816,12 +827,49 @@ void gg_destroy(gg_context *ctx)
     delete ctx;
 }
 
+// The per-cell constants of detect_ground_patches (gg_internal.h Arena::patch_table), in the reference's own arithmetic: every cell
+// used to recompute them for every cloud -- a dozen binary64 operations and the sheared layer index per cell and call, a sixth of
+// k_patch's instructions -- although they depend on the cell and the configuration only.
+static int rebuild_patch_table(gg_context *ctx)
+{
+    const Geometry &g = ctx->arena.g;
+    const DevConfig &cfg = ctx->arena.cfg;
+    const int rows = g.rows, cols = g.cols;
+    std::vector<float> t((size_t)g.C * 4);
+    const double res2 = (double)g.resolution_f * (double)g.resolution_f;
+    for (int j = 0; j < cols; ++j)
+        for (int i = 0; i < rows; ++i) {
+            float *e = &t[((size_t)i + (size_t)j * rows) * 4];
+            const float expected = ctx->h_expected[(size_t)i + (size_t)j * rows];
+            // the four quadrants (:325-328) cover rows [2, 2 * (cols / 2) - 2) and cols [2, rows - 2)
+            const bool visited = i >= 2 && j >= 2 && !(i >= 2 * (cols / 2) - 2 || j >= rows - 2);
+            const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
+            const float sqdist = (float)((di * di + dj * dj) * res2);                          // :332
+            const bool near = (double)sqdist <= cfg.patch_size_change_distance_sq;             // :334
+            const double S = near ? 3.0 : 5.0;
+            const double thr = std::max(floor(cfg.gpd_min_point_count_threshold * S * (double)expected), 3.0); // :364 (an integer-valued double)
+            const float thr_f = (float)thr;
+            e[0] = expected;
+            // (a threshold too large for an exact float -- absurd configurations -- can never be met by a count below 2^24 either)
+            e[1] = !visited || !(thr < 16777216.0) ? INFINITY : (near ? -thr_f : thr_f);
+            e[2] = (float)std::min(std::max((double)sqdist * cfg.distance_factor_sq, cfg.minimum_distance_factor_sq), cfg.minimum_distance_factor_x10_sq); // :369
+            const int gidx = gp_index(ctx->arena.gpl, i, j);
+            memcpy(&e[3], &gidx, 4);
+        }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // (batches may be reading the old table: wait for them; gg_set_config is a rare, synchronous call)
+    if (ctx->have_batch_event) HIPCHK(ctx, hipEventSynchronize(ctx->batch_event));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(const_cast<float4 *>(ctx->arena.patch_table), t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    return GG_OK;
+}
+
 int gg_set_config(gg_context *ctx, const gg_config *cfg)
 {
     if (!ctx || !cfg) return GG_ERR_INVALID;
     ctx->cfg = *cfg; // src/GroundSegmentation.cpp:468-471
     make_dev_config(ctx->cfg, ctx->arena.cfg);
-    return GG_OK;
+    return rebuild_patch_table(ctx);
 }
 
 int gg_get_config(const gg_context *ctx, gg_config *cfg)

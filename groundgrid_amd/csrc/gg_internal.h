@@ -90,6 +90,11 @@ struct Arena {
     DevConfig cfg;
     // shared
     const float *expected;        // [C]
+    const float4 *patch_table;    // [C] what detect_ground_patches needs to know about a cell that depends on the geometry and the
+                                  // configuration only (rebuilt by gg_set_config, k3_patch.hip PatchCell): x = expectedPoints (:358),
+                                  // y = the point-count threshold of :364-365, NEGATIVE when the cell takes 3 x 3 blocks (:334), +inf
+                                  // when the quadrant loops never visit it (:325-328); z = varThresholdsq (:369); w = the cell's
+                                  // element in the (ground, confidence) layer (an int, gp_layout.h)
     const uint16_t *tile_rank;    // [T] tile (tr + tc*tiles_r) -> Morton rank
     const uint16_t *rank_tile;    // [T] Morton rank -> tile
     const uint32_t *rank_cell0;   // [T] Morton rank -> first row | first col << 16 of the tile (per-point lookups: no division)

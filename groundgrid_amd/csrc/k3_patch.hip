@@ -27,7 +27,7 @@ struct PatchCarry {
     bool live;          // the block sum passed :364-365
     int gidx;           // element of the cell in the (ground, confidence) layer
     float2 old;         // (ground, confidence), in flight
-    float pointsblockSum, expected, localmin, maxVar, groundlevel, sqdist;
+    float pointsblockSum, expected, localmin, maxVar, groundlevel, varThresholdsq;
     int S;
 };
 
@@ -118,9 +118,7 @@ GG_DEV void detect_ground_patch_b(const Arena &a, const PatchCarry &pc, float2 *
     const float oldConfidence = pc.old.y;   // :360
     const float oldGroundheight = pc.old.x; // :361
     const float pointsblockSum = pc.pointsblockSum, groundlevel = pc.groundlevel, maxVar = pc.maxVar;
-    // :369
-    const float varThresholdsq =
-        (float)std_min(std_max((double)pc.sqdist * cfg.distance_factor_sq, cfg.minimum_distance_factor_sq), cfg.minimum_distance_factor_x10_sq);
+    const float varThresholdsq = pc.varThresholdsq; // :369, from the per-cell table (gg_internal.h Arena::patch_table)
     // :376
     const float groundDiff = std_max((groundlevel - oldGroundheight) * (2.0f * oldConfidence), 1.0f);
     // :379-380
@@ -209,14 +207,9 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
 
     // staging registers: up to LC columns x LR rows = 432 cells, two per thread
     float sp[2], sv[2], sm[2];
-    float exp_next = 0.0f; // expectedPoints of this thread's cell in the requested block
+    float4 cell_next = make_float4(0.0f, __builtin_inff(), 0.0f, 0.0f); // the per-cell constants (Arena::patch_table) of this thread's cell in the requested block
     const int tr = tid % PR, tcl = tid / PR;
     const int i = r0 + tr;
-    auto cell_visited = [&](int jj) {
-        // the four quadrants (:325-328) cover rows [2, 2 * (cols / 2) - 2) -- the FIRST loop variable, bounded by cols / 2, is
-        // used as the row index -- and cols [2, rows - 2): for odd sizes row n - 3 is never visited
-        return !(i >= 2 * (cols / 2) - 2 || jj >= rows - 2);
-    };
     // Every load of the walk is UNCONDITIONAL (lanes with nothing to fetch read element 0, one broadcast line): loads and
     // stores share one in-order counter, and the compiler can only leave younger loads in flight across a wait when it knows how
     // many there are.  With a load under a branch every wait became vmcnt(0): the block's sums waited for the NEXT block's
@@ -224,9 +217,9 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     auto request = [&](int b, int first_col, int n_cols) { // columns [first_col, first_col + n_cols) of block b's window
         {
             const int jj = HALO + PC * b + tcl;
-            const bool v = cell_visited(jj) && jj < cols;
-            const float e = a.expected[v ? (size_t)i + (size_t)jj * rows : (size_t)0]; // :358
-            exp_next = v ? e : 0.0f;
+            const bool v = i < rows && jj < cols;
+            const float4 e = a.patch_table[v ? (size_t)i + (size_t)jj * rows : (size_t)0]; // :358, :334, :364, :369 and the layer element
+            cell_next = make_float4(e.x, v ? e.y : __builtin_inff(), e.z, e.w); // (no such cell: never visited)
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -276,7 +269,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     // (conditional), 1 load (this block's old cells) -- the next wait for the columns leaves that one load in flight.
     auto block_step = [&](PatchCarry &produce, PatchCarry &consume) {
         deposit(req_first, req_cols);
-        const float expected = exp_next;
+        const float4 cell_const = cell_next;
         // the next block that can change anything: its new columns travel while this one is computed (past the last block: a
         // request that fetches nothing); requested as soon as the staging registers are free, before the barrier
         const int nb = next_block(b + 1);
@@ -287,13 +280,12 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         detect_ground_patch_b(a, consume, gp2); // the previous block's cell: its old (ground, confidence) has arrived meanwhile
         consume.live = false;
 
-        const int j = HALO + PC * b + tcl;
         const int base = (PC * b) & (RING - 1); // 0, 8, 16 or 24: the window is slots base .. base + LC - 1
         const int lr = tr + HALO, lc = tcl + HALO;
-        // :332
-        const double di = (double)i - (double)rows / 2.0, dj = (double)j - (double)cols / 2.0;
-        const float sqdist = (float)((di * di + dj * dj) * ((double)a.g.resolution_f * (double)a.g.resolution_f));
-        const bool visited = cell_visited(j), near = (double)sqdist <= a.cfg.patch_size_change_distance_sq; // :334
+        // :332-334 and the right side of :364-365 come from the per-cell table: the threshold's sign says 3 x 3 or 5 x 5 blocks,
+        // +inf that the quadrant loops (:325-328) never visit the cell
+        const bool near = cell_const.y < 0.0f;
+        const float threshold = fabsf(cell_const.y);
         // :359 the block's point count from the vertical partial sums (exact: integers, see v5 / v3)
         for (int e = tid; e < LC * PR; e += 256) {
             const int c = e / PR, r = e % PR;
@@ -303,21 +295,18 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             v5[c][r] = (col[0] + col[4]) + mid;
         }
         __syncthreads();
-        float pointsblockSum = 0.0f;
-        if (visited)
-            pointsblockSum = near ? (v3[tcl + 1][tr] + v3[tcl + 2][tr]) + v3[tcl + 3][tr]
-                                  : ((v5[tcl][tr] + v5[tcl + 1][tr]) + (v5[tcl + 2][tr] + v5[tcl + 3][tr])) + v5[tcl + 4][tr];
+        const float pointsblockSum = near ? (v3[tcl + 1][tr] + v3[tcl + 2][tr]) + v3[tcl + 3][tr]
+                                          : ((v5[tcl][tr] + v5[tcl + 1][tr]) + (v5[tcl + 2][tr] + v5[tcl + 3][tr])) + v5[tcl + 4][tr];
         const int S = near ? 3 : 5;
-        // :364-365
-        const bool pass = visited && !((double)pointsblockSum < std_max(floor(a.cfg.gpd_min_point_count_threshold * (double)S * (double)expected), 3.0)) &&
-                          a.k3_debug != 3;
-        produce.gidx = pass ? gp_idx(a, i, j) : 0; // the (ground, confidence) layer has its own element order (gp_layout.h)
+        // :364-365 (count and threshold are integer-valued floats: the comparison is the reference's binary64 one)
+        const bool pass = !(pointsblockSum < threshold) && a.k3_debug != 3;
+        produce.gidx = pass ? __float_as_int(cell_const.w) : 0; // the (ground, confidence) layer has its own element order (gp_layout.h)
         produce.old = gp2[produce.gidx];           // :360-361, used one block later
         produce.live = pass;
         produce.S = S;
         produce.pointsblockSum = pointsblockSum;
-        produce.expected = expected;
-        produce.sqdist = sqdist;
+        produce.expected = cell_const.x;
+        produce.varThresholdsq = cell_const.z;
         group_fence();
         if (pass) {
             if (near)
