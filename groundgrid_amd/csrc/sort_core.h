@@ -211,18 +211,21 @@ template <bool PACKED, bool AGENT>
 GG_DEV void scatter_chunk(uint32_t *offs, __amdgpu_buffer_rsrc_t hist, uint32_t row_word, const uint2 *__restrict__ rec, uint2 *__restrict__ sorted,
                           int base, int end, int lane)
 {
-    constexpr int SI = 4; // windows in flight
-    for (int p0 = base; p0 < end; p0 += 64 * SI) {
-        uint2 r[SI];
+    constexpr int SI = 4; // windows per batch
+    if (base >= end) return;
+    // The records of the NEXT batch are requested before this batch is placed (two register sets that take turns: a copy at the
+    // loop's back edge would wait for the load where it is issued; unconditional loads at clamped indices: a load under a branch
+    // makes every later wait a vmcnt(0)): a batch is a chain -- records, ballots, LDS add, permute, store -- and the first link
+    // of the next one now travels during the others.
+    auto request = [&](uint2 (&r)[SI], int p0) {
 #pragma unroll
-        for (int j = 0; j < SI; ++j) {
-            const int p = p0 + 64 * j + lane;
-            r[j] = make_uint2(0u, KEY_OUTSIDE);
-            if (p < end) r[j] = rec[p];
-        }
+        for (int j = 0; j < SI; ++j) r[j] = rec[min(p0 + 64 * j + lane, end - 1)];
+    };
+    auto place = [&](uint2 (&r)[SI], int p0) {
         uint32_t dst[SI];
 #pragma unroll
         for (int j = 0; j < SI; ++j) {
+            if (p0 + 64 * j + lane >= end) r[j].y = KEY_OUTSIDE; // (the clamped lanes of the chunk's last batch)
             const bool inmap = r[j].y != KEY_OUTSIDE;
             const uint32_t t = r[j].y >> KEY_TILE_SHIFT;
             uint32_t first_pos = 0u;
@@ -258,6 +261,15 @@ GG_DEV void scatter_chunk(uint32_t *offs, __amdgpu_buffer_rsrc_t hist, uint32_t 
 #pragma unroll
         for (int j = 0; j < SI; ++j)
             if (r[j].y != KEY_OUTSIDE) sorted[dst[j]] = r[j];
+    };
+    uint2 ra[SI], rb[SI];
+    request(ra, base);
+    for (int p0 = base; p0 < end; p0 += 2 * 64 * SI) {
+        request(rb, min(p0 + 64 * SI, end - 1));
+        place(ra, p0);
+        if (p0 + 64 * SI >= end) break;
+        request(ra, min(p0 + 2 * 64 * SI, end - 1));
+        place(rb, p0 + 64 * SI);
     }
 }
 
