@@ -69,12 +69,14 @@ def make_clouds(batch: int, rank: int, n_scenes: int = N_SCENES, seed0: int = 20
     return clouds
 
 
-def algorithmic_bytes(n_pts, n_in, n_kept, C, T, nch, full_layers=True):
+def algorithmic_bytes(n_pts, n_in, n_kept, C, T, nch, full_layers=True, cold=True):
     """minimal compulsory traffic per cloud, per kernel (bytes).  The sort kernels have no row of their own
     in 8(d) (their bytes are part of K2's 20 N): scan = the chunk histograms read and written once, scatter = one (z, key)
-    record read and written per in-map point."""
+    record read and written per in-map point.  cold: every map of the step is freshly initialised -- no confidence anywhere, so the
+    line-of-sight test (:243-275) cannot fire and k_classify does not gather the old ground: the 4 N_in of 8(d)'s K1 row are not
+    compulsory there and are not counted."""
     return {
-        "k_classify": 16 * n_pts + 4 * n_in + 4 * n_pts + 1 * n_pts,
+        "k_classify": 16 * n_pts + (0 if cold else 4 * n_in) + 4 * n_pts + 1 * n_pts,
         "k_scan": 2 * 4 * nch * T,
         "k_scatter": 8 * n_in + 8 * n_in,
         "k_reduce": 8 * n_in + (9 if full_layers else 6) * 4 * C,

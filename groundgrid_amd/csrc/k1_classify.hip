@@ -259,10 +259,15 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
             bool inmap_[ITEMS];
             float og[ITEMS];
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) { // index math for all windows, then all old-ground gathers in flight together
-                inmap_[j] = locate_point(a, cp, pt[j], gi0[j], gi1[j]) && valid[j];
-                og[j] = gp2[inmap_[j] ? gp_idx(a, gi0[j], gi1[j]) : 0].x; // :243
-            }
+            for (int j = 0; j < ITEMS; ++j) inmap_[j] = locate_point(a, cp, pt[j], gi0[j], gi1[j]) && valid[j];
+            // index math for all windows, then all old-ground gathers in flight together.  The old ground only feeds the entry test
+            // of the line-of-sight walk (:243-244), and a map without any confidence above 0.01 -- every map of a cold step -- cannot
+            // produce an outlier (:269, classify_point): no walk, so nothing to gather either (a quarter of this kernel's reads).  The
+            // load stays unconditional (element 0, one broadcast line, for the lanes with nothing to fetch): a load under a branch
+            // costs the warm case its schedule
+            const bool need_ground = !cp.no_confidence;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) og[j] = gp2[(inmap_[j] && need_ground) ? gp_idx(a, gi0[j], gi1[j]) : 0].x; // :243
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const int p = p0 + j * 64 + lane;
