@@ -167,12 +167,15 @@ def ordered_line(result, world):
                                     "binding_like": pick(result, "host_api", "binding_like_vs_cpu_1thread"),
                                     "device_resident_binding": pick(result, "host_api", "device_resident_binding_vs_cpu_1thread")},
         "single_cloud_latency_ms": result.get("single_cloud_latency_ms"),
+        "lazy_layers": {"clouds_per_s": pick(result, "lazy_layers", "clouds_per_s"), "reduce_ms": pick(result, "lazy_layers", "kernel_ms", "k_reduce"),
+                        "materialise_ms_per_map": pick(result, "lazy_layers", "materialise_ms_per_map")},
         "config3_clouds_per_s": pick(result, "config3", "clouds_per_s"),
         "config4": {"clouds_per_s": pick(result, "config4", "clouds_per_s"), "all_kernels_frac_hbm": pick(result, "config4", "all_kernels_frac_hbm"),
                     "dominant_frac": pick(result, "config4", "roofline", "frac"), "single_cloud_latency_ms": pick(result, "config4", "single_cloud", "latency_ms"),
                     "cpu_clouds_per_s": pick(result, "config4", "cpu_baseline", "value")},
         "parity_checked_in_run": {"headline": result.get("parity_checked_in_run"), "warm": pick(result, "warm_map", "parity_checked_in_run"),
                                   "config3": pick(result, "config3", "parity_checked_in_run"), "config4": pick(result, "config4", "parity_checked_in_run"),
+                                  "lazy_layers": pick(result, "lazy_layers", "parity_checked_in_run"),
                                   "config4_single": pick(result, "config4", "single_cloud", "parity_checked_in_run")},
     }
     head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
@@ -544,6 +547,40 @@ def main():
                     hs = [cold_last] + warm.shifts + mixed.shifts
                     result["warm_map_unrelated_scenes"]["parity_checked_in_run"] = check_timed_outputs(
                         mixed, clouds, 120.0, 0.33, n_check=1, seed=6, history_of=lambda slot: [int((slot - s) % B) for s in hs])[0]
+
+    # ---------------------------------------------------------------- lazily materialised layers (a separate leg, not the headline)
+    if extras and rank == 0 and world == 1 and not args.minimal_layers:
+        # SURVEY Appendix E / VERDICT r3 2(c): k_reduce maintains the six per-call layers the path reads; maxGroundHeight,
+        # groundCandidates and planeDist are computed when a reader asks (gg_get_layer), from the records the call left behind.
+        seg.set_flags(minimal_layers=True, profile=not args.no_profile)
+        lazy = Pipeline(seg, points, n_points, origins, base_z, cold=True)
+        l_steps = max(4, args.steps // 2)
+        l_elapsed, l_kt = lazy.timed(l_steps, 2)
+        leg = {"clouds_per_s": round(B * l_steps / l_elapsed, 1), "ms_per_step": round(1e3 * l_elapsed / l_steps, 4),
+               "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in l_kt.items()},
+               "note": "GG_FLAG_MINIMAL_LAYERS: per cloud only the six per-call layers the path reads; the three published-only ones are "
+                       "computed on the first read of one of them (`materialise_ms_per_map`: that read against a read of a maintained layer)"}
+        n_read = min(16, B)  # (a read = extract + 0.5 MB over PCIe; the lazy read also runs the three recurrences of that map first)
+        t0 = time.perf_counter()
+        for sl in range(n_read):
+            seg.map(sl)["m2"]
+        t1 = time.perf_counter()
+        for sl in range(n_read):
+            seg.map(sl)["planeDist"]
+        t2 = time.perf_counter()
+        leg["layer_read_ms"] = round(1e3 * (t1 - t0) / n_read, 4)
+        leg["materialise_ms_per_map"] = round(1e3 * ((t2 - t1) - (t1 - t0)) / n_read, 4)
+        if do_checks:
+            from oracle import oracle
+            okl, chk = check_timed_outputs(lazy, clouds, 120.0, 0.33, n_check=2, seed=4)
+            for c in chk:  # ... and all 11 layers of those maps, the lazily computed ones among them
+                ref = oracle.OracleMap(120.0, 0.33)
+                ref.filter_cloud(clouds[c["cloud"]], (0.0, 0.0, 0.0), -1.73)
+                got = seg.map(c["slot"]).layers()
+                okl &= all(nan_equal(got[name], ref.layer(name)) for name in oracle.LAYERS)
+            leg["parity_checked_in_run"] = bool(okl)
+        seg.set_flags(minimal_layers=False, profile=not args.no_profile)
+        result["lazy_layers"] = leg
 
     # ---------------------------------------------------------------- configs[2]: 64 clouds in total, 64 / N per GPU
     if extras:

@@ -59,6 +59,10 @@ struct gg_context {
     std::vector<double> pos_x, pos_y; // per slot map position
     std::vector<char> slot_seen;      // scratch of gg_filter_batch's check of gg_batch.slots
     std::vector<char> no_confidence;  // per slot: groundpatch <= 0.01 everywhere for sure (set by gg_reset_map, cleared by any writer)
+    // GG_FLAG_MINIMAL_LAYERS: the slot's last cloud left maxGroundHeight / groundCandidates / planeDist unwritten; a reader of one of
+    // them has them computed first, from what that call left in the slot's buffers and with its parameters (ensure_lazy_layers)
+    std::vector<char> lazy_pending;
+    std::vector<gg::CloudParams> lazy_params;
 
     gg_conventions conv{};
     gg::sweep::Params sweep_params{};
@@ -328,6 +332,8 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
         ctx->no_confidence[slot] = 0; // the sweep of this call writes confidences
         for (int k = 0; k < 12; ++k) p.tf[k] = b->transforms ? b->transforms[(size_t)i * 12 + k] : 0.0;
         max_n = std::max(max_n, p.n_points);
+        ctx->lazy_pending[slot] = (ctx->flags & GG_FLAG_MINIMAL_LAYERS) ? 1 : 0;
+        if (ctx->flags & GG_FLAG_MINIMAL_LAYERS) ctx->lazy_params[slot] = p;
     }
     // order this batch after everything that touched map state on the context's stream, and after an earlier batch that ran
     // on another stream
@@ -412,6 +418,19 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
 
 bool slot_ok(const gg_context *ctx, int slot) { return ctx && slot >= 0 && slot < ctx->n_slots; }
 
+// Before anything reads (or densifies) one of the three layers GG_FLAG_MINIMAL_LAYERS leaves out: compute them for this slot, once,
+// on the context's stream (the callers have ordered it behind the batches).  SURVEY Appendix E: the published-only layers are
+// materialised when somebody asks, from the retained tile-sorted records; gg_get_layer returns at all times what the reference holds.
+int ensure_lazy_layers(gg_context *ctx, int slot, bool wanted)
+{
+    if (!wanted || !ctx->lazy_pending[slot]) return GG_OK;
+    launch_reduce_lazy(ctx->arena, ctx->lazy_params[slot], ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->lazy_pending[slot] = 0;
+    return GG_OK;
+}
+bool lazy_layer(int layer) { return layer == GG_LAYER_MAXGROUNDHEIGHT || layer == GG_LAYER_GROUNDCANDIDATES || layer == GG_LAYER_PLANEDIST; }
+
 } // namespace
 
 static int rebuild_patch_table(gg_context *ctx);
@@ -492,6 +511,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     gg_default_config(&ctx->cfg);
     ctx->pos_x.assign(n_slots, 0.0);
     ctx->no_confidence.assign(n_slots, 0); // layers start as zeros, but only gg_reset_map makes a slot usable
+    ctx->lazy_pending.assign(n_slots, 0);
+    ctx->lazy_params.assign(n_slots, CloudParams{});
     ctx->pos_y.assign(n_slots, 0.0);
 
 #define CREATE_CHK(call)                                             \
@@ -986,6 +1007,7 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
     // spaced, so one strided fill per layer covers all n slots.
     const float init[GG_NUM_LAYERS] = {0.0f, odom_z, (float)0.0000001, (float)100.0, (float)-100.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!persistent_only) {
+        for (int s = first_slot; s < first_slot + n; ++s) ctx->lazy_pending[s] = 0;
         launch_fill_percall(a, first_slot, n, init, st);
         // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
         launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)first_slot * a.tile_live_stride), (size_t)n * a.tile_live_stride * 4, 0xFF, st);
@@ -1063,6 +1085,7 @@ int gg_set_layer(gg_context *ctx, int slot, int layer, const float *src)
     } else {
         // the per-call layers are stored sparsely behind ONE set of liveness masks (gg_internal.h tile_live): make all nine dense
         // (reset values into the dead half columns, every half column live), then overwrite this one with the host's matrix
+        if (const int rc = ensure_lazy_layers(ctx, slot, true)) return rc;
         launch_materialise_layers(ctx->arena, slot, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, src, (size_t)ctx->arena.g.C * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1081,6 +1104,7 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     // both kinds of layer have a device representation of their own (sheared pairs / sparse tile blocks): extract the dense plane
+    if (const int rc = ensure_lazy_layers(ctx, slot, lazy_layer(layer))) return rc;
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH)
         launch_plane_extract(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_image, ctx->stream);
     else
@@ -1105,6 +1129,8 @@ int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
     // pageable matrices is staged by the runtime in small pieces: 0.7 ms for eleven 364 x 364 layers, against 0.15 ms), and the
     // context's host threads move them on to where the caller wants them.
     int want[GG_NUM_LAYERS], n_want = 0;
+    for (int l = 0; l < GG_NUM_LAYERS; ++l)
+        if (const int rc = ensure_lazy_layers(ctx, slot, dst[l] && lazy_layer(l))) return rc;
     for (int l = 0; l < GG_NUM_LAYERS; ++l) {
         if (!dst[l]) continue;
         float *d = ctx->d_planes + (size_t)n_want * plane;
@@ -1136,6 +1162,7 @@ int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, fl
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const Geometry &g = ctx->arena.g;
     uint8_t *d_img = reinterpret_cast<uint8_t *>(ctx->d_image);
+    if (const int rc = ensure_lazy_layers(ctx, slot, lazy_layer(layer))) return rc;
     if (layer == GG_LAYER_GROUND || layer == GG_LAYER_GROUNDPATCH)
         launch_plane_extract(ctx->arena, slot, layer == GG_LAYER_GROUNDPATCH, ctx->d_scroll_scratch, ctx->stream);
     else

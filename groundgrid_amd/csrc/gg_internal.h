@@ -259,6 +259,7 @@ int launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &
 void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, int max_n, hipStream_t s);
 void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
+void launch_reduce_lazy(const Arena &a, const CloudParams &cp, hipStream_t s); // (GG_FLAG_MINIMAL_LAYERS: the other three layers, one slot)
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 namespace sweep {
 struct Params;

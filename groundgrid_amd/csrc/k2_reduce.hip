@@ -114,11 +114,19 @@ GG_DEV float min3_abs(float a, float b, float m) // min(|a|, |b|, m)
     return r;
 }
 
+// What a launch of the kernel maintains: all nine per-call layers; the six that the path itself reads (GG_FLAG_MINIMAL_LAYERS);
+// or -- afterwards, on demand, from the records the call left behind -- the other three (gg_context.hip ensure_lazy_layers).
+enum : int { K2_MINIMAL = 0, K2_FULL = 1, K2_LAZY3 = 2 };
+
 enum : int { R_MEAN = 1 /* meanVariance, m2 */, R_GC = 2 /* groundCandidates, maxGroundHeight */, R_PDM = 4 /* planeDist */, R_MN = 8 /* minGroundHeight */ };
 
 struct CellState {
     float gc, mean, pdm, m2, mx, mn;
 };
+template <int MODE> constexpr int chains_of()
+{
+    return MODE == K2_FULL ? (R_MEAN | R_GC | R_PDM | R_MN) : MODE == K2_MINIMAL ? (R_MEAN | R_MN) : (R_GC | R_PDM);
+}
 
 // The reference's recurrence (:295-309) of the lane's cell over its `np` heights at `zseg` (cloud order), restricted to
 // the chains in R.  The chains only share the point count, and every cell starts the call at count 0 (:61-75), so point i
@@ -306,17 +314,19 @@ union ReduceLds {
 // the 9 per-call layers of one cell (minimal layers: the three that nothing in the path reads are not maintained); B = the tile's
 // block of the per-call layers (gg_internal.h percall_index: [layer position][cell]), `cell` = row in tile + 16 * column in tile.
 // (Cells of a border tile beyond the map's last row / column exist in the block and are written like the others: nobody reads them.)
-template <bool FULL>
+template <int MODE>
 GG_DEV void write_cell(float *B, int cell, float c, float raw, const CellState &st)
 {
     constexpr int P = TILE * TILE;
-    B[PL_POINTS * P + cell] = c;
-    B[PL_MINGROUNDHEIGHT * P + cell] = st.mn;
-    B[PL_M2 * P + cell] = st.m2;
-    B[PL_VARIANCE * P + cell] = st.m2 / (c + FLT_MIN); // :323
-    B[PL_POINTSRAW * P + cell] = raw;
-    B[PL_MEANVARIANCE * P + cell] = st.mean;
-    if (FULL) {
+    if (MODE != K2_LAZY3) { // (K5 has counted the non-ground points into `points` since: a later launch must leave it alone)
+        B[PL_POINTS * P + cell] = c;
+        B[PL_MINGROUNDHEIGHT * P + cell] = st.mn;
+        B[PL_M2 * P + cell] = st.m2;
+        B[PL_VARIANCE * P + cell] = st.m2 / (c + FLT_MIN); // :323
+        B[PL_POINTSRAW * P + cell] = raw;
+        B[PL_MEANVARIANCE * P + cell] = st.mean;
+    }
+    if (MODE != K2_MINIMAL) {
         B[PL_MAXGROUNDHEIGHT * P + cell] = st.mx;
         B[PL_GROUNDCANDIDATES * P + cell] = st.gc;
         B[PL_PLANEDIST * P + cell] = st.pdm;
@@ -348,7 +358,7 @@ GG_DEV void load_light_records(uint2 (&rw)[WB], const uint2 *sorted, uint32_t st
     }
 }
 
-template <bool FULL>
+template <int MODE>
 GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint4 *tile_list, int n_light, int first, int stride, LightLds &lds)
 {
     if (first >= n_light) return;
@@ -358,7 +368,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
     const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX};
     const float oz = cp.oz;
     const bool timing = a.k2_debug == 9;
-    constexpr int RL = FULL ? (R_MEAN | R_GC | R_PDM | R_MN) : (R_MEAN | R_MN);
+    constexpr int RL = chains_of<MODE>();
 
     // the work list's entries say everything about a tile (gg_internal.h); the entry of the tile after this one is requested a
     // tile ahead (unconditionally, at a clamped index), its records while this tile's recurrences run
@@ -477,13 +487,13 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
                 const uint32_t cb = half_column_bits(__ballot((wv >> 16) != 0u)); // (pointsRaw > 0: the cell holds an in-map record)
                 cols_now |= cb << (8 * k);
                 if ((cb >> (lane >> 3)) & 1u)
-                    write_cell<FULL>(L + percall_index(rank, 0, 0), cell, (float)np, (float)(wv >> 16), st);
+                    write_cell<MODE>(L + percall_index(rank, 0, 0), cell, (float)np, (float)(wv >> 16), st);
                 seg = seg_end;
             }
             lds_order(); // (the next tile reuses the memory)
             if (timing && lane == 0) dbg_add(a, 28, __builtin_readcyclecounter() - t_p1); // chains + writes
         }
-        if (lane == 0) tile_live[rank] = cols_now;
+        if (MODE != K2_LAZY3 && lane == 0) tile_live[rank] = cols_now; // (K2_LAZY3: the same half columns as when the call wrote them)
         if (timing && lane == 0) {
             dbg_add(a, had_points ? 8 : 12, 1ull);
             dbg_add(a, had_points ? 9 : 14, (unsigned long long)(end - start));
@@ -497,7 +507,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
 }
 
 // ---- dense tiles: one work-group per tile -----------------------------------------------------------------------------------
-template <bool FULL>
+template <int MODE>
 GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4 ent, DenseLds &lds, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -636,11 +646,11 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
         ex[0 * TILE_CELLS + cell] = (float)lds.ctot[cell];
         ex[3 * TILE_CELLS + cell] = (float)lds.craw[cell];
     };
-    const bool split = FULL && (lds.wave_full[0] | lds.wave_full[1] | lds.wave_full[2] | lds.wave_full[3]) != 0u; // (uniform)
+    const bool split = MODE == K2_FULL && (lds.wave_full[0] | lds.wave_full[1] | lds.wave_full[2] | lds.wave_full[3]) != 0u; // (uniform)
     if (!split) {
         const int cell = (int)lds.perm[tid];
         CellState st = reset;
-        run_cells<FULL ? (R_MEAN | R_GC | R_PDM | R_MN) : (R_MEAN | R_MN), 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st);
+        run_cells<chains_of<MODE>(), 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st);
         put_shared(cell);
         ex[1 * TILE_CELLS + cell] = st.mn;
         ex[2 * TILE_CELLS + cell] = st.m2;
@@ -702,7 +712,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     st.gc = ex[6 * TILE_CELLS + tid];
     st.pdm = ex[7 * TILE_CELLS + tid];
     if (half_column_written)
-        write_cell<FULL>(percall_ptr(a, cp.slot) + percall_index(rank, 0, 0), tid, ex[0 * TILE_CELLS + tid], ex[3 * TILE_CELLS + tid], st);
+        write_cell<MODE>(percall_ptr(a, cp.slot) + percall_index(rank, 0, 0), tid, ex[0 * TILE_CELLS + tid], ex[3 * TILE_CELLS + tid], st);
     if (timing && tid == 0) {
         tmark[5] = __builtin_readcyclecounter();
         dbg_add(a, 0, 1ull);                       // dense tiles
@@ -717,7 +727,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
 // are stored sparsely -- tile_live[rank] says which half columns of a tile physically hold values (the ones with in-map records of
 // this cloud), every other cell logically holds the per-call reset values (:61-75), and the readers substitute them
 // (gg_internal.h tile_live).  Exact: gg_get_layer returns at all times what the reference's layers would hold.
-template <bool FULL>
+template <int MODE>
 GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params, ReduceLds &lds, int cloud, int group, int n_groups, int n_dense_groups)
 {
     const CloudParams cp = params[cloud];
@@ -737,9 +747,9 @@ GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params,
             __asm__ volatile("" : "+v"(tid));
             const uint4 ent = tile_list[a.g.T - 1 - j];
             const int rank = (int)(ent.x & 0xFFFFu);
-            reduce_dense_tile<FULL>(a, cp, ent, lds.dense, tid);
+            reduce_dense_tile<MODE>(a, cp, ent, lds.dense, tid);
             __syncthreads(); // (the next tile reuses the shared memory)
-            if (tid == 0) // the tile's half columns that hold records now (every wavefront left its eight bits)
+            if (MODE != K2_LAZY3 && tid == 0) // the tile's half columns that hold records now (every wavefront left its eight bits)
                 (a.tile_live + (size_t)cp.slot * a.tile_live_stride)[rank] =
                     lds.dense.wave_full[0] | (lds.dense.wave_full[1] << 8) | (lds.dense.wave_full[2] << 16) | (lds.dense.wave_full[3] << 24);
         }
@@ -747,12 +757,12 @@ GG_DEV void reduce_share(const Arena &a, const CloudParams *__restrict__ params,
         const int n_light = a.k2_skip == 1 ? 0 : (int)list_cnt[0];
         const int n_waves = (n_groups - n_dense_groups) * 4;
         const int wave = threadIdx.x >> 6;
-        reduce_light_tiles<FULL>(a, cp, tile_list, n_light, (group - n_dense_groups) * 4 + wave, n_waves, lds.light[wave]);
+        reduce_light_tiles<MODE>(a, cp, tile_list, n_light, (group - n_dense_groups) * 4 + wave, n_waves, lds.light[wave]);
     }
 }
 
 // grid = (GD + GL, clouds): one work-group per share.
-template <bool FULL>
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reduce(const Arena a, const CloudParams *__restrict__ params, int n_dense_groups)
 {
     __shared__ ReduceLds lds;
@@ -772,7 +782,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         atomicMax(&census[2], r);
         atomicMin(&census[4], t_wg);
     }
-    reduce_share<FULL>(a, params, lds, cloud, group, (int)gridDim.x, n_dense_groups);
+    reduce_share<MODE>(a, params, lds, cloud, group, (int)gridDim.x, n_dense_groups);
     if (a.k2_debug == 6 && threadIdx.x == 0 && item < 65536u) { // (tools/k2_trace.py: one record per work-group)
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         unsigned long long *rec = a.k2_dbg + (size_t)item * 4;
@@ -805,9 +815,26 @@ void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hi
     const int gd = std::max(1, per_cloud * dense_share / 16), gl = std::max(1, per_cloud - gd);
     dim3 grid(gd + gl, n_clouds);
     if (a.flags & GG_FLAG_MINIMAL_LAYERS)
-        hipLaunchKernelGGL(k_reduce<false>, grid, dim3(256), 0, s, a, d_params, gd);
+        hipLaunchKernelGGL(k_reduce<K2_MINIMAL>, grid, dim3(256), 0, s, a, d_params, gd);
     else
-        hipLaunchKernelGGL(k_reduce<true>, grid, dim3(256), 0, s, a, d_params, gd);
+        hipLaunchKernelGGL(k_reduce<K2_FULL>, grid, dim3(256), 0, s, a, d_params, gd);
+}
+
+// The three layers nothing in the path reads (maxGroundHeight, groundCandidates, planeDist), for ONE slot whose last cloud was
+// processed with GG_FLAG_MINIMAL_LAYERS: the same walk over the tile lists and the tile-sorted records that call left in the
+// slot's buffers, running only those layers' recurrences (they share nothing with the others but the point count) and
+// storing only those three planes.  `cp` = the parameters of that call (by value: there is no batch).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_reduce_lazy(const Arena a, const CloudParams cp, int n_dense_groups)
+{
+    __shared__ ReduceLds lds;
+    reduce_share<K2_LAZY3>(a, &cp, lds, 0, (int)blockIdx.x, (int)gridDim.x, n_dense_groups);
+}
+
+void launch_reduce_lazy(const Arena &a, const CloudParams &cp, hipStream_t s)
+{
+    const int per_cloud = std::min(4096, 2 * a.g.T);
+    const int gd = std::max(1, per_cloud * 12 / 16), gl = std::max(1, per_cloud - gd);
+    hipLaunchKernelGGL(k_reduce_lazy, dim3(gd + gl), dim3(256), 0, s, a, cp, gd);
 }
 
 } // namespace gg

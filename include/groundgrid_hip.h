@@ -112,9 +112,11 @@ enum { GG_CLASS_OUTSIDE = 0, GG_CLASS_IGNORED = 1, GG_CLASS_OUTLIER = 2, GG_CLAS
 
 /* gg_set_flags bits */
 enum {
-    GG_FLAG_MINIMAL_LAYERS = 1, /* do not maintain the three layers nothing in the path reads (groundCandidates, planeDist,
-                                   maxGroundHeight: their content is unspecified while the flag is set; clearing it makes
-                                   the next cloud rewrite them everywhere); default off */
+    GG_FLAG_MINIMAL_LAYERS = 1, /* the three layers nothing in the path reads (groundCandidates, planeDist, maxGroundHeight,
+                                   src/GroundSegmentation.cpp:296,303,307) are not maintained per cloud; a reader of one of them
+                                   (gg_get_layer, gg_get_layers, gg_get_layer_image_u8, gg_set_layer) has them computed first, from
+                                   the tile-sorted records the slot's last cloud left on the device -- so every layer reads at all
+                                   times as the reference's would; default off */
     GG_FLAG_PROFILE = 2         /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
 };
 

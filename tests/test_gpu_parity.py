@@ -551,6 +551,72 @@ def test_minimal_layers_flag_keeps_labels_and_terrain():
     assert_same_state(seg.map(0), ref, "after leaving minimal layers")
 
 
+def test_minimal_layers_materialise_the_other_three_on_demand():
+    """GG_FLAG_MINIMAL_LAYERS (lazily materialised layers): k_reduce maintains only the six per-call layers the
+    path reads; maxGroundHeight / groundCandidates / planeDist (src/GroundSegmentation.cpp:296,303,307) are computed when somebody
+    asks, from the tile-sorted records the call left behind.  All 11 layers against the oracle through gg_get_layer, gg_get_layers and
+    the 8-bit image; light and dense tiles (sensor cloud, thousands of points in four cells, NaN heights); several slots of one batch,
+    asked in another order than they ran; a host write in between; a second read costs nothing and changes nothing."""
+    rng = np.random.default_rng(14)
+    n = 20000
+    xy = rng.choice(np.array([5.0, 5.2, 5.4, 7.7]), size=(n, 2)) + rng.uniform(0, 0.05, size=(n, 2))
+    dense = synth.make_cloud(np.column_stack([xy, rng.normal(-1.7, 0.05, size=n)]), ring=rng.integers(0, 64, n))
+    dense["z"][::977] = np.float32("nan")
+    clouds = [synth.hdl64_cloud(seed=8, n_az=600), dense, synth.random_cloud(3000, seed=3, extent=50.0), synth.empty_cloud(0)]
+    for cloud in clouds:
+        seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=max(len(cloud), 1))
+        seg.set_flags(minimal_layers=True)
+        ref = oracle.OracleMap(120.0, 0.33)
+        for f in range(2):
+            _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+            r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+            assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"])
+            if f == 0:
+                assert_same_state(seg.map(0), ref, "one layer at a time")  # (gg_get_layer, in the layers' own order)
+            else:
+                got = seg.map(0).layers()  # (gg_get_layers: one call)
+                for name in oracle.LAYERS:
+                    assert nan_equal(got[name], ref.layer(name)), name
+            assert_same_state(seg.map(0), ref, "second read")
+        img, lo, hi = seg.map(0).image_u8("maxGroundHeight")
+        want = ref.layer("maxGroundHeight")
+        assert lo == np.nanmin(want) and hi == np.nanmax(want)
+        seg.close()
+    # a batch of four slots; the layers of slot 2 are asked first, slot 0 only after another cloud went through slot 1
+    B = 4
+    batch = [synth.hdl64_cloud(seed=40 + b, n_az=300 + 50 * b) for b in range(B)]
+    stride = (max(len(c) for c in batch) + 3) // 4 * 4
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride)
+    seg.set_flags(minimal_layers=True)
+    refs = [oracle.OracleMap(120.0, 0.33) for _ in range(B)]
+    for b in range(B):
+        seg.map(b).reset()
+    seg.filter_batch(_batch_inputs(16, batch, stride), [len(c) for c in batch], np.zeros((B, 3), np.float32), np.full(B, -1.73))
+    for b in range(B):
+        refs[b].filter_cloud(batch[b], ORIGIN0, -1.73)
+    assert_same_state(seg.map(2), refs[2], "slot 2")
+    seg.filter_cloud(batch[3], ORIGIN0, -1.73, map=seg.map(1))
+    refs[1].filter_cloud(batch[3], ORIGIN0, -1.73)
+    for b in (0, 1, 3, 2):
+        assert_same_state(seg.map(b), refs[b], f"slot {b}")
+    # a host write of a maintained layer densifies all nine: the three must have been computed before
+    mine = np.full(refs[0].layer("m2").shape, 2.5, dtype=np.float32)
+    seg.filter_cloud(batch[0], ORIGIN0, -1.73, map=seg.map(0))
+    refs[0].filter_cloud(batch[0], ORIGIN0, -1.73)
+    seg.map(0).set("m2", mine)
+    for name in oracle.LAYERS:
+        assert nan_equal(seg.map(0)[name], mine if name == "m2" else refs[0].layer(name)), name
+    # the flag cleared with a slot still owing its three layers: they are still delivered, and the next cloud writes all nine
+    seg.filter_cloud(batch[1], ORIGIN0, -1.73, map=seg.map(3))
+    refs[3].filter_cloud(batch[1], ORIGIN0, -1.73)
+    seg.set_flags(minimal_layers=False)
+    assert_same_state(seg.map(3), refs[3], "after clearing the flag")
+    seg.filter_cloud(batch[2], ORIGIN0, -1.73, map=seg.map(3))
+    refs[3].filter_cloud(batch[2], ORIGIN0, -1.73)
+    assert_same_state(seg.map(3), refs[3], "full layers again")
+    seg.close()
+
+
 def test_sparse_per_call_layers_at_the_host_boundary():
     """The nine per-call layers are stored sparsely (only the half columns with records of the last cloud hold values): gg_get_layer,
     the 8-bit images and the terrain image must still show the reference's dense matrices, a host write of ONE per-call layer
@@ -704,6 +770,27 @@ def test_index_fast_path_boundaries():
     pos = (float(np.float64(np.float32(5.0)) - half), float(np.float64(np.float32(-7.25)) - half))
     pts = np.array([[5.0, -7.25, -1.0], [5.0, -7.0, -1.0], [4.9, -7.25, -1.2], [3.0, -9.0, -1.1]], dtype=np.float32)
     run_pair(synth.make_cloud(pts), pos=pos, origin=(pos[0], pos[1], 0.0), frames=1)
+
+
+@pytest.mark.parametrize("pos", [(0.0, 0.0), (500000.3, 5800000.7), (-1.0e7, 3.3e6), (9.0e8, -9.9e8), (3.0e9, -2.0e10), (1.0e15, 1.0e15)])
+def test_map_border_points_near_and_far_from_the_frame_origin(pos):
+    """isInside (grid_map GridMapMath.cpp checkIfPositionWithinMap, called from src/GroundSegmentation.cpp:230) and getIndex at
+    the map's four borders: points on, next to and beyond them, at UTM-sized map positions and at positions so far out that an
+    ulp of the coordinates is larger than a cell, have to match the oracle.  (Written for an experiment that took the isInside
+    test only for points whose index is not strictly interior -- tools/experiments/k1_interior_index_shortcut.patch: exact, no
+    faster -- and kept for the cases.)"""
+    m = oracle.OracleMap(120.0, 0.33, pos=pos)
+    half, res = 0.5 * m.length[0], m.resolution
+    offs = []
+    for k in (-2, -1, 0, 1, 2, 3, 180, 361, 362, 363, 364, 365):
+        for d in (0.0, 1e-7, -1e-7, 0.5 * res):
+            offs.append(half - k * res + d)
+    offs = np.array(offs + [1e30, -1e30, np.inf, np.nan])
+    xs = (np.float64(pos[0]) + offs).astype(np.float32)
+    ys = (np.float64(pos[1]) + offs).astype(np.float32)
+    X, Y = np.meshgrid(xs, ys)
+    pts = np.column_stack([X.ravel(), Y.ravel(), np.full(X.size, -1.7, dtype=np.float32)])
+    run_pair(synth.make_cloud(pts), pos=pos, origin=(np.float32(pos[0]), np.float32(pos[1]), 0.0), frames=2)
 
 
 # ---------------------------------------------------------------- N1: map follows the vehicle (GroundGrid::update)
