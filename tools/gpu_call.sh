@@ -2,9 +2,12 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -12 > gpurun_out/t19_tests.log
+cat gpurun_out/t19_tests.log
 V=$GRAFT_REPO_ROOT/groundgrid_amd/variants
 for rep in 1 2 3; do
   GROUNDGRID_HIP_LIB=$V/lib_base.so timeout 200 python tools/ab_kernels.py 1024 8 base 2>&1 | tail -1
-  GROUNDGRID_HIP_LIB=$V/lib_occ5.so timeout 200 python tools/ab_kernels.py 1024 8 old_code_5_waves 2>&1 | tail -1
-  timeout 200 python tools/ab_kernels.py 1024 8 k2_light_by_record 2>&1 | tail -1
-done | tee gpurun_out/t18_ab.log
+  timeout 200 python tools/ab_kernels.py 1024 8 k2_dense_roles_rotated 2>&1 | tail -1
+done | tee gpurun_out/t19_ab.log
+GROUNDGRID_HIP_LIB=$V/lib_base.so timeout 300 python tools/ab_config4.py 128 base 2>&1 | tail -1 | tee gpurun_out/t19_c4.log
+timeout 300 python tools/ab_config4.py 128 k2_dense_roles_rotated 2>&1 | tail -1 | tee -a gpurun_out/t19_c4.log
