@@ -156,6 +156,7 @@ int device_error(gg_context *ctx)
     const uint32_t code = ctx->h_dev_error ? *ctx->h_dev_error : 0u;
     if (code == GG_DEVERR_NONE) return GG_OK;
     return fail(ctx, GG_ERR_HIP, code == GG_DEVERR_FRONT_WAIT ? "k_classify: a cloud's tile scan never completed (bounded wait ran out); the outputs of that batch are void"
+                                 : code == GG_DEVERR_SCAN_WAIT ? "k_scan: the sums of an earlier part of a cloud never arrived (bounded wait ran out); the outputs of that batch are void"
                                  : code == GG_DEVERR_SWEEP_WAIT ? "k_sweep: a hand-over between work-groups never arrived (bounded wait ran out); the outputs of that batch are void"
                                                                 : "a kernel reported an unknown device-side error");
 }
@@ -637,6 +638,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_tlcnt = carve((size_t)n_slots * 2 * 4);
     const size_t o_fsync = carve(((size_t)2 * n_slots + 16) * 4);
     const size_t o_ssync = carve(64);
+    const size_t o_scansync = carve((size_t)n_slots * SCAN_SYNC_WORDS * 8);
     a.sweep_xchg_stride = align_up(std::max<size_t>(gg::sweep_xchg_entries(ctx->sweep_params), 1) * 16, A) / 8;
     const size_t o_xchg = carve((size_t)n_slots * a.sweep_xchg_stride * 8);
     const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
@@ -688,6 +690,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
     a.front_sync = (uint32_t *)(base + o_fsync);
     a.sweep_sync = (uint32_t *)(base + o_ssync);
+    a.scan_sync = (unsigned long long *)(base + o_scansync);
     {
         const uint32_t first_epoch[4] = {0u, 0u, 1u, 0u}; // (the exchange region starts zeroed: tag 0 is never current)
         CREATE_CHK(hipMemcpyAsync(a.sweep_sync, first_epoch, sizeof first_epoch, hipMemcpyHostToDevice, ctx->stream));
@@ -1545,6 +1548,8 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     else if (!strcmp(key, "sweep_split")) ctx->arena.tune_sweep_split = value;
     else if (!strcmp(key, "front")) ctx->arena.tune_front = std::min(value, 3);
     else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
+    else if (!strcmp(key, "scan_parts")) ctx->arena.tune_scan_parts = value;
+    else if (!strcmp(key, "scan_fault")) ctx->arena.tune_scan_fault = value;
     else if (!strcmp(key, "sweep_fault")) ctx->arena.tune_sweep_fault = value;
     else if (!strcmp(key, "clear_device_error")) *ctx->h_dev_error = 0u;
     else if (!strcmp(key, "k2_per_cloud")) ctx->arena.tune_k2_per_cloud = value;

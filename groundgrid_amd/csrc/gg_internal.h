@@ -36,6 +36,7 @@ constexpr int PACKED_TILE_COUNTERS_MIN_T = 1024; // maps with more tiles keep K1
 constexpr int K2_LIGHT_MAX = 512; // tiles with at most this many records are reduced by a single wavefront (k2_reduce.hip)
 // key = tile_rank << 12 | emit << 10 | class << 8 | cell_in_tile (row_in_tile | col_in_tile << 4)
 constexpr int KEY_TILE_SHIFT = 12;
+constexpr int SCAN_MAX_PARTS = 16, SCAN_SYNC_WORDS = 1 + SCAN_MAX_PARTS; // (k_sort.hip k_scan_parts)
 constexpr uint32_t KEY_EMIT_BIT = 1u << 10;
 constexpr int KEY_CLASS_SHIFT = 8;
 
@@ -129,6 +130,8 @@ struct Arena {
                                                      // lookup: x = Morton rank, y / z = first / end
                                                      // of its records in `sorted`, w = first row | first col << 16
     uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
+    unsigned long long *scan_sync; // [n_slots][SCAN_SYNC_WORDS] k_scan as several work-groups per cloud (sort_core.h "PARTS"): ticket counter, then one
+                                   // word per part; zeroed before every such launch
     uint32_t *sweep_sync; // [4] ticket counter, finished work-groups, epoch of k_sweep launches with several work-groups per cloud (k4_sweep.hip)
     unsigned long long *sweep_xchg; size_t sweep_xchg_stride; // [slot] exchange region between the work-groups of one sweep (sweep_core.h "Parts"), in 64-bit words
     int n_slots; // independent map states of the context
@@ -142,6 +145,8 @@ struct Arena {
     int tune_sweep_split;   // k_sweep "split steps": 0 = when a launch has one ring group per work-group and at most 256 work-groups, 1 = whenever gpw == 1, 2 = never
     int tune_sweep_poll_cap; // tests: polls after which k_sweep's waits give up (0 = about a second)
     int tune_sweep_fault;   // tests: sweep::Params::debug_fault
+    int tune_scan_fault;    // tests: 1 = the first part of a cloud's scan never publishes its sums (the waits of the others run out: GG_DEVERR_SCAN_WAIT)
+    int tune_scan_parts;    // tests: work-groups per cloud in k_scan (0 = the launcher's choice, k_sort.hip scan_parts)
     int tune_front;         // the front end (classify + tile sort): 0 = the launcher's choice, 1 = three launches (k_classify, k_scan,
                             // k_scatter), 2 = the scan inside k_classify (the last work-group of a cloud to finish scans it), 3 = one launch
                             // (after the scan every work-group scatters its own chunks)
@@ -248,7 +253,8 @@ struct PerDeviceOnce {
 };
 
 // codes a kernel leaves in Arena::dev_error when it gives up a bounded wait
-enum : uint32_t { GG_DEVERR_NONE = 0, GG_DEVERR_FRONT_WAIT = 1 /* k_classify: a cloud's scan never completed */, GG_DEVERR_SWEEP_WAIT = 2 /* k_sweep: a hand-over never arrived */ };
+enum : uint32_t { GG_DEVERR_NONE = 0, GG_DEVERR_FRONT_WAIT = 1 /* k_classify: a cloud's scan never completed */, GG_DEVERR_SWEEP_WAIT = 2 /* k_sweep: a hand-over never arrived */,
+                  GG_DEVERR_SCAN_WAIT = 3 /* k_scan in parts: an earlier part's sums never arrived */ };
 // the front end's launch shapes (Arena::tune_front)
 enum : int { FRONT_AUTO = 0, FRONT_THREE_LAUNCHES = 1, FRONT_SCAN_IN_CLASSIFY = 2, FRONT_ONE_LAUNCH = 3 };
 constexpr int FRONT_DEFAULT_SHAPE = FRONT_THREE_LAUNCHES;

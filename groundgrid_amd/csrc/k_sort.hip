@@ -13,6 +13,8 @@
 #include "gg_device.h"
 #include "sort_core.h"
 
+#include <algorithm>
+
 namespace gg {
 
 __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams *__restrict__ params)
@@ -23,10 +25,41 @@ __global__ __launch_bounds__(1024) void k_scan(const Arena a, const CloudParams 
     scan_cloud<16, false>(a, cp, (cp.n_points + a.PW - 1) / a.PW, lds, part);
 }
 
+// ... of one cloud by gridDim.x work-groups (sort_core.h scan_cloud "PARTS"): few clouds on a map with thousands of tiles
+// (configs[3]: 3969 tiles x 257 chunk rows = 4 MB of counters per cloud, and one work-group per cloud would leave half the CUs idle).
+__global__ __launch_bounds__(1024) void k_scan_parts(const Arena a, const CloudParams *__restrict__ params)
+{
+    __shared__ uint32_t lds[32];
+    __shared__ u32x4 part[1024];
+    const CloudParams cp = params[blockIdx.y];
+    unsigned long long *sync = a.scan_sync + (size_t)blockIdx.y * SCAN_SYNC_WORDS;
+    if (threadIdx.x == 0) lds[0] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(sync), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int my_part = (int)lds[0]; // (a ticket, not blockIdx: the parts before this one are running or done)
+    __syncthreads();
+    scan_cloud<16, false>(a, cp, (cp.n_points + a.PW - 1) / a.PW, lds, part, my_part, (int)gridDim.x, sync + 1);
+}
+
+// parts per cloud: only where a part still has >= 64 tile groups and the launch would not fill the chip by itself; a part's
+// range must fit one round of the work-group (1024 tile groups)
+int scan_parts(const Arena &a, int n_clouds)
+{
+    const int G = a.hist_pitch / 4;
+    if (a.tune_scan_parts > 0) return std::max((G + 1023) / 1024, std::min(a.tune_scan_parts, SCAN_MAX_PARTS));
+    if (G < 512 || n_clouds >= 512) return 1;
+    return std::max((G + 1023) / 1024, std::min(std::min(SCAN_MAX_PARTS, G / 64), 512 / n_clouds));
+}
+
 void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)
 {
     if (n_clouds == 0) return;
-    hipLaunchKernelGGL(k_scan, dim3(n_clouds), dim3(1024), 0, s, a, d_params);
+    const int parts = scan_parts(a, n_clouds);
+    if (parts <= 1) { // (one work-group walks any number of rounds)
+        hipLaunchKernelGGL(k_scan, dim3(n_clouds), dim3(1024), 0, s, a, d_params);
+        return;
+    }
+    hipMemsetAsync(a.scan_sync, 0, (size_t)n_clouds * SCAN_SYNC_WORDS * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_scan_parts, dim3(parts, n_clouds), dim3(1024), 0, s, a, d_params);
 }
 
 __global__ __launch_bounds__(256) void k_scatter(const Arena a, const CloudParams *__restrict__ params)

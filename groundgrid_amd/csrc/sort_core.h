@@ -82,8 +82,16 @@ template <bool AGENT> GG_DEV void store16_row(__amdgpu_buffer_rsrc_t r, uint32_t
     else __builtin_amdgcn_raw_buffer_store_b128(v, r, word * 4u, 0, 0);
 }
 
+// PARTS (k_scan only, maps with many tiles and few clouds per launch): the cloud's tile groups are cut into `n_parts` consecutive
+// ranges, one work-group each (`part` = a ticket taken when the work-group started: whoever waits, waits for work-groups that are
+// already running, in any dispatch order).  A part sums its own columns, leaves (records, light tiles, dense tiles) of its range
+// in ONE 64-bit word of `sync` (valid bit 63: no second flag, nothing to order), waits -- bounded -- for the words of the parts
+// before it, and goes on from their sum.  The hand-over costs every part one agent-scope round trip in a kernel that is two
+// passes over a 4 MB histogram (n = 1000).  `sync` == nullptr: one work-group does it all.
+constexpr uint32_t SCAN_WAIT_POLLS = 1u << 20; // x s_sleep(16): about half a second
 template <int NW, bool AGENT>
-GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t *lds /*[NW + 1]*/, u32x4 *part = nullptr /*[64 NW]*/)
+GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t *lds /*[NW + 1]*/, u32x4 *part = nullptr /*[64 NW]*/,
+                       int my_part = 0, int n_parts = 1, unsigned long long *sync = nullptr /*[n_parts]*/)
 {
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x;
@@ -92,15 +100,18 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
     uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
     uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     uint4 *tile_list = a.tile_list + (size_t)cp.slot * a.tile_list_stride;
+    // this work-group's tile groups [G_lo, G_hi) (a part's range fits one round: launch_scan)
+    const int Gp = (G + n_parts - 1) / n_parts;
+    const int G_lo = min(G, my_part * Gp), G_hi = min(G, G_lo + Gp);
     // GS tile groups per round, each shared by Q threads (chunk ranges); thread -> (share q, group gi)
-    const int GS = part ? min(NT, (G + 63) & ~63) : NT, Q = part ? NT / GS : 1;
+    const int GS = part ? min(NT, (max(G_hi - G_lo, 1) + 63) & ~63) : NT, Q = part ? NT / GS : 1;
     const int gi = tid % GS, q = tid / GS;
     const int c_lo = q < Q ? (int)((long long)nch * q / Q) : 0, c_hi = q < Q ? (int)((long long)nch * (q + 1) / Q) : 0;
 
     uint32_t carry = 0, lcarry = 0, dcarry = 0;
-    for (int g0 = 0; g0 < G; g0 += GS) {
+    for (int g0 = G_lo; g0 < G_hi || (sync && g0 == G_lo); g0 += GS) { // (a part without tile groups still says so)
         const int g = g0 + gi;
-        const bool have = g < G && q < Q;
+        const bool have = g < G_hi && q < Q;
         u32x4 s = {0u, 0u, 0u, 0u};
         if (have) {
 #pragma unroll 16
@@ -142,6 +153,27 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
             }
             uint32_t ltotal;
             const uint32_t lexcl = block_exclusive_scan<NW>(nl | (nd << 16), lds, ltotal);
+            if (sync) { // (one round per part)
+                if (tid == 0 && !(a.tune_scan_fault && my_part == 0)) // (tests: the first part withholds its word, the others' waits must run out)
+                    __hip_atomic_store(&sync[my_part], (unsigned long long)total | ((unsigned long long)(ltotal & 0xFFFFu) << 32) |
+                                       ((unsigned long long)(ltotal >> 16) << 47) | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long w = 1ull << 63;
+                if (tid < my_part) {
+                    uint32_t polls = 0;
+                    while (((w = __hip_atomic_load(&sync[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull && polls < SCAN_WAIT_POLLS) {
+                        __builtin_amdgcn_s_sleep(16);
+                        ++polls;
+                    }
+                    if ((w >> 63) == 0ull) __hip_atomic_store(a.dev_error, (uint32_t)GG_DEVERR_SCAN_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                const bool mine = tid < my_part;
+                uint32_t before_t, before_l;
+                block_exclusive_scan<NW>(mine ? (uint32_t)w : 0u, lds, before_t);
+                block_exclusive_scan<NW>(mine ? (uint32_t)((w >> 32) & 0x7FFFu) | ((uint32_t)((w >> 47) & 0x7FFFu) << 16) : 0u, lds, before_l);
+                carry = before_t;
+                lcarry = before_l & 0xFFFFu;
+                dcarry = before_l >> 16;
+            }
             uint32_t li = lcarry + (lexcl & 0xFFFFu), di = dcarry + (lexcl >> 16), start = carry + excl;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -176,12 +208,13 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
         }
         carry += total;
     }
-    if (tid == 0) {
+    if (tid == 0 && my_part == n_parts - 1) { // (the last part knows the sums over all of them)
         tile_start[T] = carry;
         uint32_t *lc = a.tile_list_cnt + (size_t)cp.slot * 2;
         lc[0] = lcarry;
         lc[1] = dcarry;
     }
+    if (my_part != 0) return; // (the part that waits for nobody also does the emission counters)
 
     // emission counters: exclusive prefix over chunks for each of the 4 categories (read by K5, the next kernel but two)
     const __amdgpu_buffer_rsrc_t ce = words_rsrc(a.chunk_emit + (size_t)cp.slot * a.emit_stride, a.emit_stride);

@@ -358,6 +358,79 @@ def test_front_end_in_one_two_and_three_launches(shape, pw, n_az, geometry, monk
     seg.close()
 
 
+@pytest.mark.parametrize("length,resolution,pw,parts", [(120.0, 0.33, 2048, 5), (120.0, 0.33, 64, 16), (200.0, 0.2, 0, 0), (200.0, 0.2, 1024, 3),
+                                                         (200.0, 0.2, 256, 16), (280.0, 0.2, 0, 0), (280.0, 0.2, 512, 2), (280.0, 0.2, 2048, 13)])
+def test_tile_scan_cut_into_several_work_groups(length, resolution, pw, parts, monkeypatch):
+    """k_scan with several work-groups per cloud (sort_core.h scan_cloud "PARTS": a part sums its tile groups' columns, publishes
+    its sums in one 64-bit word, waits for the parts before it): forced part counts 2 .. 16 (0 = the launcher's own choice for
+    maps with thousands of tiles and few clouds) on 529, 3969 and 7744 tiles, part ranges that are ragged or shorter than a
+    wavefront, 1 .. ~270 chunk rows, clouds of very different sizes and an empty one in the same launch.  Two frames, labels /
+    order / counts and all 11 layers against the oracle."""
+    if pw:
+        monkeypatch.setenv("GG_PW", str(pw))
+    k = np.float32(length / 120.0)
+    clouds = []
+    for j, frac in enumerate([1.0, 0.2, 0.6]):
+        c = synth.clone_cloud(synth.hdl64_cloud(seed=930 + j, n_az=max(8, int(280 * frac))))
+        c["x"] *= k
+        c["y"] *= k
+        clouds.append(c)
+    clouds.insert(1, synth.empty_cloud(0))
+    B, stride = len(clouds), (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=B, max_points=stride)
+    seg.debug_set_tuning("scan_parts", parts)
+    pts = _batch_inputs(16, clouds, stride)
+    import torch
+
+    refs = [oracle.OracleMap(length, resolution) for _ in clouds]
+    out = None
+    for frame in range(2):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73), out=out)
+        torch.cuda.synchronize()
+        seg.synchronize()
+        labels, index, counts = out.labels.cpu().numpy(), out.out_index.cpu().numpy(), out.counts.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, ORIGIN0, -1.73)
+            n = len(c)
+            assert np.array_equal(labels[b, :n], r["label"]), (frame, b)
+            assert np.array_equal(index[b, :n], r["index"]), (frame, b)
+            assert counts[b, 0] == len(r["out_points"]) and counts[b, 3] == (r["cls"] == oracle.OUTLIER).sum(), (frame, b)
+            assert_same_state(seg.map(b), refs[b], f"{parts} parts, frame {frame}, cloud {b}")
+    seg.close()
+
+
+def test_scan_part_that_never_publishes_is_an_error_not_a_hang():
+    """The parts of a cloud's scan wait for the sums of the parts before them -- bounded: a part whose predecessor never
+    publishes (debug knob) gives up after about half a second, the kernels run to their end and the next synchronising call
+    reports GG_ERR_HIP with the reason; afterwards the context works again."""
+    import torch
+
+    clouds = _rotated_clouds(2, 120.0)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=2, max_points=stride)
+    seg.debug_set_tuning("scan_parts", 4)
+    seg.debug_set_tuning("scan_fault", 1)
+    pts = _batch_inputs(16, clouds, stride)
+    n, org, bz = [len(c) for c in clouds], np.zeros((2, 3), np.float32), np.full(2, -1.73)
+    seg.filter_batch(pts, n, org, bz)
+    torch.cuda.synchronize()  # (returns: the kernels ended)
+    with pytest.raises(api.GroundGridError, match="k_scan: the sums of an earlier part"):
+        seg.synchronize()
+    seg.debug_set_tuning("scan_fault", 0)
+    seg.debug_set_tuning("clear_device_error", 0)
+    seg.reset_maps(0, 2)
+    refs = [oracle.OracleMap(120.0, 0.33) for _ in clouds]
+    out = seg.filter_batch(pts, n, org, bz)
+    torch.cuda.synchronize()
+    seg.synchronize()
+    labels = out.labels.cpu().numpy()
+    for b, c in enumerate(clouds):
+        r = refs[b].filter_cloud(c, ORIGIN0, -1.73)
+        assert np.array_equal(labels[b, : len(c)], r["label"]), b
+        assert_same_state(seg.map(b), refs[b], f"after the fault, cloud {b}")
+    seg.close()
+
+
 def test_batch_with_a_slot_permutation():
     """gg_batch.slots (ABI v3): cloud b meets map slots[b]; the maps keep their own histories under changing permutations, and
     duplicate / out-of-range entries are rejected."""

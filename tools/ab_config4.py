@@ -12,6 +12,8 @@ base = synth.os128_cloud_fast(seed=20240113)
 n, stride = len(base), (len(base) + 63) // 64 * 64
 seg = api.GroundSegmentation().init(200.0, 0.2, n_slots=B, max_points=stride)
 seg.set_flags(profile=True)
+if os.environ.get("SCAN_PARTS"):
+    seg.debug_set_tuning("scan_parts", int(os.environ["SCAN_PARTS"]))
 pts = torch.zeros((B, stride, 16), dtype=torch.uint8, device="cuda")
 for b in range(B):
     ang = np.float32(2.0 * np.pi * b / B)

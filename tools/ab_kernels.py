@@ -14,6 +14,8 @@ n = [len(c) for c in clouds]
 stride = (max(n) + 63) // 64 * 64
 seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=batch, max_points=stride)
 seg.set_flags(profile=True)
+if os.environ.get("SCAN_PARTS"):
+    seg.debug_set_tuning("scan_parts", int(os.environ["SCAN_PARTS"]))
 host = np.zeros((batch, stride), dtype=api.POINT16_DTYPE)
 for b, c in enumerate(clouds):
     host[b, : len(c)] = api.pack16(c)

@@ -2,12 +2,19 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -12 > gpurun_out/t19_tests.log
-cat gpurun_out/t19_tests.log
-V=$GRAFT_REPO_ROOT/groundgrid_amd/variants
-for rep in 1 2 3; do
-  GROUNDGRID_HIP_LIB=$V/lib_base.so timeout 200 python tools/ab_kernels.py 1024 8 base 2>&1 | tail -1
-  timeout 200 python tools/ab_kernels.py 1024 8 k2_dense_roles_rotated 2>&1 | tail -1
-done | tee gpurun_out/t19_ab.log
-GROUNDGRID_HIP_LIB=$V/lib_base.so timeout 300 python tools/ab_config4.py 128 base 2>&1 | tail -1 | tee gpurun_out/t19_c4.log
-timeout 300 python tools/ab_config4.py 128 k2_dense_roles_rotated 2>&1 | tail -1 | tee -a gpurun_out/t19_c4.log
+{
+timeout 300 python tools/ab_config4.py 128 parts_auto 2>&1 | tail -1
+SCAN_PARTS=8 timeout 300 python tools/ab_config4.py 128 parts8 2>&1 | tail -1
+SCAN_PARTS=16 timeout 300 python tools/ab_config4.py 128 parts16 2>&1 | tail -1
+GG_K2_PER_CLOUD=128 timeout 300 python tools/ab_config4.py 128 k2_per_cloud128 2>&1 | tail -1
+GG_K2_DENSE_SHARE=14 timeout 300 python tools/ab_config4.py 128 k2_dense14 2>&1 | tail -1
+GG_K2_DENSE_SHARE=8 timeout 300 python tools/ab_config4.py 128 k2_dense8 2>&1 | tail -1
+GG_K2_PER_CLOUD=128 GG_K2_DENSE_SHARE=14 timeout 300 python tools/ab_config4.py 128 k2_128_dense14 2>&1 | tail -1
+} | tee gpurun_out/t21_c4.log
+{
+timeout 200 python tools/ab_kernels.py 1 40 one_cloud_auto 2>&1 | tail -1
+SCAN_PARTS=2 timeout 200 python tools/ab_kernels.py 1 40 one_cloud_parts2 2>&1 | tail -1
+SCAN_PARTS=4 timeout 200 python tools/ab_kernels.py 1 40 one_cloud_parts4 2>&1 | tail -1
+timeout 200 python tools/ab_kernels.py 8 40 eight_auto 2>&1 | tail -1
+SCAN_PARTS=2 timeout 200 python tools/ab_kernels.py 8 40 eight_parts2 2>&1 | tail -1
+} | tee gpurun_out/t21_one.log
