@@ -2,19 +2,13 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-{
-timeout 300 python tools/ab_config4.py 128 parts_auto 2>&1 | tail -1
-SCAN_PARTS=8 timeout 300 python tools/ab_config4.py 128 parts8 2>&1 | tail -1
-SCAN_PARTS=16 timeout 300 python tools/ab_config4.py 128 parts16 2>&1 | tail -1
-GG_K2_PER_CLOUD=128 timeout 300 python tools/ab_config4.py 128 k2_per_cloud128 2>&1 | tail -1
-GG_K2_DENSE_SHARE=14 timeout 300 python tools/ab_config4.py 128 k2_dense14 2>&1 | tail -1
-GG_K2_DENSE_SHARE=8 timeout 300 python tools/ab_config4.py 128 k2_dense8 2>&1 | tail -1
-GG_K2_PER_CLOUD=128 GG_K2_DENSE_SHARE=14 timeout 300 python tools/ab_config4.py 128 k2_128_dense14 2>&1 | tail -1
-} | tee gpurun_out/t21_c4.log
-{
-timeout 200 python tools/ab_kernels.py 1 40 one_cloud_auto 2>&1 | tail -1
-SCAN_PARTS=2 timeout 200 python tools/ab_kernels.py 1 40 one_cloud_parts2 2>&1 | tail -1
-SCAN_PARTS=4 timeout 200 python tools/ab_kernels.py 1 40 one_cloud_parts4 2>&1 | tail -1
-timeout 200 python tools/ab_kernels.py 8 40 eight_auto 2>&1 | tail -1
-SCAN_PARTS=2 timeout 200 python tools/ab_kernels.py 8 40 eight_parts2 2>&1 | tail -1
-} | tee gpurun_out/t21_one.log
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r04c_tests.log
+cat gpurun_out/r04c_tests.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+bash tools/profile_round.sh r04c > gpurun_out/r04c_profile.log 2>&1
+tail -3 gpurun_out/r04c_profile.log
+bash tools/sq_pmc.sh > gpurun_out/r04c/sq_counters.txt 2>&1
+rm -rf gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3
+cp profiles/pmc_summary.json gpurun_out/r04c/pmc_summary_final.json
+cp gpurun_out/r04c_tests.log gpurun_out/r04c/gpu_tests.log
+ls gpurun_out/r04c

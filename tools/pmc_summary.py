@@ -24,6 +24,7 @@ def per_kernel(path, biggest_only=False):
     vals = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].replace("gg::", "")
+        k = {"k_scan_parts": "k_scan"}.get(k, k)  # (the scan of one cloud by several work-groups: the same row of the tables)
         if k in KERNELS:
             vals[k].append(float(r["Counter_Value"]))
     if biggest_only:
