@@ -1,14 +1,15 @@
 # scratch: what the next gpurun call runs (edited per call)
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r04c_tests.log
-cat gpurun_out/r04c_tests.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash tools/profile_round.sh r04c > gpurun_out/r04c_profile.log 2>&1
-tail -3 gpurun_out/r04c_profile.log
-bash tools/sq_pmc.sh > gpurun_out/r04c/sq_counters.txt 2>&1
-rm -rf gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3
-cp profiles/pmc_summary.json gpurun_out/r04c/pmc_summary_final.json
-cp gpurun_out/r04c_tests.log gpurun_out/r04c/gpu_tests.log
-ls gpurun_out/r04c
+REPO=$GRAFT_REPO_ROOT; OUT=$REPO/gpurun_out/r04c_c4; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+C4="python $REPO/bench.py --only-config4 --cpu-seconds 0"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch4" -o f -- $C4 > /dev/null 2> "$OUT/fetch4.err"
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write4" -o w -- $C4 > /dev/null 2> "$OUT/write4.err"
+F4=$(find "$OUT/fetch4" -name '*counter_collection.csv' | head -1)
+W4=$(find "$OUT/write4" -name '*counter_collection.csv' | head -1)
+python "$REPO/tools/pmc_summary.py" "$F4" "$W4" "$REPO/profiles/r04c" 128 config4_kernels > "$OUT/pmc_summary_config4.log" 2>&1
+cp "$REPO/profiles/r04c/pmc_raw_per_launch_config4_kernels.json" "$REPO/profiles/pmc_summary.json" "$OUT/"
+rm -rf "$OUT/fetch4" "$OUT/write4"
+cat $OUT/pmc_summary_config4.log | tail -12
+cd $REPO && timeout 600 python bench.py --only-config4 > $OUT/config4_line.json 2> $OUT/config4_line.err; tail -c 600 $OUT/config4_line.json
