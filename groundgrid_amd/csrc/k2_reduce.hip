@@ -249,9 +249,12 @@ GG_DEV void four_points(const float (&z)[4], uint32_t i, uint32_t np, const doub
 // the chains in R.  The chains only share the point count, and every cell starts the call at count 0 (:61-75), so point i
 // of every lane has c = i: wave-uniform, and 1 / (c + 1) comes from a table through the scalar cache.
 template <int R, int NB>
-GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s, bool dbg_one_line = false)
+GG_DEV void run_cells(const float *zseg, uint32_t np, float oz, CellState &s, bool dbg_one_line = false, const float *dbg_coalesced = nullptr)
 {
-    const zquad *zq = reinterpret_cast<const zquad *>(zseg);
+    // (measurement only, results void: GG_K2_DEBUG=4 every lane re-reads the first 16 bytes of its own segment -- 64 lines per load
+    // instruction, all cache hits; GG_K2_DEBUG=7 the lanes read 64 CONSECUTIVE 16-byte pieces -- 8 lines per instruction)
+    const zquad *zq = reinterpret_cast<const zquad *>(dbg_coalesced ? dbg_coalesced + 4 * (threadIdx.x & 63) : zseg);
+    if (dbg_coalesced) dbg_one_line = true;
     uint32_t nmax = np;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
@@ -650,7 +653,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     if (!split) {
         const int cell = (int)lds.perm[tid];
         CellState st = reset;
-        run_cells<chains_of<MODE>(), 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st);
+        run_cells<chains_of<MODE>(), 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st, a.k2_debug == 4, a.k2_debug == 7 ? zc : nullptr);
         put_shared(cell);
         ex[1 * TILE_CELLS + cell] = st.mn;
         ex[2 * TILE_CELLS + cell] = st.m2;
@@ -666,16 +669,16 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
         const float *zseg = zc + lds.cseg[cell];
         const uint32_t np = lds.ctot[cell];
         if (wave == 0) {
-            run_cells<R_MEAN, 6>(zseg, np, oz, st, a.k2_debug == 4);
+            run_cells<R_MEAN, 6>(zseg, np, oz, st, a.k2_debug == 4, a.k2_debug == 7 ? zc : nullptr);
             put_shared(cell);
             ex[2 * TILE_CELLS + cell] = st.m2;
             ex[4 * TILE_CELLS + cell] = st.mean;
         } else if (wave == 1) {
-            run_cells<R_GC, 6>(zseg, np, oz, st, a.k2_debug == 4);
+            run_cells<R_GC, 6>(zseg, np, oz, st, a.k2_debug == 4, a.k2_debug == 7 ? zc : nullptr);
             ex[5 * TILE_CELLS + cell] = st.mx;
             ex[6 * TILE_CELLS + cell] = st.gc;
         } else {
-            run_cells<R_PDM | R_MN, 6>(zseg, np, oz, st, a.k2_debug == 4);
+            run_cells<R_PDM | R_MN, 6>(zseg, np, oz, st, a.k2_debug == 4, a.k2_debug == 7 ? zc : nullptr);
             ex[1 * TILE_CELLS + cell] = st.mn;
             ex[7 * TILE_CELLS + cell] = st.pdm;
         }
@@ -683,7 +686,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
         for (int g = 1; g < 4; ++g) {
             const int cell = (int)lds.perm[g * 64 + lane];
             CellState st = reset;
-            run_cells<R_MEAN | R_GC | R_PDM | R_MN, 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st);
+            run_cells<R_MEAN | R_GC | R_PDM | R_MN, 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st, a.k2_debug == 4, a.k2_debug == 7 ? zc : nullptr);
             put_shared(cell);
             ex[1 * TILE_CELLS + cell] = st.mn;
             ex[2 * TILE_CELLS + cell] = st.m2;
