@@ -61,6 +61,7 @@ struct gg_context {
     std::vector<char> no_confidence;  // per slot: groundpatch <= 0.01 everywhere for sure (set by gg_reset_map, cleared by any writer)
     // GG_FLAG_MINIMAL_LAYERS: the slot's last cloud left maxGroundHeight / groundCandidates / planeDist unwritten; a reader of one of
     // them has them computed first, from what that call left in the slot's buffers and with its parameters (ensure_lazy_layers)
+    bool probe_unordered_streams = false; // measurement only: batches and resets on different caller streams are NOT ordered by the library
     std::vector<char> lazy_pending;
     std::vector<gg::CloudParams> lazy_params;
 
@@ -339,7 +340,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     // order this batch after everything that touched map state on the context's stream, and after an earlier batch that ran
     // on another stream
     if (s != ctx->stream && ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->map_event, 0));
-    if (ctx->have_batch_event && ctx->last_batch_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->batch_event, 0));
+    if (ctx->have_batch_event && ctx->last_batch_stream != s && !ctx->probe_unordered_streams) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->batch_event, 0));
     if (ctx->gather_lo) { // an all-gather still reads label masks: a batch on another stream that rewrites them waits for it
         auto overlaps = [&](const uint8_t *p, size_t bytes) { return p && p < ctx->gather_hi && p + bytes > ctx->gather_lo; };
         const size_t per_cloud = b->cloud_stride;
@@ -998,7 +999,7 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
         if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     } else { // ordered like a batch on the caller's stream
         if (ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->map_event, 0));
-        if (ctx->have_batch_event && ctx->last_batch_stream != st) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->batch_event, 0));
+        if (ctx->have_batch_event && ctx->last_batch_stream != st && !ctx->probe_unordered_streams) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->batch_event, 0));
     }
     const Arena &a = ctx->arena;
     for (int s = first_slot; s < first_slot + n; ++s) {
@@ -1551,6 +1552,7 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     else if (!strcmp(key, "scan_parts")) ctx->arena.tune_scan_parts = value;
     else if (!strcmp(key, "scan_fault")) ctx->arena.tune_scan_fault = value;
     else if (!strcmp(key, "sweep_fault")) ctx->arena.tune_sweep_fault = value;
+    else if (!strcmp(key, "probe_unordered_streams")) ctx->probe_unordered_streams = value != 0; // (tools/fill_overlap_probe.py: the CALLER orders its streams)
     else if (!strcmp(key, "clear_device_error")) *ctx->h_dev_error = 0u;
     else if (!strcmp(key, "k2_per_cloud")) ctx->arena.tune_k2_per_cloud = value;
     else if (!strcmp(key, "k2_dense_share")) ctx->arena.tune_k2_dense_share = std::min(value, 15);
