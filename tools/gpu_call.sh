@@ -2,4 +2,4 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for rep in 1 2; do timeout 300 python tools/fill_overlap_probe.py 1024 2>&1 | tail -1; done | tee gpurun_out/t25_fill.log
+timeout 1200 python tools/fuzz_knobs.py 0 120 2>&1 | grep -v amdgpu.ids | tail -12 | tee gpurun_out/t28_fuzz_knobs.log
