@@ -667,7 +667,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
         const int cell = (int)lds.perm[lane];
         CellState st = reset;
         const float *zseg = zc + lds.cseg[cell];
-        const uint32_t np = lds.ctot[cell];
+        const uint32_t np = a.k2_debug == 8 ? 0u : lds.ctot[cell]; // (GG_K2_DEBUG=8, timing only: what the tile's 64 fullest cells cost)
         if (wave == 0) {
             run_cells<R_MEAN, 6>(zseg, np, oz, st, a.k2_debug == 4, a.k2_debug == 7 ? zc : nullptr);
             put_shared(cell);

@@ -2,4 +2,10 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python tools/fuzz_knobs.py 0 120 2>&1 | grep -v amdgpu.ids | tail -12 | tee gpurun_out/t28_fuzz_knobs.log
+for rep in 1 2; do
+  timeout 200 python tools/ab_kernels.py 1024 8 normal 2>&1 | tail -1
+  GG_K2_DEBUG=8 timeout 200 python tools/ab_kernels.py 1024 8 without_the_64_fullest_cells_chains 2>&1 | tail -1
+  GG_K2_DEBUG=3 timeout 200 python tools/ab_kernels.py 1024 8 dense_tiles_stop_after_placing 2>&1 | tail -1
+  GG_K2_SKIP=2 timeout 200 python tools/ab_kernels.py 1024 8 no_dense_tiles 2>&1 | tail -1
+  GG_K2_SKIP=1 timeout 200 python tools/ab_kernels.py 1024 8 no_light_tiles 2>&1 | tail -1
+done | tee gpurun_out/t29_ab.log
