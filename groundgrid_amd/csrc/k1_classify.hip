@@ -177,7 +177,7 @@ GG_DEV uint32_t make_key(const Arena &a, const uint16_t *tile_rank, int gi0, int
 constexpr uint32_t FRONT_WAIT_POLLS = 1u << 22; // x ~0.3 us: gives up after about a second
 
 template <int FMT, int SHAPE>
-__global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io, int n_counters)
+__global__ __launch_bounds__(256, 5) void k_classify(const Arena a, const CloudParams *__restrict__ params, const BatchIO io, int n_counters)
 {
     // dynamic LDS only (a static variable would shift its base off 16 bytes): [4][words] histograms, the tile ranks, 16 scratch words
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
@@ -242,15 +242,18 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
         // ITEMS independent 64-point windows per trip: all point loads are issued before the first classification, so
         // several HBM / L2 round trips (point record, then the old-ground gather) are in flight per lane.
         constexpr int ITEMS = 4;
+        // ... and the points of the NEXT trip are requested before this one is classified (unconditional loads at clamped indices; the
+        // registers change hands at the loop's back edge, where the wait for them is the wait the next trip would start with)
+        PointIn pt[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) pt[j] = load_point<FMT>(pts, (size_t)min(base + j * 64 + lane, end - 1));
         for (int p0 = base; p0 < end; p0 += 64 * ITEMS) {
-            PointIn pt[ITEMS];
+            PointIn pt_next[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) pt_next[j] = load_point<FMT>(pts, (size_t)min(p0 + 64 * ITEMS + j * 64 + lane, end - 1));
             bool valid[ITEMS];
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const int p = p0 + j * 64 + lane;
-                valid[j] = p < end;
-                pt[j] = load_point<FMT>(pts, (size_t)(valid[j] ? p : base));
-            }
+            for (int j = 0; j < ITEMS; ++j) valid[j] = p0 + j * 64 + lane < end;
             if (cp.has_tf) { // N2: cloud still in the sensor frame (uniform branch)
 #pragma unroll
                 for (int j = 0; j < ITEMS; ++j) transform_point(cp.tf, pt[j].x, pt[j].y, pt[j].z);
@@ -305,6 +308,8 @@ __global__ __launch_bounds__(256, 6) void k_classify(const Arena a, const CloudP
                 n_ign += (uint32_t)__popcll(__ballot(emit && cls == GG_CLASS_IGNORED));
                 n_outl += (uint32_t)__popcll(__ballot(inmap && cls == GG_CLASS_OUTLIER));
             }
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) pt[j] = pt_next[j];
         }
 
         // the chunk's row of `hist` (zeros in its padding) and its emission counters, 16 bytes at a time
