@@ -2,6 +2,8 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/final_tests.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; head -c 2400 gpurun_out/final_bench.json
+for rep in 1 2; do
+  timeout 200 python tools/ab_kernels.py 1024 8 normal 2>&1 | tail -1
+  GG_K3_DEBUG=3 timeout 200 python tools/ab_kernels.py 1024 8 k3_no_cell_passes 2>&1 | tail -1
+  GG_K3_DEBUG=1 timeout 200 python tools/ab_kernels.py 1024 8 k3_prologue_only 2>&1 | tail -1
+done | tee gpurun_out/t33_ab.log
