@@ -710,6 +710,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.k2_debug = getenv("GG_K2_DEBUG") ? atoi(getenv("GG_K2_DEBUG")) : 0;
     a.k2_dbg = (unsigned long long *)(base + o_k2dbg);
     a.k3_debug = getenv("GG_K3_DEBUG") ? atoi(getenv("GG_K3_DEBUG")) : 0;
+    a.k5_debug = getenv("GG_K5_DEBUG") ? atoi(getenv("GG_K5_DEBUG")) : 0;
     ctx->d_params = (CloudParams *)(base + o_params);
     ctx->d_stage_pts = (gg_point16 *)(base + o_spts);
     ctx->d_stage_labels = (uint8_t *)(base + o_slab);

@@ -157,6 +157,8 @@ struct Arena {
     int k2_debug;        // env GG_K2_DEBUG (measurement only): 1 = k_reduce stops after the tile lookup, 2 = after step 1, 3 = after step 3,
                          // 9 = per-phase cycle counters into k2_dbg (tools/k2_phases.py)
     unsigned long long *k2_dbg; // [64] when k2_debug == 9
+    int k5_debug;        // env GG_K5_DEBUG (measurement only, results void), bits: 1 = no gathers (every lane reads element 0), 2 = no label / index stores,
+                         // 4 = no `points` atomics
     int k3_debug;        // env GG_K3_DEBUG (measurement only): 1 = k_patch stops after the tile check, 2 = after staging, 3 = after the first test (:364)
     int eigen_reduction; // gg_conventions::eigen_reduction (GG_EIGEN_33 / GG_EIGEN_34_SSE): order of the 5x5 block sums in K3
 };
