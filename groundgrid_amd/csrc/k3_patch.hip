@@ -147,7 +147,7 @@ constexpr int RING = 32, SLOTS = RING + 4, MAXTC = 256;
 
 __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams *__restrict__ params, int n_bands, int blocks_per_segment)
 {
-    __shared__ float pts[SLOTS][LR], var[SLOTS][LR], mnl[SLOTS][LR];
+    __shared__ __attribute__((aligned(16))) float pts[SLOTS][LR], var[SLOTS][LR], mnl[SLOTS][LR]; // (LR * 4 bytes = 9 x 16: every row quad is 16-byte aligned)
     // vertical partial sums of `points` over the window's 12 columns and the block's 32 rows: 5 rows (v5) and the middle 3 (v3).
     // `points` holds COUNTS -- integer-valued floats far below 2^24 -- so the S x S block sum of :359 is an exact integer in ANY
     // order of addition: the one float sum of the path that may be taken as a separable box filter (5 + 5 taps instead of 25,
@@ -205,11 +205,17 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     const float *gp_min = L + percall_index(0, PL_MINGROUNDHEIGHT, 0);
     float2 *gp2 = gp2_ptr(a, cp.slot);
 
-    // staging registers: up to LC columns x LR rows = 432 cells, two per thread
-    float sp[2], sv[2], sm[2];
+    // staging registers: LC columns x LR rows = 12 x 9 QUADS of four rows, the three layers of one quad per thread (threads
+    // 0 .. 107): a tile's block of a layer holds a column's 16 rows contiguously and the window starts at a tile row, so a quad
+    // is 16 aligned bytes of one half column -- one 16-byte load costs the CU's vector-memory front end what a 4-byte one does
+    // (tools/ubench/ta_lines.hip), and the liveness of a half column (8 rows) covers the whole quad
+    constexpr int QR = LR / 4; // quads per window column
+    static_assert(LR % 4 == 0 && TILE % 4 == 0, "row quads must not straddle half columns");
+    float4 sp4 = make_float4(0.f, 0.f, 0.f, 0.f), sv4 = sp4, sm4 = sp4;
     float4 cell_next = make_float4(0.0f, __builtin_inff(), 0.0f, 0.0f); // the per-cell constants (Arena::patch_table) of this thread's cell in the requested block
     const int tr = tid % PR, tcl = tid / PR;
     const int i = r0 + tr;
+    const int q_lc = tid / QR, q_lr = 4 * (tid % QR); // this thread's quad: window column, first window row
     // Every load of the walk is UNCONDITIONAL (lanes with nothing to fetch read element 0, one broadcast line): loads and
     // stores share one in-order counter, and the compiler can only leave younger loads in flight across a wait when it knows how
     // many there are.  With a load under a branch every wait became vmcnt(0): the block's sums waited for the NEXT block's
@@ -221,40 +227,34 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             const float4 e = a.patch_table[v ? (size_t)i + (size_t)jj * rows : (size_t)0]; // :358, :334, :364, :369 and the layer element
             cell_next = make_float4(e.x, v ? e.y : __builtin_inff(), e.z, e.w); // (no such cell: never visited)
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = tid + 256 * h;
-            const int lr = k % LR, lc = k / LR;
-            const int gr = r0 - HALO + lr, gcol = first_col + lc;
-            const bool ok = lc < n_cols && gr < rows && gcol < cols;
-            // the per-call layers are sparse (gg_internal.h tile_live): a half column that holds no record of this cloud has stale
-            // bytes and logically the reset values of :61-75 -- points 0, variance 0 / (0 + FLT_MIN) = 0, minGroundHeight FLT_MAX.
-            // Its lanes fetch element 0 like the out-of-range ones (still unconditional loads): no HBM traffic for dead half columns
-            const int btr = ok ? (gr - (r0 - HALO)) / TILE : 0, btc = ok ? gcol / TILE : 0;
-            const int cell_in_tile = (gr % TILE) + (gcol % TILE) * TILE;
-            const bool live = ok && ((live_cols[btr][btc] >> live_bit(cell_in_tile)) & 1u) != 0u;
-            const size_t idx = live ? percall_index((int)band_rank[btr][btc], 0, cell_in_tile) : (size_t)0;
-            const float p = gp_pts[idx], v = gp_var[idx], m = gp_min[idx];
-            sp[h] = live ? p : 0.0f;
-            sv[h] = live ? v : 0.0f;
-            sm[h] = live ? m : (ok ? FLT_MAX : 0.0f);
-        }
+        const int gr = r0 - HALO + q_lr, gcol = first_col + q_lc;
+        const bool ok = q_lc < n_cols && gr < rows && gcol < cols;
+        // the per-call layers are sparse (gg_internal.h tile_live): a half column that holds no record of this cloud has stale
+        // bytes and logically the reset values of :61-75 -- points 0, variance 0 / (0 + FLT_MIN) = 0, minGroundHeight FLT_MAX.
+        // Its lanes fetch element 0 like the out-of-range ones (still unconditional loads): no HBM traffic for dead half columns
+        const int btr = ok ? q_lr / TILE : 0, btc = ok ? gcol / TILE : 0;
+        const int cell_in_tile = (gr % TILE) + (gcol % TILE) * TILE;
+        const bool live = ok && ((live_cols[btr][btc] >> live_bit(cell_in_tile)) & 1u) != 0u;
+        const size_t idx = live ? percall_index((int)band_rank[btr][btc], 0, cell_in_tile) : (size_t)0;
+        const float4 p = *reinterpret_cast<const float4 *>(gp_pts + idx), v = *reinterpret_cast<const float4 *>(gp_var + idx),
+                     m = *reinterpret_cast<const float4 *>(gp_min + idx);
+        // (rows of a border tile beyond the map's last row exist in the block and hold nothing: they count as outside)
+        const bool l0 = live, l1 = live && gr + 1 < rows, l2 = live && gr + 2 < rows, l3 = live && gr + 3 < rows;
+        const bool o0 = ok, o1 = ok && gr + 1 < rows, o2 = ok && gr + 2 < rows, o3 = ok && gr + 3 < rows;
+        sp4 = make_float4(l0 ? p.x : 0.0f, l1 ? p.y : 0.0f, l2 ? p.z : 0.0f, l3 ? p.w : 0.0f);
+        sv4 = make_float4(l0 ? v.x : 0.0f, l1 ? v.y : 0.0f, l2 ? v.z : 0.0f, l3 ? v.w : 0.0f);
+        sm4 = make_float4(l0 ? m.x : (o0 ? FLT_MAX : 0.0f), l1 ? m.y : (o1 ? FLT_MAX : 0.0f), l2 ? m.z : (o2 ? FLT_MAX : 0.0f), l3 ? m.w : (o3 ? FLT_MAX : 0.0f));
     };
     auto deposit = [&](int first_col, int n_cols) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = tid + 256 * h;
-            const int lr = k % LR, lc = k / LR;
-            if (lc < n_cols) {
-                const int slot = (first_col + lc) & (RING - 1);
-                pts[slot][lr] = sp[h];
-                var[slot][lr] = sv[h];
-                mnl[slot][lr] = sm[h];
-                if (slot < SLOTS - RING) { // the mirror
-                    pts[slot + RING][lr] = sp[h];
-                    var[slot + RING][lr] = sv[h];
-                    mnl[slot + RING][lr] = sm[h];
-                }
+        if (q_lc < n_cols) { // (threads beyond the window's quads hold nothing)
+            const int slot = (first_col + q_lc) & (RING - 1);
+            *reinterpret_cast<float4 *>(&pts[slot][q_lr]) = sp4;
+            *reinterpret_cast<float4 *>(&var[slot][q_lr]) = sv4;
+            *reinterpret_cast<float4 *>(&mnl[slot][q_lr]) = sm4;
+            if (slot < SLOTS - RING) { // the mirror
+                *reinterpret_cast<float4 *>(&pts[slot + RING][q_lr]) = sp4;
+                *reinterpret_cast<float4 *>(&var[slot + RING][q_lr]) = sv4;
+                *reinterpret_cast<float4 *>(&mnl[slot + RING][q_lr]) = sm4;
             }
         }
     };
