@@ -287,12 +287,15 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         const bool near = cell_const.y < 0.0f;
         const float threshold = fabsf(cell_const.y);
         // :359 the block's point count from the vertical partial sums (exact: integers, see v5 / v3)
-        for (int e = tid; e < LC * PR; e += 256) {
-            const int c = e / PR, r = e % PR;
+        if (tid < LC * (PR / 2)) { // two vertically adjacent outputs per thread: six reads instead of ten (192 threads, one pass)
+            const int c = tid / (PR / 2), r = 2 * (tid % (PR / 2));
             const float *col = pts[base + c] + r; // rows r .. r + 4 of the window = output row r - 2 .. r + 2
-            const float mid = (col[1] + col[2]) + col[3];
-            v3[c][r] = mid;
-            v5[c][r] = (col[0] + col[4]) + mid;
+            const float x0 = col[0], x1 = col[1], x2 = col[2], x3 = col[3], x4 = col[4], x5 = col[5];
+            const float mid0 = (x1 + x2) + x3, mid1 = (x2 + x3) + x4;
+            v3[c][r] = mid0;
+            v5[c][r] = (x0 + x4) + mid0;
+            v3[c][r + 1] = mid1;
+            v5[c][r + 1] = (x1 + x5) + mid1;
         }
         __syncthreads();
         const float pointsblockSum = near ? (v3[tcl + 1][tr] + v3[tcl + 2][tr]) + v3[tcl + 3][tr]
