@@ -1136,15 +1136,13 @@ int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
     int want[GG_NUM_LAYERS], n_want = 0;
     for (int l = 0; l < GG_NUM_LAYERS; ++l)
         if (const int rc = ensure_lazy_layers(ctx, slot, dst[l] && lazy_layer(l))) return rc;
+    unsigned want_mask = 0u;
     for (int l = 0; l < GG_NUM_LAYERS; ++l) {
         if (!dst[l]) continue;
-        float *d = ctx->d_planes + (size_t)n_want * plane;
-        if (l == GG_LAYER_GROUND || l == GG_LAYER_GROUNDPATCH)
-            launch_plane_extract(ctx->arena, slot, l == GG_LAYER_GROUNDPATCH, d, ctx->stream);
-        else
-            launch_layer_extract(ctx->arena, slot, l, d, ctx->stream);
+        want_mask |= 1u << l;
         want[n_want++] = l;
     }
+    if (n_want) launch_layers_extract(ctx->arena, slot, want_mask, ctx->d_planes, plane, ctx->stream); // (plane k = the k-th requested layer)
     if (n_want == 0) return GG_OK;
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_planes, ctx->d_planes, (size_t)n_want * plane * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

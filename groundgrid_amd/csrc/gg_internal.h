@@ -287,7 +287,8 @@ void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
 void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s); // sheared layer -> column-major plane
 void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, hipStream_t s);
-void launch_layer_extract(const Arena &a, int slot, int layer, float *dst, hipStream_t s); // per-call layer -> dense column-major plane (reset values outside the live columns)
+void launch_layer_extract(const Arena &a, int slot, int layer, float *dst, hipStream_t s);
+void launch_layers_extract(const Arena &a, int slot, unsigned want, float *dst, size_t plane_floats, hipStream_t s); // (all requested layers, one launch) // per-call layer -> dense column-major plane (reset values outside the live columns)
 void launch_materialise_layers(const Arena &a, int slot, hipStream_t s);                  // write the reset values into every dead column of the slot's per-call layers, mark all live
 void launch_layer_to_u8(const float *layer, int rows, int cols, float *d_bounds, uint8_t *d_img, hipStream_t s);
 void launch_terrain_image(const Arena &a, int slot, float *d_img, hipStream_t s);

@@ -101,6 +101,40 @@ void launch_layer_extract(const Arena &a, int slot, int layer, float *dst, hipSt
     hipLaunchKernelGGL(k_layer_extract, dim3(blocks), dim3(256), 0, s, a, slot, layer, dst);
 }
 
+// ... and all the layers a caller asked for in one launch (gg_get_layers): `want` = bit per gg_layer, plane k of `dst` = the k-th
+// requested layer in gg_layer order.  The cell's liveness, its place in the tile blocks and its element of the sheared
+// (ground, confidence) layer are worked out once for all of them -- eleven launches of the kernels above are eleven launch
+// latencies for 0.5 MB each.
+__global__ __launch_bounds__(256) void k_layers_extract(const Arena a, int slot, unsigned want, float *__restrict__ dst, size_t plane)
+{
+    const float *src = percall_ptr(a, slot);
+    const float2 *gp2 = gp2_ptr(a, slot);
+    const int rows = a.g.rows;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.g.C; i += gridDim.x * blockDim.x) {
+        const int r = i % rows, c = i / rows;
+        const bool live = cell_is_live(a, slot, r, c);
+        const size_t at = percall_index_of(a, 0, r, c);
+        float2 g = make_float2(0.f, 0.f);
+        if (want & ((1u << GG_LAYER_GROUND) | (1u << GG_LAYER_GROUNDPATCH))) g = gp2[gp_idx(a, r, c)];
+        int k = 0;
+#pragma unroll
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) {
+            if (!((want >> l) & 1u)) continue; // (uniform)
+            float v;
+            if (l == GG_LAYER_GROUND) v = g.x;
+            else if (l == GG_LAYER_GROUNDPATCH) v = g.y;
+            else v = live ? src[at + (size_t)percall_position(l) * (TILE * TILE)] : layer_reset_value(l);
+            dst[(size_t)k * plane + i] = v;
+            ++k;
+        }
+    }
+}
+void launch_layers_extract(const Arena &a, int slot, unsigned want, float *dst, size_t plane_floats, hipStream_t s)
+{
+    const int blocks = (a.g.C + 255) / 256 < 2048 ? (a.g.C + 255) / 256 : 2048;
+    hipLaunchKernelGGL(k_layers_extract, dim3(blocks), dim3(256), 0, s, a, slot, want, dst, plane_floats);
+}
+
 // Make a slot's per-call layers dense in place: every dead column receives the reset values, then every column is marked live.
 // Needed before the host overwrites ONE per-call layer (gg_set_layer): the liveness masks are shared by the nine layers.
 __global__ __launch_bounds__(256) void k_materialise(const Arena a, int slot)
