@@ -22,7 +22,7 @@ STATUS = {
     -6: "GG_ERR_NO_DEVICE",
 }
 
-GG_ABI_VERSION = 4  # include/groundgrid_hip.h
+GG_ABI_VERSION = 5  # include/groundgrid_hip.h
 GG_POINT32, GG_POINT16 = 0, 1
 GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE = 1, 2
 GG_NUM_KERNELS = 7
@@ -41,6 +41,7 @@ SYMBOLS = [
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
     "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep",
+    "gg_device_error", "gg_run_stage", "gg_filter_cloud_pc2_out", "gg_get_gridmap_message",
     "gg_collective_available", "gg_comm_unique_id", "gg_comm_init_rank", "gg_comm_init_rank_for", "gg_comm_destroy", "gg_allgather_label_masks",
 ]
 
@@ -102,7 +103,21 @@ class GGBatch(C.Structure):
         ("d_out_counts", C.c_void_p),
         ("d_label_masks", C.c_void_p),
         ("slots", C.POINTER(C.c_int32)),
+        ("d_out_pc2", C.c_void_p),
     ]
+
+
+GG_PC2_POINT_STEP = 18
+GG_STAGE_DETECT_GROUND_PATCHES, GG_STAGE_SPIRAL_GROUND_INTERPOLATION = 1, 2
+GG_STAGE_DETECT_GROUND_PATCH_3, GG_STAGE_DETECT_GROUND_PATCH_5, GG_STAGE_INTERPOLATE_CELL = 3, 4, 5
+
+
+class GGStageArgs(C.Structure):
+    _fields_ = [("section", C.c_int), ("i", C.c_int), ("j", C.c_int), ("base_z", C.c_double)]
+
+
+class GGGridMapHeader(C.Structure):
+    _fields_ = [("seq", C.c_uint32), ("stamp_sec", C.c_uint32), ("stamp_nsec", C.c_uint32), ("frame_id", C.c_char_p), ("basic_layers", C.c_uint)]
 
 
 class GroundGridError(RuntimeError):
@@ -156,10 +171,14 @@ def load():
     L.gg_filter_cloud_tf.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, vp, P(C.c_size_t), vp, vp]
     L.gg_filter_cloud_pc2.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, vp, vp, P(C.c_size_t)]
     L.gg_get_layers.argtypes = [vp, C.c_int, P(vp)]
+    L.gg_filter_cloud_pc2_out.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, vp, P(C.c_size_t)]
+    L.gg_get_gridmap_message.argtypes = [vp, C.c_int, C.c_uint, P(GGGridMapHeader), vp, C.c_size_t, P(C.c_size_t)]
+    L.gg_run_stage.argtypes = [vp, C.c_int, C.c_int, P(GGStageArgs)]
     L.gg_get_layer_image_u8.argtypes = [vp, C.c_int, C.c_int, vp, P(C.c_float), P(C.c_float)]
     L.gg_get_terrain_image.argtypes = [vp, C.c_int, vp]
     L.gg_filter_batch.argtypes = [vp, P(GGBatch), vp]
     L.gg_synchronize.argtypes = [vp]
+    L.gg_device_error.argtypes = [vp, C.c_int]
     L.gg_get_point_classes.argtypes = [vp, C.c_int, C.c_size_t, vp, vp]
     L.gg_get_kernel_times.argtypes = [vp, P(C.c_double), P(C.c_int64), C.c_int]
     L.gg_set_conventions.argtypes = [vp, P(GGConventions)]

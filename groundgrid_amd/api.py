@@ -26,6 +26,16 @@ DROPPED, GROUND, NONGROUND = 0, 49, 99
 OUTSIDE, IGNORED, OUTLIER, KEPT = 0, 1, 2, 3
 
 POINT16_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("ring", "<u2"), ("pad", "<u2")])
+# the 18-byte sensor_msgs/PointCloud2 record of scripts/kitti_data_publisher.py:139-150
+PC2_DTYPE = np.dtype({"names": ["x", "y", "z", "intensity", "ring"], "formats": ["<f4", "<f4", "<f4", "<f4", "<u2"], "offsets": [0, 4, 8, 12, 16], "itemsize": 18})
+
+
+def to_pc2(cloud: np.ndarray) -> np.ndarray:
+    """PointXYZIR (32 B) -> the 18-byte PointCloud2 records a publisher would send."""
+    out = np.zeros(cloud.shape[0], dtype=PC2_DTYPE)
+    for k in ("x", "y", "z", "intensity", "ring"):
+        out[k] = cloud[k]
+    return out
 
 
 def default_config() -> GGConfig:
@@ -139,6 +149,37 @@ class GridMap:
         _check(L, ctx, L.gg_get_layer_image_u8(ctx, self.slot, LAYERS.index(layer), img.ctypes.data, C.byref(lo), C.byref(hi)), "gg_get_layer_image_u8")
         return img, lo.value, hi.value
 
+    def gridmap_message(self, layers=None, seq: int = 0, stamp=(0, 0), frame_id: str = "map", basic_layers=()) -> bytes:
+        """The serialised grid_map_msgs/GridMap the nodelet publishes per cloud (Nodelet.cpp:211-214), ROS 1 wire format."""
+        L, ctx = self._seg._L, self._seg._ctx
+        mask = 0 if layers is None else sum(1 << LAYERS.index(k) for k in layers)
+        hdr = _lib.GGGridMapHeader(int(seq), int(stamp[0]), int(stamp[1]), frame_id.encode(), sum(1 << LAYERS.index(k) for k in basic_layers))
+        size = C.c_size_t(0)
+        _check(L, ctx, L.gg_get_gridmap_message(ctx, self.slot, mask, C.byref(hdr), None, 0, C.byref(size)), "gg_get_gridmap_message")
+        buf = np.empty(size.value, dtype=np.uint8)
+        _check(L, ctx, L.gg_get_gridmap_message(ctx, self.slot, mask, C.byref(hdr), buf.ctypes.data, buf.size, C.byref(size)), "gg_get_gridmap_message")
+        return buf.tobytes()
+
+    # -- the stage members of the reference's class on this map as it stands (include/groundgrid/GroundSegmentation.h:59-62)
+    def _stage(self, stage, section=0, i=0, j=0, base_z=0.0):
+        L, ctx = self._seg._L, self._seg._ctx
+        args = _lib.GGStageArgs(int(section), int(i), int(j), float(base_z))
+        _check(L, ctx, L.gg_run_stage(ctx, self.slot, stage, C.byref(args)), "gg_run_stage")
+
+    def detect_ground_patches(self, section: int = -1):
+        """detect_ground_patches(map, section) (:314-340): section 0..3, or -1 for all four quadrants."""
+        self._stage(_lib.GG_STAGE_DETECT_GROUND_PATCHES, section=section)
+
+    def detect_ground_patch(self, S: int, i: int, j: int):
+        assert S in (3, 5)
+        self._stage(_lib.GG_STAGE_DETECT_GROUND_PATCH_3 if S == 3 else _lib.GG_STAGE_DETECT_GROUND_PATCH_5, i=i, j=j)
+
+    def spiral_ground_interpolation(self, toBase_z: float):
+        self._stage(_lib.GG_STAGE_SPIRAL_GROUND_INTERPOLATION, base_z=toBase_z)
+
+    def interpolate_cell(self, x: int, y: int):
+        self._stage(_lib.GG_STAGE_INTERPOLATE_CELL, i=x, j=y)
+
     def terrain_image(self) -> np.ndarray:
         """The 32FC3 terrain image of Nodelet.cpp:247-268: rows x cols x (ground, visited flag, pointsRaw)."""
         L, ctx = self._seg._L, self._seg._ctx
@@ -154,6 +195,7 @@ class BatchOutputs:
     counts: "object"      # torch.int32 [B, 4]: returned size, kept, ignored, outliers
     out_clouds: "object" = None
     label_masks: "object" = None  # torch.uint8 [B, stride // 4]: 2 bits per point (0 dropped, 1 ground, 2 non-ground)
+    out_pc2: "object" = None      # torch.uint8 [B, stride * 18]: the returned clouds as 18-byte PointCloud2 records
 
 
 class GroundSegmentation:
@@ -303,6 +345,24 @@ class GroundSegmentation:
         _check(self._L, self._ctx, rc, "gg_filter_cloud_pc2")
         return labels[:n], index[:n], out_n.value
 
+    def filter_cloud_pc2_out(self, data: bytes, n: int, point_step: int, offsets, cloudOrigin, mapToBase_z: float,
+                             map: Optional[GridMap] = None, map_from_cloud=None) -> np.ndarray:
+        """PointCloud2 payload in, PointCloud2 payload out: the returned cloud as 18-byte records (x, y, z, intensity, ring --
+        PC2_DTYPE), written by the label kernel.  Returns the structured array of the returned points."""
+        gm = map if map is not None else self._maps[0]
+        buf = np.frombuffer(data, dtype=np.uint8)
+        assert buf.size >= n * point_step
+        out = np.empty(max(n, 1) * _lib.GG_PC2_POINT_STEP, dtype=np.uint8)
+        out_n = C.c_size_t(0)
+        org = (C.c_float * 3)(*[float(v) for v in cloudOrigin])
+        tf = None
+        if map_from_cloud is not None:
+            tf = (C.c_double * 12)(*[float(v) for v in np.asarray(map_from_cloud, dtype=np.float64).reshape(-1)[:12]])
+        rc = self._L.gg_filter_cloud_pc2_out(self._ctx, gm.slot, buf.ctypes.data, n, point_step, offsets[0], offsets[1], offsets[2], offsets[3],
+                                             tf, org, float(mapToBase_z), out.ctypes.data, C.byref(out_n))
+        _check(self._L, self._ctx, rc, "gg_filter_cloud_pc2_out")
+        return out[: out_n.value * _lib.GG_PC2_POINT_STEP].view(PC2_DTYPE)
+
     # -- insert_cloud's per-point decision (include/groundgrid/GroundSegmentation.h:55)
     def point_classes(self, n: int, map: Optional[GridMap] = None):
         gm = map if map is not None else self._maps[0]
@@ -315,7 +375,7 @@ class GroundSegmentation:
     # -- batched device-resident form
     def filter_batch(self, points, n_points: Sequence[int], origins, base_z, *, first_slot: int = 0,
                      out: Optional[BatchOutputs] = None, want_clouds: bool = False, want_masks: bool = False, stream=None,
-                     transforms=None, slots=None) -> BatchOutputs:
+                     transforms=None, slots=None, want_pc2: bool = False) -> BatchOutputs:
         """points: CUDA torch tensor [B, stride, 16] (packed gg_point16) or [B, stride, 32] (PointXYZIR), uint8.
         Enqueues on the current torch stream and returns without synchronising."""
         import torch
@@ -332,6 +392,7 @@ class GroundSegmentation:
                 counts=torch.empty((B, 4), dtype=torch.int32, device=points.device),
                 out_clouds=torch.empty((B, stride, 32), dtype=torch.uint8, device=points.device) if want_clouds else None,
                 label_masks=torch.zeros((B, stride // 4), dtype=torch.uint8, device=points.device) if want_masks else None,
+                out_pc2=torch.empty((B, stride * _lib.GG_PC2_POINT_STEP), dtype=torch.uint8, device=points.device) if want_pc2 else None,
             )
         npts = (C.c_int32 * B)(*[int(v) for v in n_points])
         org = np.ascontiguousarray(np.asarray(origins, dtype=np.float32).reshape(B, 3))
@@ -353,6 +414,7 @@ class GroundSegmentation:
         b.d_out_clouds = out.out_clouds.data_ptr() if out.out_clouds is not None else None
         b.d_out_counts = out.counts.data_ptr()
         b.d_label_masks = out.label_masks.data_ptr() if out.label_masks is not None else None
+        b.d_out_pc2 = out.out_pc2.data_ptr() if out.out_pc2 is not None else None
         s = stream if stream is not None else torch.cuda.current_stream(points.device).cuda_stream
         # torch hands out 0 for its default stream = the legacy null stream; NULL would mean "the context's own stream" to
         # the library, which is not ordered with torch ops / RCCL -- so name the default stream explicitly

@@ -119,6 +119,7 @@ struct gg_context {
     float *d_planes = nullptr;         // GG_NUM_LAYERS * Cpad floats: dense planes of gg_get_layers (allocated on first use)
     float *h_planes = nullptr;         // ... and their pinned landing zone on the host (one download for all requested layers)
     float *d_bounds = nullptr;         // 2 floats
+    uint8_t *d_pc2 = nullptr, *h_pc2 = nullptr; // gg_filter_cloud_pc2_out: [64 B counts][max_points * 18 B records], device and pinned host (allocated on first use)
     volatile uint32_t *h_dev_error = nullptr;  // host view of Arena::dev_error (mapped pinned memory)
     unsigned long long *d_sweep_dbg = nullptr; // GG_SWEEP_TIMING=1: cycle counters of the sweep's wavefronts (cloud 0 of a batch)
 
@@ -152,10 +153,14 @@ int fail(gg_context *ctx, int code, const char *what, hipError_t e = hipSuccess)
 
 // After a synchronisation: did a kernel give up a bounded wait (Arena::dev_error)?  The reference has no error path at all
 // (SURVEY 5); a library that spins inside kernels must at least say so instead of hanging or returning garbage silently.
+// The word is read AND cleared here: the report is about the batches enqueued since the last report -- their outputs are void, the
+// map states they touched should be re-initialised (gg_reset_map) -- and the context goes on working (a sticky word turned one
+// spurious timeout into GG_ERR_HIP from every later call, gg_reset_map + gg_synchronize included).
 int device_error(gg_context *ctx)
 {
     const uint32_t code = ctx->h_dev_error ? *ctx->h_dev_error : 0u;
     if (code == GG_DEVERR_NONE) return GG_OK;
+    *ctx->h_dev_error = GG_DEVERR_NONE;
     return fail(ctx, GG_ERR_HIP, code == GG_DEVERR_FRONT_WAIT ? "k_classify: a cloud's tile scan never completed (bounded wait ran out); the outputs of that batch are void"
                                  : code == GG_DEVERR_SCAN_WAIT ? "k_scan: the sums of an earlier part of a cloud never arrived (bounded wait ran out); the outputs of that batch are void"
                                  : code == GG_DEVERR_SWEEP_WAIT ? "k_sweep: a hand-over between work-groups never arrived (bounded wait ran out); the outputs of that batch are void"
@@ -360,6 +365,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     io.d_out_clouds = b->d_out_clouds;
     io.d_out_counts = b->d_out_counts;
     io.d_label_masks = b->d_label_masks;
+    io.d_out_pc2 = b->d_out_pc2;
 
     Arena a = ctx->arena;
     a.flags = ctx->flags;
@@ -435,7 +441,7 @@ bool lazy_layer(int layer) { return layer == GG_LAYER_MAXGROUNDHEIGHT || layer =
 
 } // namespace
 
-static int rebuild_patch_table(gg_context *ctx);
+static int rebuild_patch_table(gg_context *ctx, const DevConfig &cfg);
 
 extern "C" {
 
@@ -789,7 +795,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
 
     ctx->helper.configure((getenv("GG_HOST_THREADS") ? std::max(1, std::min(atoi(getenv("GG_HOST_THREADS")), 16)) : 4) - 1);
     {
-        const int rc = rebuild_patch_table(ctx);
+        const int rc = rebuild_patch_table(ctx, a.cfg);
         if (rc != GG_OK) {
             gg_destroy(ctx);
             return rc;
@@ -847,6 +853,8 @@ void gg_destroy(gg_context *ctx)
     if (ctx->h_stage_index) hipHostFree(ctx->h_stage_index);
     if (ctx->h_stage_counts) hipHostFree(ctx->h_stage_counts);
     if (ctx->d_planes) hipFree(ctx->d_planes);
+    if (ctx->d_pc2) hipFree(ctx->d_pc2);
+    if (ctx->h_pc2) hipHostFree(ctx->h_pc2);
     if (ctx->h_planes) hipHostFree(ctx->h_planes);
     if (ctx->d_arena) hipFree(ctx->d_arena);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -856,10 +864,11 @@ void gg_destroy(gg_context *ctx)
 // The per-cell constants of detect_ground_patches (gg_internal.h Arena::patch_table), in the reference's own arithmetic: every cell
 // used to recompute them for every cloud -- a dozen binary64 operations and the sheared layer index per cell and call, a sixth of
 // k_patch's instructions -- although they depend on the cell and the configuration only.
-static int rebuild_patch_table(gg_context *ctx)
+// `cfg`: the configuration the table is for -- the caller commits it to the context only when the table is in place, so that k_patch's
+// thresholds and the rest of the path never come from two configurations.
+static int rebuild_patch_table(gg_context *ctx, const DevConfig &cfg)
 {
     const Geometry &g = ctx->arena.g;
-    const DevConfig &cfg = ctx->arena.cfg;
     const int rows = g.rows, cols = g.cols;
     std::vector<float> t((size_t)g.C * 4);
     const double res2 = (double)g.resolution_f * (double)g.resolution_f;
@@ -893,9 +902,14 @@ static int rebuild_patch_table(gg_context *ctx)
 int gg_set_config(gg_context *ctx, const gg_config *cfg)
 {
     if (!ctx || !cfg) return GG_ERR_INVALID;
-    ctx->cfg = *cfg; // src/GroundSegmentation.cpp:468-471
-    make_dev_config(ctx->cfg, ctx->arena.cfg);
-    return rebuild_patch_table(ctx);
+    // src/GroundSegmentation.cpp:468-471.  Unlike the reference's struct copy this call BLOCKS: it waits for the batches in flight
+    // (they read the old table), rebuilds the per-cell table of detect_ground_patches on the host (O(cells)) and uploads it.
+    DevConfig dev;
+    make_dev_config(*cfg, dev);
+    if (const int rc = rebuild_patch_table(ctx, dev)) return rc; // (on failure the context keeps its old configuration AND table)
+    ctx->cfg = *cfg;
+    ctx->arena.cfg = dev;
+    return GG_OK;
 }
 
 int gg_get_config(const gg_context *ctx, gg_config *cfg)
@@ -1121,10 +1135,9 @@ int gg_get_layer(gg_context *ctx, int slot, int layer, float *dst)
     return GG_OK;
 }
 
-int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
+// dst[l] (nullable) receives layer l; the destinations need not be aligned (they may sit inside a serialised message)
+static int get_layers_impl(gg_context *ctx, int slot, void *const dst[GG_NUM_LAYERS])
 {
-    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
-    if (!dst) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     const size_t plane = align_up((size_t)ctx->arena.g.C * 4, 256) / 4;
@@ -1151,10 +1164,98 @@ int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
     ctx->helper.split((size_t)n_want * C, [&](size_t lo, size_t hi) {
         for (size_t k = lo / C; k < (size_t)n_want && k * C < hi; ++k) {
             const size_t a0 = std::max(lo, k * C) - k * C, a1 = std::min(hi, (k + 1) * C) - k * C;
-            memcpy(dst[want[k]] + a0, ctx->h_planes + k * plane + a0, (a1 - a0) * sizeof(float));
+            memcpy((char *)dst[want[k]] + a0 * sizeof(float), ctx->h_planes + k * plane + a0, (a1 - a0) * sizeof(float));
         }
     });
     return GG_OK;
+}
+
+int gg_get_layers(gg_context *ctx, int slot, float *const dst[GG_NUM_LAYERS])
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!dst) return GG_ERR_INVALID;
+    void *d[GG_NUM_LAYERS];
+    for (int l = 0; l < GG_NUM_LAYERS; ++l) d[l] = dst[l];
+    return get_layers_impl(ctx, slot, d);
+}
+
+// grid_map_msgs/GridMap, ROS 1 serialisation (include/groundgrid_hip.h): the skeleton is written by the host, the layer planes land
+// in their data[] arrays straight from the pinned download
+int gg_get_gridmap_message(gg_context *ctx, int slot, unsigned layer_mask, const gg_gridmap_header *header, uint8_t *dst, size_t capacity, size_t *size)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!size) return fail(ctx, GG_ERR_INVALID, "gg_get_gridmap_message: null size");
+    static const char *const names[GG_NUM_LAYERS] = {"points", "ground", "groundpatch", "minGroundHeight", "maxGroundHeight", "groundCandidates",
+                                                     "planeDist", "m2", "meanVariance", "pointsRaw", "variance"}; // src/GroundGrid.cpp:55, src/GroundSegmentation.cpp:61-75
+    if (layer_mask == 0u) layer_mask = (1u << GG_NUM_LAYERS) - 1u;
+    layer_mask &= (1u << GG_NUM_LAYERS) - 1u;
+    const gg_gridmap_header none{};
+    const gg_gridmap_header &h = header ? *header : none;
+    const char *frame = h.frame_id ? h.frame_id : "map";
+    const Geometry &g = ctx->arena.g;
+    const size_t C = (size_t)g.C;
+    // two passes over the same writer: the first only measures
+    size_t data_at[GG_NUM_LAYERS] = {};
+    auto write = [&](uint8_t *out) -> size_t {
+        size_t at = 0;
+        auto put = [&](const void *p, size_t n) {
+            if (out) memcpy(out + at, p, n);
+            at += n;
+        };
+        auto u32 = [&](uint32_t v) { put(&v, 4); };
+        auto f64 = [&](double v) { put(&v, 8); };
+        auto str = [&](const char *t) {
+            u32((uint32_t)strlen(t));
+            put(t, strlen(t));
+        };
+        u32(h.seq); // info.header
+        u32(h.stamp_sec);
+        u32(h.stamp_nsec);
+        str(frame);
+        f64(g.resolution);
+        f64(g.length0);
+        f64(g.length1);
+        f64(ctx->pos_x[slot]); // pose.position
+        f64(ctx->pos_y[slot]);
+        f64(0.0);
+        f64(0.0); // pose.orientation
+        f64(0.0);
+        f64(0.0);
+        f64(1.0);
+        u32((uint32_t)__builtin_popcount(layer_mask)); // layers
+        for (int l = 0; l < GG_NUM_LAYERS; ++l)
+            if ((layer_mask >> l) & 1u) str(names[l]);
+        u32((uint32_t)__builtin_popcount(h.basic_layers & layer_mask)); // basic_layers
+        for (int l = 0; l < GG_NUM_LAYERS; ++l)
+            if ((h.basic_layers & layer_mask) >> l & 1u) str(names[l]);
+        u32((uint32_t)__builtin_popcount(layer_mask)); // data
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) {
+            if (!((layer_mask >> l) & 1u)) continue;
+            u32(2u); // layout.dim (GridMapMsgHelpers: column-major storage -> "column_index" first)
+            str("column_index");
+            u32((uint32_t)g.cols);
+            u32((uint32_t)C);
+            str("row_index");
+            u32((uint32_t)g.rows);
+            u32((uint32_t)g.rows);
+            u32(0u); // layout.data_offset
+            u32((uint32_t)C);
+            data_at[l] = at;
+            at += C * 4;
+        }
+        const uint16_t zero = 0;
+        put(&zero, 2); // outer_start_index
+        put(&zero, 2); // inner_start_index
+        return at;
+    };
+    const size_t need = write(nullptr);
+    *size = need;
+    if (!dst) return GG_OK;
+    if (capacity < need) return fail(ctx, GG_ERR_CAPACITY, "gg_get_gridmap_message: buffer smaller than the message");
+    write(dst);
+    void *planes[GG_NUM_LAYERS];
+    for (int l = 0; l < GG_NUM_LAYERS; ++l) planes[l] = ((layer_mask >> l) & 1u) ? (void *)(dst + data_at[l]) : nullptr;
+    return get_layers_impl(ctx, slot, planes);
 }
 
 int gg_get_layer_image_u8(gg_context *ctx, int slot, int layer, uint8_t *dst, float *lower, float *upper)
@@ -1243,6 +1344,63 @@ int gg_filter_cloud_pc2(gg_context *ctx, int slot, const uint8_t *data, size_t n
     return GG_OK;
 }
 
+// ... and with the returned cloud coming back as 18-byte PointCloud2 records written by the label kernel (gg_batch.d_out_pc2)
+int gg_filter_cloud_pc2_out(gg_context *ctx, int slot, const uint8_t *data, size_t n, size_t point_step, size_t off_x, size_t off_y,
+                            size_t off_z, size_t off_ring, const double *map_from_cloud, const float origin[3], double base_z,
+                            uint8_t *out_data, size_t *out_n)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if ((!data && n) || !origin || (!out_data && n)) return fail(ctx, GG_ERR_INVALID, "null data / origin / out_data");
+    if (n > ctx->max_points) return fail(ctx, GG_ERR_CAPACITY, "cloud larger than max_points");
+    if (off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step || off_ring + 2 > point_step)
+        return fail(ctx, GG_ERR_INVALID, "field offset outside point_step");
+    if (ctx->next_ticket != ctx->oldest_ticket) return fail(ctx, GG_ERR_INVALID, "gg_filter_cloud_pc2_out while async tickets are outstanding");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t block = 64 + ctx->max_points * GG_PC2_POINT_STEP;
+    if (!ctx->d_pc2) HIPCHK(ctx, hipMalloc((void **)&ctx->d_pc2, block));
+    if (!ctx->h_pc2) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_pc2, block, hipHostMallocDefault));
+    hipStream_t s = ctx->stream;
+    for (int c = 0; c < 2; ++c) { // pack and upload in two pieces, as the 32-byte entry point does
+        const size_t lo = n * c / 2, hi = n * (c + 1) / 2;
+        if (hi == lo) continue;
+        ctx->helper.split(hi - lo, [&](size_t a0, size_t a1) {
+            for (size_t i = lo + a0; i < lo + a1; ++i) {
+                const uint8_t *p = data + i * point_step;
+                gg_point16 &d = ctx->h_stage_pts[i];
+                memcpy(&d.x, p + off_x, 4);
+                memcpy(&d.y, p + off_y, 4);
+                memcpy(&d.z, p + off_z, 4);
+                memcpy(&d.ring, p + off_ring, 2);
+                d.pad = 0;
+            }
+        });
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage_pts + lo, ctx->h_stage_pts + lo, (hi - lo) * sizeof(gg_point16), hipMemcpyHostToDevice, s));
+    }
+    const int32_t n32 = (int32_t)n;
+    gg_batch b{};
+    b.n_clouds = 1;
+    b.first_slot = slot;
+    b.point_format = GG_POINT16;
+    b.d_points = ctx->d_stage_pts;
+    b.cloud_stride = ctx->max_points;
+    b.n_points = &n32;
+    b.origins = origin;
+    b.base_z = &base_z;
+    b.transforms = map_from_cloud;
+    b.d_out_counts = reinterpret_cast<int32_t *>(ctx->d_pc2);
+    b.d_out_pc2 = ctx->d_pc2 + 64;
+    const int rc = enqueue_batch(ctx, &b, s);
+    if (rc != GG_OK) return rc;
+    // counts and records in one copy: the size of the returned cloud is only known on the device, and it is nearly n
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pc2, ctx->d_pc2, 64 + n * GG_PC2_POINT_STEP, hipMemcpyDeviceToHost, s));
+    SYNCCHK(ctx, hipStreamSynchronize(s));
+    const size_t got = (size_t)reinterpret_cast<const int32_t *>(ctx->h_pc2)[0];
+    if (out_n) *out_n = got;
+    const uint8_t *src = ctx->h_pc2 + 64;
+    ctx->helper.split(got * GG_PC2_POINT_STEP, [&](size_t a0, size_t a1) { memcpy(out_data + a0, src + a0, a1 - a0); });
+    return GG_OK;
+}
+
 int gg_get_expected_points(const gg_context *ctx, float *dst)
 {
     if (!ctx || !dst) return GG_ERR_INVALID;
@@ -1275,6 +1433,14 @@ int gg_filter_batch(gg_context *ctx, const gg_batch *b, void *stream)
             return fail(ctx, GG_ERR_CAPACITY, "n_points exceeds max_points / cloud_stride");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return enqueue_batch(ctx, b, pick_stream(ctx, stream));
+}
+
+int gg_device_error(gg_context *ctx, int clear)
+{
+    if (!ctx || !ctx->h_dev_error) return GG_ERR_INVALID;
+    const uint32_t code = *ctx->h_dev_error;
+    if (clear) *ctx->h_dev_error = GG_DEVERR_NONE;
+    return (int)code;
 }
 
 int gg_synchronize(gg_context *ctx)
@@ -1536,6 +1702,69 @@ int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class
     return GG_OK;
 }
 
+// The public stage members of the reference's class (include/groundgrid_hip.h "the stage members"), on the slot's layers as they stand.
+int gg_run_stage(gg_context *ctx, int slot, int stage, const gg_stage_args *args)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!args) return fail(ctx, GG_ERR_INVALID, "gg_run_stage: null arguments");
+    const Geometry &g = ctx->arena.g;
+    switch (stage) {
+    case GG_STAGE_DETECT_GROUND_PATCHES:
+        if (args->section < -1 || args->section > 3) return fail(ctx, GG_ERR_INVALID, "gg_run_stage: section must be 0..3 or -1");
+        break;
+    case GG_STAGE_SPIRAL_GROUND_INTERPOLATION: break;
+    case GG_STAGE_DETECT_GROUND_PATCH_3:
+    case GG_STAGE_DETECT_GROUND_PATCH_5: {
+        const int h = stage == GG_STAGE_DETECT_GROUND_PATCH_3 ? 1 : 2; // (the S x S blocks of :355 must stay inside the map: UB in the reference)
+        if (args->i < h || args->j < h || args->i >= g.rows - h || args->j >= g.cols - h) return fail(ctx, GG_ERR_INVALID, "gg_run_stage: the cell's block leaves the map");
+        break;
+    }
+    case GG_STAGE_INTERPOLATE_CELL:
+        if (args->i < 1 || args->j < 1 || args->i >= g.rows - 1 || args->j >= g.cols - 1) return fail(ctx, GG_ERR_INVALID, "gg_run_stage: the cell's block leaves the map");
+        break;
+    default: return fail(ctx, GG_ERR_INVALID, "gg_run_stage: unknown stage");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
+    const hipStream_t s = ctx->stream;
+    Arena a = ctx->arena;
+    a.flags = ctx->flags;
+    a.eigen_reduction = ctx->conv.eigen_reduction;
+    if (stage == GG_STAGE_DETECT_GROUND_PATCHES || stage == GG_STAGE_SPIRAL_GROUND_INTERPOLATION) {
+        // the many-cell stages are the path's own kernels: they take their slot and base_z from a parameter record like a batch of one
+        const int r = ctx->ring_next;
+        ctx->ring_next = (r + 1) % PARAM_RING;
+        if (ctx->ring_used[r]) HIPCHK(ctx, hipEventSynchronize(ctx->ring_done[r]));
+        CloudParams *hp = ctx->h_params + (size_t)r * ctx->n_slots, *dp = ctx->d_params + (size_t)r * ctx->n_slots;
+        hp[0] = CloudParams{};
+        hp[0].slot = slot;
+        hp[0].base_z = (float)args->base_z;
+        hp[0].pos_x = ctx->pos_x[slot];
+        hp[0].pos_y = ctx->pos_y[slot];
+        HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams), hipMemcpyHostToDevice, s));
+        if (stage == GG_STAGE_DETECT_GROUND_PATCHES) {
+            launch_patch_stage(a, dp, slot, args->section, s);
+        } else {
+            sweep::Params sp = ctx->sweep_params;
+            sp.decrease = ctx->cfg.occupied_cells_decrease_factor;
+            sp.inv_decrease = 1.0 / sp.decrease;
+            sp.decay_fast = sp.decrease >= 1.25 && sp.decrease < 1e300;
+            sp.keep_points = 1;
+            launch_sweep(a, sp, dp, 1, s, nullptr);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipEventRecord(ctx->ring_done[r], s));
+        ctx->ring_used[r] = true;
+    } else {
+        launch_stage_cell(a, slot, stage, args->i, args->j, s);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    ctx->no_confidence[slot] = 0; // (every stage may write confidences)
+    if (const int rc = own_stream_mutated_map(ctx)) return rc;
+    SYNCCHK(ctx, hipStreamSynchronize(s));
+    return GG_OK;
+}
+
 // tools and tests only (not in the header): override the launch geometry the library would pick from the batch size (0 = back
 // to the default).  key: "sweep_waves", "k2_per_cloud", "k2_dense_share".  Returns the chunk size PW for key "pw" (read-only:
 // the arena is carved for it at gg_create; set GG_PW in the environment before gg_create to change it).
@@ -1549,6 +1778,7 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     else if (!strcmp(key, "front")) ctx->arena.tune_front = std::min(value, 3);
     else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
     else if (!strcmp(key, "scan_parts")) ctx->arena.tune_scan_parts = value;
+    else if (!strcmp(key, "scan_poll_cap")) ctx->arena.tune_scan_poll_cap = value;
     else if (!strcmp(key, "scan_fault")) ctx->arena.tune_scan_fault = value;
     else if (!strcmp(key, "sweep_fault")) ctx->arena.tune_sweep_fault = value;
     else if (!strcmp(key, "probe_unordered_streams")) ctx->probe_unordered_streams = value != 0; // (tools/fill_overlap_probe.py: the CALLER orders its streams)

@@ -146,6 +146,7 @@ struct Arena {
     int tune_sweep_poll_cap; // tests: polls after which k_sweep's waits give up (0 = about a second)
     int tune_sweep_fault;   // tests: sweep::Params::debug_fault
     int tune_scan_fault;    // tests: 1 = the first part of a cloud's scan never publishes its sums (the waits of the others run out: GG_DEVERR_SCAN_WAIT)
+    int tune_scan_poll_cap; // tests: polls after which a scan part's wait gives up (0 = sort_core.h SCAN_WAIT_POLLS, several seconds)
     int tune_scan_parts;    // tests: work-groups per cloud in k_scan (0 = the launcher's choice, k_sort.hip scan_parts)
     int tune_front;         // the front end (classify + tile sort): 0 = the launcher's choice, 1 = three launches (k_classify, k_scan,
                             // k_scatter), 2 = the scan inside k_classify (the last work-group of a cloud to finish scans it), 3 = one launch
@@ -231,6 +232,7 @@ struct BatchIO {
     gg_point32 *d_out_clouds;
     int32_t *d_out_counts;
     uint8_t *d_label_masks;
+    uint8_t *d_out_pc2;
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: the launchers that need more than 64 KiB of dynamic
@@ -269,6 +271,8 @@ void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, i
 void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_reduce_lazy(const Arena &a, const CloudParams &cp, hipStream_t s); // (GG_FLAG_MINIMAL_LAYERS: the other three layers, one slot)
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
+void launch_patch_stage(const Arena &a, const CloudParams *d_params, int slot, int section, hipStream_t s); // gg_run_stage: :323 + one quadrant (-1: all) on the slot's layers as they stand
+void launch_stage_cell(const Arena &a, int slot, int stage, int i, int j, hipStream_t s);                    // gg_run_stage: detect_ground_patch<S> / interpolate_cell of one cell
 namespace sweep {
 struct Params;
 Params make_params(int n, double resolution, float min_dist_squared, double decrease); // sweep_emul.hip (host)

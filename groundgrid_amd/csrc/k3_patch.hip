@@ -145,7 +145,12 @@ GG_DEV void detect_ground_patch_b(const Arena &a, const PatchCarry &pc, float2 *
 // work-groups spent 0.6 ms of 1.6 on launching work-groups and another 0.4 on their first loads.)
 constexpr int RING = 32, SLOTS = RING + 4, MAXTC = 256;
 
-__global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams *__restrict__ params, int n_bands, int blocks_per_segment)
+// STAGE: the kernel as the stand-alone stage detect_ground_patches(map, section) (gg_run_stage, include/groundgrid/GroundSegmentation.h:59):
+// the layers are whatever the slot holds -- not what k_reduce left a moment ago -- so no block is skipped on the strength of the last
+// cloud's record counts, the S x S point count of :359 is summed in Eigen's order like the two weighted sums (a host-written `points`
+// layer need not hold integers), and only the cells of the quadrant `bounds` = {i_lo, i_hi, j_lo, j_hi} (:325-328) are visited.
+template <bool STAGE>
+__global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams *__restrict__ params, int n_bands, int blocks_per_segment, const int4 bounds)
 {
     __shared__ __attribute__((aligned(16))) float pts[SLOTS][LR], var[SLOTS][LR], mnl[SLOTS][LR]; // (LR * 4 bytes = 9 x 16: every row quad is 16-byte aligned)
     // vertical partial sums of `points` over the window's 12 columns and the block's 32 rows: 5 rows (v5) and the middle 3 (v3).
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         for (int k = tid; k < ntr * tiles_c; k += 256) {
             const int tc = k / ntr, tile = (tr_lo + k % ntr) + tc * a.g.tiles_r;
             const int rank = a.tile_rank[tile];
-            if (tile_start[rank + 1] != tile_start[rank]) col_has_points[tc] = 1u;
+            if (STAGE || tile_start[rank + 1] != tile_start[rank]) col_has_points[tc] = 1u;
             band_rank[k % ntr][tc] = (uint16_t)rank;
             live_cols[k % ntr][tc] = tile_live[rank]; // (PR + 2 HALO rows starting at a multiple of TILE: at most three tile rows)
         }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     auto request = [&](int b, int first_col, int n_cols) { // columns [first_col, first_col + n_cols) of block b's window
         {
             const int jj = HALO + PC * b + tcl;
-            const bool v = i < rows && jj < cols;
+            const bool v = i < rows && jj < cols && (!STAGE || (i >= bounds.x && i < bounds.y && jj >= bounds.z && jj < bounds.w));
             const float4 e = a.patch_table[v ? (size_t)i + (size_t)jj * rows : (size_t)0]; // :358, :334, :364, :369 and the layer element
             cell_next = make_float4(e.x, v ? e.y : __builtin_inff(), e.z, e.w); // (no such cell: never visited)
         }
@@ -298,8 +303,17 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
             v5[c][r + 1] = (x1 + x5) + mid1;
         }
         __syncthreads();
-        const float pointsblockSum = near ? (v3[tcl + 1][tr] + v3[tcl + 2][tr]) + v3[tcl + 3][tr]
-                                          : ((v5[tcl][tr] + v5[tcl + 1][tr]) + (v5[tcl + 2][tr] + v5[tcl + 3][tr])) + v5[tcl + 4][tr];
+        float pointsblockSum = near ? (v3[tcl + 1][tr] + v3[tcl + 2][tr]) + v3[tcl + 3][tr]
+                                    : ((v5[tcl][tr] + v5[tcl + 1][tr]) + (v5[tcl + 2][tr] + v5[tcl + 3][tr])) + v5[tcl + 4][tr];
+        if (STAGE) { // arbitrary layer contents: :359 in Eigen's order
+            const float(*w)[LR] = pts + base;
+            if (near)
+                pointsblockSum = stream_tree9([&](int s) { return w[lc - 1 + s / 3][lr - 1 + s % 3]; });
+            else if (a.eigen_reduction == GG_EIGEN_34_SSE)
+                pointsblockSum = stream_tree25_eigen34([&](int s) { return w[lc - 2 + s / 5][lr - 2 + s % 5]; });
+            else
+                pointsblockSum = stream_tree25([&](int s) { return w[lc - 2 + s / 5][lr - 2 + s % 5]; });
+        }
         const int S = near ? 3 : 5;
         // :364-365 (count and threshold are integer-valued floats: the comparison is the reference's binary64 one)
         const bool pass = !(pointsblockSum < threshold) && a.k3_debug != 3;
@@ -346,7 +360,42 @@ void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hip
     const int segments = std::max(1, std::min(n_blocks, 8192 / std::max(1, n_clouds * n_bands)));
     const int per_segment = (n_blocks + segments - 1) / segments;
     dim3 grid(n_bands * ((n_blocks + per_segment - 1) / per_segment), n_clouds);
-    hipLaunchKernelGGL(k_patch, grid, dim3(256), 0, s, a, d_params, n_bands, per_segment);
+    hipLaunchKernelGGL(k_patch<false>, grid, dim3(256), 0, s, a, d_params, n_bands, per_segment, make_int4(0, 0, 0, 0));
+}
+
+// :323 on its own: variance := m2 ./ (points + FLT_MIN) over the slot's live half columns (a dead one logically holds
+// 0 / (0 + FLT_MIN) = 0, the layer's reset value: nothing to write)
+__global__ __launch_bounds__(256) void k_variance(const Arena a, int slot)
+{
+    float *L = percall_ptr(a, slot);
+    const uint32_t *tile_live = a.tile_live + (size_t)slot * a.tile_live_stride;
+    for (int rank = blockIdx.x; rank < a.g.T; rank += gridDim.x) {
+        const uint32_t live = tile_live[rank];
+        const int cell = threadIdx.x;
+        if (!((live >> live_bit(cell)) & 1u)) continue;
+        L[percall_index(rank, PL_VARIANCE, cell)] = L[percall_index(rank, PL_M2, cell)] / (L[percall_index(rank, PL_POINTS, cell)] + FLT_MIN);
+    }
+}
+
+// detect_ground_patches(map, section) as a stage of its own (gg_run_stage): section 0..3 = one quadrant (:325-328), -1 = all four
+void launch_patch_stage(const Arena &a, const CloudParams *d_params, int slot, int section, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_variance, dim3(std::min(a.g.T, 1024)), dim3(TILE_CELLS), 0, s, a, slot);
+    const int ir = a.g.rows - 2 * HALO, ic = a.g.cols - 2 * HALO;
+    if (ir <= 0 || ic <= 0 || a.g.tiles_c > MAXTC) return;
+    const int gcols = a.g.cols, grows = a.g.rows;
+    int4 b = make_int4(0, grows, 0, gcols); // (the table's "visited" flag already restricts to the union of the quadrants)
+    if (section >= 0) {
+        b.x = 2 + section % 2 * (gcols / 2 - 2);        // :325 (the reference's `i`, used as the ROW of detect_ground_patch)
+        b.y = gcols / 2 + section % 2 * (gcols / 2 - 2); // :327
+        b.z = section >= 2 ? grows / 2 : 2;              // :326 (`j`, the column)
+        b.w = section >= 2 ? grows - 2 : grows / 2;      // :328
+    }
+    const int n_bands = (ir + PR - 1) / PR, n_blocks = (ic + PC - 1) / PC;
+    const int segments = std::max(1, std::min(n_blocks, 8192 / std::max(1, n_bands)));
+    const int per_segment = (n_blocks + segments - 1) / segments;
+    dim3 grid(n_bands * ((n_blocks + per_segment - 1) / per_segment), 1);
+    hipLaunchKernelGGL(k_patch<true>, grid, dim3(256), 0, s, a, d_params, n_bands, per_segment, b);
 }
 
 } // namespace gg

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     // :147 map["points"].setConstant(0.0) -- K3 was the last reader of the KEPT counts; K5 re-counts non-ground points.  Only the
     // half columns of tiles that received records hold anything but 0 (K2's tile_live invariant): one wavefront per such tile, 4 cells
     // per lane
-    {
+    if (!P.keep_points) {
         const uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
         const int lane_ = threadIdx.x & 63, wave_ = (int)(threadIdx.x >> 6) + part * (nthreads >> 6), nwaves = (nthreads >> 6) * n_parts; // (shared by the parts)
         for (int rank = wave_; rank < a.g.T; rank += nwaves) {

@@ -28,7 +28,32 @@ GG_DEV void load_xy(const char *pts, int p, const CloudParams &cp, float &x, flo
     }
 }
 
-template <int FMT>
+// One record of the returned cloud in the 18-byte sensor_msgs/PointCloud2 layout of scripts/kitti_data_publisher.py:139-150 -- x@0 y@4
+// z@8 intensity@12 (float32) ring@16 (uint16), point_step 18 -- at position idx: 18 idx is a multiple of 4 for even idx and 2 more
+// for odd ones, so a record is four aligned words and one half word, in that order or the other.
+GG_DEV void store_pc2_record(uint8_t *out, int32_t idx, uint32_t x, uint32_t y, uint32_t z, uint32_t intensity, uint32_t ring)
+{
+    uint8_t *p = out + (size_t)idx * GG_PC2_POINT_STEP;
+    if (idx & 1) {
+        *reinterpret_cast<uint16_t *>(p) = (uint16_t)x;
+        uint32_t *w = reinterpret_cast<uint32_t *>(p + 2);
+        w[0] = (x >> 16) | (y << 16);
+        w[1] = (y >> 16) | (z << 16);
+        w[2] = (z >> 16) | (intensity << 16);
+        w[3] = (intensity >> 16) | (ring << 16);
+    } else {
+        uint32_t *w = reinterpret_cast<uint32_t *>(p);
+        w[0] = x;
+        w[1] = y;
+        w[2] = z;
+        w[3] = intensity;
+        *reinterpret_cast<uint16_t *>(p + 16) = (uint16_t)ring;
+    }
+}
+
+// PC2: the instantiation that also emits the returned cloud as 18-byte PointCloud2 records (gg_batch.d_out_pc2) -- a twin, so that the
+// throughput kernel keeps its registers
+template <int FMT, bool PC2>
 __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams *__restrict__ params, const BatchIO io)
 {
     // XCD-aware (gg_device.h): the chunks of one cloud run on one XCD, so its layers / records are cached in ONE L2
@@ -66,6 +91,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
     uint8_t *masks = io.d_label_masks ? io.d_label_masks + (size_t)cloud * ((io.cloud_stride + 3) / 4) : nullptr;
     int32_t *out_index = io.d_out_index ? io.d_out_index + (size_t)cloud * io.cloud_stride : nullptr;
     gg_point32 *out_cloud = (FMT == GG_POINT32 && io.d_out_clouds) ? io.d_out_clouds + (size_t)cloud * io.cloud_stride : nullptr;
+    uint8_t *out_pc2 = PC2 ? io.d_out_pc2 + (size_t)cloud * io.cloud_stride * GG_PC2_POINT_STEP : nullptr;
 
     const uint32_t *ce = a.chunk_emit + (size_t)cp.slot * a.emit_stride + (size_t)chunk * 4;
     uint32_t kept_base = ce[0];
@@ -205,6 +231,21 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                     dst[0] = lo;
                     dst[1] = hi;
                 }
+                if (PC2 && idx >= 0) { // (src/GroundGridNodelet.cpp:196-200: the returned cloud goes out as a PointCloud2)
+                    const uint4 v = *reinterpret_cast<const uint4 *>(pts + (size_t)p * (FMT == GG_POINT16 ? 16 : 32));
+                    uint32_t x = v.x, y = v.y, ring;
+                    if (FMT == GG_POINT16)
+                        ring = v.w & 0xFFFFu;
+                    else
+                        ring = *reinterpret_cast<const uint16_t *>(pts + (size_t)p * 32 + 20);
+                    if (cp.has_tf) { // the returned cloud is in the map frame
+                        float fx, fy;
+                        load_xy<FMT>(pts, p, cp, fx, fy);
+                        x = __float_as_uint(fx);
+                        y = __float_as_uint(fy);
+                    }
+                    store_pc2_record(out_pc2, idx, x, y, r[j].x, __float_as_uint((float)label), ring);
+                }
             }
             kept_base += (uint32_t)__popcll(mk);
             ign_base += (uint32_t)__popcll(mi);
@@ -228,10 +269,17 @@ void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io
     if (nch == 0) nch = 1; // still publish the (all-zero) counts
     dim3 grid((nch + 3) / 4, n_clouds);
     const size_t lds = (size_t)a.g.T * sizeof(uint32_t);
-    if (io.point_format == GG_POINT16)
-        hipLaunchKernelGGL(k_label<GG_POINT16>, grid, dim3(256), lds, s, a, d_params, io);
-    else
-        hipLaunchKernelGGL(k_label<GG_POINT32>, grid, dim3(256), lds, s, a, d_params, io);
+    if (io.point_format == GG_POINT16) {
+        if (io.d_out_pc2)
+            hipLaunchKernelGGL((k_label<GG_POINT16, true>), grid, dim3(256), lds, s, a, d_params, io);
+        else
+            hipLaunchKernelGGL((k_label<GG_POINT16, false>), grid, dim3(256), lds, s, a, d_params, io);
+    } else {
+        if (io.d_out_pc2)
+            hipLaunchKernelGGL((k_label<GG_POINT32, true>), grid, dim3(256), lds, s, a, d_params, io);
+        else
+            hipLaunchKernelGGL((k_label<GG_POINT32, false>), grid, dim3(256), lds, s, a, d_params, io);
+    }
 }
 
 } // namespace gg

@@ -45,9 +45,9 @@ __global__ __launch_bounds__(1024) void k_scan_parts(const Arena a, const CloudP
 int scan_parts(const Arena &a, int n_clouds)
 {
     const int G = a.hist_pitch / 4;
-    if (a.tune_scan_parts > 0) return std::max((G + 1023) / 1024, std::min(a.tune_scan_parts, SCAN_MAX_PARTS));
+    if (a.tune_scan_parts > 0) return std::max((G + SCAN_PART_MAX_GROUPS - 1) / SCAN_PART_MAX_GROUPS, std::min(a.tune_scan_parts, SCAN_MAX_PARTS));
     if (G < 512 || n_clouds >= 512) return 1;
-    return std::max((G + 1023) / 1024, std::min(std::min(SCAN_MAX_PARTS, G / 64), 512 / n_clouds));
+    return std::max((G + SCAN_PART_MAX_GROUPS - 1) / SCAN_PART_MAX_GROUPS, std::min(std::min(SCAN_MAX_PARTS, G / 64), 512 / n_clouds));
 }
 
 void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)

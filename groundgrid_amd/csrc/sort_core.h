@@ -88,7 +88,13 @@ template <bool AGENT> GG_DEV void store16_row(__amdgpu_buffer_rsrc_t r, uint32_t
 // in ONE 64-bit word of `sync` (valid bit 63: no second flag, nothing to order), waits -- bounded -- for the words of the parts
 // before it, and goes on from their sum.  The hand-over costs every part one agent-scope round trip in a kernel that is two
 // passes over a 4 MB histogram (n = 1000).  `sync` == nullptr: one work-group does it all.
-constexpr uint32_t SCAN_WAIT_POLLS = 1u << 20; // x s_sleep(16): about half a second
+constexpr uint32_t SCAN_WAIT_POLLS = 1u << 24; // x s_sleep(16): several seconds.  A part only ever waits for parts that are running or done (tickets), so the
+                                               // bound is a backstop against a lost work-group, not a scheduling assumption: a work-group that is merely
+                                               // preempted or time-sliced on a shared GPU must not trip it.  Tests shorten it (Arena::tune_scan_poll_cap).
+// the hand-over word of a part: bits 0..31 records, 32..46 light tiles, 47..61 dense tiles, 63 valid.  A part covers at most one
+// round of the work-group = 1024 tile groups of 4 tiles (k_sort.hip scan_parts), so both tile counts stay below 2^15.
+constexpr int SCAN_PART_MAX_GROUPS = 1024;
+static_assert(4 * SCAN_PART_MAX_GROUPS < (1 << 15), "the light / dense tile counts of a scan part must fit their 15-bit fields");
 template <int NW, bool AGENT>
 GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t *lds /*[NW + 1]*/, u32x4 *part = nullptr /*[64 NW]*/,
                        int my_part = 0, int n_parts = 1, unsigned long long *sync = nullptr /*[n_parts]*/)
@@ -155,12 +161,13 @@ GG_DEV void scan_cloud(const Arena &a, const CloudParams &cp, int nch, uint32_t 
             const uint32_t lexcl = block_exclusive_scan<NW>(nl | (nd << 16), lds, ltotal);
             if (sync) { // (one round per part)
                 if (tid == 0 && !(a.tune_scan_fault && my_part == 0)) // (tests: the first part withholds its word, the others' waits must run out)
-                    __hip_atomic_store(&sync[my_part], (unsigned long long)total | ((unsigned long long)(ltotal & 0xFFFFu) << 32) |
-                                       ((unsigned long long)(ltotal >> 16) << 47) | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&sync[my_part], (unsigned long long)total | ((unsigned long long)(ltotal & 0x7FFFu) << 32) |
+                                       ((unsigned long long)((ltotal >> 16) & 0x7FFFu) << 47) | (1ull << 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned long long w = 1ull << 63;
                 if (tid < my_part) {
                     uint32_t polls = 0;
-                    while (((w = __hip_atomic_load(&sync[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull && polls < SCAN_WAIT_POLLS) {
+                    const uint32_t poll_cap = a.tune_scan_poll_cap > 0 ? (uint32_t)a.tune_scan_poll_cap : SCAN_WAIT_POLLS;
+                    while (((w = __hip_atomic_load(&sync[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull && polls < poll_cap) {
                         __builtin_amdgcn_s_sleep(16);
                         ++polls;
                     }

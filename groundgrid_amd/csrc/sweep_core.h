@@ -89,6 +89,8 @@ struct Params {
     int poll_cap;    // polls after which a wait gives up (k4_sweep.hip "Bounded waits"; emulator: unused)
     int debug_fault; // tests only: 1 = the parts of a cloud take their tickets in REVERSE order (consumers start before their producers),
                      // 2 = the exporter withholds the joins of its last ring (the next part's wait must run out, not hang)
+    int keep_points; // 1: the sweep as the stand-alone stage spiral_ground_interpolation (gg_run_stage): filter_cloud's reset of `points`
+                     // (:147, folded into this kernel's prologue) is not part of it
     GpLayout gl; // where cell (row, col) of the layer lives (gp_layout.h): a wavefront's 64 cells of a step are contiguous
 };
 

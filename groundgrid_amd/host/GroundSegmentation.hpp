@@ -6,6 +6,8 @@
 //     setConfig(config)                      .h:56
 //     filter_cloud(cloud, origin, mapToBase, map) -> cloud        .h:54
 //     insert_cloud(cloud, start, end, origin, point_index, ignored, outliers, map)   .h:55
+//     detect_ground_patches(map, section), detect_ground_patch<S>(map, i, j), spiral_ground_interpolation(map, toBase),
+//     interpolate_cell(map, x, y)            .h:59-62
 // but with dependency-free value types, because PCL / grid_map / ROS headers do not exist in this image:
 //     pcl::PointCloud<PointXYZIR>::Ptr        -> std::vector<gg_point32>          (identical 32-byte records)
 //     geometry_msgs::TransformStamped         -> double mapToBase_z              (the only field used, .cpp:406-411)
@@ -147,12 +149,31 @@ class GroundSegmentation {
         }
     }
 
+    // The stage members (include/groundgrid/GroundSegmentation.h:59-62), each on `map` as it stands (gg_run_stage)
+    void detect_ground_patches(GridMap &map, unsigned short section) const { stage(map, GG_STAGE_DETECT_GROUND_PATCHES, section, 0, 0, 0.0); }
+    template <int S> void detect_ground_patch(GridMap &map, size_t i, size_t j) const
+    {
+        static_assert(S == 3 || S == 5, "the reference instantiates detect_ground_patch<3> and <5> (src/GroundSegmentation.cpp:335,337)");
+        stage(map, S == 3 ? GG_STAGE_DETECT_GROUND_PATCH_3 : GG_STAGE_DETECT_GROUND_PATCH_5, 0, (int)i, (int)j, 0.0);
+    }
+    void spiral_ground_interpolation(GridMap &map, double toBase_z) const { stage(map, GG_STAGE_SPIRAL_GROUND_INTERPOLATION, 0, 0, 0, toBase_z); }
+    void interpolate_cell(GridMap &map, const size_t x, const size_t y) const { stage(map, GG_STAGE_INTERPOLATE_CELL, 0, (int)x, (int)y, 0.0); }
+
     // per input point of the last filter_cloud call: GG_LABEL_* and position in the returned cloud (-1: dropped)
     const std::vector<uint8_t> &labels() const { return labels_; }
     const std::vector<int32_t> &out_index() const { return index_; }
     gg_context *context() { return ctx_; }
 
   private:
+    void stage(GridMap &map, int which, int section, int i, int j, double base_z) const
+    {
+        gg_stage_args a{};
+        a.section = section;
+        a.i = i;
+        a.j = j;
+        a.base_z = base_z;
+        if (gg_run_stage(ctx_, map.slot(), which, &a) != GG_OK) throw std::runtime_error(std::string("gg_run_stage: ") + gg_last_error(ctx_));
+    }
     gg_context *ctx_ = nullptr;
     std::vector<GridMap> maps_;
     std::vector<uint8_t> labels_;

@@ -164,6 +164,41 @@ class Core {
         return rc_down;
     }
 
+    // ---- the stage members (include/groundgrid/GroundSegmentation.h:59-62) on the caller's map ----
+    // A host-managed map holds the layers the stage reads on the host: they are uploaded first (detect_ground_patches /
+    // detect_ground_patch<S>: points, m2, minGroundHeight, variance, ground, groundpatch; the sweep and interpolate_cell: ground,
+    // groundpatch); a device-resident map already has them.  What the stage writes -- ground, groundpatch, and `variance` for
+    // detect_ground_patches (:323) -- is written back into the view's planes either way: these are rare, explicit calls.
+    int run_stage(const MapView &view, int stage, int section, int i, int j, double base_z)
+    {
+        if (!ctx_) return GG_ERR_INVALID;
+        const bool detect = stage == GG_STAGE_DETECT_GROUND_PATCHES || stage == GG_STAGE_DETECT_GROUND_PATCH_3 || stage == GG_STAGE_DETECT_GROUND_PATCH_5;
+        const unsigned reads = (1u << GG_LAYER_GROUND) | (1u << GG_LAYER_GROUNDPATCH) |
+                               (detect ? (1u << GG_LAYER_POINTS) | (1u << GG_LAYER_M2) | (1u << GG_LAYER_MINGROUNDHEIGHT) | (1u << GG_LAYER_VARIANCE) : 0u);
+        const unsigned writes = (1u << GG_LAYER_GROUND) | (1u << GG_LAYER_GROUNDPATCH) | (stage == GG_STAGE_DETECT_GROUND_PATCHES ? 1u << GG_LAYER_VARIANCE : 0u);
+        if (!device_resident_) {
+            int rc = gg_set_map_position(ctx_, 0, view.pos_x, view.pos_y);
+            for (int l = 0; l < GG_NUM_LAYERS && rc == GG_OK; ++l)
+                if (((reads >> l) & 1u) && view.layer[l]) rc = gg_set_layer(ctx_, 0, l, view.layer[l]);
+            if (rc != GG_OK) return note("uploading the layers of a stage"), rc;
+            have_position_ = true;
+            pos_x_ = view.pos_x;
+            pos_y_ = view.pos_y;
+        }
+        gg_stage_args a{};
+        a.section = section;
+        a.i = i;
+        a.j = j;
+        a.base_z = base_z;
+        const int rc = gg_run_stage(ctx_, 0, stage, &a);
+        if (rc != GG_OK) return note("gg_run_stage"), rc;
+        float *dst[GG_NUM_LAYERS];
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) dst[l] = ((writes >> l) & 1u) ? view.layer[l] : nullptr;
+        const int rc_down = gg_get_layers(ctx_, 0, dst);
+        if (rc_down != GG_OK) note("downloading the layers of a stage");
+        return rc_down;
+    }
+
     // a cloud larger than the context was created for: re-create it with headroom.  A device-resident map is carried over
     // (ground, groundpatch and the position take the round trip through the host once); a host-managed one is uploaded again
     // by the next filter() anyway.
@@ -232,12 +267,17 @@ class Core {
 // its Core from init() on; a GroundGrid object that keeps its map on the device binds the map object it hands out to the Core
 // that will filter against it -- the first Core that has no map yet, i.e. the GroundSegmentation of the same nodelet
 // (src/GroundGridNodelet.cpp:89-95 constructs the pair).
+// Lifetime.  The reference's GroundSegmentation has no destructor to hook (its header cannot change), so a Core outlives its
+// object until the address is used again -- init() on a known address re-creates the context and drops every map bound to it -- or until
+// the host calls forget_object (a nodelet's own destructor can: groundgrid_hip::Registry::instance().forget_object(&ground_segmentation_)).
+// GroundGrid does have a destructor: it unbinds its map (forget_map), and initGroundGrid unbinds the map it replaces.  The registry
+// itself is never destroyed: tearing down HIP contexts from a static destructor can run after the HIP runtime is gone.
 class Registry {
   public:
     static Registry &instance()
     {
-        static Registry r;
-        return r;
+        static Registry *const r = new Registry(); // (leaked on purpose, see above)
+        return *r;
     }
     Core *core_of_object(const void *segmentation, bool create)
     {
@@ -268,6 +308,19 @@ class Registry {
             if (!taken && c->ok()) return by_map_[map] = c;
         }
         return nullptr;
+    }
+    // the map object is going away (GroundGrid::~GroundGrid) or being replaced (initGroundGrid): its Core serves no map again
+    void forget_map(const void *map)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        by_map_.erase(map);
+    }
+    // init() on an object that already has a Core (a re-initialised nodelet, or a new object at a recycled address): the maps bound
+    // to the old context name nothing any more
+    void unbind_maps_of(const Core *c)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        for (auto m = by_map_.begin(); m != by_map_.end();) m = m->second == c ? by_map_.erase(m) : std::next(m);
     }
     void forget_object(const void *segmentation)
     {

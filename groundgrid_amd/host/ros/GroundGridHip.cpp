@@ -31,7 +31,10 @@ using groundgrid_hip::Registry;
 
 GroundGrid::GroundGrid() : mTf2_listener(mTfBuffer) {}
 
-GroundGrid::~GroundGrid() {}
+GroundGrid::~GroundGrid()
+{
+    if (mMap_ptr) Registry::instance().forget_map(mMap_ptr.get()); // the context serves no map until a new one is bound
+}
 
 void GroundGrid::setConfig(groundgrid::GroundGridConfig &config) { config_ = config; }
 
@@ -39,6 +42,7 @@ void GroundGrid::setConfig(groundgrid::GroundGridConfig &config) { config_ = con
 void GroundGrid::initGroundGrid(const nav_msgs::OdometryConstPtr &inOdom)
 {
     // the host object: frame, geometry and the five layers the reference creates (:55).  Their contents live on the device.
+    if (mMap_ptr) Registry::instance().forget_map(mMap_ptr.get()); // (re-initialisation: the old object's address may be recycled)
     mMap_ptr = std::make_shared<grid_map::GridMap, const std::vector<std::string>>({"points", "ground", "groundpatch", "minGroundHeight", "maxGroundHeight"});
     grid_map::GridMap &map = *mMap_ptr;
     map.setFrameId("map");

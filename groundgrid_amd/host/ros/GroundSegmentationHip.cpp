@@ -18,7 +18,7 @@
 //     and the terrain image read, :251-253; "none"; or a comma-separated list of layer names).
 //   * DEVICE-RESIDENT: when ros/GroundGridHip.cpp is compiled instead of src/GroundGrid.cpp as well, GroundGrid::update runs on
 //     the device (gg_move_map) and binds the map object it returns to this object's context: nothing is uploaded, and only the
-//     layers somebody subscribed to come back (default "none" unless GROUNDGRID_HIP_LAYERS says otherwise).
+//     layers somebody subscribed to come back (default "state" unless GROUNDGRID_HIP_LAYERS says otherwise; a warning says so once).
 // One device context per GroundSegmentation OBJECT (keyed by `this`: the reference's header cannot grow a member): two objects
 // in one process keep separate maps, unlike the reference's function-local statics (src/GroundSegmentation.cpp:76-78,203-213).
 #include <cstdlib>
@@ -59,6 +59,7 @@ void GroundSegmentation::init(ros::NodeHandle &nodeHandle, const size_t dimensio
     geometry.vertical_point_ang_dist = verticalPointAngDist;
     geometry.min_dist_squared = minDistSquared;
     Core *core = Registry::instance().core_of_object(this, true);
+    if (core->ok()) Registry::instance().unbind_maps_of(core); // a second init(), or a new object at a recycled address: start clean
     if (!core->create(geometry, initial_capacity())) {
         ROS_FATAL("groundgrid_hip: %s", core->last_error().c_str());
         return;
@@ -117,7 +118,14 @@ pcl::PointCloud<GroundSegmentation::PCLPoint>::Ptr GroundSegmentation::filter_cl
     view.pos_x = map.getPosition().x();
     view.pos_y = map.getPosition().y();
     for (int l = 0; l < GG_NUM_LAYERS; ++l) view.layer[l] = map[names[l]].data(); // (Eigen::MatrixXf, column-major: as the library wants it)
-    const unsigned download = groundgrid_hip::layers_from_env(core->device_resident() ? groundgrid_hip::LAYERS_NONE : groundgrid_hip::LAYERS_ALL);
+    // Default: host-managed maps get every layer back (the nodelet publishes the whole grid_map per cloud, Nodelet.cpp:211-214); a
+    // device-resident map gets what GroundGrid::update and the terrain image read (LAYERS_STATE) -- the other planes of the host
+    // object are NOT refreshed unless GROUNDGRID_HIP_LAYERS says so, and a publisher of the full grid_map should set it to "all"
+    // (or publish gg_get_gridmap_message, which serialises straight from the device).
+    const unsigned download = groundgrid_hip::layers_from_env(core->device_resident() ? groundgrid_hip::LAYERS_STATE : groundgrid_hip::LAYERS_ALL);
+    if (core->device_resident() && download != groundgrid_hip::LAYERS_ALL)
+        ROS_WARN_ONCE("groundgrid_hip: the map lives on the device; only the layers selected by GROUNDGRID_HIP_LAYERS (default: ground, groundpatch, points, "
+                      "pointsRaw) are copied into the host grid_map per cloud -- set GROUNDGRID_HIP_LAYERS=all if every layer is published");
 
     const size_t n = cloud->points.size();
     filtered_cloud->points.resize(n);
@@ -160,26 +168,51 @@ void GroundSegmentation::insert_cloud(const pcl::PointCloud<PCLPoint>::Ptr cloud
     }
 }
 
-// The stage functions are public in the header (.h:59-62) but have no caller outside filter_cloud; on the device they are
-// stages of one fused launch sequence, not separately callable.  They are defined so that the library exports every
-// symbol the header declares.
-void GroundSegmentation::detect_ground_patches(grid_map::GridMap &, unsigned short) const
+// The stage functions (.h:59-62).  Nothing outside filter_cloud calls them in the reference; here each runs on `map` as it stands
+// through gg_run_stage -- the many-cell ones are the path's own kernels (k_patch on one quadrant, k_sweep), the single-cell ones a
+// kernel of their own -- so that the library answers every public member of the class the way the reference's does.
+namespace {
+
+void run_stage(const GroundSegmentation *self, grid_map::GridMap &map, int stage, int section, int i, int j, double base_z)
 {
-    ROS_ERROR("groundgrid_hip: detect_ground_patches is part of filter_cloud on the device and cannot be called on its own");
+    Core *core = Registry::instance().core_of_map(&map);
+    if (!core) core = Registry::instance().core_of_object(self, false);
+    if (!core || !core->ok()) {
+        ROS_ERROR("groundgrid_hip: a stage of filter_cloud was called before a successful init");
+        return;
+    }
+    const char *const *names = groundgrid_hip::layer_names();
+    groundgrid_hip::MapView view;
+    view.pos_x = map.getPosition().x();
+    view.pos_y = map.getPosition().y();
+    for (int l = 0; l < GG_NUM_LAYERS; ++l) view.layer[l] = map.exists(names[l]) ? map[names[l]].data() : nullptr;
+    const int rc = core->run_stage(view, stage, section, i, j, base_z);
+    if (rc != GG_OK) ROS_ERROR("groundgrid_hip: stage %d failed with status %d (%s)", stage, rc, core->last_error().c_str());
 }
-template <int S> void GroundSegmentation::detect_ground_patch(grid_map::GridMap &, size_t, size_t) const
+
+} // namespace
+
+// src/GroundSegmentation.cpp:314-340
+void GroundSegmentation::detect_ground_patches(grid_map::GridMap &map, unsigned short section) const
 {
-    ROS_ERROR("groundgrid_hip: detect_ground_patch is part of filter_cloud on the device and cannot be called on its own");
+    run_stage(this, map, GG_STAGE_DETECT_GROUND_PATCHES, section, 0, 0, 0.0);
+}
+// src/GroundSegmentation.cpp:343-395
+template <int S> void GroundSegmentation::detect_ground_patch(grid_map::GridMap &map, size_t i, size_t j) const
+{
+    run_stage(this, map, S == 3 ? GG_STAGE_DETECT_GROUND_PATCH_3 : GG_STAGE_DETECT_GROUND_PATCH_5, 0, static_cast<int>(i), static_cast<int>(j), 0.0);
 }
 template void GroundSegmentation::detect_ground_patch<3>(grid_map::GridMap &, size_t, size_t) const;
 template void GroundSegmentation::detect_ground_patch<5>(grid_map::GridMap &, size_t, size_t) const;
-void GroundSegmentation::spiral_ground_interpolation(grid_map::GridMap &, const geometry_msgs::TransformStamped &) const
+// src/GroundSegmentation.cpp:398-441 (of toBase only the translation's z is used, :406-411)
+void GroundSegmentation::spiral_ground_interpolation(grid_map::GridMap &map, const geometry_msgs::TransformStamped &toBase) const
 {
-    ROS_ERROR("groundgrid_hip: spiral_ground_interpolation is part of filter_cloud on the device and cannot be called on its own");
+    run_stage(this, map, GG_STAGE_SPIRAL_GROUND_INTERPOLATION, 0, 0, 0, toBase.transform.translation.z);
 }
-void GroundSegmentation::interpolate_cell(grid_map::GridMap &, const size_t, const size_t) const
+// src/GroundSegmentation.cpp:445-465
+void GroundSegmentation::interpolate_cell(grid_map::GridMap &map, const size_t x, const size_t y) const
 {
-    ROS_ERROR("groundgrid_hip: interpolate_cell is part of filter_cloud on the device and cannot be called on its own");
+    run_stage(this, map, GG_STAGE_INTERPOLATE_CELL, 0, static_cast<int>(x), static_cast<int>(y), 0.0);
 }
 
 } // namespace groundgrid

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 4
+#define GG_ABI_VERSION 5
 
 typedef enum gg_status {
     GG_OK = 0,
@@ -133,7 +133,9 @@ void gg_default_geometry(gg_geometry *g);   /* GroundGrid.h:70-71, GroundSegment
 int gg_create(const gg_geometry *geom, int n_slots, size_t max_points, int device, gg_context **out);
 void gg_destroy(gg_context *ctx);
 
-/* GroundSegmentation::setConfig (src/GroundSegmentation.cpp:468-471) */
+/* GroundSegmentation::setConfig (src/GroundSegmentation.cpp:468-471).  Blocking, unlike the reference's struct copy: waits for the
+ * batches in flight and rebuilds the per-cell threshold table of detect_ground_patches (O(cells) host work + one upload).  On failure
+ * the context keeps its previous configuration entirely. */
 int gg_set_config(gg_context *ctx, const gg_config *cfg);
 int gg_get_config(const gg_context *ctx, gg_config *cfg);
 int gg_set_flags(gg_context *ctx, unsigned flags);
@@ -274,10 +276,25 @@ typedef struct gg_batch {
     const int32_t *slots;    /* host [n_clouds], nullable (ABI v3): cloud b meets map slot slots[b] instead of first_slot + b
                                 (first_slot is ignored then).  Entries must be distinct and inside the context: a server that
                                 holds many streams' maps filters whichever of them received a cloud, in one set of launches */
+    uint8_t *d_out_pc2;      /* [n_clouds][cloud_stride * GG_PC2_POINT_STEP], nullable (ABI v5): the returned cloud of cloud b --
+                                kept, then ignored, then outliers, d_out_counts[b][0] records -- as sensor_msgs/PointCloud2 data in
+                                the 18-byte layout of scripts/kitti_data_publisher.py:139-150 (x@0 y@4 z@8 intensity@12 float32,
+                                ring@16 uint16; intensity = 49 / 99), written by the label kernel itself from either point format:
+                                what a publisher sends (src/GroundGridNodelet.cpp:196-200) comes down as 18 B x returned points with
+                                no host assembly.  (pcl::toROSMsg of PointXYZIR publishes the 32-byte struct as is: that layout is
+                                d_out_clouds.) */
 } gg_batch;
+#define GG_PC2_POINT_STEP 18
 #define GG_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int gg_filter_batch(gg_context *ctx, const gg_batch *batch, void *stream);
 int gg_synchronize(gg_context *ctx);
+/* The few places where a kernel waits for ANOTHER work-group (the sweep cut into parts, the tile scan cut into parts, the fused front
+ * end) bound their waits; a wait that runs out leaves a code in a host-visible word instead of hanging.  Every gg_* call that
+ * synchronises reports it ONCE as GG_ERR_HIP (text in gg_last_error) and clears it: the outputs of the batches enqueued since the
+ * previous report are void and the map states they touched should be re-initialised (gg_reset_map); the context itself keeps
+ * working.  A caller that synchronises its own stream instead of calling into the library asks here: returns the pending code
+ * (0 = none, > 0 = a wait ran out) without synchronising; clear != 0 also clears it. */
+int gg_device_error(gg_context *ctx, int clear);
 
 /* ---- the one collective of the path: the all-gather of the per-cloud label masks (BASELINE configs[2]) ----
  * The reference has no distributed code; clouds shard as independent (cloud, map) pairs and the only exchange is that every
@@ -315,6 +332,33 @@ int gg_allgather_label_masks(gg_context *ctx, void *comm, const uint8_t *d_send,
 int gg_filter_cloud_pc2(gg_context *ctx, int slot, const uint8_t *data, size_t n, size_t point_step, size_t off_x, size_t off_y,
                         size_t off_z, size_t off_ring, const double *map_from_cloud, const float origin[3], double base_z,
                         uint8_t *out_label, int32_t *out_index, size_t *out_n);
+/* PointCloud2 payload in, PointCloud2 payload out: the same call with the RETURNED CLOUD written as 18-byte records (x, y, z,
+ * intensity = 49 / 99, ring; the layout above, gg_batch.d_out_pc2) by the label kernel -- order kept, ignored, outliers as in
+ * src/GroundSegmentation.cpp:150-189 -- so that the download is 18 B per returned point and the host assembles nothing.  out_data
+ * needs room for n * GG_PC2_POINT_STEP bytes; *out_n = points of the returned cloud (= width x height of the message, row_step =
+ * 18 * width).  The input layout is free (point_step / offsets) as for gg_filter_cloud_pc2. */
+int gg_filter_cloud_pc2_out(gg_context *ctx, int slot, const uint8_t *data, size_t n, size_t point_step, size_t off_x, size_t off_y,
+                            size_t off_z, size_t off_ring, const double *map_from_cloud, const float origin[3], double base_z,
+                            uint8_t *out_data, size_t *out_n);
+
+/* The map as the serialised grid_map_msgs/GridMap the nodelet publishes per cloud (src/GroundGridNodelet.cpp:211-214:
+ * grid_map::GridMapRosConverter::toMessage, info.header.stamp := the cloud's stamp): ROS 1 wire format, little endian --
+ *   info   { header {seq, stamp, frame_id}, resolution, length_x, length_y, pose {position (map x, map y, 0), orientation (0,0,0,1)} }
+ *   layers[], basic_layers[]    names in the order the reference adds them (src/GroundGrid.cpp:55, src/GroundSegmentation.cpp:61-75)
+ *   data[]  one std_msgs/Float32MultiArray per layer: dim[0] {"column_index", cols, rows*cols}, dim[1] {"row_index", rows, rows},
+ *           data_offset 0, data = the layer column-major (Eigen's storage, copied as is)
+ *   outer_start_index = inner_start_index = 0 (GroundGrid::update ends with convertToDefaultStartIndex, src/GroundGrid.cpp:143)
+ * restated from grid_map_ros 1.6.x (GridMapRosConverter::toMessage, GridMapMsgHelpers: not under /root/reference, unpinned).
+ * layer_mask: bit per gg_layer (0 = all eleven).  The layer planes are extracted by one kernel, come down in one copy and are
+ * placed straight into the message.  dst == NULL or capacity too small: only *size is set (GG_ERR_CAPACITY in the second case). */
+typedef struct gg_gridmap_header {
+    uint32_t seq;
+    uint32_t stamp_sec, stamp_nsec;
+    const char *frame_id;   /* NULL = "map" (src/GroundGrid.cpp:57) */
+    unsigned basic_layers;  /* bit per gg_layer; the reference declares none */
+} gg_gridmap_header;
+int gg_get_gridmap_message(gg_context *ctx, int slot, unsigned layer_mask, const gg_gridmap_header *header, uint8_t *dst, size_t capacity, size_t *size);
+
 /* grid_map::GridMapCvConverter::toImage<unsigned char, 1> of one layer (Nodelet.cpp:239): rows x cols row-major bytes,
  * the layer normalised between the min and max of its finite cells (returned in lower / upper), non-finite cells 0.
  * cv::applyColorMap (:240) is left to the host. */
@@ -325,6 +369,36 @@ int gg_get_terrain_image(gg_context *ctx, int slot, float *dst);
 /* insert_cloud's per-point decision (include/groundgrid/GroundSegmentation.h:55): after a filter call,
  * class (GG_CLASS_*) and cell (row + col*rows, -1 outside) of every input point of `slot`. */
 int gg_get_point_classes(gg_context *ctx, int slot, size_t n, uint8_t *out_class, int32_t *out_cell);
+
+/* ---- the stage members of the reference's class, one by one (include/groundgrid/GroundSegmentation.h:59-62) --------
+ * filter_cloud runs them as stages of one launch sequence; the header also declares them public, so the drop-in library
+ * answers a caller that invokes one on its own.  Each runs on the slot's layers AS THEY STAND (whatever the last cloud,
+ * gg_set_layer or an earlier stage left) and leaves its results in the slot, synchronously:
+ *   GG_STAGE_DETECT_GROUND_PATCHES        detect_ground_patches(map, section), src/GroundSegmentation.cpp:314-340:
+ *                                         variance := m2 ./ (points + FLT_MIN) over the whole layer (:323), then
+ *                                         detect_ground_patch<3|5> for every cell of quadrant `section` (0: top-left, 1: top-right,
+ *                                         2: bottom-left, 3: bottom-right, :325-328; -1: all four, what filter_cloud's four threads do)
+ *   GG_STAGE_SPIRAL_GROUND_INTERPOLATION  spiral_ground_interpolation(map, toBase), :398-441, base_z = toBase.transform.translation.z
+ *                                         (the only field the function uses, :406-411).  filter_cloud's reset of `points` (:147)
+ *                                         is NOT part of it.
+ *   GG_STAGE_DETECT_GROUND_PATCH_3 / _5   detect_ground_patch<S>(map, i, j), :343-395 (reads `variance` as it stands)
+ *   GG_STAGE_INTERPOLATE_CELL             interpolate_cell(map, x = i, y = j), :445-465
+ * The many-cell stages are the kernels of the path (k_patch without the skipping of blocks the last cloud left empty and with
+ * the :359 count in Eigen's order, k_sweep); the single-cell ones are one lane of a kernel of their own.  Cell indices whose
+ * blocks would leave the map -- UB in the reference -- are GG_ERR_INVALID. */
+enum {
+    GG_STAGE_DETECT_GROUND_PATCHES = 1,
+    GG_STAGE_SPIRAL_GROUND_INTERPOLATION = 2,
+    GG_STAGE_DETECT_GROUND_PATCH_3 = 3,
+    GG_STAGE_DETECT_GROUND_PATCH_5 = 4,
+    GG_STAGE_INTERPOLATE_CELL = 5
+};
+typedef struct gg_stage_args {
+    int section;   /* GG_STAGE_DETECT_GROUND_PATCHES: 0..3, or -1 for all four quadrants */
+    int i, j;      /* the single-cell stages: row and column */
+    double base_z; /* GG_STAGE_SPIRAL_GROUND_INTERPOLATION */
+} gg_stage_args;
+int gg_run_stage(gg_context *ctx, int slot, int stage, const gg_stage_args *args);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 

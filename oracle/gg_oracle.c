@@ -510,34 +510,53 @@ GGO_ALWAYS_INLINE void detect_ground_patch(ggo_map *m, const ggo_config *cfg, co
     }
 }
 
-void ggo_stage_detect(ggo_map *m, const ggo_config *cfg)
+/* :323 variance = m2 ./ (points + FLT_MIN): every call of detect_ground_patches recomputes the whole layer */
+static void detect_variance(ggo_map *m)
 {
     const size_t C = (size_t)m->rows * (size_t)m->cols;
-    /* :323 variance = m2 ./ (points + FLT_MIN) */
     for (size_t k = 0; k < C; ++k)
         m->layer[GGO_VARIANCE][k] = m->layer[GGO_M2][k] / (m->layer[GGO_POINTS][k] + FLT_MIN);
+}
 
+/* detect_ground_patches(map, section) (src/GroundSegmentation.cpp:314-340): one quadrant, 0: top-left .. 3: bottom-right */
+void ggo_stage_detect_section(ggo_map *m, const ggo_config *cfg, unsigned short section)
+{
+    detect_variance(m);
     const int size0 = m->rows, size1 = m->cols;
     const float resolution = (float)m->resolution; /* :318 */
-    for (unsigned short section = 0; section < 4; ++section) { /* :130-131, order irrelevant: no inter-cell dependency */
-        const int gcols = m->cols, grows = m->rows;
-        const int cols_start = 2 + section % 2 * (gcols / 2 - 2);             /* :325 */
-        const int rows_start = section >= 2 ? grows / 2 : 2;                   /* :326 */
-        const int cols_end = (gcols) / 2 + section % 2 * (gcols / 2 - 2);      /* :327 */
-        const int rows_end = section >= 2 ? grows - 2 : (grows) / 2;           /* :328 */
-        for (int i = cols_start; i < cols_end; ++i) {
-            for (int j = rows_start; j < rows_end; ++j) {
-                /* :332 */
-                const double di = (double)i - (double)size0 / 2.0, dj = (double)j - (double)size1 / 2.0;
-                const float sqdist = (float)((di * di + dj * dj) * ((double)resolution * (double)resolution));
-                /* :334 */
-                if ((double)sqdist <= cfg->patch_size_change_distance * cfg->patch_size_change_distance)
-                    detect_ground_patch(m, cfg, 3, (size_t)i, (size_t)j);
-                else
-                    detect_ground_patch(m, cfg, 5, (size_t)i, (size_t)j);
-            }
+    const int gcols = m->cols, grows = m->rows;
+    const int cols_start = 2 + section % 2 * (gcols / 2 - 2);             /* :325 */
+    const int rows_start = section >= 2 ? grows / 2 : 2;                   /* :326 */
+    const int cols_end = (gcols) / 2 + section % 2 * (gcols / 2 - 2);      /* :327 */
+    const int rows_end = section >= 2 ? grows - 2 : (grows) / 2;           /* :328 */
+    for (int i = cols_start; i < cols_end; ++i) {
+        for (int j = rows_start; j < rows_end; ++j) {
+            /* :332 */
+            const double di = (double)i - (double)size0 / 2.0, dj = (double)j - (double)size1 / 2.0;
+            const float sqdist = (float)((di * di + dj * dj) * ((double)resolution * (double)resolution));
+            /* :334 */
+            if ((double)sqdist <= cfg->patch_size_change_distance * cfg->patch_size_change_distance)
+                detect_ground_patch(m, cfg, 3, (size_t)i, (size_t)j);
+            else
+                detect_ground_patch(m, cfg, 5, (size_t)i, (size_t)j);
         }
     }
+}
+
+void ggo_stage_detect(ggo_map *m, const ggo_config *cfg)
+{
+    /* :130-131, order irrelevant: no inter-cell dependency (a cell reads neighbours' points / variance / minGroundHeight and
+     * writes only its own ground / groundpatch) */
+    for (unsigned short section = 0; section < 4; ++section) ggo_stage_detect_section(m, cfg, section);
+}
+
+/* detect_ground_patch<S>(map, i, j) (:343-395) on its own: S = 3 or 5; reads `variance` as it stands (the caller ran :323) */
+void ggo_detect_ground_patch(ggo_map *m, const ggo_config *cfg, int S, size_t i, size_t j)
+{
+    if (S == 3)
+        detect_ground_patch(m, cfg, 3, i, j);
+    else
+        detect_ground_patch(m, cfg, 5, i, j);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -593,6 +612,9 @@ void ggo_stage_spiral(ggo_map *m, const ggo_config *cfg, double base_z)
         }
     }
 }
+
+/* interpolate_cell(map, x, y) (:445-465) on its own */
+void ggo_interpolate_cell(ggo_map *m, const ggo_config *cfg, size_t x, size_t y) { interpolate_cell(m, cfg, x, y); }
 
 size_t ggo_spiral_visit_count(int rows)
 {

@@ -140,6 +140,10 @@ void ggo_stage_insert(ggo_map *m, const ggo_config *cfg, const ggo_point *cloud,
                       const float origin[3], uint8_t *cls, int32_t *cell); /* :200-311 */
 void ggo_stage_detect(ggo_map *m, const ggo_config *cfg);           /* :314-395 */
 void ggo_stage_spiral(ggo_map *m, const ggo_config *cfg, double base_z); /* :398-465 */
+/* the public stage members of include/groundgrid/GroundSegmentation.h:59-62 one by one */
+void ggo_stage_detect_section(ggo_map *m, const ggo_config *cfg, unsigned short section); /* detect_ground_patches(map, section), :314-340 */
+void ggo_detect_ground_patch(ggo_map *m, const ggo_config *cfg, int S, size_t i, size_t j); /* detect_ground_patch<S>(map, i, j), :343-395 */
+void ggo_interpolate_cell(ggo_map *m, const ggo_config *cfg, size_t x, size_t y);         /* interpolate_cell(map, x, y), :445-465 */
 
 /* GroundGrid::update (src/GroundGrid.cpp:83-147) on an already initialised map: grid_map::GridMap::move to the odometry
  * position (snapped to whole cells), newly exposed cells get ground = -(z of (cell centre, 0) in base_link) and

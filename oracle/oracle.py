@@ -118,6 +118,9 @@ def lib():
         ]
         L.ggo_stage_detect.argtypes = [C.POINTER(_Map), C.POINTER(Config)]
         L.ggo_stage_spiral.argtypes = [C.POINTER(_Map), C.POINTER(Config), C.c_double]
+        L.ggo_stage_detect_section.argtypes = [C.POINTER(_Map), C.POINTER(Config), C.c_ushort]
+        L.ggo_detect_ground_patch.argtypes = [C.POINTER(_Map), C.POINTER(Config), C.c_int, C.c_size_t, C.c_size_t]
+        L.ggo_interpolate_cell.argtypes = [C.POINTER(_Map), C.POINTER(Config), C.c_size_t, C.c_size_t]
         L.ggo_set_eigen_reduction.argtypes = [C.c_int]
         L.ggo_get_eigen_reduction.restype = C.c_int
         L.ggo_rotation_from_quaternion.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -298,6 +301,17 @@ class OracleMap:
 
     def stage_spiral(self, base_z=0.0):
         self._L.ggo_stage_spiral(self._m, C.byref(self.cfg), float(base_z))
+
+    # the public stage members of include/groundgrid/GroundSegmentation.h:59-62, one by one
+    def stage_detect_section(self, section: int):
+        """detect_ground_patches(map, section): variance := m2 ./ (points + FLT_MIN), then one quadrant (0..3)."""
+        self._L.ggo_stage_detect_section(self._m, C.byref(self.cfg), int(section))
+
+    def detect_ground_patch(self, S: int, i: int, j: int):
+        self._L.ggo_detect_ground_patch(self._m, C.byref(self.cfg), int(S), int(i), int(j))
+
+    def interpolate_cell(self, x: int, y: int):
+        self._L.ggo_interpolate_cell(self._m, C.byref(self.cfg), int(x), int(y))
 
 
 def tree_sum(vals) -> float:

@@ -8,5 +8,6 @@ namespace decl_only { void log(const char *fmt, ...); }
 #define ROS_ERROR(...) ::decl_only::log(__VA_ARGS__)
 #define ROS_FATAL(...) ::decl_only::log(__VA_ARGS__)
 #define ROS_WARN(...) ::decl_only::log(__VA_ARGS__)
+#define ROS_WARN_ONCE(...) ::decl_only::log(__VA_ARGS__)
 #define ROS_INFO(...) ::decl_only::log(__VA_ARGS__)
 #define ROS_DEBUG(...) ::decl_only::log(__VA_ARGS__)

@@ -159,6 +159,55 @@ int main()
             ok &= same;
         }
     }
+    // ---- the stage members of the class on their own (include/groundgrid/GroundSegmentation.h:59-62) ----
+    {
+        // A, host-managed: the host map's planes are uploaded, the stage runs on the device, what it wrote comes back into the planes
+        MapView va;
+        va.pos_x = host_a->position[0];
+        va.pos_y = host_a->position[1];
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) va.layer[l] = host_a->layer[l];
+        // (the host may have edited its map since the last cloud: give two cells counts and heights no cloud produced)
+        for (ggo_map *m : {host_a, ref_a}) {
+            m->layer[GGO_POINTS][200 + 180 * (size_t)m->rows] = 25.f;
+            m->layer[GGO_MINGROUNDHEIGHT][200 + 180 * (size_t)m->rows] = -1.9f;
+            m->layer[GGO_M2][200 + 180 * (size_t)m->rows] = 1e-4f;
+            m->layer[GGO_GROUNDPATCH][150 + 150 * (size_t)m->rows] = 0.95f;
+        }
+        ok &= a->run_stage(va, GG_STAGE_DETECT_GROUND_PATCHES, 1, 0, 0, 0.0) == GG_OK;
+        ggo_stage_detect_section(ref_a, &rcfg_a, 1);
+        ok &= a->run_stage(va, GG_STAGE_DETECT_GROUND_PATCH_5, 0, 200, 180, 0.0) == GG_OK;
+        ggo_detect_ground_patch(ref_a, &rcfg_a, 5, 200, 180);
+        ok &= a->run_stage(va, GG_STAGE_INTERPOLATE_CELL, 0, 150, 151, 0.0) == GG_OK;
+        ggo_interpolate_cell(ref_a, &rcfg_a, 150, 151);
+        ok &= a->run_stage(va, GG_STAGE_SPIRAL_GROUND_INTERPOLATION, 0, 0, 0, -1.6) == GG_OK;
+        ggo_stage_spiral(ref_a, &rcfg_a, -1.6);
+        for (int l : {(int)GG_LAYER_GROUND, (int)GG_LAYER_GROUNDPATCH, (int)GG_LAYER_VARIANCE, (int)GG_LAYER_POINTS}) ok &= same_floats(host_a->layer[l], ref_a->layer[l], C);
+        std::printf("stages on the host-managed map -> %s\n", ok ? "identical" : "MISMATCH");
+        // B, device-resident: nothing is uploaded; the view's planes only receive what the stage wrote
+        std::vector<float> gb(C), pb(C), vbv(C);
+        MapView vb;
+        vb.pos_x = ref_b->position[0];
+        vb.pos_y = ref_b->position[1];
+        vb.layer[GG_LAYER_GROUND] = gb.data();
+        vb.layer[GG_LAYER_GROUNDPATCH] = pb.data();
+        vb.layer[GG_LAYER_VARIANCE] = vbv.data();
+        ok &= b->run_stage(vb, GG_STAGE_DETECT_GROUND_PATCHES, 2, 0, 0, 0.0) == GG_OK;
+        ggo_stage_detect_section(ref_b, &rcfg_b, 2);
+        ok &= b->run_stage(vb, GG_STAGE_SPIRAL_GROUND_INTERPOLATION, 0, 0, 0, 0.4) == GG_OK;
+        ggo_stage_spiral(ref_b, &rcfg_b, 0.4);
+        ok &= same_floats(gb.data(), ref_b->layer[GGO_GROUND], C) && same_floats(pb.data(), ref_b->layer[GGO_GROUNDPATCH], C) && same_floats(vbv.data(), ref_b->layer[GGO_VARIANCE], C);
+        ok &= b->run_stage(vb, GG_STAGE_DETECT_GROUND_PATCH_3, 0, 0, 7, 0.0) == GG_ERR_INVALID; // (the block would leave the map: UB in the reference)
+        std::printf("stages on the device-resident map -> %s\n", ok ? "identical" : "MISMATCH");
+    }
+    // ---- lifetime: a map that goes away frees its Core for the next map; a re-initialised object drops its maps ----
+    {
+        const int map_a2 = 0;
+        ok &= Registry::instance().bind_map(&map_a2) == nullptr; // (both Cores serve a map)
+        Registry::instance().forget_map(&map_a_dummy);           // GroundGrid::~GroundGrid / initGroundGrid of a new map
+        ok &= Registry::instance().core_of_map(&map_a_dummy) == nullptr && Registry::instance().bind_map(&map_a2) == a;
+        Registry::instance().unbind_maps_of(a);                   // GroundSegmentation::init on an object that already had a context
+        ok &= Registry::instance().core_of_map(&map_a2) == nullptr && Registry::instance().core_of_map(&map_b) == b;
+    }
     // the layer selection of GROUNDGRID_HIP_LAYERS
     setenv("GROUNDGRID_HIP_LAYERS", "ground,variance", 1);
     ok &= groundgrid_hip::layers_from_env(0u) == ((1u << GG_LAYER_GROUND) | (1u << GG_LAYER_VARIANCE));

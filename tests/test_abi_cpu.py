@@ -40,7 +40,9 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_kernel_names(lib):
-    assert lib.gg_abi_version() == 4  # v2: gg_move_map takes matrix entries, conventions, async host call; v3: gg_batch.slots; v4: gg_comm_init_rank_for
+    # v2: gg_move_map takes matrix entries, conventions, async host call; v3: gg_batch.slots; v4: gg_comm_init_rank_for;
+    # v5: gg_batch.d_out_pc2, gg_run_stage, gg_filter_cloud_pc2_out, gg_get_gridmap_message, gg_device_error
+    assert lib.gg_abi_version() == 5
     names = [lib.gg_kernel_name(k).decode() for k in range(_lib.GG_NUM_KERNELS)]
     assert names == ["k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_sweep", "k_label"]
 
@@ -48,7 +50,8 @@ def test_abi_version_and_kernel_names(lib):
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.GGGeometry) == 16
     assert C.sizeof(_lib.GGConfig) == 104          # 2 int, 11 double, 1 int (+pad) as the C compiler lays it out
-    assert C.sizeof(_lib.GGBatch) == 112           # ABI v3: + slots
+    assert C.sizeof(_lib.GGBatch) == 120           # ABI v3: + slots, v5: + d_out_pc2
+    assert C.sizeof(_lib.GGStageArgs) == 24 and C.sizeof(_lib.GGGridMapHeader) == 32
     assert C.sizeof(_lib.GGConventions) == 32
     from groundgrid_amd import api, synth
     assert synth.POINT_DTYPE.itemsize == 32 and api.POINT16_DTYPE.itemsize == 16
@@ -57,9 +60,10 @@ def test_struct_layouts_match_the_header():
     #include <stdio.h>
     #include <stddef.h>
     #include "groundgrid_hip.h"
-    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\n", sizeof(gg_point32), sizeof(gg_point16), sizeof(gg_config),
+    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %d %zu %zu %zu %zu\n", sizeof(gg_point32), sizeof(gg_point16), sizeof(gg_config),
         sizeof(gg_geometry), sizeof(gg_batch), offsetof(gg_point32, ring), offsetof(gg_batch, d_out_counts),
-        sizeof(gg_conventions), GG_ASYNC_DEPTH); return 0; }
+        sizeof(gg_conventions), GG_ASYNC_DEPTH, offsetof(gg_batch, d_out_pc2), sizeof(gg_stage_args), offsetof(gg_stage_args, base_z),
+        sizeof(gg_gridmap_header)); return 0; }
     '''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -67,7 +71,8 @@ def test_struct_layouts_match_the_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         vals = list(map(int, subprocess.check_output([os.path.join(d, "t")], text=True).split()))
     assert vals == [32, 16, C.sizeof(_lib.GGConfig), 16, C.sizeof(_lib.GGBatch), 20, _lib.GGBatch.d_out_counts.offset,
-                    C.sizeof(_lib.GGConventions), _lib.GG_ASYNC_DEPTH]
+                    C.sizeof(_lib.GGConventions), _lib.GG_ASYNC_DEPTH, _lib.GGBatch.d_out_pc2.offset, C.sizeof(_lib.GGStageArgs),
+                    _lib.GGStageArgs.base_z.offset, C.sizeof(_lib.GGGridMapHeader)]
 
 
 def test_defaults_are_the_reference_cfg(lib):

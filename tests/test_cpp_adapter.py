@@ -10,13 +10,20 @@ from oracle import oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "test_adapter")
+# every program below is compiled against these: a struct that grows in the C ABI (gg_batch in ABI v5) must rebuild them all
+HEADERS = [os.path.join(ROOT, "include", "groundgrid_hip.h"), os.path.join(ROOT, "groundgrid_amd", "host", "GroundSegmentation.hpp"),
+           os.path.join(ROOT, "groundgrid_amd", "host", "binding_core.hpp"), os.path.join(ROOT, "oracle", "gg_oracle.h")]
+
+
+def stale(exe, *srcs):
+    return not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(f) for f in list(srcs) + HEADERS)
 
 
 def compile_adapter():
     build.build()
     oracle.build()
     src = os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp")
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(src):
+    if stale(EXE, src):
         subprocess.check_call([
             "g++", "-O1", "-std=c++17", src, "-o", EXE,
             "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "groundgrid_amd", "host"), "-I", os.path.join(ROOT, "oracle"),
@@ -35,7 +42,7 @@ def compile_binding_core():
     oracle.build()
     src = os.path.join(ROOT, "tests", "cpp", "test_binding_core.cpp")
     hdr = os.path.join(ROOT, "groundgrid_amd", "host", "binding_core.hpp")
-    if not os.path.exists(BINDING_EXE) or os.path.getmtime(BINDING_EXE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if stale(BINDING_EXE, src, hdr):
         subprocess.check_call([
             "g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", src, "-o", BINDING_EXE,
             "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "groundgrid_amd", "host"), "-I", os.path.join(ROOT, "oracle"),
@@ -70,7 +77,7 @@ def compile_streams():
     build.build()
     oracle.build()
     src = os.path.join(ROOT, "tests", "cpp", "test_streams.c")
-    if not os.path.exists(STREAMS_EXE) or os.path.getmtime(STREAMS_EXE) < os.path.getmtime(src):
+    if stale(STREAMS_EXE, src):
         subprocess.check_call([
             "gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__", src, "-o", STREAMS_EXE,
             "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), "-I", "/opt/rocm/include",

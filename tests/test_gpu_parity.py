@@ -410,6 +410,7 @@ def test_scan_part_that_never_publishes_is_an_error_not_a_hang():
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=2, max_points=stride)
     seg.debug_set_tuning("scan_parts", 4)
     seg.debug_set_tuning("scan_fault", 1)
+    seg.debug_set_tuning("scan_poll_cap", 20000)  # (the default bound is several seconds)
     pts = _batch_inputs(16, clouds, stride)
     n, org, bz = [len(c) for c in clouds], np.zeros((2, 3), np.float32), np.full(2, -1.73)
     seg.filter_batch(pts, n, org, bz)
@@ -417,7 +418,8 @@ def test_scan_part_that_never_publishes_is_an_error_not_a_hang():
     with pytest.raises(api.GroundGridError, match="k_scan: the sums of an earlier part"):
         seg.synchronize()
     seg.debug_set_tuning("scan_fault", 0)
-    seg.debug_set_tuning("clear_device_error", 0)
+    seg.debug_set_tuning("scan_poll_cap", 0)
+    assert seg._L.gg_device_error(seg._ctx, 0) == 0  # reported once and cleared: the context works again by itself
     seg.reset_maps(0, 2)
     refs = [oracle.OracleMap(120.0, 0.33) for _ in clouds]
     out = seg.filter_batch(pts, n, org, bz)
@@ -564,7 +566,7 @@ def test_sweep_hand_over_that_never_arrives_is_an_error_not_a_hang():
         seg.synchronize()
     seg.debug_set_tuning("sweep_fault", 0)
     seg.debug_set_tuning("sweep_poll_cap", 0)
-    seg.debug_set_tuning("clear_device_error", 0)
+    assert seg._L.gg_device_error(seg._ctx, 0) == 0  # reported once and cleared
     seg.reset_maps(0, 2)
     refs = [oracle.OracleMap(120.0, 0.33) for _ in clouds]
     out = seg.filter_batch(pts, n, org, bz)

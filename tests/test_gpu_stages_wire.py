@@ -1,0 +1,270 @@
+"""GPU parity (pytest -m gpu) of what round 5 added around the path:
+
+* the public stage members of the reference's class one by one (include/groundgrid/GroundSegmentation.h:59-62) through
+  gg_run_stage, on layers that were NOT produced by the insert kernels, against the oracle's ggo_stage_* / single-cell twins;
+* the emission side of the wire formats: the returned cloud as 18-byte PointCloud2 records written by the label
+  kernel, and the serialised grid_map_msgs/GridMap.
+
+Bit-exact throughout (NaN == NaN).  Nothing here reads /root/reference.
+"""
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from groundgrid_amd import api, synth  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+ORIGIN0 = (0.0, 0.0, 0.0)
+
+
+def nan_equal(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def assert_layers(seg_map, ref, names, tag=""):
+    for name in names:
+        a, b = seg_map[name], ref.layer(name)
+        if not nan_equal(a, b):
+            bad = np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b))))
+            raise AssertionError(f"{tag} layer {name}: {len(bad)} cells differ, first {bad[:3].tolist()} "
+                                 f"gpu={[float(a[tuple(i)]) for i in bad[:3]]} ref={[float(b[tuple(i)]) for i in bad[:3]]}")
+
+
+def synthetic_layers(n, seed, integer_points=True):
+    """Layer contents no cloud produced: patchy counts, heights on a slope with steps, small and large variances, old terrain with
+    confidences on both sides of every threshold of :379-393."""
+    rng = np.random.default_rng(seed)
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    pts = rng.integers(0, 30, (n, n)).astype(np.float32) * (rng.random((n, n)) < 0.45)
+    if not integer_points:
+        pts = (pts * rng.uniform(0.5, 1.5, (n, n))).astype(np.float32)
+    slope = (-1.7 + 0.01 * (ii - n / 2) + 0.2 * np.sin(jj / 9.0)).astype(np.float32)
+    mn = np.where(pts > 0, slope + rng.normal(0, 0.02, (n, n)).astype(np.float32), np.float32(3.402823466e+38)).astype(np.float32)
+    m2 = (pts * rng.choice(np.array([1e-5, 3e-4, 2e-2], dtype=np.float32), (n, n)) * rng.random((n, n)).astype(np.float32)).astype(np.float32)
+    ground = (slope + rng.normal(0, 0.3, (n, n))).astype(np.float32)
+    patch = rng.choice(np.array([0.0, 1e-7, 0.2, 0.45, 0.55, 0.9, 1.0], dtype=np.float32), (n, n))
+    return dict(points=pts, minGroundHeight=mn, m2=m2, ground=ground, groundpatch=patch.astype(np.float32))
+
+
+def pair_with_layers(length, resolution, layers):
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=1, max_points=64)
+    ref = oracle.OracleMap(length, resolution)
+    for name, arr in layers.items():
+        seg.map(0).set(name, arr)
+        ref.set_layer(name, arr)
+    return seg, ref
+
+
+@pytest.mark.parametrize("length,resolution,integer_points", [(120.0, 0.33, True), (33.0, 0.33, False), (61.0, 0.25, True)])
+def test_stage_detect_ground_patches_by_section_on_foreign_layers(length, resolution, integer_points):
+    n = oracle.OracleMap(length, resolution).rows
+    seg, ref = pair_with_layers(length, resolution, synthetic_layers(n, seed=n, integer_points=integer_points))
+    for section in (2, 0, 3, 1):  # any order: a quadrant writes only its own cells
+        seg.map(0).detect_ground_patches(section)
+        ref.stage_detect_section(section)
+        assert_layers(seg.map(0), ref, ("ground", "groundpatch", "variance", "points", "minGroundHeight", "m2"), f"section {section}")
+    # ... and all four at once on what that left (second pass: old confidences now above 0.5 in many cells)
+    seg.map(0).detect_ground_patches(-1)
+    ref.stage_detect()
+    assert_layers(seg.map(0), ref, ("ground", "groundpatch", "variance"), "all sections")
+    seg.close()
+
+
+def test_stage_detect_with_the_other_eigen_order():
+    n = oracle.OracleMap(61.0, 0.25).rows
+    seg, ref = pair_with_layers(61.0, 0.25, synthetic_layers(n, seed=5, integer_points=False))
+    seg.set_conventions(eigen_reduction=1)
+    oracle.set_eigen_reduction(1)
+    try:
+        seg.map(0).detect_ground_patches(-1)
+        ref.stage_detect()
+        assert_layers(seg.map(0), ref, ("ground", "groundpatch", "variance"))
+    finally:
+        oracle.set_eigen_reduction(0)
+    seg.close()
+
+
+@pytest.mark.parametrize("length,resolution", [(120.0, 0.33), (10.0, 0.5), (150.0, 0.25)])
+def test_stage_spiral_ground_interpolation_on_foreign_layers(length, resolution):
+    n = oracle.OracleMap(length, resolution).rows
+    layers = synthetic_layers(n, seed=3 * n)
+    seg, ref = pair_with_layers(length, resolution, layers)
+    for base_z in (-1.73, 0.25):
+        seg.map(0).spiral_ground_interpolation(base_z)
+        ref.stage_spiral(base_z)
+        # the stage is not filter_cloud: `points` keeps its counts (:147 is the caller's)
+        assert_layers(seg.map(0), ref, ("ground", "groundpatch", "points"), f"base_z {base_z}")
+    seg.close()
+
+
+def test_stage_after_a_cloud_then_filter_again():
+    """The stages work on what a cloud left (sparse per-call layers, K2's tile lists) and the next cloud works on what they left."""
+    cloud = synth.hdl64_cloud(seed=21, n_az=400)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    ref = oracle.OracleMap(120.0, 0.33)
+    seg.filter_cloud(cloud, ORIGIN0, -1.73)
+    ref.filter_cloud(cloud, ORIGIN0, -1.73)
+    seg.map(0).detect_ground_patches(1)
+    ref.stage_detect_section(1)
+    seg.map(0).spiral_ground_interpolation(-1.5)
+    ref.stage_spiral(-1.5)
+    for name in oracle.LAYERS:
+        assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+    _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+    r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+    assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"])
+    for name in oracle.LAYERS:
+        assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+    seg.close()
+
+
+def test_single_cell_stages():
+    n = oracle.OracleMap(33.0, 0.33).rows
+    layers = synthetic_layers(n, seed=77, integer_points=False)
+    seg, ref = pair_with_layers(33.0, 0.33, layers)
+    seg.map(0).detect_ground_patches(0)  # (gives `variance` contents)
+    ref.stage_detect_section(0)
+    rng = np.random.default_rng(1)
+    for _ in range(40):
+        S = int(rng.choice([3, 5]))
+        i, j = (int(v) for v in rng.integers(S // 2, n - S // 2, 2))
+        seg.map(0).detect_ground_patch(S, i, j)
+        ref.detect_ground_patch(S, i, j)
+        x, y = (int(v) for v in rng.integers(1, n - 1, 2))
+        seg.map(0).interpolate_cell(x, y)
+        ref.interpolate_cell(x, y)
+    assert_layers(seg.map(0), ref, ("ground", "groundpatch"))
+    # blocks that would leave the map are UB in the reference and an error here
+    with pytest.raises(api.GroundGridError):
+        seg.map(0).detect_ground_patch(5, 1, 10)
+    with pytest.raises(api.GroundGridError):
+        seg.map(0).interpolate_cell(0, 3)
+    with pytest.raises(api.GroundGridError):
+        seg.map(0).detect_ground_patches(4)
+    seg.close()
+
+
+# ---------------------------------------------------------------- N4: the emission side
+
+def expected_pc2(out_points):
+    return api.to_pc2(out_points).tobytes()
+
+
+@pytest.mark.parametrize("with_tf", [False, True])
+def test_returned_cloud_as_18_byte_pointcloud2_records(with_tf):
+    cloud = synth.hdl64_cloud(seed=13, n_az=500)
+    low = synth.clone_cloud(cloud)
+    rng = np.random.default_rng(2)
+    sel = rng.random(len(low)) < 0.1
+    low["z"][sel] -= np.float32(1.0)  # outlier candidates for the second frame: all three parts of the returned cloud
+    n = len(cloud)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=n)
+    ref = oracle.OracleMap(120.0, 0.33)
+    tf = None
+    if with_tf:  # the payload is still in the sensor frame: rotate / shift it back on the host for the oracle's input
+        tf = api.transform_from_pose((1.5, -0.5, 0.2, 0.0, 0.0, np.sin(0.15), np.cos(0.15)))
+    n_outliers = 0
+    for frame, c in enumerate((cloud, low, low)):
+        wire = api.to_pc2(c)
+        ref_in = c
+        if with_tf:
+            ref_in = synth.clone_cloud(c)
+            R, t = tf[:, :3], tf[:, 3]
+            p = np.stack([c["x"], c["y"], c["z"]], 1).astype(np.float64)
+            for k, name in enumerate(("x", "y", "z")):  # tf2::doTransform: dot products left to right in double, cast to float
+                ref_in[name] = (((R[k, 0] * p[:, 0] + R[k, 1] * p[:, 1]) + R[k, 2] * p[:, 2]) + t[k]).astype(np.float32)
+        out = seg.filter_cloud_pc2_out(wire.tobytes(), n, 18, (0, 4, 8, 16), ORIGIN0, -1.73, map_from_cloud=tf)
+        r = ref.filter_cloud(ref_in, ORIGIN0, -1.73)
+        assert len(out) == len(r["out_points"]), frame
+        assert out.tobytes() == expected_pc2(r["out_points"]), frame
+        n_outliers += int((r["cls"] == oracle.OUTLIER).sum())
+    assert n_outliers > 0
+    for name in ("ground", "groundpatch", "points"):
+        assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+    seg.close()
+
+
+def test_pc2_records_from_the_batched_call_both_point_formats():
+    import torch
+
+    clouds = [synth.hdl64_cloud(seed=40 + k, n_az=200 + 37 * k) for k in range(3)] + [synth.empty_cloud(0)]
+    stride = max(len(c) for c in clouds) + 7
+    B = len(clouds)
+    for rec in (16, 32):
+        seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride)
+        pts = np.zeros((B, stride, rec), dtype=np.uint8)
+        for b, c in enumerate(clouds):
+            src = api.pack16(c) if rec == 16 else c
+            pts[b, : len(c)] = np.frombuffer(src.tobytes(), dtype=np.uint8).reshape(len(c), rec)
+        d = torch.from_numpy(pts).cuda()
+        o = seg.filter_batch(d, [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73), want_pc2=True)
+        torch.cuda.synchronize()
+        counts = o.counts.cpu().numpy()
+        raw = o.out_pc2.cpu().numpy()
+        for b, c in enumerate(clouds):
+            ref = oracle.OracleMap(120.0, 0.33)
+            r = ref.filter_cloud(c, ORIGIN0, -1.73)
+            assert counts[b, 0] == len(r["out_points"])
+            assert raw[b, : counts[b, 0] * 18].tobytes() == expected_pc2(r["out_points"]), (rec, b)
+        seg.close()
+
+
+class Reader:
+    def __init__(self, buf):
+        self.b, self.at = buf, 0
+
+    def take(self, fmt):
+        v = struct.unpack_from("<" + fmt, self.b, self.at)
+        self.at += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+
+    def string(self):
+        n = self.take("I")
+        s = self.b[self.at : self.at + n].decode()
+        self.at += n
+        return s
+
+
+def parse_gridmap(buf):
+    """grid_map_msgs/GridMap, ROS 1 serialisation (the message definition of grid_map_msgs 1.6.x)."""
+    r = Reader(buf)
+    m = dict(seq=r.take("I"), stamp=r.take("II"), frame_id=r.string(), resolution=r.take("d"), length=r.take("dd"), position=r.take("ddd"),
+             orientation=r.take("dddd"))
+    m["layers"] = [r.string() for _ in range(r.take("I"))]
+    m["basic_layers"] = [r.string() for _ in range(r.take("I"))]
+    m["data"] = []
+    for _ in range(r.take("I")):
+        dims = [(r.string(), r.take("I"), r.take("I")) for _ in range(r.take("I"))]
+        offset = r.take("I")
+        count = r.take("I")
+        arr = np.frombuffer(buf, dtype="<f4", count=count, offset=r.at)
+        r.at += 4 * count
+        m["data"].append((dims, offset, arr))
+    m["start"] = r.take("HH")
+    assert r.at == len(buf)
+    return m
+
+
+def test_gridmap_message_payload():
+    cloud = synth.hdl64_cloud(seed=31, n_az=300)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=2, max_points=len(cloud))
+    ref = oracle.OracleMap(120.0, 0.33, pos=(3.3, -6.6))
+    seg.map(1).reset(pos=(3.3, -6.6))
+    seg.filter_cloud(cloud, (3.0, -6.0, 0.0), -1.73, map=seg.map(1))
+    ref.filter_cloud(cloud, (3.0, -6.0, 0.0), -1.73)
+    m = parse_gridmap(seg.map(1).gridmap_message(seq=7, stamp=(1234, 5678)))
+    assert (m["seq"], m["stamp"], m["frame_id"]) == (7, (1234, 5678), "map")
+    assert m["resolution"] == ref.resolution and m["length"] == ref.length and m["position"] == (3.3, -6.6, 0.0) and m["orientation"] == (0.0, 0.0, 0.0, 1.0)
+    assert m["layers"] == oracle.LAYERS and m["basic_layers"] == [] and m["start"] == (0, 0)
+    n = ref.rows
+    for name, (dims, offset, arr) in zip(m["layers"], m["data"]):
+        assert dims == [("column_index", n, n * n), ("row_index", n, n)] and offset == 0
+        assert nan_equal(arr.reshape((n, n), order="F"), ref.layer(name)), name
+    # a subset, with basic layers, as a publisher with two subscribers would ask for it
+    m = parse_gridmap(seg.map(1).gridmap_message(layers=["ground", "variance"], frame_id="odom", basic_layers=["ground"]))
+    assert m["layers"] == ["ground", "variance"] and m["basic_layers"] == ["ground"] and m["frame_id"] == "odom"
+    assert nan_equal(m["data"][1][2].reshape((n, n), order="F"), ref.layer("variance"))
+    seg.close()
