@@ -162,7 +162,7 @@ def ordered_line(result, world):
         "kernel_ms": {k.replace("k_", ""): v["avg_ms"] for k, v in (result.get("kernels") or {}).items()},
         "cpu_1thread_clouds_per_s": {"cold": pick(result, "cpu_baseline", "value"), "warm": pick(result, "cpu_baseline_warm", "value")},
         "speedup_vs_cpu_1thread": {"cold": pick(result, "speedup_vs_cpu_1thread", "cold_over_cold"), "warm": pick(result, "speedup_vs_cpu_1thread", "warm_over_warm")},
-        "host_api_clouds_per_s": {k: pick(result, "host_api", k + "_clouds_per_s") for k in ("sync", "pipelined", "binding_like", "device_resident_binding")},
+        "host_api_clouds_per_s": {k: pick(result, "host_api", k + "_clouds_per_s") for k in ("sync", "pipelined", "binding_like", "binding_like_registered", "pc2_out", "device_resident_binding")},
         "host_api_vs_cpu_1thread": {"sync": pick(result, "host_api", "sync_vs_cpu_1thread"), "pipelined": pick(result, "host_api", "vs_cpu_1thread"),
                                     "binding_like": pick(result, "host_api", "binding_like_vs_cpu_1thread"),
                                     "device_resident_binding": pick(result, "host_api", "device_resident_binding_vs_cpu_1thread")},
@@ -664,8 +664,10 @@ def main():
         seq = [clouds[b % min(B, 8)] for b in range(64)]
         for c in seq[:4]:
             chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73)
-        t_sync = t_pipe = t_bind = t_dev = float("inf")
-        layer_buf = {}
+        t_sync = t_pipe = t_bind = t_bind_pin = t_dev = t_pc2 = t_two = float("inf")
+        layer_buf = chk.alloc_layers(register=False)   # the planes of a host grid_map::GridMap: allocated once, written per cloud
+        layer_pin = chk.alloc_layers(register=True)    # ... and registered with the context (what ros/GroundGridHip.cpp does for the map it owns)
+        wire_seq = [api.to_pc2(c).tobytes() for c in seq[:8]]
         for _rep in range(3):  # best of three passes (the leg is host-bound: page placement and clocks of the box vary)
             t0 = time.perf_counter()
             for c in seq:
@@ -679,10 +681,22 @@ def main():
                 tick = nxt
             t_pipe = min(t_pipe, (time.perf_counter() - t0) / len(seq))
             t0 = time.perf_counter()
-            for c in seq[:32]:  # what the reference-typed binding does per callback (GROUNDGRID_HIP_LAYERS=all)
-                chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73, reuse_buffers=True)
-                layer_buf = chk.map(0).layers()
+            for c in seq[:32]:  # what the reference-typed binding does per callback (GROUNDGRID_HIP_LAYERS=all): one fused call
+                chk.filter_cloud_with_layers(c, (0.0, 0.0, 0.0), -1.73, layer_buf, reuse_buffers=True)
             t_bind = min(t_bind, (time.perf_counter() - t0) / 32)
+            t0 = time.perf_counter()
+            for c in seq[:32]:
+                chk.filter_cloud_with_layers(c, (0.0, 0.0, 0.0), -1.73, layer_pin, reuse_buffers=True)
+            t_bind_pin = min(t_bind_pin, (time.perf_counter() - t0) / 32)
+            t0 = time.perf_counter()
+            for c in seq[:32]:  # the round-4 shape of the same thing: two calls, the layers after the cloud
+                chk.filter_cloud(c, (0.0, 0.0, 0.0), -1.73, reuse_buffers=True)
+                chk.map(0).layers()
+            t_two = min(t_two, (time.perf_counter() - t0) / 32)
+            t0 = time.perf_counter()
+            for k in range(32):  # wire to wire: 18-byte PointCloud2 payload in, 18-byte records of the returned cloud out
+                chk.filter_cloud_pc2_out(wire_seq[k % 8], len(seq[k % 8]), 18, (0, 4, 8, 16), (0.0, 0.0, 0.0), -1.73)
+            t_pc2 = min(t_pc2, (time.perf_counter() - t0) / 32)
             # the device-resident binding (groundgrid_amd/host/ros/GroundGridHip.cpp + GroundSegmentationHip.cpp): GroundGrid::update
             # runs on the device before every cloud (the map scrolls by a cell per frame: a moving vehicle), nothing is uploaded and
             # no layer is downloaded (no subscriber)
@@ -697,36 +711,67 @@ def main():
         result["host_api"] = {
             "sync_clouds_per_s": round(1.0 / t_sync, 1), "pipelined_clouds_per_s": round(1.0 / t_pipe, 1),
             "binding_like_clouds_per_s": round(1.0 / t_bind, 1), "device_resident_binding_clouds_per_s": round(1.0 / t_dev, 1),
+            "binding_like_registered_clouds_per_s": round(1.0 / t_bind_pin, 1), "binding_like_two_calls_clouds_per_s": round(1.0 / t_two, 1),
+            "pc2_out_clouds_per_s": round(1.0 / t_pc2, 1),
             "sync_ms": round(1e3 * t_sync, 4), "pipelined_ms": round(1e3 * t_pipe, 4), "binding_like_ms": round(1e3 * t_bind, 4),
+            "binding_like_registered_ms": round(1e3 * t_bind_pin, 4), "binding_like_two_calls_ms": round(1e3 * t_two, 4), "pc2_out_ms": round(1e3 * t_pc2, 4),
             "device_resident_binding_ms": round(1e3 * t_dev, 4),
             "vs_cpu_1thread": round((1.0 / t_pipe) / cpu_warm, 1),  # (consecutive clouds on one map: the warm CPU figure)
             "sync_vs_cpu_1thread": round((1.0 / t_sync) / cpu_warm, 1),
             "binding_like_vs_cpu_1thread": round((1.0 / t_bind) / cpu_warm, 1),
+            "binding_like_registered_vs_cpu_1thread": round((1.0 / t_bind_pin) / cpu_warm, 1),
+            "pc2_out_vs_cpu_1thread": round((1.0 / t_pc2) / cpu_warm, 1),
             "device_resident_binding_vs_cpu_1thread": round((1.0 / t_dev) / cpu_warm, 1),
             "note": "gg_filter_cloud: 32-byte PointXYZIR cloud in host memory -> returned cloud in host memory, one map, consecutive clouds; "
                     "pipelined = gg_filter_cloud_async two clouds deep (pack + upload of cloud k+1 overlap the kernels of cloud k); binding_like = "
-                    "the synchronous call followed by the download of all 11 layers (what groundgrid_amd/host/ros/GroundSegmentationHip.cpp does "
-                    "per callback when the map is host-managed and every layer is published); device_resident_binding = the same call with "
+                    "gg_filter_cloud_layers with all 11 layers into plain host planes (what groundgrid_amd/host/ros/GroundSegmentationHip.cpp does "
+                    "per callback when the map is host-managed and every layer is published: the layers the insertion finishes travel while the "
+                    "sweep runs); binding_like_registered = the same into planes registered with gg_host_register (the device writes them, no "
+                    "staging copy); binding_like_two_calls = round 4's shape, gg_filter_cloud then gg_get_layers; pc2_out = gg_filter_cloud_pc2_out, "
+                    "18-byte PointCloud2 payload in and 18-byte records of the returned cloud out (the label kernel writes them); device_resident_binding = the same call with "
                     "GroundGrid::update on the device before every cloud (gg_move_map, the map scrolls a cell per frame) and no layer downloaded: "
                     "what the pair ros/GroundGridHip.cpp + ros/GroundSegmentationHip.cpp does per callback; 64 clouds of 8 different scenes in "
                     "turn, best of three passes",
         }
-        del layer_buf
+        chk.release_layers(layer_pin)
+        del layer_buf, layer_pin
 
-        # single-cloud latency through the same kernels (one cloud per launch, device-resident input)
-        chk.set_flags(profile=True)
+        # single-cloud latency through the same kernels (one cloud per launch, device-resident input): the captured graph, then the
+        # eager launches with an event pair around every kernel (where the time goes; the events cost a little themselves)
         p1 = points[:1].contiguous()
         o1 = None
-        for _ in range(5):
-            o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
-        chk.synchronize()
-        chk.kernel_times(reset=True)
-        t1 = time.perf_counter()
-        for _ in range(20):
-            o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
-        chk.synchronize()
-        result["single_cloud_latency_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
-        result["single_cloud_kernel_ms"] = {k: round(v[0] / max(1, v[1]), 4) for k, v in chk.kernel_times(reset=True).items()}
+        side = torch.cuda.Stream(device=dev)  # (graphs are captured on a real stream, not the legacy default one)
+        with torch.cuda.stream(side):
+            for _ in range(5):
+                o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
+            chk.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(40):
+                o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
+            chk.synchronize()
+            result["single_cloud_latency_ms"] = round((time.perf_counter() - t1) / 40 * 1e3, 4)
+            chk.debug_set_tuning("graphs", 1)  # the same 40 calls as replays of a captured HIP graph (opt-in, GG_GRAPH=1)
+            for _ in range(5):
+                o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
+            chk.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(40):
+                o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
+            chk.synchronize()
+            result["single_cloud_latency_graph_replay_ms"] = round((time.perf_counter() - t1) / 40 * 1e3, 4)
+            result["single_cloud_graph_replays"] = chk.debug_set_tuning("graph_replays", 0)
+            chk.debug_set_tuning("graphs", 0)
+            chk.set_flags(profile=True)
+            for _ in range(5):
+                o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
+            chk.synchronize()
+            chk.kernel_times(reset=True)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                o1 = chk.filter_batch(p1, n_points[:1], origins[:1], base_z[:1], out=o1)
+            chk.synchronize()
+            result["single_cloud_latency_eager_profiled_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+            result["single_cloud_kernel_ms"] = {k: round(v[0] / max(1, v[1]), 4) for k, v in chk.kernel_times(reset=True).items()}
         chk.close()
 
         # BASELINE configs[3]: dense OS-128-style clouds, 200 m / 0.2 m -> 1000 x 1000 cells

@@ -326,6 +326,48 @@ class GroundSegmentation:
 
     segment = filter_cloud  # BASELINE.json's north_star calls the entry point segment(); same thing
 
+    def alloc_layers(self, names=None, register: bool = True) -> dict:
+        """Host planes for filter_cloud_with_layers: one (rows, cols) Fortran-ordered float32 array per layer (Eigen::MatrixXf storage),
+        registered with the context (gg_host_register) so that the device writes them directly -- what a host does once with the
+        planes of its grid_map::GridMap."""
+        names = list(LAYERS) if names is None else list(names)
+        planes = {k: np.zeros((self.rows, self.cols), dtype=np.float32, order="F") for k in names}
+        if register:
+            for v in planes.values():
+                _check(self._L, self._ctx, self._L.gg_host_register(self._ctx, v.ctypes.data, v.nbytes), "gg_host_register")
+        return planes
+
+    def release_layers(self, planes: dict):
+        for v in planes.values():
+            self._L.gg_host_unregister(self._ctx, v.ctypes.data)
+
+    def filter_cloud_with_layers(self, cloud: np.ndarray, cloudOrigin: Sequence[float], mapToBase_z: float, planes: dict, map: Optional[GridMap] = None,
+                                 return_details: bool = False, map_from_cloud=None, reuse_buffers: bool = False):
+        """filter_cloud and the download of the layers in `planes` ({name: (rows, cols) F-ordered float32 array}) as ONE call
+        (gg_filter_cloud_layers): what the reference's nodelet does per cloud -- filter, then publish every layer
+        (src/GroundGridNodelet.cpp:196-228) -- with the layer traffic overlapping the terrain sweep."""
+        assert cloud.dtype == POINT_DTYPE
+        gm = map if map is not None else self._maps[0]
+        cloud = np.ascontiguousarray(cloud)
+        n = cloud.shape[0]
+        out, labels, index = self._host_buffers(n, reuse_buffers)
+        out_n = C.c_size_t(0)
+        org = (C.c_float * 3)(*[float(v) for v in cloudOrigin])
+        lab_p, idx_p = (labels.ctypes.data, index.ctypes.data) if return_details else (None, None)
+        tf = None
+        if map_from_cloud is not None:
+            tf = (C.c_double * 12)(*[float(v) for v in np.asarray(map_from_cloud, dtype=np.float64).reshape(-1)[:12]])
+        for k, v in planes.items():
+            assert v.dtype == np.float32 and v.shape == (self.rows, self.cols) and v.flags.f_contiguous, k
+        ptrs = (C.c_void_p * len(LAYERS))(*[planes[k].ctypes.data if k in planes else None for k in LAYERS])
+        rc = self._L.gg_filter_cloud_layers(self._ctx, gm.slot, cloud.ctypes.data, n, tf, org, float(mapToBase_z), out.ctypes.data, C.byref(out_n),
+                                            lab_p, idx_p, ptrs)
+        _check(self._L, self._ctx, rc, "gg_filter_cloud_layers")
+        seg = out[: out_n.value]
+        if return_details:
+            return seg, labels[:n], index[:n]
+        return seg
+
     def filter_cloud_pc2(self, data: bytes, n: int, point_step: int, offsets, cloudOrigin, mapToBase_z: float,
                          map: Optional[GridMap] = None, map_from_cloud=None):
         """filter_cloud straight from a sensor_msgs/PointCloud2 payload; offsets = (x, y, z, ring) byte offsets.

@@ -93,6 +93,8 @@ struct gg_context {
     } async_slot[GG_ASYNC_DEPTH];
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     int next_ticket = 0, oldest_ticket = 0;
+    int slot_of_ticket[GG_ASYNC_DEPTH] = {}; // staging set of an outstanding ticket (a synchronous call always takes set 0)
+    int next_label_shift = 0;                // enqueue_ticket -> enqueue_batch: CloudParams::label_shift of the one cloud
     double host_t[4] = {0, 0, 0, 0}; // GG_HOST_TIMING: pack+upload, enqueue, wait, copy-out
     long host_calls = 0;
 
@@ -122,6 +124,39 @@ struct gg_context {
     uint8_t *d_pc2 = nullptr, *h_pc2 = nullptr; // gg_filter_cloud_pc2_out: [64 B counts][max_points * 18 B records], device and pinned host (allocated on first use)
     volatile uint32_t *h_dev_error = nullptr;  // host view of Arena::dev_error (mapped pinned memory)
     unsigned long long *d_sweep_dbg = nullptr; // GG_SWEEP_TIMING=1: cycle counters of the sweep's wavefronts (cloud 0 of a batch)
+
+    // One cloud per call -- the reference's own call shape (src/GroundGridNodelet.cpp:196) -- replays a captured HIP graph: the seven
+    // launches (and, for the fused filter + layers call, the layer extraction and downloads on a side branch) are handed to the device
+    // as ONE submission.  A captured sequence bakes in everything but the cloud's parameter record, which every replay reads from the
+    // same device address (d_gparams, refreshed by a copy in front of the graph): key = what else the launchers were given.
+    struct GraphKey {
+        BatchIO io;
+        int max_n, slot;
+        unsigned flags;
+        int eigen;
+        unsigned long long generation; // bumped by whatever changes the kernels' by-value arguments (configuration, tuning, conventions)
+        unsigned layer_mask;           // fused call: layers extracted and downloaded inside the graph ...
+        void *layer_dst[GG_NUM_LAYERS]; // ... and where to (pinned staging or the caller's registered planes)
+        hipStream_t stream;
+    };
+    struct GraphEntry {
+        GraphKey key;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        int uses = 0;
+        unsigned long long last_use = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    unsigned long long graph_generation = 1, graph_clock = 0;
+    bool graphs_enabled = false; // opt-in (GG_GRAPH=1, gg_debug_set_tuning("graphs", 1)): measured on MI355X / ROCm 7.0.2 a replay is no faster than the
+                                 // seven eager launches -- one cloud, device-resident input: 0.420 against 0.416 ms, the synchronous host call 0.589
+                                 // against 0.571 (profiles/r05a/host_call_probe*.json): the launches of a call already queue up behind the first
+                                 // kernel, there are no gaps left for a graph to close
+    long graph_replays = 0, graph_captures = 0;
+    CloudParams *d_gparams = nullptr;
+    hipEvent_t fork_event = nullptr, join_event = nullptr; // the side branch of the fused filter + layers call
+    hipEvent_t layers_event = nullptr;                     // ... and its late layers (behind the results on the context's stream)
+    std::vector<std::pair<char *, size_t>> registered;     // gg_host_register: host ranges downloads may land in directly
 
     // profiling
     std::vector<EventPair> pending;
@@ -311,8 +346,180 @@ int drain_profile(gg_context *ctx)
     return GG_OK;
 }
 
+// layers the fused filter + layers call (gg_filter_cloud_layers) extracts and downloads inside the launch sequence
+struct LayerPlan {
+    unsigned mask = 0u;                 // bit per gg_layer
+    void *dst[GG_NUM_LAYERS] = {};      // where layer l lands: the caller's registered plane, or its plane of the pinned staging block
+};
+// the eight per-call layers that are final once k_reduce has run (K3 / K4 / K5 only read them; `points` is rewritten by K4 / K5,
+// ground / groundpatch by K3 / K4): their extraction and download overlap the terrain sweep on a side branch
+constexpr unsigned EARLY_LAYERS = (1u << GG_LAYER_MINGROUNDHEIGHT) | (1u << GG_LAYER_MAXGROUNDHEIGHT) | (1u << GG_LAYER_GROUNDCANDIDATES) | (1u << GG_LAYER_PLANEDIST) |
+                                  (1u << GG_LAYER_M2) | (1u << GG_LAYER_MEANVARIANCE) | (1u << GG_LAYER_POINTSRAW) | (1u << GG_LAYER_VARIANCE);
+
+// extraction kernel + one download per layer of `mask` on stream `st`.  The early group owns planes 0..7 of d_planes, the late group
+// (ground, groundpatch, points) planes 8..10: the two never share one.
+void enqueue_layer_downloads(gg_context *ctx, const Arena &a, int slot, unsigned mask, const LayerPlan &plan, hipStream_t st)
+{
+    if (!mask) return;
+    const size_t plane = align_up((size_t)a.g.C * 4, 256) / 4;
+    float *base = ctx->d_planes + (size_t)((mask & EARLY_LAYERS) ? 0 : 8) * plane;
+    launch_layers_extract(a, slot, mask, base, plane, st); // (plane k of `base` = the k-th layer of `mask`)
+    int k = 0;
+    for (int l = 0; l < GG_NUM_LAYERS; ++l) {
+        if (!((mask >> l) & 1u)) continue;
+        hipMemcpyAsync(plan.dst[l], base + (size_t)k * plane, (size_t)a.g.C * sizeof(float), hipMemcpyDeviceToHost, st);
+        ++k;
+    }
+}
+
+// the kernels of one batched filter_cloud call (and the layer branch of the fused call), on stream s
+void launch_sequence(gg_context *ctx, const Arena &a, const CloudParams *dp, const BatchIO &io, int nb, int max_n, hipStream_t s, const LayerPlan *plan, int slot0,
+                     bool profile)
+{
+    Profiler prof{ctx, s, profile};
+    {
+        StageRange stage("rasterization"); // insert_cloud, :98-124
+        // the front end in one, two or three launches (k1_classify.hip): what launch_classify did not do itself follows here
+        prof.begin(GG_K_CLASSIFY);
+        const int front = launch_classify(a, dp, io, nb, max_n, s);
+        prof.end();
+        if (front == FRONT_THREE_LAUNCHES) {
+            prof.begin(GG_K_SCAN);
+            launch_scan(a, dp, nb, s);
+            prof.end();
+        }
+        if (front != FRONT_ONE_LAUNCH) {
+            prof.begin(GG_K_SCATTER);
+            launch_scatter(a, dp, nb, max_n, s);
+            prof.end();
+        }
+        prof.begin(GG_K_REDUCE);
+        launch_reduce(a, dp, nb, s);
+        prof.end();
+    }
+    const bool side = plan && (plan->mask & EARLY_LAYERS);
+    if (side) { // fork: the layers k_reduce has just finished travel while the stencil and the sweep run
+        hipEventRecord(ctx->fork_event, s);
+        hipStreamWaitEvent(ctx->d2h_stream, ctx->fork_event, 0);
+        enqueue_layer_downloads(ctx, a, slot0, plan->mask & EARLY_LAYERS, *plan, ctx->d2h_stream);
+        hipEventRecord(ctx->join_event, ctx->d2h_stream);
+    }
+    {
+        StageRange stage("patch detection"); // detect_ground_patches, :126-138
+        prof.begin(GG_K_PATCH);
+        launch_patch(a, dp, nb, s);
+        prof.end();
+    }
+    prof.begin(GG_K_SPIRAL);
+    {
+        StageRange stage("interpolation"); // spiral_ground_interpolation, :141-144
+        sweep::Params sp = ctx->sweep_params;
+        sp.decrease = ctx->cfg.occupied_cells_decrease_factor;
+        sp.inv_decrease = 1.0 / sp.decrease;
+        sp.decay_fast = sp.decrease >= 1.25 && sp.decrease < 1e300;
+        launch_sweep(a, sp, dp, nb, s, ctx->d_sweep_dbg);
+    }
+    prof.end();
+    {
+        StageRange stage("segmentation"); // the label loop, :146-194
+        prof.begin(GG_K_LABEL);
+        launch_label(a, dp, io, nb, max_n, s);
+        prof.end();
+    }
+    if (side) hipStreamWaitEvent(s, ctx->join_event, 0); // join (the late layers -- ground, groundpatch, points -- follow the results: enqueue_ticket)
+}
+
+void drop_graphs(gg_context *ctx)
+{
+    for (auto &e : ctx->graphs) {
+        if (e.exec) hipGraphExecDestroy(e.exec);
+        if (e.graph) hipGraphDestroy(e.graph);
+    }
+    ctx->graphs.clear();
+}
+
+// One cloud per call replays a captured graph (gg_context::GraphKey); everything else, and the first call of a kind, launches eagerly.
+int launch_or_replay(gg_context *ctx, const Arena &a, const CloudParams *hp, CloudParams *dp, const BatchIO &io, int nb, int max_n, hipStream_t s, const LayerPlan *plan)
+{
+    const bool profile = (ctx->flags & GG_FLAG_PROFILE) != 0;
+    // (the fused filter + layers call stays eager: its side branch runs on a second stream beside the sweep, and a captured graph
+    // executed the branch's nodes one after the other -- 0.77 against 0.72 ms per call, profiles/r05a)
+    const bool eligible = nb == 1 && !plan && ctx->graphs_enabled && !profile && !ctx->d_sweep_dbg && s != nullptr && !a.k2_debug && !a.k3_debug && !a.k5_debug && !a.k2_skip;
+    if (!eligible) {
+        HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * nb, hipMemcpyHostToDevice, s));
+        launch_sequence(ctx, a, dp, io, nb, max_n, s, plan, hp[0].slot, profile);
+        return GG_OK;
+    }
+    gg_context::GraphKey key;
+    memset(&key, 0, sizeof key); // (padding included: keys are compared bytewise)
+    key.io = io;
+    // the grids of a captured sequence cover the largest cloud the buffers can hold: work-groups beyond this cloud's chunks leave at once
+    key.max_n = (int)std::min(ctx->max_points, io.cloud_stride);
+    key.slot = hp[0].slot;
+    key.flags = ctx->flags;
+    key.eigen = a.eigen_reduction;
+    key.generation = ctx->graph_generation;
+    key.stream = s;
+    if (plan) {
+        key.layer_mask = plan->mask & EARLY_LAYERS; // (what the captured sequence itself downloads)
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) key.layer_dst[l] = ((key.layer_mask >> l) & 1u) ? plan->dst[l] : nullptr;
+    }
+    gg_context::GraphEntry *entry = nullptr;
+    for (auto &e : ctx->graphs)
+        if (memcmp(&e.key, &key, sizeof key) == 0) entry = &e;
+    if (!entry) {
+        if (ctx->graphs.size() >= 8) { // evict the least recently used
+            size_t victim = 0;
+            for (size_t k = 1; k < ctx->graphs.size(); ++k)
+                if (ctx->graphs[k].last_use < ctx->graphs[victim].last_use) victim = k;
+            if (ctx->graphs[victim].exec) hipGraphExecDestroy(ctx->graphs[victim].exec);
+            if (ctx->graphs[victim].graph) hipGraphDestroy(ctx->graphs[victim].graph);
+            ctx->graphs.erase(ctx->graphs.begin() + (long)victim);
+        }
+        ctx->graphs.emplace_back();
+        entry = &ctx->graphs.back();
+        entry->key = key;
+    }
+    entry->last_use = ++ctx->graph_clock;
+    // the parameter record of THIS cloud, at the address every capture reads it from (stream order: behind the previous replay)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_gparams, hp, sizeof(CloudParams), hipMemcpyHostToDevice, s));
+    if (entry->exec) {
+        HIPCHK(ctx, hipGraphLaunch(entry->exec, s));
+        ++ctx->graph_replays;
+        return GG_OK;
+    }
+    if (entry->uses++ == 0) { // first call of a kind: eager (per-device one-time settings of the launchers happen here, outside any capture)
+        launch_sequence(ctx, a, ctx->d_gparams, io, 1, key.max_n, s, plan, key.slot, false);
+        return GG_OK;
+    }
+    HIPCHK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    launch_sequence(ctx, a, ctx->d_gparams, io, 1, key.max_n, s, plan, key.slot, false);
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(s, &graph);
+    if (e_end != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        ctx->graphs_enabled = false; // (a runtime that cannot capture this sequence: stay eager)
+        launch_sequence(ctx, a, ctx->d_gparams, io, 1, key.max_n, s, plan, key.slot, false);
+        return GG_OK;
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        hipGraphDestroy(graph);
+        ctx->graphs_enabled = false;
+        launch_sequence(ctx, a, ctx->d_gparams, io, 1, key.max_n, s, plan, key.slot, false);
+        return GG_OK;
+    }
+    entry->graph = graph;
+    entry->exec = exec;
+    ++ctx->graph_captures;
+    HIPCHK(ctx, hipGraphLaunch(exec, s));
+    ++ctx->graph_replays;
+    return GG_OK;
+}
+
 // enqueue the seven kernels of one batched filter_cloud call
-int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
+int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const LayerPlan *plan = nullptr)
 {
     const int nb = b->n_clouds;
     if (nb == 0) return GG_OK;
@@ -338,6 +545,8 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
         p.no_confidence = ctx->no_confidence[slot] ? 1 : 0;
         ctx->no_confidence[slot] = 0; // the sweep of this call writes confidences
         for (int k = 0; k < 12; ++k) p.tf[k] = b->transforms ? b->transforms[(size_t)i * 12 + k] : 0.0;
+        p.label_shift = nb == 1 ? ctx->next_label_shift : 0;
+        p.pad_ = 0;
         max_n = std::max(max_n, p.n_points);
         ctx->lazy_pending[slot] = (ctx->flags & GG_FLAG_MINIMAL_LAYERS) ? 1 : 0;
         if (ctx->flags & GG_FLAG_MINIMAL_LAYERS) ctx->lazy_params[slot] = p;
@@ -354,7 +563,6 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
         if (ctx->gather_stream == s || overlaps(b->d_label_masks, (size_t)nb * ((per_cloud + 3) / 4)) || overlaps(b->d_labels, (size_t)nb * per_cloud))
             ctx->gather_lo = ctx->gather_hi = nullptr; // (ordered now, by the stream or by the event)
     }
-    HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * nb, hipMemcpyHostToDevice, s));
 
     BatchIO io;
     io.d_points = b->d_points;
@@ -370,50 +578,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s)
     Arena a = ctx->arena;
     a.flags = ctx->flags;
     a.eigen_reduction = ctx->conv.eigen_reduction;
-    Profiler prof{ctx, s, (ctx->flags & GG_FLAG_PROFILE) != 0};
-
-    {
-        StageRange stage("rasterization"); // insert_cloud, :98-124
-        // the front end in one, two or three launches (k1_classify.hip): what launch_classify did not do itself follows here
-        prof.begin(GG_K_CLASSIFY);
-        const int front = launch_classify(a, dp, io, nb, max_n, s);
-        prof.end();
-        if (front == FRONT_THREE_LAUNCHES) {
-            prof.begin(GG_K_SCAN);
-            launch_scan(a, dp, nb, s);
-            prof.end();
-        }
-        if (front != FRONT_ONE_LAUNCH) {
-            prof.begin(GG_K_SCATTER);
-            launch_scatter(a, dp, nb, max_n, s);
-            prof.end();
-        }
-        prof.begin(GG_K_REDUCE);
-        launch_reduce(a, dp, nb, s);
-        prof.end();
-    }
-    {
-        StageRange stage("patch detection"); // detect_ground_patches, :126-138
-        prof.begin(GG_K_PATCH);
-        launch_patch(a, dp, nb, s);
-        prof.end();
-    }
-    prof.begin(GG_K_SPIRAL);
-    {
-        StageRange stage("interpolation"); // spiral_ground_interpolation, :141-144
-        sweep::Params sp = ctx->sweep_params;
-        sp.decrease = ctx->cfg.occupied_cells_decrease_factor;
-        sp.inv_decrease = 1.0 / sp.decrease;
-        sp.decay_fast = sp.decrease >= 1.25 && sp.decrease < 1e300;
-        launch_sweep(a, sp, dp, nb, s, ctx->d_sweep_dbg);
-    }
-    prof.end();
-    {
-        StageRange stage("segmentation"); // the label loop, :146-194
-        prof.begin(GG_K_LABEL);
-        launch_label(a, dp, io, nb, max_n, s);
-        prof.end();
-    }
+    if (const int rc = launch_or_replay(ctx, a, hp, dp, io, nb, max_n, s, plan)) return rc;
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ring_done[g], s));
     ctx->ring_used[g] = true;
@@ -540,6 +705,10 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipEventCreateWithFlags(&ctx->map_event, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->batch_event, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->gather_event, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->layers_event, hipEventDisableTiming));
+    if (const char *e = getenv("GG_GRAPH")) ctx->graphs_enabled = atoi(e) != 0; // (1 = one cloud per call replays a captured graph)
 
     Arena &a = ctx->arena;
     Geometry &g = a.g;
@@ -649,6 +818,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.sweep_xchg_stride = align_up(std::max<size_t>(gg::sweep_xchg_entries(ctx->sweep_params), 1) * 16, A) / 8;
     const size_t o_xchg = carve((size_t)n_slots * a.sweep_xchg_stride * 8);
     const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
+    const size_t o_gparams = carve(sizeof(CloudParams));
     const size_t o_spts = carve(max_points * sizeof(gg_point16));
     const size_t o_slab = carve(max_points);
     const size_t o_sidx = carve(max_points * 4);
@@ -718,6 +888,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.k3_debug = getenv("GG_K3_DEBUG") ? atoi(getenv("GG_K3_DEBUG")) : 0;
     a.k5_debug = getenv("GG_K5_DEBUG") ? atoi(getenv("GG_K5_DEBUG")) : 0;
     ctx->d_params = (CloudParams *)(base + o_params);
+    ctx->d_gparams = (CloudParams *)(base + o_gparams);
     ctx->d_stage_pts = (gg_point16 *)(base + o_spts);
     ctx->d_stage_labels = (uint8_t *)(base + o_slab);
     ctx->d_stage_index = (int32_t *)(base + o_sidx);
@@ -793,7 +964,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         CREATE_CHK(hipEventCreateWithFlags(&as.downloaded, hipEventDisableTiming));
     }
 
-    ctx->helper.configure((getenv("GG_HOST_THREADS") ? std::max(1, std::min(atoi(getenv("GG_HOST_THREADS")), 16)) : 4) - 1);
+    ctx->helper.configure((getenv("GG_HOST_THREADS") ? std::max(1, std::min(atoi(getenv("GG_HOST_THREADS")), 16)) : 8) - 1); // (never more than the usable CPUs - 1: host_helper.h)
     {
         const int rc = rebuild_patch_table(ctx, a.cfg);
         if (rc != GG_OK) {
@@ -844,6 +1015,12 @@ void gg_destroy(gg_context *ctx)
     if (ctx->map_event) hipEventDestroy(ctx->map_event);
     if (ctx->batch_event) hipEventDestroy(ctx->batch_event);
     if (ctx->gather_event) hipEventDestroy(ctx->gather_event);
+    drop_graphs(ctx);
+    if (ctx->fork_event) hipEventDestroy(ctx->fork_event);
+    if (ctx->join_event) hipEventDestroy(ctx->join_event);
+    if (ctx->layers_event) hipEventDestroy(ctx->layers_event);
+    for (auto &r : ctx->registered) hipHostUnregister(r.first);
+    ctx->registered.clear();
     if (ctx->h2d_stream) hipStreamDestroy(ctx->h2d_stream);
     if (ctx->d2h_stream) hipStreamDestroy(ctx->d2h_stream);
     if (ctx->h_dev_error) hipHostFree((void *)ctx->h_dev_error);
@@ -909,6 +1086,7 @@ int gg_set_config(gg_context *ctx, const gg_config *cfg)
     if (const int rc = rebuild_patch_table(ctx, dev)) return rc; // (on failure the context keeps its old configuration AND table)
     ctx->cfg = *cfg;
     ctx->arena.cfg = dev;
+    drop_graphs(ctx); // (captured launches carry the old configuration by value)
     return GG_OK;
 }
 
@@ -924,6 +1102,7 @@ int gg_set_flags(gg_context *ctx, unsigned flags)
     if (!ctx) return GG_ERR_INVALID;
     // (leaving GG_FLAG_MINIMAL_LAYERS needs no repair: the next cloud writes all nine layers in the half columns it marks live, and
     // every other column logically holds the reset values anyway -- gg_internal.h tile_live)
+    if (flags != ctx->flags) drop_graphs(ctx);
     ctx->flags = flags;
     return GG_OK;
 }
@@ -935,6 +1114,7 @@ int gg_set_conventions(gg_context *ctx, const gg_conventions *conv)
     for (int r : conv->reserved)
         if (r != 0) return fail(ctx, GG_ERR_INVALID, "gg_conventions.reserved must be 0");
     ctx->conv = *conv;
+    drop_graphs(ctx);
     return GG_OK;
 }
 
@@ -1456,14 +1636,17 @@ int gg_synchronize(gg_context *ctx)
 // they overlap the neighbouring tickets' kernels (gg_filter_cloud_async); a synchronous call has nothing to overlap with and puts
 // everything on the context's stream instead -- no cross-stream events (four API calls, ~15 us per cloud)
 static int enqueue_ticket(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *tf, const float origin[3], double base_z,
-                          int *ticket, bool pipelined)
+                          int *ticket, bool pipelined, const LayerPlan *plan = nullptr)
 {
     if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
     if ((!cloud && n) || !origin || !ticket) return fail(ctx, GG_ERR_INVALID, "null cloud / origin / ticket");
     if (n > ctx->max_points) return fail(ctx, GG_ERR_CAPACITY, "cloud larger than max_points");
     if (ctx->next_ticket - ctx->oldest_ticket >= GG_ASYNC_DEPTH) return fail(ctx, GG_ERR_CAPACITY, "GG_ASYNC_DEPTH tickets outstanding: wait for the oldest first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    gg_context::AsyncSlot &as = ctx->async_slot[ctx->next_ticket % GG_ASYNC_DEPTH];
+    // (a synchronous call has no ticket outstanding: always the same staging set, so that its launches are one kind for the graph cache)
+    const int set = pipelined ? ctx->next_ticket % GG_ASYNC_DEPTH : 0;
+    ctx->slot_of_ticket[ctx->next_ticket % GG_ASYNC_DEPTH] = set;
+    gg_context::AsyncSlot &as = ctx->async_slot[set];
 
     static const bool host_timing = getenv("GG_HOST_TIMING") != nullptr; // (tools: where does the host call spend its time)
     const auto t_pack0 = std::chrono::steady_clock::now();
@@ -1494,11 +1677,13 @@ static int enqueue_ticket(gg_context *ctx, int slot, const gg_point32 *cloud, si
     b.transforms = tf;
     as.d_labels = reinterpret_cast<uint8_t *>(as.d_index + n); // [counts][index: n][labels: n]
     as.h_labels = reinterpret_cast<uint8_t *>(as.h_index + n);
-    b.d_labels = as.d_labels;
+    b.d_labels = reinterpret_cast<uint8_t *>(as.d_index); // (+ label_shift = 4 n on the device: the launch's arguments do not depend on n)
+    ctx->next_label_shift = (int)(n * 4);
     b.d_out_index = as.d_index;
     b.d_out_clouds = nullptr;
     b.d_out_counts = as.d_counts;
-    const int rc = enqueue_batch(ctx, &b, ctx->stream);
+    const int rc = enqueue_batch(ctx, &b, ctx->stream, plan);
+    ctx->next_label_shift = 0;
     if (rc != GG_OK) return rc;
     // results come back on their own stream, so that the next ticket's kernels do not queue behind this download
     const hipStream_t down = pipelined ? ctx->d2h_stream : ctx->stream;
@@ -1508,6 +1693,12 @@ static int enqueue_ticket(gg_context *ctx, int slot, const gg_point32 *cloud, si
     }
     HIPCHK(ctx, hipMemcpyAsync(as.h_counts, as.d_counts, 64 + n * 5, hipMemcpyDeviceToHost, down)); // counts + index + labels: one copy
     HIPCHK(ctx, hipEventRecord(as.downloaded, down));
+    if (plan && (plan->mask & ~EARLY_LAYERS)) { // the layers that are only final now (ground, groundpatch, points) follow the results: the host
+        Arena a = ctx->arena;                   // assembles the returned cloud while they travel
+        enqueue_layer_downloads(ctx, a, slot, plan->mask & ~EARLY_LAYERS, *plan, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if (plan) HIPCHK(ctx, hipEventRecord(ctx->layers_event, ctx->stream));
 
     as.cloud = cloud;
     as.n = n;
@@ -1530,7 +1721,7 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
     if (!ctx) return GG_ERR_INVALID;
     if (ticket != ctx->oldest_ticket || ticket >= ctx->next_ticket) return fail(ctx, GG_ERR_INVALID, "tickets are waited for in issue order");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    gg_context::AsyncSlot &as = ctx->async_slot[ticket % GG_ASYNC_DEPTH];
+    gg_context::AsyncSlot &as = ctx->async_slot[ctx->slot_of_ticket[ticket % GG_ASYNC_DEPTH]];
     ctx->oldest_ticket = ticket + 1; // (also on error below: the slot is reusable either way)
     static const bool host_timing = getenv("GG_HOST_TIMING") != nullptr;
     const auto t_w0 = std::chrono::steady_clock::now();
@@ -1585,6 +1776,97 @@ int gg_filter_cloud_tf(gg_context *ctx, int slot, const gg_point32 *cloud, size_
 {
     if (!map_from_cloud) return GG_ERR_INVALID;
     return filter_cloud_impl(ctx, slot, cloud, n, map_from_cloud, origin, base_z, out_cloud, out_n, out_label, out_index);
+}
+
+// gg_filter_cloud + the layers the caller publishes, as one call (include/groundgrid_hip.h): the eight layers that are final after
+// k_reduce are extracted and downloaded on a side branch while the stencil and the sweep run, the other three follow the results
+static bool host_range_registered(const gg_context *ctx, const void *p, size_t bytes)
+{
+    const char *c = static_cast<const char *>(p);
+    for (const auto &r : ctx->registered)
+        if (c >= r.first && c + bytes <= r.first + r.second) return true;
+    return false;
+}
+
+int gg_host_register(gg_context *ctx, void *ptr, size_t bytes)
+{
+    if (!ctx || !ptr || !bytes) return GG_ERR_INVALID;
+    if (host_range_registered(ctx, ptr, bytes)) return GG_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    ctx->registered.emplace_back(static_cast<char *>(ptr), bytes);
+    return GG_OK;
+}
+
+int gg_host_unregister(gg_context *ctx, void *ptr)
+{
+    if (!ctx || !ptr) return GG_ERR_INVALID;
+    for (auto it = ctx->registered.begin(); it != ctx->registered.end(); ++it)
+        if (it->first == static_cast<char *>(ptr)) {
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (nothing in flight may still write into it)
+            HIPCHK(ctx, hipStreamSynchronize(ctx->d2h_stream));
+            drop_graphs(ctx);                               // (captured downloads name the range)
+            HIPCHK(ctx, hipHostUnregister(ptr));
+            ctx->registered.erase(it);
+            return GG_OK;
+        }
+    return fail(ctx, GG_ERR_INVALID, "gg_host_unregister: not a registered range");
+}
+
+int gg_filter_cloud_layers(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *map_from_cloud, const float origin[3], double base_z,
+                           gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index, float *const layers[GG_NUM_LAYERS])
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (ctx->next_ticket != ctx->oldest_ticket) return fail(ctx, GG_ERR_INVALID, "gg_filter_cloud_layers while async tickets are outstanding");
+    unsigned mask = 0u;
+    if (layers)
+        for (int l = 0; l < GG_NUM_LAYERS; ++l)
+            if (layers[l]) mask |= 1u << l;
+    if (!mask || (ctx->flags & GG_FLAG_MINIMAL_LAYERS)) { // nothing to fuse / three layers are owed and computed on demand: one after the other
+        const int rc = filter_cloud_impl(ctx, slot, cloud, n, map_from_cloud, origin, base_z, out_cloud, out_n, out_label, out_index);
+        if (rc != GG_OK || !mask) return rc;
+        void *d[GG_NUM_LAYERS];
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) d[l] = layers[l];
+        return get_layers_impl(ctx, slot, d);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t C = (size_t)ctx->arena.g.C, plane = align_up(C * 4, 256) / 4;
+    if (!ctx->d_planes) HIPCHK(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)GG_NUM_LAYERS * plane * sizeof(float)));
+    if (!ctx->h_planes) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_planes, (size_t)GG_NUM_LAYERS * plane * sizeof(float), hipHostMallocDefault));
+    LayerPlan plan;
+    plan.mask = mask;
+    bool staged[GG_NUM_LAYERS] = {};
+    for (int l = 0; l < GG_NUM_LAYERS; ++l) {
+        if (!((mask >> l) & 1u)) continue;
+        staged[l] = !host_range_registered(ctx, layers[l], C * sizeof(float));
+        plan.dst[l] = staged[l] ? (void *)(ctx->h_planes + (size_t)l * plane) : (void *)layers[l];
+    }
+    int ticket = -1;
+    const int rc = enqueue_ticket(ctx, slot, cloud, n, map_from_cloud, origin, base_z, &ticket, false, &plan);
+    if (rc != GG_OK) return rc;
+    // planes that came down into the staging block move on to the caller's: the early ones WHILE the device sweeps, the late ones at the end
+    auto copy_staged = [&](unsigned group) {
+        int want[GG_NUM_LAYERS], n_want = 0;
+        for (int l = 0; l < GG_NUM_LAYERS; ++l)
+            if (staged[l] && ((group >> l) & 1u)) want[n_want++] = l;
+        if (n_want)
+            ctx->helper.split((size_t)n_want * C, [&](size_t lo, size_t hi) {
+                for (size_t k = lo / C; k < (size_t)n_want && k * C < hi; ++k) {
+                    const size_t a0 = std::max(lo, k * C) - k * C, a1 = std::min(hi, (k + 1) * C) - k * C;
+                    memcpy(layers[want[k]] + a0, ctx->h_planes + (size_t)want[k] * plane + a0, (a1 - a0) * sizeof(float));
+                }
+            });
+    };
+    if (mask & EARLY_LAYERS) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->join_event)); // (the side branch: behind k_reduce, beside k_patch / k_sweep)
+        copy_staged(EARLY_LAYERS);
+    }
+    const int rc_wait = gg_filter_cloud_wait(ctx, ticket, out_cloud, out_n, out_label, out_index); // (assembles the returned cloud while the late layers travel)
+    SYNCCHK(ctx, hipEventSynchronize(ctx->layers_event));
+    if (rc_wait != GG_OK) return rc_wait;
+    copy_staged(~EARLY_LAYERS);
+    return GG_OK;
 }
 
 // ---- RCCL, bound at run time (include/groundgrid_hip.h "the one collective of the path") --------------------------------
@@ -1772,6 +2054,13 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
 {
     if (!ctx || !key || value < 0) return GG_ERR_INVALID;
     if (!strcmp(key, "pw")) return ctx->arena.PW;
+    if (!strcmp(key, "graph_replays")) return (int)std::min<long>(ctx->graph_replays, 1 << 30); // (read-only: how many calls replayed a captured graph)
+    if (!strcmp(key, "graphs")) { // 0 = every call launches eagerly, 1 = one cloud per call replays a captured graph (the default)
+        ctx->graphs_enabled = value != 0;
+        drop_graphs(ctx);
+        return GG_OK;
+    }
+    drop_graphs(ctx); // (every other key changes what the launchers pick)
     if (!strcmp(key, "sweep_waves")) ctx->arena.tune_sweep_waves = value;
     else if (!strcmp(key, "sweep_gpw")) ctx->arena.tune_sweep_gpw = value;
     else if (!strcmp(key, "sweep_split")) ctx->arena.tune_sweep_split = value;

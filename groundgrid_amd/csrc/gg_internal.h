@@ -83,6 +83,9 @@ struct CloudParams {
     int no_confidence; // the slot's groundpatch layer is known to hold nothing above 0.01 (fresh or only scrolled since
                     // gg_reset_map): the line-of-sight test (:269 needs groundpatch(I) > 0.01f) cannot fire, K1 skips the walks
     double tf[12];  // map <- cloud frame, 3x4 row-major (R | t)
+    int label_shift; // bytes added to this cloud's d_labels row (the host call places a cloud's labels right behind its n index entries -- one
+                     // download for both -- and a captured launch must not bake that n in: it travels here)
+    int pad_;
 };
 
 // everything a kernel needs to find its data

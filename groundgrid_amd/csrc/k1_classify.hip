@@ -15,12 +15,12 @@
 
 namespace gg {
 
-constexpr int WALK_COOPERATIVE_MAX = 12; // candidates per 64-point window up to which their rays are walked cooperatively
 // The reference walks a candidate's ray one metre per step until it reaches the point (:258) with no bound of its own: a
 // corrupt z of -1e9 costs it seconds, and past 2^31 steps its int counter overflows (UB).  A library that takes raw
 // sensor buffers must not hang the GPU on such a record, so steps >= WALK_MAX_STEP are not evaluated (documented
 // deviation, mirrored by the oracle): it only matters for points more than 65 km away from the sensor.
 constexpr int WALK_MAX_STEP = 1 << 16;
+constexpr int WALK_PACKED_MAX = 12; // candidates per 64-point window up to which their steps are dealt to the lanes (walk_packed); above, a ray per lane
 
 struct PointIn {
     float x, y, z;
@@ -74,12 +74,18 @@ GG_DEV int classify_point(const Arena &a, const CloudParams &cp, const PointIn &
     return GG_CLASS_KEPT;
 }
 
-// :246-275 -- the line-of-sight walk of ONE point, run by a whole wavefront: lane l evaluates the steps 3 + l, 67 + l, ...
-// The reference walks `step` = 3, 4, ... while |step * v|^2 < len^2 and stops at the first cell whose stored ground lies
-// above the ray.  The steps do not depend on each other and the continuation test is monotonic in `step` (a product with
-// a fixed float factor is monotonic), so "some step before the end of the ray hits" is the same predicate -- evaluated
-// 64 steps at a time instead of one lane idling its 63 neighbours through up to a hundred serial steps.
-GG_DEV bool ray_walk_hits(const Arena &a, const CloudParams &cp, const float2 *__restrict__ gp2, float px, float py, float pz, int lane)
+// :246-275 -- the line-of-sight walks of a 64-point window, PACKED: the reference walks `step` = 3, 4, ... along a candidate's ray while
+// |step * v|^2 < len^2 and stops at the first cell whose stored ground lies above the ray.  The steps do not depend on each other and
+// the continuation test is monotonic in `step` (a product with a fixed float factor is monotonic), so "some step before the end of
+// the ray hits" is the same predicate, and the (candidate, step) pairs of a window are independent work items.  A ray of length len
+// has at most floor(len) + 2 - 3 steps (|v| is 1 within a few 2^-24, so |step v|^2 < len^2 implies step <= floor(len) + 1).  The
+// wavefront takes the items 64 at a time: the candidates are consumed in lane order by a SCALAR cursor (candidate, next step, steps
+// left) that deals consecutive lanes to consecutive steps and moves on to the next candidate when a ray is used up -- a pass holds the
+// end of one ray and the beginning of the next (or a dozen short rays) -- with the ray's parameters broadcast from its lane
+// (v_readlane); a candidate that has hit gives up the rest of its steps.  Round 4 walked one candidate per pass (64 steps, mostly
+// beyond the end of a 20-step ray) or, above a dozen candidates, every lane its own ray serially.  Returns the lanes whose ray hits.
+GG_DEV float lane_value(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+GG_DEV unsigned long long walk_packed(const Arena &a, const CloudParams &cp, const float2 *__restrict__ gp2, float px, float py, float pz, bool walk, int lane)
 {
     const Geometry &g = a.g;
     const int rows = g.rows, cols = g.cols;
@@ -88,37 +94,73 @@ GG_DEV bool ray_walk_hits(const Arena &a, const CloudParams &cp, const float2 *_
     vx /= len;                                                      // :253-255
     vy /= len;
     vz /= len;
-    const double len2 = (double)len * (double)len;
-    for (int base = 3; base < WALK_MAX_STEP; base += 64) { // :258
-        const int step = base + lane;
-        const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
+    const float len2_f = len; // (the ray's owner squares it in double: one float travels instead of a double)
+    // steps 3 .. smax can be on the ray (:258: needs vec.z < -0.01f; a NaN anywhere compares false: no step)
+    const int smax = min((int)fminf(len, 70000.0f) + 1, WALK_MAX_STEP - 1);
+    const int count = (walk && vz < -0.01f && smax >= 3) ? smax - 2 : 0;
+    unsigned long long todo = __ballot(count > 0), hits = 0ull;
+    int cur = 0, cur_left = 0, cur_step = 3; // (scalar) the candidate being consumed
+    float cvx = 0.f, cvy = 0.f, cvz = 0.f, clen = 0.f;
+    while (todo != 0ull || cur_left > 0) { // one pass of up to 64 items (uniform)
+        float ovx = 0.f, ovy = 0.f, ovz = 0.f, olen = 0.f;
+        int step = 0, owner = 0;
+        bool item = false;
+        int fill = 0;
+        while (fill < 64 && (cur_left > 0 || todo != 0ull)) { // (uniform) deal lanes [fill, fill + take) to the cursor's candidate
+            if (cur_left == 0) {
+                cur = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                cvx = lane_value(vx, cur), cvy = lane_value(vy, cur), cvz = lane_value(vz, cur), clen = lane_value(len2_f, cur);
+                cur_left = __builtin_amdgcn_readlane(count, cur);
+                cur_step = 3;
+            }
+            const int take = min(cur_left, 64 - fill);
+            const bool mine = (unsigned)(lane - fill) < (unsigned)take;
+            ovx = mine ? cvx : ovx, ovy = mine ? cvy : ovy, ovz = mine ? cvz : ovz, olen = mine ? clen : olen;
+            step = mine ? cur_step + (lane - fill) : step;
+            owner = mine ? cur : owner;
+            item = item || mine;
+            fill += take;
+            cur_left -= take;
+            cur_step += take;
+        }
+        const float sx = (float)step * ovx, sy = (float)step * ovy, sz = (float)step * ovz;
         const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
-        const bool on_ray = d2 < len2 && vz < -0.01f && step < WALK_MAX_STEP;
+        const bool on_ray = item && d2 < (double)olen * (double)olen; // (:258; vec.z < -0.01f is in `count`)
         bool hit = false;
+        int r0 = 2, c0 = 2;
         if (on_ray) {
             const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
             int I0, I1;
             index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0, I1); // :261
             if (!(I0 <= 0 || I1 <= 0 || I0 >= rows - 1 || I1 >= cols - 1)) {              // :264-265
-                const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                       // :268
+                // :269 is a conjunction of three pure reads: the two conditions on the cell itself first (one gather) -- along most of a
+                // ray the stored ground lies BELOW the ray, so they rule the step out -- and the 3 x 3 confidence sum (nine gathers in the
+                // sheared layer, the walk's traffic) only for the steps they let through
+                const float2 gI = gp2[gp_idx(a, I0, I1)];
+                hit = gI.y > 0.01f && (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance;
+                r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2); // :268
+            }
+        }
+        unsigned long long hm = __ballot(hit);
+        if (hm != 0ull) { // (uniform; rare)
+            if (hit) {
                 float e[9];
 #pragma unroll
                 for (int s = 0; s < 9; ++s) e[s] = gp2[gp_idx(a, r0 + s % 3, c0 + s / 3)].y;
-                const float bsum = tree9(e);
-                const float2 gI = gp2[gp_idx(a, I0, I1)];
-                hit = (double)bsum > a.cfg.min_outlier_detection_ground_confidence && gI.y > 0.01f &&
-                      (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance; // :269
+                hit = (double)tree9(e) > a.cfg.min_outlier_detection_ground_confidence;
             }
+            for (hm = __ballot(hit); hm != 0ull; hm &= hm - 1ull) hits |= 1ull << __builtin_amdgcn_readlane(owner, __builtin_ctzll(hm));
+            if ((hits >> cur) & 1ull) cur_left = 0; // the ray in hand has its answer: its remaining steps are not needed
         }
-        if (__ballot(hit) != 0ull) return true;
-        if (__ballot(on_ray) != ~0ull) return false; // the ray ended inside this group of steps
     }
-    return false;
+    return hits;
 }
 
-// The same walk, one point per lane, serially (the reference's loop as written).  Used when most lanes of a window are
-// candidates -- a freshly initialised map has ground = 0, so every return from the road surface is "below ground" -- where
-// 64 lanes walking their own rays in parallel beat 64 cooperative walks one after the other.
+// The walk of one point per lane, serially (the reference's loop as written).  Used when most lanes of a window are candidates --
+// a map that meets an unrelated scene: the near rings' returns all lie under the stored terrain, 64 candidates with rays of five to
+// thirty steps -- where 64 lanes walking their own rays side by side, each leaving at its first hit, beat any dealing of items
+// (measured on that stress case: 3.2 ms per 1024 clouds against 6.4 for walk_packed, profiles/r05a/walk_ab.log).
 GG_DEV bool ray_walk_hits_lane(const Arena &a, const CloudParams &cp, const float2 *__restrict__ gp2, float px, float py, float pz)
 {
     const Geometry &g = a.g;
@@ -129,23 +171,39 @@ GG_DEV bool ray_walk_hits_lane(const Arena &a, const CloudParams &cp, const floa
     vy /= len;
     vz /= len;
     const double len2 = (double)len * (double)len;
-    for (int step = 3; step < WALK_MAX_STEP; ++step) { // :258
-        const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
-        const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
-        if (!(d2 < len2 && vz < -0.01f)) return false;
-        const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
-        int I0, I1;
-        index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0, I1); // :261
-        if (I0 <= 0 || I1 <= 0 || I0 >= rows - 1 || I1 >= cols - 1) continue;         // :264-265
-        const int r0 = max(I0 - 1, 2), c0 = max(I1 - 1, 2);                            // :268
-        float e[9];
+    if (!(vz < -0.01f)) return false; // :258 (no step at all)
+    // WALK_UNROLL steps per trip, their cells' gathers in flight together: the steps are independent, and a trip of the serial loop
+    // is one dependent round trip to the layer per step
+    constexpr int WALK_UNROLL = 2;
+    for (int base = 3; base < WALK_MAX_STEP; base += WALK_UNROLL) { // :258
+        bool on[WALK_UNROLL], inside[WALK_UNROLL];
+        int I0[WALK_UNROLL], I1[WALK_UNROLL];
+        float rz[WALK_UNROLL];
+        float2 gI[WALK_UNROLL];
 #pragma unroll
-        for (int s = 0; s < 9; ++s) e[s] = gp2[gp_idx(a, r0 + s % 3, c0 + s / 3)].y;
-        const float bsum = tree9(e);
-        const float2 gI = gp2[gp_idx(a, I0, I1)];
-        if ((double)bsum > a.cfg.min_outlier_detection_ground_confidence && gI.y > 0.01f &&
-            (double)gI.x >= (double)(sz + cp.oz) + a.cfg.outlier_tolerance) // :269
-            return true;
+        for (int k = 0; k < WALK_UNROLL; ++k) {
+            const int step = base + k;
+            const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
+            const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
+            on[k] = d2 < len2; // (monotonic in step: once false, false for every later step)
+            const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
+            index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0[k], I1[k]); // :261
+            inside[k] = on[k] && !(I0[k] <= 0 || I1[k] <= 0 || I0[k] >= rows - 1 || I1[k] >= cols - 1); // :264-265
+            rz[k] = sz + cp.oz;
+            gI[k] = gp2[inside[k] ? gp_idx(a, I0[k], I1[k]) : 0]; // (unconditional load at a clamped index)
+        }
+        if (!on[0]) return false;
+#pragma unroll
+        for (int k = 0; k < WALK_UNROLL; ++k) {
+            // :269, the cell's own two conditions first (most steps of a ray run above the stored ground: they end here)
+            if (!(inside[k] && gI[k].y > 0.01f && (double)gI[k].x >= (double)rz[k] + a.cfg.outlier_tolerance)) continue;
+            const int r0 = max(I0[k] - 1, 2), c0 = max(I1[k] - 1, 2); // :268
+            float e[9];
+#pragma unroll
+            for (int s = 0; s < 9; ++s) e[s] = gp2[gp_idx(a, r0 + s % 3, c0 + s / 3)].y;
+            if ((double)tree9(e) > a.cfg.min_outlier_detection_ground_confidence) return true;
+        }
+        if (!on[WALK_UNROLL - 1]) return false;
     }
     return false;
 }
@@ -277,15 +335,12 @@ __global__ __launch_bounds__(256, 5) void k_classify(const Arena a, const CloudP
                 int cls = GG_CLASS_KEPT;
                 bool walk = false;
                 if (inmap_[j]) cls = classify_point(a, cp, pt[j], og[j], walk);
-                unsigned long long todo = __ballot(walk);
-                if (__popcll(todo) > WALK_COOPERATIVE_MAX) { // (uniform) most lanes are candidates: everybody walks its own ray
+                const int n_walk = __popcll(__ballot(walk));
+                if (n_walk > WALK_PACKED_MAX) { // (uniform) most lanes are candidates: every lane walks its own ray
                     if (walk && ray_walk_hits_lane(a, cp, gp2, pt[j].x, pt[j].y, pt[j].z)) cls = GG_CLASS_OUTLIER;
-                    todo = 0ull;
-                }
-                for (; todo != 0ull; todo &= todo - 1ull) { // (uniform loop, rarely entered)
-                    const int src = __builtin_ctzll(todo);
-                    const bool hit = ray_walk_hits(a, cp, gp2, __shfl(pt[j].x, src, 64), __shfl(pt[j].y, src, 64), __shfl(pt[j].z, src, 64), lane);
-                    if (lane == src && hit) cls = GG_CLASS_OUTLIER;
+                } else if (n_walk > 0) { // (uniform) a few candidates: their steps dealt to the 64 lanes
+                    const unsigned long long hits = walk_packed(a, cp, gp2, pt[j].x, pt[j].y, pt[j].z, walk, lane);
+                    if ((hits >> lane) & 1ull) cls = GG_CLASS_OUTLIER;
                 }
                 uint32_t key = KEY_OUTSIDE;
                 if (inmap_[j]) key = make_key(a, lds_tile_rank, gi0[j], gi1[j], cls);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
     float *points = const_cast<float *>(L) + percall_index(0, PL_POINTS, 0);
     const uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
     const char *pts = reinterpret_cast<const char *>(io.d_points) + (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
-    uint8_t *labels = io.d_labels ? io.d_labels + (size_t)cloud * io.cloud_stride : nullptr;
+    uint8_t *labels = io.d_labels ? io.d_labels + (size_t)cloud * io.cloud_stride + cp.label_shift : nullptr;
     uint8_t *masks = io.d_label_masks ? io.d_label_masks + (size_t)cloud * ((io.cloud_stride + 3) / 4) : nullptr;
     int32_t *out_index = io.d_out_index ? io.d_out_index + (size_t)cloud * io.cloud_stride : nullptr;
     gg_point32 *out_cloud = (FMT == GG_POINT32 && io.d_out_clouds) ? io.d_out_clouds + (size_t)cloud * io.cloud_stride : nullptr;

@@ -147,21 +147,30 @@ class Core {
             pos_x_ = view.pos_x;
             pos_y_ = view.pos_y;
         }
-        size_t got = 0;
-        const int rc = gg_filter_cloud(ctx_, 0, cloud, n, origin, base_z, out, &got, nullptr, nullptr);
-        if (rc != GG_OK) return note("gg_filter_cloud"), rc;
-        if (n_out) *n_out = got;
+        // the cloud and the layers somebody reads afterwards as ONE call: the eight layers the insertion finishes travel while the
+        // stencil and the sweep run, the other three while the returned cloud is assembled (gg_filter_cloud_layers)
         float *dst[GG_NUM_LAYERS];
-        bool any = false;
-        for (int l = 0; l < GG_NUM_LAYERS; ++l) {
-            dst[l] = ((download >> l) & 1u) ? view.layer[l] : nullptr;
-            any |= dst[l] != nullptr;
-        }
-        if (!any) return GG_OK;
-        // the extraction kernels and the downloads are enqueued back to back and waited for once
-        const int rc_down = gg_get_layers(ctx_, 0, dst);
-        if (rc_down != GG_OK) note("downloading the layers");
-        return rc_down;
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) dst[l] = ((download >> l) & 1u) ? view.layer[l] : nullptr;
+        if (pin_planes_) pin(dst);
+        size_t got = 0;
+        const int rc = gg_filter_cloud_layers(ctx_, 0, cloud, n, nullptr, origin, base_z, out, &got, nullptr, nullptr, dst);
+        if (rc != GG_OK) return note("gg_filter_cloud_layers"), rc;
+        if (n_out) *n_out = got;
+        return GG_OK;
+    }
+
+    // Planes the device may write directly (gg_host_register): only for a map whose owner tells the Core when its planes go away
+    // (release_planes) -- a registration that outlives its memory would send a later download to pages nobody reads.
+    void set_pin_planes(bool on)
+    {
+        if (!on) release_planes();
+        pin_planes_ = on;
+    }
+    void release_planes()
+    {
+        for (void *p : pinned_)
+            if (ctx_) gg_host_unregister(ctx_, p);
+        pinned_.clear();
     }
 
     // ---- the stage members (include/groundgrid/GroundSegmentation.h:59-62) on the caller's map ----
@@ -232,8 +241,25 @@ class Core {
     }
 
   private:
+    void pin(float *const dst[GG_NUM_LAYERS])
+    {
+        int rows = 0, cols = 0;
+        gg_get_size(ctx_, &rows, &cols);
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) {
+            if (!dst[l]) continue;
+            bool known = false;
+            for (void *p : pinned_) known |= p == dst[l];
+            if (known) continue;
+            if (pinned_.size() >= 4 * GG_NUM_LAYERS) { // planes that keep changing their address: not worth pinning, and never a leak
+                set_pin_planes(false);
+                return;
+            }
+            if (gg_host_register(ctx_, dst[l], (size_t)rows * cols * sizeof(float)) == GG_OK) pinned_.push_back(dst[l]);
+        }
+    }
     bool recreate(size_t capacity)
     {
+        pinned_.clear(); // (gg_destroy unregisters what the old context had registered)
         if (gg_abi_version() != GG_ABI_VERSION) return error_ = "libgroundgrid_hip.so and groundgrid_hip.h disagree on the ABI version", false;
         gg_destroy(ctx_);
         ctx_ = nullptr;
@@ -259,6 +285,8 @@ class Core {
     int device_ = 0;
     size_t capacity_ = 0;
     bool have_position_ = false, device_resident_ = false;
+    bool pin_planes_ = false;
+    std::vector<void *> pinned_;
     double pos_x_ = 0.0, pos_y_ = 0.0;
     std::string error_;
 };
@@ -313,7 +341,10 @@ class Registry {
     void forget_map(const void *map)
     {
         std::lock_guard<std::mutex> g(m_);
-        by_map_.erase(map);
+        auto it = by_map_.find(map);
+        if (it == by_map_.end()) return;
+        it->second->release_planes(); // (the map's planes are about to be freed)
+        by_map_.erase(it);
     }
     // init() on an object that already has a Core (a re-initialised nodelet, or a new object at a recycled address): the maps bound
     // to the old context name nothing any more

@@ -62,6 +62,10 @@ void GroundGrid::initGroundGrid(const nav_msgs::OdometryConstPtr &inOdom)
     }
     const int rc = core->reset_map(inOdom->pose.pose.position.x, inOdom->pose.pose.position.y, static_cast<float>(inOdom->pose.pose.position.z));
     if (rc != GG_OK) ROS_ERROR("groundgrid_hip: initialising the map on the device failed with status %d (%s)", rc, core->last_error().c_str());
+    // this object owns the host map and says when its planes go away (forget_map above and in the destructor): the layers that are
+    // downloaded may be written by the device straight into them (GROUNDGRID_HIP_PIN_LAYERS=0: through a staging copy instead)
+    const char *pin = std::getenv("GROUNDGRID_HIP_PIN_LAYERS");
+    core->set_pin_planes(!pin || std::atoi(pin) != 0);
 }
 
 // src/GroundGrid.cpp:83-147

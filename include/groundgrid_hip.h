@@ -243,6 +243,27 @@ int gg_filter_cloud_async(gg_context *ctx, int slot, const gg_point32 *cloud, si
 int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label,
                          int32_t *out_index);
 
+/* filter_cloud AND the layers a publisher needs afterwards, as one call: what the nodelet does per cloud is filter_cloud followed
+ * by reading every layer of the map (grid_map message + images, src/GroundGridNodelet.cpp:196-228).  layers[l] (nullable) receives
+ * layer l, column-major rows x cols, like gg_get_layers -- but the eight layers that are final once the insertion has run
+ * (minGroundHeight, maxGroundHeight, groundCandidates, planeDist, m2, meanVariance, pointsRaw, variance) are extracted and
+ * downloaded on a side branch WHILE the patch stencil and the terrain sweep run, and ground / groundpatch / points follow the
+ * per-point results while the host assembles the returned cloud.  map_from_cloud nullable (as gg_filter_cloud_async).
+ * Destinations inside a range passed to gg_host_register are written by the device directly (no staging copy on the host): a host
+ * whose map planes keep their addresses from cloud to cloud -- grid_map::GridMap does -- registers them once. */
+int gg_filter_cloud_layers(gg_context *ctx, int slot, const gg_point32 *cloud, size_t n, const double *map_from_cloud, const float origin[3],
+                           double base_z, gg_point32 *out_cloud, size_t *out_n, uint8_t *out_label, int32_t *out_index,
+                           float *const layers[GG_NUM_LAYERS]);
+/* hipHostRegister / hipHostUnregister of a host range for a caller that has no HIP headers: downloads of this context whose
+ * destination lies inside a registered range (gg_filter_cloud_layers) land there directly.  Unregister before freeing the memory;
+ * gg_destroy unregisters what is left. */
+int gg_host_register(gg_context *ctx, void *ptr, size_t bytes);
+int gg_host_unregister(gg_context *ctx, void *ptr);
+
+/* With GG_GRAPH=1 in the environment, one cloud per call (gg_filter_cloud*, gg_filter_batch with n_clouds == 1 on a stream other
+ * than the legacy default one) replays a captured HIP graph from the third call of a kind on: the seven launches of the path reach
+ * the device as one submission.  Off by default: measured, a replay is no faster than the eager launches. */
+
 /* Batched, device-resident form of the same call: n_clouds independent (cloud, map-state) pairs in
  * one set of launches, slot first_slot + b (or slots[b]) for cloud b.  Pointers prefixed d_ are device memory.
  * Enqueues on `stream` (a hipStream_t passed as void*; NULL = the context's own stream, GG_STREAM_DEFAULT = the legacy

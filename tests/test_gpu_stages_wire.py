@@ -268,3 +268,115 @@ def test_gridmap_message_payload():
     assert m["layers"] == ["ground", "variance"] and m["basic_layers"] == ["ground"] and m["frame_id"] == "odom"
     assert nan_equal(m["data"][1][2].reshape((n, n), order="F"), ref.layer("variance"))
     seg.close()
+
+
+# ---------------------------------------------------------------- the reference call shape: graph replay, fused filter + layers
+
+def test_one_cloud_per_call_replays_a_captured_graph_100_times():
+    """the single-slot sequence as a HIP graph; replayed 100 times against the oracle, with clouds of different
+    sizes (the captured grids cover the buffer's capacity), a configuration change in between (captures are dropped) and eager
+    calls mixed in."""
+    clouds = [synth.hdl64_cloud(seed=60 + k, n_az=150 + 53 * k) for k in range(5)] + [synth.empty_cloud(0), synth.hdl64_cloud(seed=70, n_az=40)[:37]]
+    cap = max(len(c) for c in clouds) + 1000
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=2, max_points=cap)
+    ref = oracle.OracleMap(120.0, 0.33)
+    seg.debug_set_tuning("graphs", 1)  # (opt-in: GG_GRAPH=1)
+    before = seg.debug_set_tuning("graph_replays", 0)
+    for it in range(100):
+        c = clouds[it % len(clouds)]
+        if it == 40:  # a new configuration: what was captured carries the old one by value
+            cfg = seg.getConfig()
+            cfg.max_ring = 50
+            cfg.outlier_tolerance = 0.15
+            seg.setConfig(cfg)
+            ref.cfg.max_ring = 50
+            ref.cfg.outlier_tolerance = 0.15
+        if it == 70:
+            seg.debug_set_tuning("graphs", 0)
+        if it == 75:
+            seg.debug_set_tuning("graphs", 1)
+        out, labels, index = seg.filter_cloud(c, (0.3, -0.2, 0.1), -1.73, return_details=True)
+        r = ref.filter_cloud(c, (0.3, -0.2, 0.1), -1.73)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), it
+        assert out.tobytes() == r["out_points"].tobytes(), it
+        if it % 10 == 9 or it in (2, 3, 41, 42, 43):
+            for name in oracle.LAYERS:
+                assert nan_equal(seg.map(0)[name], ref.layer(name)), (it, name)
+    replays = seg.debug_set_tuning("graph_replays", 0) - before
+    assert replays >= 80, replays  # (the first two calls of a kind are eager and capturing; five calls ran with graphs off)
+    seg.close()
+
+
+@pytest.mark.parametrize("registered", [False, True])
+def test_filter_cloud_with_layers_fused_call(registered):
+    """gg_filter_cloud_layers: the returned cloud and all eleven layers of one call; the early layers travel while the sweep runs.
+    Registered planes are written by the device directly, others through the staging block; both over several clouds (graph replay),
+    with a subset of layers, and next to plain gg_filter_cloud / gg_get_layers calls on the same context."""
+    clouds = [synth.hdl64_cloud(seed=80 + k, n_az=260 + 40 * k) for k in range(3)]
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=max(len(c) for c in clouds))
+    ref = oracle.OracleMap(120.0, 0.33)
+    planes = seg.alloc_layers(register=registered)
+    some = {k: planes[k] for k in ("ground", "variance", "points")}
+    for it in range(12):
+        c = clouds[it % 3]
+        use = some if it in (5, 6, 7) else planes
+        if it == 9:  # a plain call in between: the next fused call sees its state
+            seg.filter_cloud(c, ORIGIN0, -1.73)
+            ref.filter_cloud(c, ORIGIN0, -1.73)
+            continue
+        for v in use.values():
+            v[...] = np.float32(-7.0)
+        out, labels, index = seg.filter_cloud_with_layers(c, ORIGIN0, -1.73, use, return_details=True)
+        r = ref.filter_cloud(c, ORIGIN0, -1.73)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]) and out.tobytes() == r["out_points"].tobytes(), it
+        for name, v in use.items():
+            assert nan_equal(v, ref.layer(name)), (it, name)
+        if it == 3:
+            for name in oracle.LAYERS:
+                assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+    if registered:
+        seg.release_layers(planes)
+    seg.close()
+
+
+def test_fused_call_with_lazily_materialised_layers_falls_back():
+    cloud = synth.hdl64_cloud(seed=90, n_az=300)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    seg.set_flags(minimal_layers=True)
+    ref = oracle.OracleMap(120.0, 0.33)
+    planes = seg.alloc_layers(register=False)
+    for it in range(3):
+        seg.filter_cloud_with_layers(cloud, ORIGIN0, -1.73, planes)
+        ref.filter_cloud(cloud, ORIGIN0, -1.73)
+        for name, v in planes.items():
+            assert nan_equal(v, ref.layer(name)), (it, name)
+    seg.close()
+
+
+def test_minimal_layers_reads_after_set_config_and_move():
+    """the layers GG_FLAG_MINIMAL_LAYERS owes are computed from what the LAST cloud left in the slot -- also when the
+    configuration has changed since (they are that cloud's: its classes were decided under the old configuration), and over a drive
+    with the map scrolling between the clouds."""
+    cloud = synth.hdl64_cloud(seed=91, n_az=300)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    seg.set_flags(minimal_layers=True)
+    ref = oracle.OracleMap(120.0, 0.33)
+    owed = ("maxGroundHeight", "groundCandidates", "planeDist")
+    seg.filter_cloud(cloud, ORIGIN0, -1.73)
+    ref.filter_cloud(cloud, ORIGIN0, -1.73)
+    cfg = seg.getConfig()
+    cfg.max_ring = 40
+    seg.setConfig(cfg)  # (blocking; rebuilds the patch table)
+    for name in owed + ("minGroundHeight", "m2", "ground"):
+        assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+    ref.cfg.max_ring = 40
+    pose = (-0.7, 0.0, 1.73, 0.0, 0.0, 0.0, 1.0)
+    for it in range(3):
+        moved_gpu = seg.map(0).move(0.7 * (it + 1), 0.0, pose)
+        moved_ref = ref.update(0.7 * (it + 1), 0.0, pose)
+        assert moved_ref[1] == tuple(moved_gpu)
+        seg.filter_cloud(cloud, (0.7 * (it + 1), 0.0, 0.0), -1.73)
+        ref.filter_cloud(cloud, (0.7 * (it + 1), 0.0, 0.0), -1.73)
+        for name in owed if it < 2 else oracle.LAYERS:
+            assert nan_equal(seg.map(0)[name], ref.layer(name)), (it, name)
+    seg.close()

@@ -9,7 +9,7 @@ from groundgrid_amd import api
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 tag = sys.argv[3] if len(sys.argv) > 3 else ""
-clouds = bench.make_clouds(batch, 0, n_scenes=8)
+clouds = bench.make_clouds(batch, 0, n_scenes=int(os.environ.get("N_SCENES", "8")))
 n = [len(c) for c in clouds]
 stride = (max(n) + 63) // 64 * 64
 seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=batch, max_points=stride)
@@ -24,12 +24,13 @@ org, bz = np.zeros((batch, 3), np.float32), np.full(batch, -1.73)
 ids = np.arange(batch)
 out, shift = None, 0
 res = {}
-for mode in ("cold", "warm"):
+for mode in os.environ.get("MODES", "cold,warm").split(","):  # mixed = warm maps, the clouds rotate: unrelated scenes meet (the ray-walk stress)
     for k in range(3 + steps):
         if k == 3:
             seg.synchronize(); seg.kernel_times(reset=True); t0 = time.perf_counter()
         if mode == "cold":
             seg.reset_maps(0, batch, persistent_only=True, on_torch_stream=True)
+        if mode in ("cold", "mixed"):
             shift = (shift + bench.ROT) % batch
         out = seg.filter_batch(pts, n, org, bz, out=out, slots=((ids + shift) % batch).astype(np.int32))
     seg.synchronize()

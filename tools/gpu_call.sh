@@ -1,7 +1,10 @@
-# scratch: what the next gpurun call runs (edited per call)
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_stages_wire.py -x -q 2>&1 | tail -25 | tee gpurun_out/r05_new_tests.log
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 | tee gpurun_out/r05_all_tests.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+V=$PWD/groundgrid_amd/variants
+for r in 1 2; do
+  for lib in default prio3; do
+    if [ $lib = default ]; then unset GROUNDGRID_HIP_LIB; else export GROUNDGRID_HIP_LIB=$V/lib_$lib.so; fi
+    SKIP_BIG=1 BATCHES_SMALL=1,8 timeout 200 python tools/latency_probe.py 2>/dev/null | tail -1 | tee -a gpurun_out/r05_prio_ab.log
+  done
+done
