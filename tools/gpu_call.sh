@@ -1,10 +1,7 @@
+# scratch: what the next gpurun call runs (edited per call)
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-V=$PWD/groundgrid_amd/variants
-for r in 1 2; do
-  for lib in default prio3; do
-    if [ $lib = default ]; then unset GROUNDGRID_HIP_LIB; else export GROUNDGRID_HIP_LIB=$V/lib_$lib.so; fi
-    SKIP_BIG=1 BATCHES_SMALL=1,8 timeout 200 python tools/latency_probe.py 2>/dev/null | tail -1 | tee -a gpurun_out/r05_prio_ab.log
-  done
-done
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee gpurun_out/r05_all_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python bench.py > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err; head -c 3000 gpurun_out/r05_bench.json; tail -3 gpurun_out/r05_bench.err
