@@ -1,7 +1,6 @@
-# scratch: what the next gpurun call runs (edited per call)
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee gpurun_out/r05_all_tests.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 900 python bench.py > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err; head -c 3000 gpurun_out/r05_bench.json; tail -3 gpurun_out/r05_bench.err
+SKIP_BIG=1 BATCHES_SMALL=1,8 timeout 200 python tools/latency_probe.py 2>/dev/null | tail -1 | tee gpurun_out/r05_pf_latency.log
+BATCHES_BIG=1 SKIP_SMALL=1 timeout 200 python tools/latency_probe.py 2>/dev/null | tail -1 | tee -a gpurun_out/r05_pf_latency.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "sweep or geometr or hdl64 or config4 or golden" 2>&1 | tail -3
