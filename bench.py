@@ -167,6 +167,7 @@ def ordered_line(result, world):
                                     "binding_like": pick(result, "host_api", "binding_like_vs_cpu_1thread"),
                                     "device_resident_binding": pick(result, "host_api", "device_resident_binding_vs_cpu_1thread")},
         "single_cloud_latency_ms": result.get("single_cloud_latency_ms"),
+        "concurrent_halves_clouds_per_s": pick(result, "concurrent_halves", "clouds_per_s"),
         "lazy_layers": {"clouds_per_s": pick(result, "lazy_layers", "clouds_per_s"), "reduce_ms": pick(result, "lazy_layers", "kernel_ms", "k_reduce"),
                         "materialise_ms_per_map": pick(result, "lazy_layers", "materialise_ms_per_map")},
         "config3_clouds_per_s": pick(result, "config3", "clouds_per_s"),
@@ -175,7 +176,7 @@ def ordered_line(result, world):
                     "cpu_clouds_per_s": pick(result, "config4", "cpu_baseline", "value")},
         "parity_checked_in_run": {"headline": result.get("parity_checked_in_run"), "warm": pick(result, "warm_map", "parity_checked_in_run"),
                                   "config3": pick(result, "config3", "parity_checked_in_run"), "config4": pick(result, "config4", "parity_checked_in_run"),
-                                  "lazy_layers": pick(result, "lazy_layers", "parity_checked_in_run"),
+                                  "lazy_layers": pick(result, "lazy_layers", "parity_checked_in_run"), "concurrent_halves": pick(result, "concurrent_halves", "parity_checked_in_run"),
                                   "config4_single": pick(result, "config4", "single_cloud", "parity_checked_in_run")},
     }
     head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
@@ -547,6 +548,38 @@ def main():
                     hs = [cold_last] + warm.shifts + mixed.shifts
                     result["warm_map_unrelated_scenes"]["parity_checked_in_run"] = check_timed_outputs(
                         mixed, clouds, 120.0, 0.33, n_check=1, seed=6, history_of=lambda slot: [int((slot - s) % B) for s in hs])[0]
+
+    # ---------------------------------------------------------------- the headline's cold steps as two concurrent halves (a separate leg)
+    if extras and rank == 0 and world == 1 and B >= 512:
+        # GG_FLAG_CONCURRENT_HALVES (include/groundgrid_hip.h): every call runs the clouds of the lower and of the upper half of the map
+        # slots as two launch sequences on two streams that never join between steps, so kernels of different kinds overlap.  Reported
+        # BESIDE the headline, not as it: with two kernels sharing the device a per-kernel event pair times half a machine, so this leg
+        # has no per-kernel table and no roofline.
+        seg.set_flags(minimal_layers=args.minimal_layers, profile=False, concurrent_halves=True)
+        saved_no_profile, args.no_profile = args.no_profile, True
+        h_steps = max(4, args.steps // 2)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):  # (a real stream: the flag is ignored on the legacy default one)
+            halves = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=pipe.shifts[-1])
+            h_elapsed, _ = halves.timed(h_steps, 4)
+            one_seq = None
+            if True:  # ... and the same steps on the same stream without the flag, right behind: the like-for-like denominator
+                seg.set_flags(minimal_layers=args.minimal_layers, profile=False)
+                plain = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=halves.shifts[-1])
+                one_seq, _ = plain.timed(h_steps, 2)
+                seg.set_flags(minimal_layers=args.minimal_layers, profile=False, concurrent_halves=True)
+                halves2 = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=plain.shifts[-1])
+                h_elapsed = min(h_elapsed, halves2.timed(h_steps, 2)[0])
+                halves = halves2
+        args.no_profile = saved_no_profile
+        seg.set_flags(minimal_layers=args.minimal_layers, profile=not args.no_profile)
+        result["concurrent_halves"] = {
+            "clouds_per_s": round(world * B * h_steps / h_elapsed, 1), "ms_per_step": round(1e3 * h_elapsed / h_steps, 4),
+            "one_sequence_same_stream_ms_per_step": round(1e3 * one_seq / h_steps, 4), "one_sequence_same_stream_clouds_per_s": round(world * B * h_steps / one_seq, 1),
+            "note": "the headline's cold steps under gg_set_flags(GG_FLAG_CONCURRENT_HALVES): the clouds whose maps are in the lower / upper half "
+                    "of the slots as two launch sequences on two streams, no join between steps (the caller fences before it reads outputs); "
+                    "results identical; per-kernel timing is not meaningful in this mode"}
+        if do_checks:
+            result["concurrent_halves"]["parity_checked_in_run"] = check_timed_outputs(halves, clouds, 120.0, 0.33, n_check=4, seed=9)[0]
 
     # ---------------------------------------------------------------- lazily materialised layers (a separate leg, not the headline)
     if extras and rank == 0 and world == 1 and not args.minimal_layers:

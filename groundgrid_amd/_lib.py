@@ -24,7 +24,7 @@ STATUS = {
 
 GG_ABI_VERSION = 5  # include/groundgrid_hip.h
 GG_POINT32, GG_POINT16 = 0, 1
-GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE = 1, 2
+GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE, GG_FLAG_CONCURRENT_HALVES = 1, 2, 4
 GG_NUM_KERNELS = 7
 GG_NUM_LAYERS = 11
 
@@ -41,7 +41,7 @@ SYMBOLS = [
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
     "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep",
-    "gg_device_error", "gg_filter_cloud_layers", "gg_host_register", "gg_host_unregister", "gg_run_stage", "gg_filter_cloud_pc2_out", "gg_get_gridmap_message",
+    "gg_batch_fence", "gg_device_error", "gg_filter_cloud_layers", "gg_host_register", "gg_host_unregister", "gg_run_stage", "gg_filter_cloud_pc2_out", "gg_get_gridmap_message",
     "gg_collective_available", "gg_comm_unique_id", "gg_comm_init_rank", "gg_comm_init_rank_for", "gg_comm_destroy", "gg_allgather_label_masks",
 ]
 
@@ -182,6 +182,7 @@ def load():
     L.gg_filter_batch.argtypes = [vp, P(GGBatch), vp]
     L.gg_synchronize.argtypes = [vp]
     L.gg_device_error.argtypes = [vp, C.c_int]
+    L.gg_batch_fence.argtypes = [vp, vp]
     L.gg_get_point_classes.argtypes = [vp, C.c_int, C.c_size_t, vp, vp]
     L.gg_get_kernel_times.argtypes = [vp, P(C.c_double), P(C.c_int64), C.c_int]
     L.gg_set_conventions.argtypes = [vp, P(GGConventions)]

@@ -271,12 +271,13 @@ class GroundSegmentation:
         _check(self._L, self._ctx, self._L.gg_get_config(self._ctx, C.byref(c)), "gg_get_config")
         return c
 
-    def set_flags(self, minimal_layers: bool = False, profile: bool = False):
+    def set_flags(self, minimal_layers: bool = False, profile: bool = False, concurrent_halves: bool = False):
         """gg_set_flags.  minimal_layers: maxGroundHeight / groundCandidates / planeDist -- written by insert_cloud
         (src/GroundSegmentation.cpp:296,303,307) and read by nothing on the path -- are computed when a layer getter asks for one of
         them instead of for every cloud; every getter still returns what the reference's layer would hold.  profile: per-kernel
         events (kernel_times)."""
-        f = (_lib.GG_FLAG_MINIMAL_LAYERS if minimal_layers else 0) | (_lib.GG_FLAG_PROFILE if profile else 0)
+        f = ((_lib.GG_FLAG_MINIMAL_LAYERS if minimal_layers else 0) | (_lib.GG_FLAG_PROFILE if profile else 0) |
+             (_lib.GG_FLAG_CONCURRENT_HALVES if concurrent_halves else 0))
         _check(self._L, self._ctx, self._L.gg_set_flags(self._ctx, f), "gg_set_flags")
 
     def expected_points(self) -> np.ndarray:
@@ -463,6 +464,14 @@ class GroundSegmentation:
         rc = self._L.gg_filter_batch(self._ctx, C.byref(b), C.c_void_p(s if s else _lib.GG_STREAM_DEFAULT))
         _check(self._L, self._ctx, rc, "gg_filter_batch")
         return out
+
+    def batch_fence(self, stream=None):
+        """GG_FLAG_CONCURRENT_HALVES: order the current torch stream (or `stream`) after both halves of the batches enqueued so far --
+        before anything the caller enqueues itself reads their outputs."""
+        import torch
+
+        h = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        _check(self._L, self._ctx, self._L.gg_batch_fence(self._ctx, C.c_void_p(h if h else _lib.GG_STREAM_DEFAULT)), "gg_batch_fence")
 
     def kernel_times(self, reset: bool = True):
         """(ms[7], launches[7]) accumulated under set_flags(profile=True)."""

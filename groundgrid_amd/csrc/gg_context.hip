@@ -77,6 +77,15 @@ struct gg_context {
     bool map_event_pending = false;          // a mutation was enqueued on ctx->stream since the last batch waited for it
     hipStream_t last_batch_stream = nullptr; // stream batch_event was last recorded on
     bool have_batch_event = false;
+    // GG_FLAG_CONCURRENT_HALVES: the clouds (and map re-initialisations) of the upper half of the slots run on half_stream; half_done is
+    // recorded there behind each of them, half_fork on the caller's stream in front (the side stream sees what the caller enqueued before)
+    hipStream_t half_stream = nullptr;
+    hipEvent_t half_fork = nullptr, half_done = nullptr;
+    bool have_half_event = false;
+    int halves_min_clouds = 256;
+    bool probe_no_fork = false;
+    hipEvent_t ring_done2[4]{};
+    bool ring_used2[4]{};
 
     // pipelined host entry point (gg_filter_cloud_async / _wait): GG_ASYNC_DEPTH staging sets + a copy stream each way
     struct AsyncSlot {
@@ -249,13 +258,19 @@ hipStream_t pick_stream(gg_context *ctx, void *stream)
     return stream ? (hipStream_t)stream : ctx->stream;
 }
 
+// `st` follows the half of every earlier batch that ran on the library's side stream (GG_FLAG_CONCURRENT_HALVES)
+int stream_waits_for_second_half(gg_context *ctx, hipStream_t st)
+{
+    if (ctx->have_half_event && st != ctx->half_stream) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->half_done, 0));
+    return GG_OK;
+}
 // Entry points that read or write map state on ctx->stream call this first: the context's stream waits for the last batch
 // that ran on another stream (gg_get_layer after a batch on a caller stream read stale layers).
 int own_stream_waits_for_batches(gg_context *ctx)
 {
     if (ctx->have_batch_event && ctx->last_batch_stream != ctx->stream)
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_event, 0));
-    return GG_OK;
+    return stream_waits_for_second_half(ctx, ctx->stream);
 }
 // ... and this after enqueueing a mutation of map state on ctx->stream (reset, move, set_layer): the next batch on any
 // other stream waits for it.
@@ -518,6 +533,13 @@ int launch_or_replay(gg_context *ctx, const Arena &a, const CloudParams *hp, Clo
     return GG_OK;
 }
 
+// which half of a context's slots a map belongs to (GG_FLAG_CONCURRENT_HALVES): the upper half runs on the library's side stream
+bool second_half_slot(const gg_context *ctx, int slot) { return slot >= (ctx->n_slots + 1) / 2; }
+bool halves_enabled(const gg_context *ctx)
+{
+    return (ctx->flags & GG_FLAG_CONCURRENT_HALVES) && !(ctx->flags & GG_FLAG_PROFILE) && !ctx->d_sweep_dbg && !ctx->arena.k2_debug && ctx->half_stream;
+}
+
 // enqueue the seven kernels of one batched filter_cloud call
 int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const LayerPlan *plan = nullptr)
 {
@@ -527,12 +549,26 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
     const int g = ctx->ring_next;
     ctx->ring_next = (g + 1) % PARAM_RING;
     if (ctx->ring_used[g]) HIPCHK(ctx, hipEventSynchronize(ctx->ring_done[g]));
+    if (ctx->ring_used2[g]) HIPCHK(ctx, hipEventSynchronize(ctx->ring_done2[g]));
+    ctx->ring_used2[g] = false;
     CloudParams *hp = ctx->h_params + (size_t)g * ctx->n_slots;
     CloudParams *dp = ctx->d_params + (size_t)g * ctx->n_slots;
-    int max_n = 0;
+    // Two halves side by side?  The clouds of the lower slots first in the parameter array, then the others: each half is a batch of its own
+    int n_first = nb;
+    // (not on the legacy default stream: its implicit synchronisation with every other stream makes the two halves slower than one
+    // sequence -- 5.75 against 5.29 ms per 1024 clouds, profiles/r05a/halves_probe_default_stream.json)
+    const bool split_wanted = halves_enabled(ctx) && !plan && nb >= ctx->halves_min_clouds && s != ctx->half_stream && s != nullptr;
+    if (split_wanted) {
+        n_first = 0;
+        for (int i = 0; i < nb; ++i) n_first += second_half_slot(ctx, b->slots ? b->slots[i] : b->first_slot + i) ? 0 : 1;
+    }
+    const bool split = split_wanted && n_first > 0 && n_first < nb;
+    if (!split) n_first = nb;
+    int max_n[2] = {0, 0}, at[2] = {0, n_first};
     for (int i = 0; i < nb; ++i) {
         const int slot = b->slots ? b->slots[i] : b->first_slot + i;
-        CloudParams &p = hp[i];
+        const int half = split && second_half_slot(ctx, slot) ? 1 : 0;
+        CloudParams &p = hp[at[half]++];
         p.slot = slot;
         p.n_points = b->n_points[i];
         p.ox = b->origins[i * 3 + 0];
@@ -546,8 +582,8 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
         ctx->no_confidence[slot] = 0; // the sweep of this call writes confidences
         for (int k = 0; k < 12; ++k) p.tf[k] = b->transforms ? b->transforms[(size_t)i * 12 + k] : 0.0;
         p.label_shift = nb == 1 ? ctx->next_label_shift : 0;
-        p.pad_ = 0;
-        max_n = std::max(max_n, p.n_points);
+        p.io_index = i;
+        max_n[half] = std::max(max_n[half], p.n_points);
         ctx->lazy_pending[slot] = (ctx->flags & GG_FLAG_MINIMAL_LAYERS) ? 1 : 0;
         if (ctx->flags & GG_FLAG_MINIMAL_LAYERS) ctx->lazy_params[slot] = p;
     }
@@ -555,13 +591,17 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
     // on another stream
     if (s != ctx->stream && ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->map_event, 0));
     if (ctx->have_batch_event && ctx->last_batch_stream != s && !ctx->probe_unordered_streams) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->batch_event, 0));
+    // ... and after the second half of earlier batches -- unless this one is divided the same way: a slot is only ever touched from its
+    // half's stream, so the halves of consecutive batches on one caller stream need not meet
+    if (!(split && ctx->last_batch_stream == s))
+        if (const int rc = stream_waits_for_second_half(ctx, s)) return rc;
     if (ctx->gather_lo) { // an all-gather still reads label masks: a batch on another stream that rewrites them waits for it
         auto overlaps = [&](const uint8_t *p, size_t bytes) { return p && p < ctx->gather_hi && p + bytes > ctx->gather_lo; };
         const size_t per_cloud = b->cloud_stride;
-        if (ctx->gather_stream != s && (overlaps(b->d_label_masks, (size_t)nb * ((per_cloud + 3) / 4)) || overlaps(b->d_labels, (size_t)nb * per_cloud)))
-            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->gather_event, 0));
-        if (ctx->gather_stream == s || overlaps(b->d_label_masks, (size_t)nb * ((per_cloud + 3) / 4)) || overlaps(b->d_labels, (size_t)nb * per_cloud))
-            ctx->gather_lo = ctx->gather_hi = nullptr; // (ordered now, by the stream or by the event)
+        const bool hit = overlaps(b->d_label_masks, (size_t)nb * ((per_cloud + 3) / 4)) || overlaps(b->d_labels, (size_t)nb * per_cloud);
+        if (ctx->gather_stream != s && hit) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->gather_event, 0));
+        if (split && hit) HIPCHK(ctx, hipStreamWaitEvent(ctx->half_stream, ctx->gather_event, 0));
+        if (ctx->gather_stream == s || hit) ctx->gather_lo = ctx->gather_hi = nullptr; // (ordered now, by the stream or by the event)
     }
 
     BatchIO io;
@@ -578,8 +618,29 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
     Arena a = ctx->arena;
     a.flags = ctx->flags;
     a.eigen_reduction = ctx->conv.eigen_reduction;
-    if (const int rc = launch_or_replay(ctx, a, hp, dp, io, nb, max_n, s, plan)) return rc;
-    HIPCHK(ctx, hipGetLastError());
+    if (split) {
+        // the side stream sees what the caller's stream holds up to here (its inputs, a re-initialisation of the maps on that stream)
+        if (!ctx->probe_no_fork) {
+            HIPCHK(ctx, hipEventRecord(ctx->half_fork, s));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->half_stream, ctx->half_fork, 0));
+        }
+        Arena a2 = a; // the words kernels of one launch synchronise through: the second half has its own
+        a2.front_sync = a.front_sync2;
+        a2.sweep_sync = a.sweep_sync2;
+        a2.scan_sync = a.scan_sync + (size_t)n_first * SCAN_SYNC_WORDS;
+        HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * n_first, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(dp + n_first, hp + n_first, sizeof(CloudParams) * (nb - n_first), hipMemcpyHostToDevice, ctx->half_stream));
+        launch_sequence(ctx, a, dp, io, n_first, max_n[0], s, nullptr, hp[0].slot, false);
+        launch_sequence(ctx, a2, dp + n_first, io, nb - n_first, max_n[1], ctx->half_stream, nullptr, hp[n_first].slot, false);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipEventRecord(ctx->ring_done2[g], ctx->half_stream));
+        ctx->ring_used2[g] = true;
+        HIPCHK(ctx, hipEventRecord(ctx->half_done, ctx->half_stream));
+        ctx->have_half_event = true;
+    } else {
+        if (const int rc = launch_or_replay(ctx, a, hp, dp, io, nb, max_n[0], s, plan)) return rc;
+        HIPCHK(ctx, hipGetLastError());
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ring_done[g], s));
     ctx->ring_used[g] = true;
     HIPCHK(ctx, hipEventRecord(ctx->batch_event, s));
@@ -702,6 +763,9 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     CREATE_CHK(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
     CREATE_CHK(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+    CREATE_CHK(hipStreamCreateWithFlags(&ctx->half_stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->half_fork, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&ctx->half_done, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->map_event, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->batch_event, hipEventDisableTiming));
     CREATE_CHK(hipEventCreateWithFlags(&ctx->gather_event, hipEventDisableTiming));
@@ -814,6 +878,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_tlcnt = carve((size_t)n_slots * 2 * 4);
     const size_t o_fsync = carve(((size_t)2 * n_slots + 16) * 4);
     const size_t o_ssync = carve(64);
+    const size_t o_fsync2 = carve(((size_t)2 * n_slots + 16) * 4);
+    const size_t o_ssync2 = carve(64);
     const size_t o_scansync = carve((size_t)n_slots * SCAN_SYNC_WORDS * 8);
     a.sweep_xchg_stride = align_up(std::max<size_t>(gg::sweep_xchg_entries(ctx->sweep_params), 1) * 16, A) / 8;
     const size_t o_xchg = carve((size_t)n_slots * a.sweep_xchg_stride * 8);
@@ -867,10 +933,14 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tile_list_cnt = (uint32_t *)(base + o_tlcnt);
     a.front_sync = (uint32_t *)(base + o_fsync);
     a.sweep_sync = (uint32_t *)(base + o_ssync);
+    a.front_sync2 = (uint32_t *)(base + o_fsync2);
+    a.sweep_sync2 = (uint32_t *)(base + o_ssync2);
     a.scan_sync = (unsigned long long *)(base + o_scansync);
     {
         const uint32_t first_epoch[4] = {0u, 0u, 1u, 0u}; // (the exchange region starts zeroed: tag 0 is never current)
         CREATE_CHK(hipMemcpyAsync(a.sweep_sync, first_epoch, sizeof first_epoch, hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t first_epoch2[4] = {0u, 0u, 0x80000001u, 0u}; // (the second set's epochs carry bit 31: k4_sweep.hip)
+        CREATE_CHK(hipMemcpyAsync(a.sweep_sync2, first_epoch2, sizeof first_epoch2, hipMemcpyHostToDevice, ctx->stream));
         CREATE_CHK(hipStreamSynchronize(ctx->stream));
     }
     {
@@ -953,6 +1023,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     CREATE_CHK(hipHostMalloc((void **)&ctx->h_stage_index, max_points * 4, hipHostMallocDefault));
     CREATE_CHK(hipHostMalloc((void **)&ctx->h_stage_counts, 64, hipHostMallocDefault));
     for (int i = 0; i < PARAM_RING; ++i) CREATE_CHK(hipEventCreateWithFlags(&ctx->ring_done[i], hipEventDisableTiming));
+    for (int i = 0; i < PARAM_RING; ++i) CREATE_CHK(hipEventCreateWithFlags(&ctx->ring_done2[i], hipEventDisableTiming));
     for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
         gg_context::AsyncSlot &as = ctx->async_slot[k];
         CREATE_CHK(hipHostMalloc((void **)&as.h_pts, max_points * sizeof(gg_point16), hipHostMallocDefault));
@@ -991,6 +1062,7 @@ void gg_destroy(gg_context *ctx)
     ctx->helper.stop();
     hipSetDevice(ctx->device);
     if (ctx->have_batch_event) hipEventSynchronize(ctx->batch_event);
+    if (ctx->half_stream) hipStreamSynchronize(ctx->half_stream);
     if (ctx->h2d_stream) hipStreamSynchronize(ctx->h2d_stream);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->d2h_stream) hipStreamSynchronize(ctx->d2h_stream);
@@ -1004,6 +1076,11 @@ void gg_destroy(gg_context *ctx)
     }
     for (int i = 0; i < PARAM_RING; ++i)
         if (ctx->ring_done[i]) hipEventDestroy(ctx->ring_done[i]);
+    for (int i = 0; i < PARAM_RING; ++i)
+        if (ctx->ring_done2[i]) hipEventDestroy(ctx->ring_done2[i]);
+    if (ctx->half_fork) hipEventDestroy(ctx->half_fork);
+    if (ctx->half_done) hipEventDestroy(ctx->half_done);
+    if (ctx->half_stream) hipStreamDestroy(ctx->half_stream);
     for (int k = 0; k < GG_ASYNC_DEPTH; ++k) {
         gg_context::AsyncSlot &as = ctx->async_slot[k];
         if (as.h_pts) hipHostFree(as.h_pts);
@@ -1071,6 +1148,7 @@ static int rebuild_patch_table(gg_context *ctx, const DevConfig &cfg)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // (batches may be reading the old table: wait for them; gg_set_config is a rare, synchronous call)
     if (ctx->have_batch_event) HIPCHK(ctx, hipEventSynchronize(ctx->batch_event));
+    if (ctx->have_half_event) HIPCHK(ctx, hipEventSynchronize(ctx->half_done));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(const_cast<float4 *>(ctx->arena.patch_table), t.data(), t.size() * 4, hipMemcpyHostToDevice));
     return GG_OK;
@@ -1190,11 +1268,17 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
     if (n == 0) return GG_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const hipStream_t st = pick_stream(ctx, stream);
+    // GG_FLAG_CONCURRENT_HALVES: on a caller stream the maps of the upper half of the slots are re-initialised on the side stream, where
+    // their batches run -- the caller's stream never has to wait for the second half of the batch before
+    const int boundary = (ctx->n_slots + 1) / 2;
+    const bool split = halves_enabled(ctx) && st != ctx->stream && st != ctx->half_stream && st != nullptr && first_slot < boundary && first_slot + n > boundary;
     if (st == ctx->stream) {
         if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
     } else { // ordered like a batch on the caller's stream
         if (ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->map_event, 0));
         if (ctx->have_batch_event && ctx->last_batch_stream != st && !ctx->probe_unordered_streams) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->batch_event, 0));
+        if (!(split && ctx->last_batch_stream == st))
+            if (const int rc = stream_waits_for_second_half(ctx, st)) return rc;
     }
     const Arena &a = ctx->arena;
     for (int s = first_slot; s < first_slot + n; ++s) {
@@ -1205,14 +1289,30 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
     // src/GroundGrid.cpp:71-75; the layers filter_cloud adds later (:61-75) start at 0.  The slots' regions are equally
     // spaced, so one strided fill per layer covers all n slots.
     const float init[GG_NUM_LAYERS] = {0.0f, odom_z, (float)0.0000001, (float)100.0, (float)-100.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!persistent_only) {
-        for (int s = first_slot; s < first_slot + n; ++s) ctx->lazy_pending[s] = 0;
-        launch_fill_percall(a, first_slot, n, init, st);
-        // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
-        launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)first_slot * a.tile_live_stride), (size_t)n * a.tile_live_stride * 4, 0xFF, st);
+    auto fill = [&](int first, int count, hipStream_t on) {
+        if (count <= 0) return;
+        if (!persistent_only) {
+            for (int s = first; s < first + count; ++s) ctx->lazy_pending[s] = 0;
+            launch_fill_percall(a, first, count, init, on);
+            // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
+            launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)first * a.tile_live_stride), (size_t)count * a.tile_live_stride * 4, 0xFF, on);
+        }
+        launch_fill2_strided(gp2_ptr(a, first), (size_t)a.gpl.elems, a.gp2_stride, count, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], a.gp_valid, on);
+    };
+    if (split) {
+        if (!ctx->probe_no_fork) {
+            HIPCHK(ctx, hipEventRecord(ctx->half_fork, st));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->half_stream, ctx->half_fork, 0));
+        }
+        fill(first_slot, boundary - first_slot, st);
+        fill(boundary, first_slot + n - boundary, ctx->half_stream);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipEventRecord(ctx->half_done, ctx->half_stream));
+        ctx->have_half_event = true;
+    } else {
+        fill(first_slot, n, st);
+        HIPCHK(ctx, hipGetLastError());
     }
-    launch_fill2_strided(gp2_ptr(a, first_slot), (size_t)a.gpl.elems, a.gp2_stride, n, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], a.gp_valid, st);
-    HIPCHK(ctx, hipGetLastError());
     if (st == ctx->stream) return own_stream_mutated_map(ctx);
     HIPCHK(ctx, hipEventRecord(ctx->batch_event, st));
     ctx->have_batch_event = true;
@@ -1623,11 +1723,18 @@ int gg_device_error(gg_context *ctx, int clear)
     return (int)code;
 }
 
+int gg_batch_fence(gg_context *ctx, void *stream)
+{
+    if (!ctx) return GG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return stream_waits_for_second_half(ctx, pick_stream(ctx, stream));
+}
+
 int gg_synchronize(gg_context *ctx)
 {
     if (!ctx) return GG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (const int rc = own_stream_waits_for_batches(ctx)) return rc; // batches on caller streams included
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc; // batches on caller streams (and their second halves) included
     SYNCCHK(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
@@ -1954,6 +2061,7 @@ int gg_allgather_label_masks(gg_context *ctx, void *comm, const uint8_t *d_send,
     const hipStream_t s = pick_stream(ctx, stream);
     // the masks are written by the last batch: order the gather after it when it runs on another stream
     if (ctx->have_batch_event && ctx->last_batch_stream != s) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->batch_event, 0));
+    if (const int rc_half = stream_waits_for_second_half(ctx, s)) return rc_half;
     const int rc = rccl().AllGather(d_send, d_recv, bytes_per_rank, /* ncclUint8 */ 1, comm, s);
     if (rc != 0) {
         char buf[256];
@@ -2068,6 +2176,8 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
     else if (!strcmp(key, "scan_parts")) ctx->arena.tune_scan_parts = value;
     else if (!strcmp(key, "scan_poll_cap")) ctx->arena.tune_scan_poll_cap = value;
+    else if (!strcmp(key, "halves_min_clouds")) ctx->halves_min_clouds = std::max(2, value); // (tests: GG_FLAG_CONCURRENT_HALVES on small batches)
+    else if (!strcmp(key, "halves_no_fork")) ctx->probe_no_fork = value != 0; // (measurement only: the side stream does not wait for the caller's)
     else if (!strcmp(key, "scan_fault")) ctx->arena.tune_scan_fault = value;
     else if (!strcmp(key, "sweep_fault")) ctx->arena.tune_sweep_fault = value;
     else if (!strcmp(key, "probe_unordered_streams")) ctx->probe_unordered_streams = value != 0; // (tools/fill_overlap_probe.py: the CALLER orders its streams)

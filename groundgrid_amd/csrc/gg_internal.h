@@ -85,7 +85,8 @@ struct CloudParams {
     double tf[12];  // map <- cloud frame, 3x4 row-major (R | t)
     int label_shift; // bytes added to this cloud's d_labels row (the host call places a cloud's labels right behind its n index entries -- one
                      // download for both -- and a captured launch must not bake that n in: it travels here)
-    int pad_;
+    int io_index;    // the cloud's row of the batch's I/O buffers (d_points, d_labels, ...): its position in gg_batch, which is not its position
+                     // in the parameter array when a batch runs as two halves (GG_FLAG_CONCURRENT_HALVES)
 };
 
 // everything a kernel needs to find its data
@@ -135,6 +136,7 @@ struct Arena {
     uint32_t *tile_list_cnt;                         // [slot][2] number of light / dense tiles
     unsigned long long *scan_sync; // [n_slots][SCAN_SYNC_WORDS] k_scan as several work-groups per cloud (sort_core.h "PARTS"): ticket counter, then one
                                    // word per part; zeroed before every such launch
+    uint32_t *front_sync2, *sweep_sync2; // the same two regions once more, for the half of a batch that runs on the library's side stream
     uint32_t *sweep_sync; // [4] ticket counter, finished work-groups, epoch of k_sweep launches with several work-groups per cloud (k4_sweep.hip)
     unsigned long long *sweep_xchg; size_t sweep_xchg_stride; // [slot] exchange region between the work-groups of one sweep (sweep_core.h "Parts"), in 64-bit words
     int n_slots; // independent map states of the context

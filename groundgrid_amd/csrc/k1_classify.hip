@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 5) void k_classify(const Arena a, const CloudP
 
     const float2 *gp2 = gp2_ptr(a, cp.slot);
     const char *pts = reinterpret_cast<const char *>(io.d_points) +
-                      (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
+                      (size_t)cp.io_index * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
     uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
     const __amdgpu_buffer_rsrc_t ghist = words_rsrc(a.hist + (size_t)cp.slot * a.hist_stride, a.hist_stride);
     const uint32_t row = (uint32_t)chunk * (uint32_t)TP; // this chunk's row of `hist`, in words

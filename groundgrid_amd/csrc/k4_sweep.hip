@@ -615,8 +615,11 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
         if (threadIdx.x == 0 && __hip_atomic_fetch_add(sync_words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
             __hip_atomic_store(sync_words + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sync_words + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t next = epoch + 1u;
-            __hip_atomic_store(sync_words + 2, next ? next : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (bit 31 names the region the epoch belongs to -- a context has two sets of these words, gg_internal.h sweep_sync2, and a map's
+            // exchange region may be written under either: the epochs of the two never meet; an epoch is never 0 in its low 31 bits)
+            uint32_t next = ((epoch + 1u) & 0x7FFFFFFFu) | (epoch & 0x80000000u);
+            if ((next & 0x7FFFFFFFu) == 0u) next |= 1u;
+            __hip_atomic_store(sync_words + 2, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
 
     const uint32_t *totals = a.totals + (size_t)cp.slot * 4;
     if (io.d_out_counts && bx == 0 && threadIdx.x == 0) {
-        int32_t *oc = io.d_out_counts + (size_t)cloud * 4;
+        int32_t *oc = io.d_out_counts + (size_t)cp.io_index * 4;
         oc[0] = (int32_t)(totals[0] + totals[1] + totals[2]);
         oc[1] = (int32_t)totals[0];
         oc[2] = (int32_t)totals[1];
@@ -86,12 +86,12 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
     const float *variance = L + percall_index(0, PL_VARIANCE, 0);
     float *points = const_cast<float *>(L) + percall_index(0, PL_POINTS, 0);
     const uint2 *rec = a.rec + (size_t)cp.slot * a.point_stride;
-    const char *pts = reinterpret_cast<const char *>(io.d_points) + (size_t)cloud * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
-    uint8_t *labels = io.d_labels ? io.d_labels + (size_t)cloud * io.cloud_stride + cp.label_shift : nullptr;
-    uint8_t *masks = io.d_label_masks ? io.d_label_masks + (size_t)cloud * ((io.cloud_stride + 3) / 4) : nullptr;
-    int32_t *out_index = io.d_out_index ? io.d_out_index + (size_t)cloud * io.cloud_stride : nullptr;
-    gg_point32 *out_cloud = (FMT == GG_POINT32 && io.d_out_clouds) ? io.d_out_clouds + (size_t)cloud * io.cloud_stride : nullptr;
-    uint8_t *out_pc2 = PC2 ? io.d_out_pc2 + (size_t)cloud * io.cloud_stride * GG_PC2_POINT_STEP : nullptr;
+    const char *pts = reinterpret_cast<const char *>(io.d_points) + (size_t)cp.io_index * io.cloud_stride * (FMT == GG_POINT16 ? 16 : 32);
+    uint8_t *labels = io.d_labels ? io.d_labels + (size_t)cp.io_index * io.cloud_stride + cp.label_shift : nullptr;
+    uint8_t *masks = io.d_label_masks ? io.d_label_masks + (size_t)cp.io_index * ((io.cloud_stride + 3) / 4) : nullptr;
+    int32_t *out_index = io.d_out_index ? io.d_out_index + (size_t)cp.io_index * io.cloud_stride : nullptr;
+    gg_point32 *out_cloud = (FMT == GG_POINT32 && io.d_out_clouds) ? io.d_out_clouds + (size_t)cp.io_index * io.cloud_stride : nullptr;
+    uint8_t *out_pc2 = PC2 ? io.d_out_pc2 + (size_t)cp.io_index * io.cloud_stride * GG_PC2_POINT_STEP : nullptr;
 
     const uint32_t *ce = a.chunk_emit + (size_t)cp.slot * a.emit_stride + (size_t)chunk * 4;
     uint32_t kept_base = ce[0];

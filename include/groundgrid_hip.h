@@ -117,7 +117,18 @@ enum {
                                    (gg_get_layer, gg_get_layers, gg_get_layer_image_u8, gg_set_layer) has them computed first, from
                                    the tile-sorted records the slot's last cloud left on the device -- so every layer reads at all
                                    times as the reference's would; default off */
-    GG_FLAG_PROFILE = 2         /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
+    GG_FLAG_PROFILE = 2,        /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
+    GG_FLAG_CONCURRENT_HALVES = 4 /* a gg_filter_batch of at least 256 clouds runs as TWO independent launch sequences side by side: the
+                                   clouds whose map slot is in the lower half of the context's slots on the caller's stream, the others
+                                   on a stream of the library's own, and gg_reset_maps on a caller stream divides its fills the same way.
+                                   A map slot is only ever touched from "its" stream, so the two sequences never wait for each other:
+                                   they drift apart, kernels of different kinds overlap and fill each other's tails (+4 % clouds/s at
+                                   1024 clouds per call).  The price: the CALLER'S STREAM IS NOT ORDERED AFTER THE SECOND HALF.  Work the
+                                   caller enqueues itself behind the call (copies of the outputs, its own kernels) must follow
+                                   gg_batch_fence(ctx, stream) first; every gg_* entry point orders itself (getters, gg_synchronize,
+                                   gg_allgather_label_masks, batches on other streams).  Ignored on the legacy default stream (its implicit synchronisation
+                                   with every other stream makes two halves slower than one sequence) and while GG_FLAG_PROFILE is set: with two
+                                   kernels sharing the device an event pair times half a machine, not a kernel.  Results identical. */
 };
 
 typedef struct gg_context gg_context;
@@ -308,6 +319,8 @@ typedef struct gg_batch {
 #define GG_PC2_POINT_STEP 18
 #define GG_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int gg_filter_batch(gg_context *ctx, const gg_batch *batch, void *stream);
+/* GG_FLAG_CONCURRENT_HALVES: orders `stream` (same convention) after both halves of every batch enqueued so far.  A no-op otherwise. */
+int gg_batch_fence(gg_context *ctx, void *stream);
 int gg_synchronize(gg_context *ctx);
 /* The few places where a kernel waits for ANOTHER work-group (the sweep cut into parts, the tile scan cut into parts, the fused front
  * end) bound their waits; a wait that runs out leaves a code in a host-visible word instead of hanging.  Every gg_* call that

@@ -2,7 +2,8 @@
  * once by gg_get_layer / gg_set_layer / gg_reset_map / gg_move_map on the context's own stream must behave like the
  * serial call sequence ("a C caller reads stale layers").  The foreign stream is kept busy with a long fill so
  * that a missing dependency shows as stale data instead of passing by luck.  Also drives the pipelined host call
- * (gg_filter_cloud_async / gg_filter_cloud_wait) two clouds deep and compares every result with the C oracle.
+ * (gg_filter_cloud_async / gg_filter_cloud_wait) two clouds deep and compares every result with the C oracle; and a batch divided
+ * into two concurrent halves (GG_FLAG_CONCURRENT_HALVES) behind a busy queue, with a getter and a fenced copy behind it.
  *   exit 0 = bit-identical, 1 = mismatch, 77 = no GPU (skipped).  Built and run by tests/test_cpp_adapter.py. */
 #include <math.h>
 #include <stdio.h>
@@ -175,6 +176,81 @@ int main(void)
         }
         CHECK(gg_get_layer(ctx, 0, GG_LAYER_GROUND, layer));
         ok &= same_floats(layer, ref->layer[GGO_GROUND], C, "ground after the async sequence");
+    }
+
+    /* 5. GG_FLAG_CONCURRENT_HALVES: a batch of four clouds on four maps runs as two halves -- slots 0, 1 on the foreign stream, slots
+     *    2, 3 on the library's side stream -- with NO join between calls.  Three steps back to back behind a busy queue (map
+     *    re-initialisation on the foreign stream, divided the same way, in front of the second), then: a getter orders itself after
+     *    both halves; the caller's own copy of the labels does so with gg_batch_fence. */
+    {
+        enum { B = 4, M = 20000 };
+        extern int gg_debug_set_tuning(gg_context *, const char *, int);
+        gg_context *ctx2 = NULL;
+        if (gg_create(NULL, B, M, 0, &ctx2) != GG_OK) return 1;
+        gg_context *const ctx_outer = ctx;
+        ctx = ctx2; /* (CHECK reports against this context) */
+        CHECK(gg_set_flags(ctx, GG_FLAG_CONCURRENT_HALVES));
+        CHECK(gg_debug_set_tuning(ctx, "halves_min_clouds", 2));
+        ggo_map *refs[B];
+        gg_point32 *hc = (gg_point32 *)malloc((size_t)B * M * sizeof *hc), *dc = NULL;
+        uint8_t *dl = NULL, *hl = (uint8_t *)malloc((size_t)B * M);
+        for (int k = 0; k < B; ++k) {
+            refs[k] = ggo_map_create(120.0f, 0.33f, 0.0, 0.0, 0.0f);
+            make_cloud(hc + (size_t)k * M, M, 1000u + (unsigned)k, 0.5f * (float)k);
+        }
+        if (hipMalloc((void **)&dc, (size_t)B * M * sizeof *dc) != hipSuccess || hipMalloc((void **)&dl, (size_t)B * M) != hipSuccess) return 1;
+        hipMemcpy(dc, hc, (size_t)B * M * sizeof *dc, hipMemcpyHostToDevice);
+        int32_t np[B], slots[B];
+        float orgs[B * 3];
+        double bzs[B];
+        for (int k = 0; k < B; ++k) np[k] = M, orgs[3 * k] = 0.1f * (float)k, orgs[3 * k + 1] = 0.0f, orgs[3 * k + 2] = 0.0f, bzs[k] = -1.73;
+        gg_batch bb;
+        memset(&bb, 0, sizeof bb);
+        bb.n_clouds = B;
+        bb.point_format = GG_POINT32;
+        bb.d_points = dc;
+        bb.cloud_stride = M;
+        bb.n_points = np;
+        bb.origins = orgs;
+        bb.base_z = bzs;
+        bb.d_labels = dl;
+        bb.slots = slots;
+        for (int k = 0; k < 12; ++k) hipMemsetAsync(d_busy, k, BUSY, foreign);
+        for (int step = 0; step < 3; ++step) {
+            for (int k = 0; k < B; ++k) slots[k] = (k + step) % B; /* cloud k meets map (k + step) mod 4: both halves change hands */
+            if (step == 1) {
+                CHECK(gg_reset_maps(ctx, 0, B, 0.0, 0.0, 0.0f, 1, foreign));
+                for (int k = 0; k < B; ++k)
+                    for (size_t i = 0; i < C; ++i) refs[k]->layer[GGO_GROUND][i] = 0.0f, refs[k]->layer[GGO_GROUNDPATCH][i] = (float)0.0000001;
+            }
+            CHECK(gg_filter_batch(ctx, &bb, foreign));
+            for (int k = 0; k < B; ++k)
+                ggo_filter_cloud(refs[slots[k]], &rcfg, (const ggo_point *)(hc + (size_t)k * M), M, orgs + 3 * k, bzs[k], NULL, rlabel + 0, NULL, NULL, NULL);
+        }
+        for (int k = 0; k < B; ++k) { /* getters: ordered after both halves by the library */
+            CHECK(gg_get_layer(ctx, k, GG_LAYER_GROUND, layer));
+            ok &= same_floats(layer, refs[k]->layer[GGO_GROUND], C, "ground of a map after three divided batches");
+            CHECK(gg_get_layer(ctx, k, GG_LAYER_POINTS, layer));
+            ok &= same_floats(layer, refs[k]->layer[GGO_POINTS], C, "points of a map after three divided batches");
+        }
+        /* the caller's own read of the outputs: behind the fence, on its stream */
+        CHECK(gg_filter_batch(ctx, &bb, foreign));
+        CHECK(gg_batch_fence(ctx, foreign));
+        hipMemcpyAsync(hl, dl, (size_t)B * M, hipMemcpyDeviceToHost, foreign);
+        hipStreamSynchronize(foreign);
+        for (int k = 0; k < B; ++k) {
+            ggo_filter_cloud(refs[slots[k]], &rcfg, (const ggo_point *)(hc + (size_t)k * M), M, orgs + 3 * k, bzs[k], NULL, rlabel, NULL, NULL, NULL);
+            ok &= memcmp(hl + (size_t)k * M, rlabel, M) == 0;
+        }
+        if (!ok) printf("step 5 (concurrent halves) failed\n");
+        CHECK(gg_synchronize(ctx));
+        for (int k = 0; k < B; ++k) ggo_map_destroy(refs[k]);
+        hipFree(dc);
+        hipFree(dl);
+        free(hc);
+        free(hl);
+        gg_destroy(ctx2);
+        ctx = ctx_outer;
     }
 
     printf(ok ? "streams + async: bit-identical to the oracle\n" : "FAILED\n");

@@ -380,3 +380,71 @@ def test_minimal_layers_reads_after_set_config_and_move():
         for name in owed if it < 2 else oracle.LAYERS:
             assert nan_equal(seg.map(0)[name], ref.layer(name)), (it, name)
     seg.close()
+
+
+# ---------------------------------------------------------------- GG_FLAG_CONCURRENT_HALVES
+
+def _halves_inputs(B, stride, clouds):
+    import torch
+
+    host = np.zeros((B, stride), dtype=api.POINT16_DTYPE)
+    for b, c in enumerate(clouds):
+        host[b, : len(c)] = api.pack16(c)
+    return torch.from_numpy(host.view(np.uint8).reshape(B, stride, 16)).cuda()
+
+
+@pytest.mark.parametrize("n_slots,B", [(8, 8), (7, 5)])
+def test_batches_as_two_concurrent_halves_match_the_oracle(n_slots, B):
+    """The clouds of a batch whose maps are in the upper half of the context's slots run on the library's side stream, the others on
+    the caller's; nothing joins them between steps.  Cold and warm steps with the clouds rotating over the slots, map
+    re-initialisation on the caller's stream (divided the same way), getters, a small undivided batch and a profiled (hence
+    undivided) batch in between: every output against the oracle."""
+    import torch
+
+    clouds = [synth.hdl64_cloud(seed=300 + k, n_az=120 + 31 * k) for k in range(B)]
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=n_slots, max_points=stride)
+    seg.set_flags(concurrent_halves=True)
+    seg.debug_set_tuning("halves_min_clouds", 2)
+    refs = [oracle.OracleMap(120.0, 0.33) for _ in range(n_slots)]
+    pts = _halves_inputs(B, stride, clouds)
+    n, org, bz = [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73)
+    side = torch.cuda.Stream()
+    out = None
+    with torch.cuda.stream(side):
+        for step in range(9):
+            slots = [(b + 3 * step) % n_slots for b in range(B)]
+            cold = step in (0, 4, 5)
+            if cold:
+                seg.reset_maps(0, n_slots, persistent_only=(step != 0), on_torch_stream=True)
+                for r in refs:
+                    if step != 0:  # (persistent_only: ground / groundpatch; the per-call layers are rewritten by the cloud anyway)
+                        r.set_layer("ground", np.zeros((r.rows, r.cols), np.float32))
+                        r.set_layer("groundpatch", np.full((r.rows, r.cols), np.float32(0.0000001)))
+                    else:
+                        r.reset_state()
+            if step == 6:  # profiling switches the division off for this call: one launch sequence on the caller's stream
+                seg.set_flags(concurrent_halves=True, profile=True)
+            if step == 7:
+                seg.set_flags(concurrent_halves=True)
+            out = seg.filter_batch(pts, n, org, bz, out=out, slots=np.asarray(slots, np.int32))
+            seg.batch_fence()  # the copies below run on this torch stream: after BOTH halves
+            labels = out.labels.cpu().numpy()
+            index = out.out_index.cpu().numpy()
+            counts = out.counts.cpu().numpy()
+            for b, c in enumerate(clouds):
+                r = refs[slots[b]].filter_cloud(c, ORIGIN0, -1.73)
+                assert np.array_equal(labels[b, : len(c)], r["label"]), (step, b)
+                assert np.array_equal(index[b, : len(c)], r["index"]), (step, b)
+                assert counts[b, 0] == len(r["out_points"]), (step, b)
+            if step in (2, 8):  # getters order themselves after both halves
+                for s in (0, n_slots - 1, n_slots // 2):
+                    for name in ("ground", "groundpatch", "variance", "points"):
+                        assert nan_equal(seg.map(s)[name], refs[s].layer(name)), (step, s, name)
+            if step == 3:  # a batch too small to divide, on upper slots: it follows the second half of the batch before
+                one = seg.filter_batch(pts[:1].contiguous(), n[:1], org[:1], bz[:1], slots=np.asarray([n_slots - 1], np.int32))
+                seg.batch_fence()
+                r = refs[n_slots - 1].filter_cloud(clouds[0], ORIGIN0, -1.73)
+                assert np.array_equal(one.labels.cpu().numpy()[0, : n[0]], r["label"])
+    seg.synchronize()
+    seg.close()

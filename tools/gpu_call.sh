@@ -1,6 +1,10 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-SKIP_BIG=1 BATCHES_SMALL=1,8 timeout 200 python tools/latency_probe.py 2>/dev/null | tail -1 | tee gpurun_out/r05_pf_latency.log
-BATCHES_BIG=1 SKIP_SMALL=1 timeout 200 python tools/latency_probe.py 2>/dev/null | tail -1 | tee -a gpurun_out/r05_pf_latency.log
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "sweep or geometr or hdl64 or config4 or golden" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_cpp_adapter.py tests/test_gpu_stages_wire.py -x -q 2>&1 | tail -5
+timeout 900 python bench.py --steps 12 --warmup 3 > gpurun_out/r05_bench2.json 2> gpurun_out/r05_bench2.err; python - <<'PY'
+import json
+j=json.loads(open('gpurun_out/r05_bench2.json').read().strip().split('\n')[-1])
+print(j['value'], j['ms_per_step'], {k:v for k,v in j.get('concurrent_halves',{}).items() if k!='note'}, j['summary']['parity_checked_in_run'])
+PY
+tail -3 gpurun_out/r05_bench2.err
