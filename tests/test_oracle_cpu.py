@@ -348,3 +348,52 @@ def test_decay_multiply_guard_is_exact():
         low = bits & np.uint64(0x1FFFFFFF)
         near = ((low - np.uint64(0x10000000 - 64)) & np.uint64(0xFFFFFFFF)) <= np.uint64(128)
         assert near.all() == (abs(delta) <= 64), delta
+
+
+def test_stage_members_one_by_one_compose_to_the_stage():
+    """The oracle's single-stage entries (the twins gg_run_stage is tested against on the GPU): the four quadrants of
+    detect_ground_patches in any order are detect_ground_patches; a quadrant is its cells' detect_ground_patch<3|5> calls; the sweep is
+    its interpolate_cell visits in the reference's order (src/GroundSegmentation.cpp:325-337, :413-439)."""
+    rng = np.random.default_rng(41)
+    xy = rng.uniform(-16, 16, size=(9000, 2))
+    z = -1.7 + 0.03 * xy[:, 0] + rng.normal(0, 0.02, size=9000)
+    z[rng.random(9000) < 0.2] += rng.uniform(0.2, 2.0)
+    cloud = oracle.make_cloud(np.column_stack([xy, z]).astype(np.float32), ring=rng.integers(0, 64, 9000))
+    a, b, c = (oracle.OracleMap(33.0, 0.33) for _ in range(3))
+    for m in (a, b, c):
+        m.filter_cloud(cloud, (0.0, 0.0, 0.0), -1.73)  # (gives every layer contents: counts, heights, m2, old terrain)
+    n = a.rows
+    a.stage_detect()
+    for section in (3, 1, 0, 2):
+        b.stage_detect_section(section)
+    # c: cell by cell, as :329-337 does
+    m2, pts = c.layer("m2"), c.layer("points")
+    c.layer("variance")[...] = m2 / (pts + np.float32(np.finfo(np.float32).tiny))
+    res = np.float32(0.33)
+    for i in range(2, 2 * (n // 2) - 2):
+        for j in range(2, n - 2):
+            sqdist = np.float32(((i - n / 2.0) ** 2 + (j - n / 2.0) ** 2) * (float(res) * float(res)))
+            c.detect_ground_patch(3 if float(sqdist) <= 400.0 else 5, i, j)
+    for name in ("ground", "groundpatch", "variance"):
+        assert np.array_equal(a.layer(name), b.layer(name), equal_nan=True), name
+        assert np.array_equal(a.layer(name), c.layer(name), equal_nan=True), name
+    # the sweep as its visits
+    a.stage_spiral(-1.5)
+    center = n // 2 - 1
+    c.layer("groundpatch")[center, center] = 1.0
+    c.layer("ground")[center, center] = np.float32(-1.5)
+    visits = 0
+    for i in range(center - 1, 0, -1):
+        rp, sl = i, (center - i) * 2
+        for side in range(2):
+            for pos in range(rp, rp + sl):
+                c.interpolate_cell(pos if side else rp, rp if side else pos)
+                visits += 1
+        R = rp + sl
+        for side in range(2):
+            for pos in range(R, R - sl - 1, -1):
+                c.interpolate_cell(pos if side else R, R if side else pos)
+                visits += 1
+    assert visits == oracle.spiral_visit_count(n)
+    for name in ("ground", "groundpatch"):
+        assert np.array_equal(a.layer(name), c.layer(name), equal_nan=True), name
