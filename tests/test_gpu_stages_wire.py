@@ -448,3 +448,34 @@ def test_batches_as_two_concurrent_halves_match_the_oracle(n_slots, B):
                 assert np.array_equal(one.labels.cpu().numpy()[0, : n[0]], r["label"])
     seg.synchronize()
     seg.close()
+
+
+def test_new_entry_points_on_empty_and_all_outside_clouds():
+    """The reference's edge cases (empty cloud, every point outside the map) through the round-5 entry points: the fused call, the
+    PointCloud2-out call and the sensor-frame transform inside the fused call."""
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=4096)
+    ref = oracle.OracleMap(120.0, 0.33)
+    planes = seg.alloc_layers(register=False)
+    far = synth.make_cloud(np.column_stack([np.full(300, 500.0), np.linspace(-5, 5, 300), np.full(300, -1.7)]).astype(np.float32), ring=np.arange(300) % 64)
+    near = synth.hdl64_cloud(seed=17, n_az=60)[:4000]
+    tf = api.transform_from_pose((0.4, -0.2, 0.1, 0.0, 0.0, np.sin(-0.3), np.cos(-0.3)))
+    for it, c in enumerate((synth.empty_cloud(0), far, near, synth.empty_cloud(0), near)):
+        use_tf = it == 4
+        ref_in = c
+        if use_tf:
+            ref_in = synth.clone_cloud(c)
+            R, t = tf[:, :3], tf[:, 3]
+            p = np.stack([c["x"], c["y"], c["z"]], 1).astype(np.float64)
+            for k, name in enumerate(("x", "y", "z")):
+                ref_in[name] = (((R[k, 0] * p[:, 0] + R[k, 1] * p[:, 1]) + R[k, 2] * p[:, 2]) + t[k]).astype(np.float32)
+        out, labels, index = seg.filter_cloud_with_layers(c, ORIGIN0, -1.73, planes, return_details=True, map_from_cloud=tf if use_tf else None)
+        r = ref.filter_cloud(ref_in, ORIGIN0, -1.73)
+        assert len(out) == len(r["out_points"]) and out.tobytes() == r["out_points"].tobytes(), it
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), it
+        for name, v in planes.items():
+            assert nan_equal(v, ref.layer(name)), (it, name)
+        wire = api.to_pc2(c)
+        rec = seg.filter_cloud_pc2_out(wire.tobytes(), len(c), 18, (0, 4, 8, 16), ORIGIN0, -1.73)
+        r2 = ref.filter_cloud(c, ORIGIN0, -1.73)
+        assert rec.tobytes() == expected_pc2(r2["out_points"]), it
+    seg.close()
