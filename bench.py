@@ -106,10 +106,61 @@ def kernel_table(ktimes, alg, clouds_per_launch):
     return rows
 
 
+LIVE_PMC = {}  # kernel -> corrected HBM bytes per cloud, measured by THIS run (live_pmc_passes); empty: the committed profile is used
+
+
+def live_pmc_passes(batch, timeout_s=150):
+    """The HBM traffic of every kernel of the headline workload, measured by this run on this box: two child runs of this script
+    (headline only, 3 timed steps) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` -- separate
+    passes, counters with the kernel trace only, collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md's HBM section
+    prescribes (tools/pmc_summary.py: the cold first launch of a kernel dropped, FETCH doubled for the kernels whose wide coalesced
+    streams gfx950 counts at half).  Returns {"source": ..., "kernels": {name: bytes per cloud}} or a dict with "error" (no rocprofv3,
+    a pass failed or ran out of time: the committed profile is used instead, and the line says so)."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return {"error": "rocprofv3 not found"}
+    spec = importlib.util.spec_from_file_location("gg_pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    out = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras", "--no-live-pmc", "--batch", str(batch)]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            except Exception as e:  # (a profiler that is missing a counter, a box without the PMC interface, a timeout)
+                return {"error": f"{counter} pass: {type(e).__name__}"}
+            found = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if not found:
+                return {"error": f"{counter} pass wrote no counter_collection.csv"}
+            out[counter] = pmc.per_kernel(found[0])
+    kernels = {}
+    for k in pmc.KERNELS:
+        if k in out["FETCH_SIZE"] and k in out["WRITE_SIZE"]:
+            f = out["FETCH_SIZE"][k] * 1024.0 * (2.0 if k in pmc.HALVED else 1.0)
+            w = out["WRITE_SIZE"][k] * 1024.0
+            kernels[k] = (f + w) / batch
+    if not kernels:
+        return {"error": "no kernel of the path in the counter files"}
+    return {"source": "live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of this script's headline workload, spawned by this run "
+                      "on this box", "seconds": round(time.perf_counter() - t0, 1), "kernels": kernels}
+
+
 def pmc_traffic(kernel, clouds_per_launch, section="kernels"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_summary.json; `section`
-    "kernels" = the headline workload, "config4_kernels" = configs[3]), scaled to this launch size; None when no profile of this
-    kernel is committed."""
+    """HBM bytes per launch of `kernel`: measured by this run (live_pmc_passes) when it could, else from the committed rocprofv3 --pmc
+    passes (profiles/pmc_summary.json; `section` "kernels" = the headline workload, "config4_kernels" = configs[3]), scaled to this
+    launch size; None when neither knows the kernel."""
+    if section == "kernels" and kernel in LIVE_PMC:
+        return int(LIVE_PMC[kernel] * clouds_per_launch)
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         summary = json.load(open(path))
@@ -223,6 +274,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no warm / config3 / config4 / host_api / CPU legs)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the two rocprofv3 --pmc passes that measure roofline.traffic on this box "
+                                                               "(the committed profile's figures are used)")
     ap.add_argument("--no-rotate", action="store_true", help="every step applies cloud b to slot b (round 2's workload)")
     ap.add_argument("--config4-batch", type=int, default=128, help="clouds per launch of the configs[3] leg (GPU-filling)")
     ap.add_argument("--abi-collective", action="store_true", help="all-gather through the C ABI (gg_allgather_label_masks, RCCL bound by the "
@@ -477,15 +530,24 @@ def main():
         pw = seg.debug_set_tuning("pw", 0)  # points per wave chunk of this context (K1 / scan / scatter / K5)
         alg = algorithmic_bytes(n_mean, n_in, n_kept, C, T, (stride + pw - 1) // pw, full_layers=not args.minimal_layers)
         table = kernel_table(ktimes, alg, B)
+        traffic_source = "profiles/pmc_summary.json (the committed profile round, rescaled to this batch)"
+        if world == 1 and dist is None and not args.no_extras and not args.no_live_pmc and not args.only_config4 and not args.minimal_layers:
+            live = live_pmc_passes(B)
+            if "kernels" in live:
+                LIVE_PMC.update(live["kernels"])
+                traffic_source = live["source"] + f" ({live['seconds']} s)"
+            else:
+                traffic_source += f"; the live passes failed: {live['error']}"
         step_real = add_real_traffic(table, B)
         dominant = max(table, key=lambda k: table[k]["avg_ms"])
         g = table[dominant]
         result["roofline"] = {
             "kernel": dominant, "bound": "hbm", "achieved": g["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g["frac_hbm"],
             "traffic": pmc_traffic(dominant, B), "real_frac": g.get("real_frac_hbm"), "traffic_ratio": g.get("traffic_ratio"),
+            "traffic_source": traffic_source,
             "note": "dominant single kernel of the timed (cold) steps; achieved = SURVEY 8(d) algorithmic bytes x clouds per launch / its "
                     "average launch duration (HIP events on the launch stream inside the timed region); real_frac = the bytes the kernel "
-                    "really moved (traffic: corrected PMC counters of the committed profile) over the same duration, traffic_ratio = "
+                    "really moved (traffic: corrected PMC counters, see traffic_source) over the same duration, traffic_ratio = "
                     "traffic / algorithmic bytes",
         }
         front = [k for k in ("k_classify", "k_scan", "k_scatter") if k in table]
