@@ -109,7 +109,7 @@ def kernel_table(ktimes, alg, clouds_per_launch):
 LIVE_PMC = {}  # kernel -> corrected HBM bytes per cloud, measured by THIS run (live_pmc_passes); empty: the committed profile is used
 
 
-def live_pmc_passes(batch, timeout_s=150):
+def live_pmc_passes(batch, timeout_s=90):
     """The HBM traffic of every kernel of the headline workload, measured by this run on this box: two child runs of this script
     (headline only, 3 timed steps) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` -- separate
     passes, counters with the kernel trace only, collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md's HBM section
