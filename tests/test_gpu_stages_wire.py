@@ -7,6 +7,7 @@
 
 Bit-exact throughout (NaN == NaN).  Nothing here reads /root/reference.
 """
+import os
 import struct
 
 import numpy as np
@@ -255,7 +256,14 @@ def test_gridmap_message_payload():
     seg.map(1).reset(pos=(3.3, -6.6))
     seg.filter_cloud(cloud, (3.0, -6.0, 0.0), -1.73, map=seg.map(1))
     ref.filter_cloud(cloud, (3.0, -6.0, 0.0), -1.73)
-    m = parse_gridmap(seg.map(1).gridmap_message(seq=7, stamp=(1234, 5678)))
+    raw = seg.map(1).gridmap_message(seq=7, stamp=(1234, 5678))
+    # the layout the pinning kit holds against a real grid_map_ros (tools/pin/compare.py gridmap_message_bytes) is the library's
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pin_compare", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pin", "compare.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    assert raw == pin.gridmap_message_bytes(ref.rows, ref.cols, ref.resolution, ref.length, (3.3, -6.6), [(k, ref.layer(k)) for k in oracle.LAYERS], (1234, 5678), seq=7)
+    m = parse_gridmap(raw)
     assert (m["seq"], m["stamp"], m["frame_id"]) == (7, (1234, 5678), "map")
     assert m["resolution"] == ref.resolution and m["length"] == ref.length and m["position"] == (3.3, -6.6, 0.0) and m["orientation"] == (0.0, 0.0, 0.0, 1.0)
     assert m["layers"] == oracle.LAYERS and m["basic_layers"] == [] and m["start"] == (0, 0)

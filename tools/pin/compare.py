@@ -179,9 +179,60 @@ def libm_section() -> dict:
         x = F32(g.wide_float() * F32(0.01))
         y = F32(g.wide_float() * F32(0.01))
         hyp.append(hex32(L.ggo_hypotf(C.c_float(float(x)), C.c_float(float(y)))))
-    e = oracle.OracleMap(120.0, 0.33).expected_points()
+    m = oracle.OracleMap(120.0, 0.33)  # (kept alive: expected_points() is a view of the map's own memory)
+    e = m.expected_points().copy()
     exp = [hex32(e[i, j]) for i in range(0, 364, 7) for j in range(0, 364, 11)]
     return {"hypotf": hyp, "expected_points": exp}
+
+
+def gridmap_message_bytes(rows, cols, resolution, length, position, layers, stamp, frame_id="map", seq=0, basic_layers=()) -> bytes:
+    """grid_map_msgs/GridMap in ROS 1 wire format the way libgroundgrid_hip's gg_get_gridmap_message lays it out (restated here in
+    Python so that the probe's bytes can be held against it without a GPU): info {header, resolution, length, pose}, layers,
+    basic_layers, one Float32MultiArray per layer (dims column_index / row_index, column-major data), start indices 0."""
+    out = bytearray()
+    u32 = lambda v: out.extend(struct.pack("<I", v))
+    f64 = lambda v: out.extend(struct.pack("<d", v))
+
+    def string(t):
+        u32(len(t))
+        out.extend(t.encode())
+
+    u32(seq), u32(stamp[0]), u32(stamp[1]), string(frame_id)
+    f64(resolution), f64(length[0]), f64(length[1])
+    f64(position[0]), f64(position[1]), f64(0.0)
+    f64(0.0), f64(0.0), f64(0.0), f64(1.0)
+    u32(len(layers))
+    for name, _ in layers:
+        string(name)
+    u32(len(basic_layers))
+    for name in basic_layers:
+        string(name)
+    u32(len(layers))
+    for _, plane in layers:
+        u32(2)
+        string("column_index"), u32(cols), u32(rows * cols)
+        string("row_index"), u32(rows), u32(rows)
+        u32(0)
+        u32(rows * cols)
+        out.extend(np.asarray(plane, dtype="<f4").reshape(-1, order="F").tobytes())
+    out.extend(struct.pack("<HH", 0, 0))
+    return bytes(out)
+
+
+def gridmap_section() -> dict:
+    """Section 6 of probe.cpp (only when it was built with -DPIN_WITH_GRID_MAP_ROS): a 5 x 4 map of two layers."""
+    res = 0.33  # (the probe passes a double; setGeometry keeps it, size = round(length / resolution), length = size * resolution)
+    rows, cols = int(round(1.65 / res)), int(round(1.32 / res))
+    g = Lcg(0x6D5A0006)
+    layers = []
+    for name in ("points", "ground"):
+        plane = np.zeros((rows, cols), dtype=np.float32)
+        for j in range(cols):
+            for i in range(rows):
+                plane[i, j] = g.wide_float()
+        layers.append((name, plane))
+    msg = gridmap_message_bytes(rows, cols, res, (rows * res, cols * res), (0.5, -0.25), layers, (1234, 5678))
+    return {"gridmap_msg": list(msg)}
 
 
 def emit(eigen: int, rotation: str) -> dict:
@@ -191,6 +242,7 @@ def emit(eigen: int, rotation: str) -> dict:
     doc.update(update_section(rotation))
     doc.update(transform_section(rotation))
     doc.update(libm_section())
+    doc.update(gridmap_section())
     return doc
 
 
@@ -246,6 +298,10 @@ def compare(doc: dict) -> int:
     rot2 = section("tf2::doTransform(PointStamped) (GroundGridNodelet.cpp:146,176)",
                    [(f'rotation="{r}"', transform_section(r)) for r in ("kdl", "tf2")], ["do_transform"])
     section("glibc hypotf / atanf (:170, :44)", [("oracle", libm_section())], ["hypotf", "expected_points"])
+    if "gridmap_msg" in doc:  # (optional: the probe was built with -DPIN_WITH_GRID_MAP_ROS)
+        section("grid_map_msgs/GridMap wire bytes (GroundGridNodelet.cpp:211-214; gg_get_gridmap_message)", [("library layout", gridmap_section())], ["gridmap_msg"])
+    else:
+        report.append("SKIP  grid_map_msgs/GridMap wire bytes: the probe was built without -DPIN_WITH_GRID_MAP_ROS")
     print("\n".join(report))
     if not failed:
         print("\nThe oracle is pinned by these vectors.  Select:")

@@ -31,6 +31,11 @@
 #include <grid_map_core/grid_map_core.hpp>
 #include <tf2_geometry_msgs/tf2_geometry_msgs.h>
 
+#ifdef PIN_WITH_GRID_MAP_ROS // optional section 6 (the serialised grid_map_msgs/GridMap): add -DPIN_WITH_GRID_MAP_ROS -lgrid_map_ros to the build line
+#include <grid_map_ros/grid_map_ros.hpp>
+#include <ros/serialization.h>
+#endif
+
 #include "pin_inputs.h" // Lcg: the seeded input generator shared with compare.py (mirrored there in Python)
 
 static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
@@ -271,6 +276,29 @@ int main()
             }
         close_array();
     }
+    #ifdef PIN_WITH_GRID_MAP_ROS
+    // ---- 6. the map as the nodelet publishes it: grid_map::GridMapRosConverter::toMessage + ROS 1 serialisation
+    //         (src/GroundGridNodelet.cpp:211-214); libgroundgrid_hip's gg_get_gridmap_message writes these bytes itself
+    {
+        grid_map::GridMap map({"points", "ground"});
+        map.setFrameId("map");
+        map.setGeometry(grid_map::Length(1.65, 1.32), 0.33, grid_map::Position(0.5, -0.25)); // 5 x 4 cells
+        Lcg g(0x6D5A0006u);
+        for (const char *layer : {"points", "ground"})
+            for (int j = 0; j < map.getSize()(1); ++j)
+                for (int i = 0; i < map.getSize()(0); ++i) map[layer](i, j) = g.wide_float();
+        grid_map_msgs::GridMap msg;
+        grid_map::GridMapRosConverter::toMessage(map, msg);
+        msg.info.header.stamp = ros::Time(1234, 5678); // :213
+        const uint32_t len = ros::serialization::serializationLength(msg);
+        std::vector<uint8_t> buf(len);
+        ros::serialization::OStream stream(buf.data(), len);
+        ros::serialization::serialize(stream, msg);
+        open_array("gridmap_msg");
+        for (uint8_t b : buf) put((int)b);
+        close_array();
+    }
+#endif
     std::printf("\n}\n");
     return 0;
 }
