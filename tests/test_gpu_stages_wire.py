@@ -487,3 +487,25 @@ def test_new_entry_points_on_empty_and_all_outside_clouds():
         r2 = ref.filter_cloud(c, ORIGIN0, -1.73)
         assert rec.tobytes() == expected_pc2(r2["out_points"]), it
     seg.close()
+
+
+def test_pc2_records_and_fused_layers_at_full_size():
+    """BASELINE configs[1] and configs[3] at full size through the round-5 entry points: 125 k points / 364 x 364 and 2.1 M points /
+    1000 x 1000 -- the 18-byte records of every returned point (both alignments of a record, all three parts of the returned cloud on
+    the warm second frame of the small case) and all eleven layers of the fused call."""
+    for cloud, length, resolution, frames in ((synth.hdl64_cloud(), 120.0, 0.33, 2), (synth.os128_cloud(seed=2), 200.0, 0.2, 1)):
+        seg = api.GroundSegmentation().init(length, resolution, n_slots=1, max_points=len(cloud))
+        ref = oracle.OracleMap(length, resolution)
+        planes = seg.alloc_layers(register=True)
+        wire = api.to_pc2(cloud).tobytes()
+        for f in range(frames):
+            rec = seg.filter_cloud_pc2_out(wire, len(cloud), 18, (0, 4, 8, 16), ORIGIN0, -1.73)
+            r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+            assert rec.tobytes() == expected_pc2(r["out_points"]), (length, f)
+            out = seg.filter_cloud_with_layers(cloud, ORIGIN0, -1.73, planes)
+            r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+            assert out.tobytes() == r["out_points"].tobytes(), (length, f)
+            for name, v in planes.items():
+                assert nan_equal(v, ref.layer(name)), (length, f, name)
+        seg.release_layers(planes)
+        seg.close()
