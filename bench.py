@@ -612,7 +612,7 @@ def main():
                         mixed, clouds, 120.0, 0.33, n_check=1, seed=6, history_of=lambda slot: [int((slot - s) % B) for s in hs])[0]
 
     # ---------------------------------------------------------------- the headline's cold steps as two concurrent halves (a separate leg)
-    if extras and rank == 0 and world == 1 and B >= 512:
+    if extras and rank == 0 and world == 1 and dist is None and B >= 512:
         # GG_FLAG_CONCURRENT_HALVES (include/groundgrid_hip.h): every call runs the clouds of the lower and of the upper half of the map
         # slots as two launch sequences on two streams that never join between steps, so kernels of different kinds overlap.  Reported
         # BESIDE the headline, not as it: with two kernels sharing the device a per-kernel event pair times half a machine, so this leg
