@@ -1,4 +1,4 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python tools/fill_in_batch_probe.py 2>&1 | tail -1 | tee gpurun_out/r05_fill_in_batch_probe.json
+LIBS="default k1ntl k5nts k5ntl allnt" REPS=2 bash tools/run_ab.sh 2>&1 | grep -v "^+" | tee gpurun_out/r05_nt_ab.log
