@@ -219,12 +219,23 @@ template <bool DBG> struct WaveClockT {
 #endif
 constexpr int SLEEP_LONG = GG_SWEEP_SLEEP_LONG;
 
+#ifndef GG_SWEEP_BATCH_KINDS
+#define GG_SWEEP_BATCH_KINDS 2
+#endif
+template <bool S, int B, int J> struct TripKind {
+    static constexpr bool starts = S;
+    static constexpr int bnd = B, join = J;
+};
+
 // SPLIT: a preparing wavefront (run_prep) does the layer half of every step (sweep_core.h "Split steps")
 template <int SIDE, bool DBG, bool SPLIT>
 GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int wave_of_side, int lane, WaveClockT<DBG> &clk, int g0, int g1)
 {
     ChainLane<SIDE> st;
     int have_prep = 0; // (split steps) cached count of prepared wave-steps
+    // a counter only lane 0 writes: the other lanes write to their scratch words instead of being masked off (an exec-mask round trip
+    // is five scalar instructions of every step)
+    const int w_take = lane == 0 ? L.take_done + SIDE : ((L.scratch + 1 + 3 * lane) & ~1) + 2;
     for (int group = g0 + wave_of_side; group < g1; group += P.waves_per_side) {
         const int r0 = LANES * group + 1;
         const int nl = min(P.rings - (r0 - 1), (int)LANES);
@@ -238,57 +249,110 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
         sync.init(r0, nl, group, P, L);
         // which third of the steps can end a chain: t = tb + u with tb = t_first (mod TRIP), TRIP = 0 (mod 3)
         const int turn = (((join_turn_residue<SIDE>(r0) - t_first) % 3) + 3) % 3; // u = turn (mod 3)
-        for (int tb = t_first; tb <= t_last; tb += TRIP) {
+        // the trips in three loops (sweep_core.h ChainLane::step_a on STARTS, BND, JOIN): the general one while lanes still start and
+        // where two ranges meet, one for the trips in which lane 0 still reads the previous group's chain and no lane is at its join,
+        // one for the trips after that -- the last two are most of a group's steps and run without the range tests
+        auto trip = [&](const int tb, auto kind) __attribute__((always_inline)) {
+            using K = decltype(kind);
+            constexpr bool STARTS = K::starts;
 #pragma unroll
             for (int u = 0; u < TRIP; ++u) {
                 const int t = tb + u;
                 sync.advance(t);
-                auto wait_for = [&](auto ready) { // (rare) something the next half step reads has not been published yet as far as the cached counters know
+                // (rare) something the next half step reads has not been published yet as far as the counters read last say.  A waiting
+                // wavefront's polls take issue slots from the working wavefronts of its SIMD: back off after the first few (the hand-over
+                // it waits for is then several steps away).  Rolled loops: this is cold code in the middle of every step of the trip
+                auto wait_a = [&]() {
                     const unsigned long long w0 = clk.out_ptr() ? __builtin_readcyclecounter() : 0ull;
-                    sync.refresh(mem);
+                    sync.poll(mem);
                     int spins = 0;
-                    while (!ready()) {
-                        // a waiting wavefront's polls take issue slots from the working wavefronts of its SIMD: back off after
-                        // the first few (the hand-over it waits for is then several steps away)
-#if defined(GG_SWEEP_TIGHT_POLL)
-                        if (spins < GG_SWEEP_TIGHT_POLL) {
-                        } else
-#endif
-                        if (spins < 4)
-                            __builtin_amdgcn_s_sleep(1);
-                        else
-                            __builtin_amdgcn_s_sleep(SLEEP_LONG);
-                        sync.refresh(mem);
+#pragma nounroll
+                    for (; spins < 4 && !sync.slow_ok_a(); ++spins) {
+                        __builtin_amdgcn_s_sleep(1);
+                        sync.poll(mem);
+                    }
+#pragma nounroll
+                    while (!sync.slow_ok_a()) {
+                        __builtin_amdgcn_s_sleep(SLEEP_LONG);
+                        sync.poll(mem);
                         ++spins;
                     }
+                    sync.cover(); // how far the counters read last are good for
                     if (clk.out_ptr()) {
                         clk.polling += __builtin_readcyclecounter() - w0;
                         clk.waits += spins ? 1 : 0;
                     }
                 };
-                if (!sync.ok_a()) wait_for([&]() { return sync.ok_a(); });
+                // the join: the wait on the sweep's critical path (the sides of a ring hand their ends to each other ring after ring).
+                // One counter, and as little as possible between seeing it and going on
+                auto wait_b = [&]() {
+                    const unsigned long long w0 = clk.out_ptr() ? __builtin_readcyclecounter() : 0ull;
+                    const int need = sync.need_join_at(t);
+                    sync.have_join = mem.counter(sync.w_join);
+                    int spins = 0;
+#pragma nounroll
+                    for (; spins < 4 && sync.have_join < need; ++spins) {
+                        __builtin_amdgcn_s_sleep(1);
+                        sync.have_join = mem.counter(sync.w_join);
+                    }
+#pragma nounroll
+                    while (sync.have_join < need) {
+                        __builtin_amdgcn_s_sleep(SLEEP_LONG);
+                        sync.have_join = mem.counter(sync.w_join);
+                        ++spins;
+                    }
+                    sync.cover_b();
+                    if (clk.out_ptr()) {
+                        clk.polling += __builtin_readcyclecounter() - w0;
+                        clk.waits += spins ? 1 : 0;
+                    }
+                };
+                if (__builtin_expect(!sync.ok_a(), 0)) wait_a();
                 const WP ho = st.handed_over();
                 const WP x_in{wave_shr1(ho.w), wave_shr1(ho.p)};
                 constexpr int t_first_mod = ((-2 - (int)PF) % (int)SKEW + (int)SKEW) % (int)SKEW; // tb = t_first (mod TRIP), TRIP = 0 (mod SKEW)
                 const int tmod = (t_first_mod + u) % (int)SKEW;
                 if (SPLIT) {
                     const int step_no = t - t_first;
-                    if (have_prep <= step_no) { // (rare) the preparing wavefront is not a step ahead
+                    if (__builtin_expect(have_prep <= step_no, 0)) { // (rare) the preparing wavefront is not a step ahead
                         have_prep = mem.counter(L.prep_done + SIDE);
                         while (have_prep <= step_no) {
                             __builtin_amdgcn_s_sleep(1);
                             have_prep = mem.counter(L.prep_done + SIDE);
                         }
                     }
-                    const PrepRec rec = mem.ring_get(L.prep + ((SIDE * (int)PREP_DEPTH + (step_no & ((int)PREP_DEPTH - 1))) * (int)LANES + lane) * (int)PREP_WORDS);
-                    st.take(t, tmod, rec, x_in, group > 0, mem);
-                    if (lane == 0) mem.set_counter(L.take_done + SIDE, step_no + 1); // (after the read above: the DS queue is in order)
+                    const PrepRec rec = mem.ring_get(L.prep + ((SIDE * (int)PREP_DEPTH + u) * (int)LANES + lane) * (int)PREP_WORDS); // slot = step_no mod PREP_DEPTH = u
+                    st.template take<STARTS, K::bnd>(t, tmod, rec, x_in, group > 0, mem);
+                    mem.set_counter(w_take, step_no + 1); // (after the read above: the DS queue is in order)
                 } else {
-                    st.step_a(t, u % (int)PF, tmod, x_in, P, L, group > 0, mem);
+                    st.template step_a<STARTS, K::bnd>(t, u % (int)PF, tmod, x_in, P, L, group > 0, mem);
                 }
-                if (!sync.ok_b()) wait_for([&]() { return sync.ok_b(); });
-                st.step_b(t, tmod, P, L, has_next, group, mem, SKEW != 1 || (u % 3) == turn);
+                if (__builtin_expect(!sync.ok_b(), 0)) wait_b();
+                st.template step_b<STARTS, K::join>(t, tmod, P, L, has_next, group, mem, SKEW != 1 || (u % 3) == turn);
             }
+        };
+        if (SPLIT || GG_SWEEP_BATCH_KINDS >= 3) {
+            const int bnd_until = min(st.u_len0, st.u_join_first);
+            for (int tb = t_first; tb <= t_last;) {
+                if (tb > st.u_start_last && tb >= st.u_join_first && (group == 0 || tb >= st.u_len0)) {
+                    for (; tb <= t_last; tb += TRIP) trip(tb, TripKind<false, 0, 2>{});
+                } else if (group > 0 && tb > st.u_start_last && tb + (int)TRIP - 1 < bnd_until) {
+                    for (; tb <= t_last && tb + (int)TRIP - 1 < bnd_until; tb += TRIP) trip(tb, TripKind<false, 2, 0>{});
+                } else {
+                    trip(tb, TripKind<true, 1, 1>{});
+                    tb += TRIP;
+                }
+            }
+        } else {
+            // (throughput launches: the work-groups of many clouds share a compute unit's instruction cache, every group at another
+            // place of its loops -- a third copy of the trip made the launch 2.5 times slower)
+            int tb = t_first;
+#if GG_SWEEP_BATCH_KINDS >= 2
+            for (; tb <= t_last && tb <= st.u_start_last; tb += TRIP) trip(tb, TripKind<true, 1, 1>{});
+            for (; tb <= t_last; tb += TRIP) trip(tb, TripKind<false, 1, 1>{});
+#else
+            for (; tb <= t_last; tb += TRIP) trip(tb, TripKind<true, 1, 1>{});
+#endif
         }
     }
 }
@@ -297,13 +361,14 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
 // steps ahead of the chain wavefront, into the side's LDS ring.
 template <int SIDE, bool DBG> GG_DEV void run_prep(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, int group)
 {
-    static_assert((PREP_DEPTH & (PREP_DEPTH - 1)) == 0, "ring slots are addressed with a mask");
     PrepLane<SIDE> st;
     const int r0 = LANES * group + 1;
     const int nl = min(P.rings - (r0 - 1), (int)LANES);
     st.init(lane, r0, nl, P);
+    static_assert((int)PREP_DEPTH == (int)TRIP, "a step's ring slot is its position in the trip");
     const int t_first = group_first_step(), t_last = group_last_step<SIDE>(r0, nl);
     int have_taken = 0;
+    const int w_prep = lane == 0 ? L.prep_done + SIDE : ((L.scratch + 1 + 3 * lane) & ~1) + 2; // (lane 0's counter; see run_chain)
     for (int tb = t_first; tb <= t_last; tb += TRIP) {
 #pragma unroll
         for (int u = 0; u < TRIP; ++u) {
@@ -316,8 +381,8 @@ template <int SIDE, bool DBG> GG_DEV void run_prep(const Params &P, const LdsMap
                 }
             }
             const PrepRec rec = st.step(t, u % (int)PF, P, mem);
-            mem.ring_put(L.prep + ((SIDE * (int)PREP_DEPTH + (step_no & ((int)PREP_DEPTH - 1))) * (int)LANES + lane) * (int)PREP_WORDS, rec);
-            if (lane == 0) mem.set_counter(L.prep_done + SIDE, step_no + 1); // (the records first: in-order DS queue)
+            mem.ring_put(L.prep + ((SIDE * (int)PREP_DEPTH + u) * (int)LANES + lane) * (int)PREP_WORDS, rec);
+            mem.set_counter(w_prep, step_no + 1); // (the records first: in-order DS queue)
         }
     }
 }

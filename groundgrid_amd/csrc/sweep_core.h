@@ -282,7 +282,7 @@ SW_HD int xchg_chain(int gb, int side, int e) { return xchg_base(gb) + side * xc
 SW_HD int xchg_misc(int gb, int k) { return xchg_base(gb) + 4 * xchg_len(gb) + k; }
 
 // g0, g1: the groups of the work-group (default: all of them)
-enum { PREP_DEPTH = 8, PREP_WORDS = 6 }; // ring slots per side; words of one PrepRec
+enum { PREP_DEPTH = TRIP, PREP_WORDS = 6 }; // ring slots per side (= TRIP: the slot of a step is a constant of the unrolled loop); words of one PrepRec
 SW_HD LdsMap lds_layout(int c, int groups, int g0 = 0, int g1 = -1, bool split_steps = false)
 {
     if (g1 < 0) g1 = groups;
@@ -339,17 +339,18 @@ SW_HD LdsMap lds_layout(int c, int groups, int g0 = 0, int g1 = -1, bool split_s
 // ---------------------------------------------------------------------------------------------------------------------
 // What a chain wavefront waits for.  Everything that crosses wavefronts sits behind three monotonic counters: the corner
 // lane's ring count, the partner side's "last value published up to ring", the previous group's boundary chain length.
-// What a group needs of each is a non-decreasing step function of the wave-step t, kept in scalar registers and
-// advanced with a few scalar instructions per step (a lone wavefront issues ~1 instruction per 4 cycles of ANY kind:
-// measured, the first version of this kernel spent more time on its scalar bookkeeping than on the float arithmetic):
+// What a group needs of each is a non-decreasing step function of the wave-step t in closed form (a lone wavefront issues ~1
+// instruction per 4 cycles of ANY kind: measured, the first version of this kernel spent more time on its scalar bookkeeping
+// than on the float arithmetic):
 //   corner  ring of the latest lane whose first step is <= t                  (lanes start every SKEW steps)
 //   join    join ring of the latest lane whose join step (s = len - 2) is <= t  (every SKEW + 2 steps)
 //   bnd     t + 1 while lane 0 still reads the previous group's chain
 // The counters are cached; LDS is polled only when a cached value is too small.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int SIDE> struct ChainSync {
-    enum { NEVER = 0x7fffffff };
-    int need_corner, need_join, need_bnd;       // what step t requires
+    enum { NEVER = 0x7fffffff, ALWAYS = 0x3fffffff };
+    int t_;                                     // the wave-step in question (advance)
+    int safe_a, safe_b;                         // the last wave-step whose step_a / step_b the cached counters cover (cover())
     int have_corner, have_join, have_bnd;       // cached counter values (lower bounds)
     int start_t0, start_r0, n_start;            // first lane start: time, ring; number of lanes with a chain
     int join_t0, join_r0;                       // first join: time, join ring (one per started lane, every SKEW + 2 steps)
@@ -363,7 +364,6 @@ template <int SIDE> struct ChainSync {
         w_corner = L.corner_done + ((SIDE == SIDE_A || SIDE == SIDE_B) ? 0 : 1);
         w_join = L.join_done + side_from;
         w_bnd = L.bnd_done + SIDE * P.groups + (group > 0 ? group - 1 : 0);
-        need_corner = need_join = need_bnd = 0;
         have_corner = have_join = have_bnd = 0;
         // lanes with a chain (len >= 1) start at t = SKEW * l and join (s = len - 2) at t = (SKEW + 2) l + 2 r0 + b - 2
         int l1 = (1 - b + 1) / 2 - r0; // smallest l with 2 (r0 + l) + b >= 1
@@ -374,22 +374,59 @@ template <int SIDE> struct ChainSync {
         join_t0 = l1 < nl ? (SKEW + 2) * l1 + 2 * r0 + b - 2 : (int)NEVER;
         join_r0 = (SIDE == SIDE_A || SIDE == SIDE_B) ? r0 + l1 - 1 : r0 + l1;
         bnd_end = group > 0 ? chain_len<SIDE>(r0) - 2 : 0;
+        t_ = -2 - (int)PF; // group_first_step()
+        cover();
     }
-    // requirements of wave-step t: non-decreasing step functions of t in closed form -- integer scalar arithmetic only (no
-    // flags carried from step to step: the compiler kept those as lane masks and converted them through vector registers)
-    SW_HD void advance(int t)
+    // requirements of wave-step t: non-decreasing step functions of t in closed form
+    SW_HD int need_corner_at(int t) const
     {
-        const int ds = t - start_t0, dj = t - join_t0; // (NEVER: negative for every t)
-        const int ks = (int)((unsigned)ds / (unsigned)SKEW), kj = (int)((unsigned)dj / ((unsigned)SKEW + 2u)); // (only used when non-negative)
-        const int last = n_start - 1;
-        need_corner = ds < 0 ? 0 : start_r0 + (ks < last ? ks : last);
-        need_join = dj < 0 ? 0 : join_r0 + (kj < last ? kj : last);
-        const int tb = t + 1 < bnd_end ? t + 1 : bnd_end;
-        need_bnd = tb > 0 ? tb : 0;
+        const int ds = t - start_t0; // (NEVER: negative for every t)
+        const int ks = (int)((unsigned)ds / (unsigned)SKEW), last = n_start - 1; // (ks only used when non-negative)
+        return ds < 0 ? 0 : start_r0 + (ks < last ? ks : last);
     }
-    SW_HD bool ok_a() const { return have_corner >= need_corner && have_bnd >= need_bnd; } // what step_a reads
-    SW_HD bool ok_b() const { return have_join >= need_join; }                              // what step_b reads
-    template <class Mem> SW_HD void refresh(Mem &mem) { mem.counters3(w_corner, w_join, w_bnd, have_corner, have_join, have_bnd); }
+    SW_HD int need_join_at(int t) const
+    {
+        const int dj = t - join_t0;
+        const int kj = (int)((unsigned)dj / ((unsigned)SKEW + 2u)), last = n_start - 1;
+        return dj < 0 ? 0 : join_r0 + (kj < last ? kj : last);
+    }
+    SW_HD int need_bnd_at(int t) const
+    {
+        const int tb = t + 1 < bnd_end ? t + 1 : bnd_end;
+        return tb > 0 ? tb : 0;
+    }
+    // ... and their inverses: the last step each cached counter is good for.  The per-step test is then ONE scalar compare per half
+    // step; the closed forms above run only when a wavefront has to poll (they took 22 scalar instructions of every step, a sixth of
+    // it, and a lone wavefront pays for a scalar instruction what it pays for a vector one).
+    SW_HD void cover()
+    {
+        const int last = n_start - 1;
+        int sc, kc = have_corner - start_r0;
+        if (start_t0 == (int)NEVER || kc >= last) sc = ALWAYS;
+        else if (kc < 0) sc = start_t0 - 1;
+        else sc = start_t0 + (int)SKEW * kc + (int)SKEW - 1;
+        const int sb = have_bnd >= bnd_end ? (int)ALWAYS : have_bnd - 1;
+        safe_a = sc < sb ? sc : sb;
+        cover_b();
+    }
+    SW_HD void cover_b()
+    {
+        const int kj = have_join - join_r0;
+        if (join_t0 == (int)NEVER || kj >= n_start - 1) safe_b = ALWAYS;
+        else if (kj < 0) safe_b = join_t0 - 1;
+        else safe_b = join_t0 + ((int)SKEW + 2) * kj + (int)SKEW + 1;
+    }
+    SW_HD void advance(int t) { t_ = t; }
+    SW_HD bool ok_a() const { return t_ <= safe_a; } // what step_a reads is there as far as the cached counters know
+    SW_HD bool ok_b() const { return t_ <= safe_b; } // what step_b reads
+    SW_HD bool slow_ok_a() const { return have_corner >= need_corner_at(t_) && have_bnd >= need_bnd_at(t_); } // the same from the closed forms
+    SW_HD bool slow_ok_b() const { return have_join >= need_join_at(t_); }
+    template <class Mem> SW_HD void poll(Mem &mem) { mem.counters3(w_corner, w_join, w_bnd, have_corner, have_join, have_bnd); }
+    template <class Mem> SW_HD void refresh(Mem &mem)
+    {
+        poll(mem);
+        cover();
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -488,7 +525,14 @@ template <int SIDE> struct ChainLane {
     // step_b takes the join, completes the inner line and makes the visit.  A wavefront waits for the join between the two:
     // the sides of a ring hand their ends to each other ring after ring (B -> C -> B ..., A -> D -> A ...), that cycle is the
     // sweep's critical path, and this way only the second half of a step sits on it.
-    template <class Mem>
+    // What a step can contain is decided by wave-uniform ranges of t (u_*).  The caller may know more than the step -- a whole trip
+    // of the unrolled loop inside or outside a range -- and says so (the device's run_chain; sweep_emul.hip runs the defaults):
+    //   STARTS = false   t > u_start_last: no lane takes its corner values any more
+    //   BND    0 / 2     no step / every step reads the previous group's boundary chain (2: has_prev_group and 0 <= t < u_len0)
+    //   JOIN   0 / 2     no step / every step can be a lane's join step (2: t >= u_join_first; past u_join_last the read is unused)
+    // (1 = test per step).  A range test is seven scalar instructions and a taken branch, the blocks meet the step at control-flow
+    // joins that cost register copies, and a lone wavefront pays ~5 cycles for an instruction of any kind.
+    template <bool STARTS = true, int BND = 1, class Mem>
     SW_HD void step_a(int t, int slot, int tmod, WP x_in, const Params &P, const LdsMap &L, bool has_prev_group, Mem &mem)
     {
         (void)L;
@@ -499,8 +543,8 @@ template <int SIDE> struct ChainLane {
         // ---- LDS: what this lane could need (garbage until published; selected only when it is) -- but only in the
         //      (wave-uniform) ranges of steps in which some lane can be at that event
         WP c_bnd{0.f, 0.f};
-        if (has_prev_group && t >= 0 && t < u_len0) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
-        if (tmod == 0 && t >= 0 && t <= u_start_last) { // a lane's first step (t = SKEW l): the corner values
+        if (BND == 2 || (BND == 1 && has_prev_group && t >= 0 && t < u_len0)) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
+        if (STARTS && tmod == 0 && t >= 0 && t <= u_start_last) { // a lane's first step (t = SKEW l): the corner values
             cs0 = mem.get(a_s0);
             cs1 = mem.get(a_s1);
             cpred = mem.get(a_pred);
@@ -543,13 +587,13 @@ template <int SIDE> struct ChainLane {
     }
 
     // step_a when a preparing wavefront did the layer half (split steps): `rec` is its record of this wave-step
-    template <class Mem>
+    template <bool STARTS = true, int BND = 1, class Mem>
     SW_HD void take(int t, int tmod, const PrepRec &rec, WP x_in, bool has_prev_group, Mem &mem)
     {
         w_new_ = rec.w_new;
         WP c_bnd{0.f, 0.f};
-        if (has_prev_group && t >= 0 && t < u_len0) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
-        if (tmod == 0 && t >= 0 && t <= u_start_last) {
+        if (BND == 2 || (BND == 1 && has_prev_group && t >= 0 && t < u_len0)) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
+        if (STARTS && tmod == 0 && t >= 0 && t <= u_start_last) {
             cs0 = mem.get(a_s0);
             cs1 = mem.get(a_s1);
             cpred = mem.get(a_pred);
@@ -571,18 +615,18 @@ template <int SIDE> struct ChainLane {
 
     // join_turn: (wave-uniform) some lane of the group can end its chain at this step -- lane l ends at t + 1 = 3 l + lend of
     // lane 0 (SKEW = 1), i.e. in every third step only; see join_turn_of
-    template <class Mem>
+    template <bool STARTS = true, int JOIN = 1, class Mem>
     SW_HD void step_b(int t, int tmod, const Params &P, const LdsMap &L, bool has_next_group, int group, Mem &mem, bool join_turn = true)
     {
         WP x = xa;
-        if (t >= u_join_first && t <= u_join_last) {
+        if (JOIN == 2 || (JOIN == 1 && t >= u_join_first && t <= u_join_last)) {
             const WP c_join = mem.get(a_join);
             x = t + 2 == lend ? c_join : x; // s + 2 == len
         }
         I[0] = I[1];
         I[1] = I[2];
         I[2] = x;
-        if (tmod == 0 && t >= 0 && t <= u_start_last) {
+        if (STARTS && tmod == 0 && t >= 0 && t <= u_start_last) {
             const bool first = t == l3;
             I[0] = first ? cs0 : I[0];
             I[1] = first ? cs1 : I[1];
@@ -611,7 +655,9 @@ template <int SIDE> struct ChainLane {
         h1 = res;
         // ---- publish what other wavefronts wait for (data first, then the counter)
         if (join_turn) mem.publish_if(t + 1 == lend && len > 0, l, L, a_pub, res, L.join_done + SIDE, r);
-        if (has_next_group && t >= u_l3_last && t < u_lend_last) // (uniform: only while the last lane runs)
+        // (uniform: only while the last lane runs.  Without STARTS t > u_start_last = u_l3_last when there is a next group, and past
+        // u_lend_last no lane is active)
+        if (has_next_group && (!STARTS || (t >= u_l3_last && t < u_lend_last)))
             mem.publish_if(l == LANES - 1 && active, l, L, L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) - L.bnd_base + (t - l3)), res,
                            L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
     }

@@ -158,8 +158,10 @@ template <int SIDE> struct ChainWave : WaveBase {
                 sync.advance(t);
                 advanced = true;
             }
+            if (sync.ok_a() != sync.slow_ok_a()) plan_mismatch = true; // (the one-compare test is the closed forms' inverse)
             if (!sync.ok_a()) {
                 sync.refresh(mem);
+                if (sync.ok_a() != sync.slow_ok_a()) plan_mismatch = true;
                 if (!sync.ok_a()) return false;
             }
             // the cached counters are lower bounds of what the step reads: hold the lazily polled protocol to the exact needs
@@ -182,8 +184,10 @@ template <int SIDE> struct ChainWave : WaveBase {
             }
             half = true;
         }
+        if (sync.ok_b() != sync.slow_ok_b()) plan_mismatch = true;
         if (!sync.ok_b()) {
             sync.refresh(mem);
+            if (sync.ok_b() != sync.slow_ok_b()) plan_mismatch = true;
             if (!sync.ok_b()) return false; // (other wavefronts run between the two halves)
         }
         for (int l = 0; l < nl; ++l) {
