@@ -175,6 +175,17 @@ template <bool DBG> struct DevMemT {
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ca) : "memory");
         return __builtin_amdgcn_readfirstlane(v);
     }
+    // a counter and the (per-lane) data word behind it in one round trip: the DS queue is in order, a counter that says "published"
+    // came back before the data was read
+    GG_DEV int counter_and_get(int counter_word, int data_word, WP &v) const
+    {
+        int c;
+        u32x2 d;
+        const uint32_t ca = (uint32_t)(counter_word * 4) + lds_base(), da = (uint32_t)(data_word * 4) + lds_base();
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c), "=&v"(d) : "v"(ca), "v"(da) : "memory");
+        v = WP{__uint_as_float(d.x), __uint_as_float(d.y)};
+        return __builtin_amdgcn_readfirstlane(c);
+    }
     GG_DEV void counters3(int w0, int w1, int w2, int &v0, int &v1, int &v2) const
     {
         int a, b, c;
@@ -189,6 +200,15 @@ template <bool DBG> struct DevMemT {
     }
     GG_DEV uint32_t lds_base() const { return (uint32_t)(uintptr_t)lds; } // LDS byte address of word 0 (an address-space-3 pointer IS the offset)
 };
+
+// a wave-uniform integer as the compiler must take it where it stands (a scalar register): a loop-invariant condition tested through
+// this is a scalar compare and branch in the step, not a lane mask kept through the loop and negated with vector instructions
+GG_DEV int scalar_here(int v)
+{
+    v = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(v));
+    return v;
+}
 
 GG_DEV float wave_shr1(float v)
 {
@@ -219,6 +239,9 @@ template <bool DBG> struct WaveClockT {
 #endif
 constexpr int SLEEP_LONG = GG_SWEEP_SLEEP_LONG;
 
+#ifndef GG_SWEEP_REC_AHEAD
+#define GG_SWEEP_REC_AHEAD 1
+#endif
 #ifndef GG_SWEEP_BATCH_KINDS
 #define GG_SWEEP_BATCH_KINDS 2
 #endif
@@ -241,20 +264,21 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
         const int nl = min(P.rings - (r0 - 1), (int)LANES);
         st.init(lane, r0, nl, group, P, L);
         const int t_first = group_first_step(), t_last = group_last_step<SIDE>(r0, nl);
-        const bool has_next = group + 1 < P.groups;
+        const int has_next = __builtin_amdgcn_readfirstlane(group + 1 < P.groups ? 1 : 0);
         // PF steps per trip, no per-step condition: a step past t_last finds every lane idle (no loads, no stores, nothing
         // to wait for), and without a conditional around it the queue registers of a slot never meet a control-flow join --
         // a join makes the compiler copy freshly loaded registers, i.e. wait for the loads it has just issued
         ChainSync<SIDE> sync;
         sync.init(r0, nl, group, P, L);
         // which third of the steps can end a chain: t = tb + u with tb = t_first (mod TRIP), TRIP = 0 (mod 3)
-        const int turn = (((join_turn_residue<SIDE>(r0) - t_first) % 3) + 3) % 3; // u = turn (mod 3)
+        const int turn = __builtin_amdgcn_readfirstlane((((join_turn_residue<SIDE>(r0) - t_first) % 3) + 3) % 3); // u = turn (mod 3)
         // the trips in three loops (sweep_core.h ChainLane::step_a on STARTS, BND, JOIN): the general one while lanes still start and
         // where two ranges meet, one for the trips in which lane 0 still reads the previous group's chain and no lane is at its join,
         // one for the trips after that -- the last two are most of a group's steps and run without the range tests
         auto trip = [&](const int tb, auto kind) __attribute__((always_inline)) {
             using K = decltype(kind);
             constexpr bool STARTS = K::starts;
+            PrepRec rec_ahead{};
 #pragma unroll
             for (int u = 0; u < TRIP; ++u) {
                 const int t = tb + u;
@@ -285,20 +309,20 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
                 };
                 // the join: the wait on the sweep's critical path (the sides of a ring hand their ends to each other ring after ring).
                 // One counter, and as little as possible between seeing it and going on
-                auto wait_b = [&]() {
+                auto wait_b = [&](WP &join_read) {
                     const unsigned long long w0 = clk.out_ptr() ? __builtin_readcyclecounter() : 0ull;
                     const int need = sync.need_join_at(t);
-                    sync.have_join = mem.counter(sync.w_join);
+                    sync.have_join = K::join == 2 ? mem.counter_and_get(sync.w_join, st.a_join, join_read) : mem.counter(sync.w_join);
                     int spins = 0;
 #pragma nounroll
                     for (; spins < 4 && sync.have_join < need; ++spins) {
                         __builtin_amdgcn_s_sleep(1);
-                        sync.have_join = mem.counter(sync.w_join);
+                        sync.have_join = K::join == 2 ? mem.counter_and_get(sync.w_join, st.a_join, join_read) : mem.counter(sync.w_join);
                     }
 #pragma nounroll
                     while (sync.have_join < need) {
                         __builtin_amdgcn_s_sleep(SLEEP_LONG);
-                        sync.have_join = mem.counter(sync.w_join);
+                        sync.have_join = K::join == 2 ? mem.counter_and_get(sync.w_join, st.a_join, join_read) : mem.counter(sync.w_join);
                         ++spins;
                     }
                     sync.cover_b();
@@ -310,25 +334,36 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
                 if (__builtin_expect(!sync.ok_a(), 0)) wait_a();
                 const WP ho = st.handed_over();
                 const WP x_in{wave_shr1(ho.w), wave_shr1(ho.p)};
+                // the lane's join slot, read a half step early (valid if the counters read last cover step_b of this step: checked below)
+                WP join_read{0.f, 0.f};
+                if (K::join == 2) join_read = mem.get(st.a_join);
                 constexpr int t_first_mod = ((-2 - (int)PF) % (int)SKEW + (int)SKEW) % (int)SKEW; // tb = t_first (mod TRIP), TRIP = 0 (mod SKEW)
                 const int tmod = (t_first_mod + u) % (int)SKEW;
                 if (SPLIT) {
                     const int step_no = t - t_first;
-                    if (__builtin_expect(have_prep <= step_no, 0)) { // (rare) the preparing wavefront is not a step ahead
+                    // the record of this step was read a step ago (the first of a trip: now), the next step's is read now: the LDS
+                    // round trip of a record is over when its step begins.  GG_SWEEP_REC_AHEAD=0: every step reads its own
+                    const int AHEAD = (GG_SWEEP_REC_AHEAD && u + 1 < (int)TRIP) ? 1 : 0;
+                    if (__builtin_expect(have_prep <= step_no + AHEAD, 0)) { // (rare) the preparing wavefront is not that far ahead
                         have_prep = mem.counter(L.prep_done + SIDE);
-                        while (have_prep <= step_no) {
+                        while (have_prep <= step_no + AHEAD) {
                             __builtin_amdgcn_s_sleep(1);
                             have_prep = mem.counter(L.prep_done + SIDE);
                         }
                     }
-                    const PrepRec rec = mem.ring_get(L.prep + ((SIDE * (int)PREP_DEPTH + u) * (int)LANES + lane) * (int)PREP_WORDS); // slot = step_no mod PREP_DEPTH = u
+                    const int rec_word = L.prep + (SIDE * (int)PREP_DEPTH * (int)LANES + lane) * (int)PREP_WORDS; // + slot * LANES * PREP_WORDS, slot = step_no mod PREP_DEPTH = u
+                    PrepRec rec;
+                    if (GG_SWEEP_REC_AHEAD && u > 0) rec = rec_ahead;
+                    else rec = mem.ring_get(rec_word + u * (int)LANES * (int)PREP_WORDS);
+                    if (AHEAD) rec_ahead = mem.ring_get(rec_word + (u + 1) * (int)LANES * (int)PREP_WORDS);
                     st.template take<STARTS, K::bnd>(t, tmod, rec, x_in, group > 0, mem);
-                    mem.set_counter(w_take, step_no + 1); // (after the read above: the DS queue is in order)
+                    mem.set_counter(w_take, step_no + 1 + AHEAD); // (after the reads above: the DS queue is in order)
                 } else {
                     st.template step_a<STARTS, K::bnd>(t, u % (int)PF, tmod, x_in, P, L, group > 0, mem);
                 }
-                if (__builtin_expect(!sync.ok_b(), 0)) wait_b();
-                st.template step_b<STARTS, K::join>(t, tmod, P, L, has_next, group, mem, SKEW != 1 || (u % 3) == turn);
+                if (__builtin_expect(!sync.ok_b(), 0)) wait_b(join_read);
+                st.template step_b<STARTS, K::join>(t, tmod, P, L, (SPLIT ? scalar_here(has_next) : has_next) != 0, group, mem,
+                                                    SKEW != 1 || (SPLIT ? scalar_here(turn) : turn) == (u % 3), join_read); // (scalar_here: worth it for a lone wavefront only)
             }
         };
         if (SPLIT || GG_SWEEP_BATCH_KINDS >= 3) {

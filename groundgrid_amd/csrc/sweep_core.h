@@ -616,11 +616,12 @@ template <int SIDE> struct ChainLane {
     // join_turn: (wave-uniform) some lane of the group can end its chain at this step -- lane l ends at t + 1 = 3 l + lend of
     // lane 0 (SKEW = 1), i.e. in every third step only; see join_turn_of
     template <bool STARTS = true, int JOIN = 1, class Mem>
-    SW_HD void step_b(int t, int tmod, const Params &P, const LdsMap &L, bool has_next_group, int group, Mem &mem, bool join_turn = true)
+    SW_HD void step_b(int t, int tmod, const Params &P, const LdsMap &L, bool has_next_group, int group, Mem &mem, bool join_turn = true, WP join_read = WP{0.f, 0.f})
     {
+        // (JOIN = 2: the caller has read this lane's join slot -- early, so that the LDS round trip is over when the step gets here)
         WP x = xa;
         if (JOIN == 2 || (JOIN == 1 && t >= u_join_first && t <= u_join_last)) {
-            const WP c_join = mem.get(a_join);
+            const WP c_join = JOIN == 2 ? join_read : mem.get(a_join);
             x = t + 2 == lend ? c_join : x; // s + 2 == len
         }
         I[0] = I[1];

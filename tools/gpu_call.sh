@@ -2,10 +2,10 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rocm-smi --showclocks 2>/dev/null | grep -iE "sclk|mclk" | head -3
-for lib in base r1 new base r1 new; do
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+for lib in base r2 noahead new base r2 noahead new; do
   L=$GRAFT_REPO_ROOT/groundgrid_amd/variants/lib_$lib.so
   [ $lib = new ] && L=$GRAFT_REPO_ROOT/groundgrid_amd/libgroundgrid_hip.so
-  GROUNDGRID_HIP_LIB=$L MODES=cold timeout 300 python tools/ab_kernels.py 1024 6 $lib 2>&1 | tail -1 | tee -a gpurun_out/ab_peel9.log
-  GROUNDGRID_HIP_LIB=$L timeout 300 python tools/host_call_probe.py 2>&1 | tail -1 | tee -a gpurun_out/ab_peel9.log
+  GROUNDGRID_HIP_LIB=$L MODES=cold timeout 300 python tools/ab_kernels.py 1024 6 $lib 2>&1 | tail -1 | tee -a gpurun_out/ab_peel11.log
+  GROUNDGRID_HIP_LIB=$L timeout 300 python tools/host_call_probe.py 2>&1 | tail -1 | tee -a gpurun_out/ab_peel11.log
 done
