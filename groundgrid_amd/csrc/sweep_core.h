@@ -445,6 +445,8 @@ template <int SIDE> struct ChainLane {
     int xold_cell, own_end; // layer elements of S[len + 1] and of the own line's far end k0 + len (it belongs to another side)
     int a_s0, a_s1, a_pred, a_join, a_bnd, a_pub; // LDS words: S[0], S[1], predecessor, join, previous group's chain, own join slot
     int r2c, r2r;       // (x-c)^2 + (y-c)^2 of the visited cell = r2r + (t + r2c)^2
+    int pb_word, pb_step, pb_cnt, pb_idle; // the boundary chain the group's last lane leaves for the next group: LDS word of step t = pb_word + pb_step t and
+                                           // its counter (the other lanes: their scratch words pb_idle, pb_idle + 2, step 0)
     // wave-uniform constants of the group (scalar registers on the device): which steps can contain the rare per-lane events
     int u_start_last;   // lanes take their corner values at steps 0, SKEW, .. <= u_start_last
     int u_join_first, u_join_last; // a lane reads its join at t = lend - 2: only for t in this range
@@ -504,6 +506,10 @@ template <int SIDE> struct ChainLane {
         // A, B) or r - (k0 + s) (C, D); its square is the same
         r2c = k0 - r - l3;
         r2r = r * r;
+        pb_idle = (L.scratch + 1 + 3 * l) & ~1;
+        pb_word = l == LANES - 1 ? L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) - L.bnd_base - l3) : pb_idle;
+        pb_step = l == LANES - 1 ? 2 : 0;
+        pb_cnt = l == LANES - 1 ? L.bnd_done + SIDE * P.groups + group : pb_idle + 2;
         u_start_last = SKEW * (nl - 1);
         u_len0 = chain_len<SIDE>(r0);
         u_join_first = u_len0 - 2;
@@ -582,7 +588,7 @@ template <int SIDE> struct ChainLane {
         U[2] = WP{out.w, out.w * out.g};
         // stream element S[s + 2]: the inner lane's step s (SKEW wave-steps ago; lane 0: the previous group's boundary chain),
         // at the far end the old cell; the join comes in step_b
-        xa = l == 0 ? c_bnd : x_in;
+        xa = (BND != 0 && l == 0) ? c_bnd : x_in; // (BND = 0: lane 0's chain is over, what it takes in is not used)
         xa = t + 1 == lend ? xold : xa; // s + 2 == len + 1
     }
 
@@ -609,7 +615,7 @@ template <int SIDE> struct ChainLane {
         U[0] = U[1];
         U[1] = U[2];
         U[2] = WP{rec.out_w, rec.out_p};
-        xa = l == 0 ? c_bnd : x_in;
+        xa = (BND != 0 && l == 0) ? c_bnd : x_in; // (BND = 0: lane 0's chain is over, what it takes in is not used)
         xa = t + 1 == lend ? xold : xa;
     }
 
@@ -659,8 +665,7 @@ template <int SIDE> struct ChainLane {
         // (uniform: only while the last lane runs.  Without STARTS t > u_start_last = u_l3_last when there is a next group, and past
         // u_lend_last no lane is active)
         if (has_next_group && (!STARTS || (t >= u_l3_last && t < u_lend_last)))
-            mem.publish_if(l == LANES - 1 && active, l, L, L.bnd + 2 * ((SIDE * L.bnd_stride) + bnd_offset(group) - L.bnd_base + (t - l3)), res,
-                           L.bnd_done + SIDE * P.groups + group, t - l3 + 1);
+            mem.publish(active ? pb_word + pb_step * t : pb_idle, res, active ? pb_cnt : pb_idle + 2, t - l3 + 1);
     }
 };
 
