@@ -308,7 +308,8 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
                     }
                 };
                 // the join: the wait on the sweep's critical path (the sides of a ring hand their ends to each other ring after ring).
-                // One counter, and as little as possible between seeing it and going on
+                // One counter, and as little as possible between seeing it and going on.  (s_sleep 1 between polls is the measured optimum
+                // for a lone cloud: s_nop gaps or none +2..5 %, s_sleep 2 / 3 +1.5 / +3.5 %)
                 auto wait_b = [&](WP &join_read) {
                     const unsigned long long w0 = clk.out_ptr() ? __builtin_readcyclecounter() : 0ull;
                     const int need = sync.need_join_at(t);
