@@ -83,6 +83,9 @@ struct gg_context {
     hipEvent_t half_fork = nullptr, half_done = nullptr;
     bool have_half_event = false;
     int halves_min_clouds = 256;
+    // gg_filter_cloud / _async / _layers: k_label writes counts, index and labels straight into the pinned host block (posted writes over
+    // the link while the kernel runs) instead of into HBM with a copy behind the kernel: one transfer and one stream hop less per call
+    int results_direct = 1;
     bool probe_no_fork = false;
     hipEvent_t ring_done2[4]{};
     bool ring_used2[4]{};
@@ -93,6 +96,7 @@ struct gg_context {
         uint8_t *h_labels = nullptr, *d_labels = nullptr;
         int32_t *h_index = nullptr, *d_index = nullptr;
         int32_t *h_counts = nullptr, *d_counts = nullptr;
+        int32_t *hd_counts = nullptr; // h_counts as the device addresses it (results_direct)
         hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
         const gg_point32 *cloud = nullptr;
         size_t n = 0;
@@ -1030,6 +1034,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         CREATE_CHK(hipHostMalloc((void **)&as.h_counts, 64 + max_points * 5 + 64, hipHostMallocDefault)); // (the same block on the host)
         as.h_index = as.h_counts + 16;
         as.h_labels = nullptr;
+        CREATE_CHK(hipHostGetDevicePointer((void **)&as.hd_counts, as.h_counts, 0));
         CREATE_CHK(hipEventCreateWithFlags(&as.uploaded, hipEventDisableTiming));
         CREATE_CHK(hipEventCreateWithFlags(&as.computed, hipEventDisableTiming));
         CREATE_CHK(hipEventCreateWithFlags(&as.downloaded, hipEventDisableTiming));
@@ -1784,22 +1789,28 @@ static int enqueue_ticket(gg_context *ctx, int slot, const gg_point32 *cloud, si
     b.transforms = tf;
     as.d_labels = reinterpret_cast<uint8_t *>(as.d_index + n); // [counts][index: n][labels: n]
     as.h_labels = reinterpret_cast<uint8_t *>(as.h_index + n);
-    b.d_labels = reinterpret_cast<uint8_t *>(as.d_index); // (+ label_shift = 4 n on the device: the launch's arguments do not depend on n)
+    const bool direct = ctx->results_direct != 0 && as.hd_counts != nullptr;
+    int32_t *const res_counts = direct ? as.hd_counts : as.d_counts, *const res_index = direct ? as.hd_counts + 16 : as.d_index;
+    b.d_labels = reinterpret_cast<uint8_t *>(res_index); // (+ label_shift = 4 n on the device: the launch's arguments do not depend on n)
     ctx->next_label_shift = (int)(n * 4);
-    b.d_out_index = as.d_index;
+    b.d_out_index = res_index;
     b.d_out_clouds = nullptr;
-    b.d_out_counts = as.d_counts;
+    b.d_out_counts = res_counts;
     const int rc = enqueue_batch(ctx, &b, ctx->stream, plan);
     ctx->next_label_shift = 0;
     if (rc != GG_OK) return rc;
-    // results come back on their own stream, so that the next ticket's kernels do not queue behind this download
-    const hipStream_t down = pipelined ? ctx->d2h_stream : ctx->stream;
-    if (pipelined) {
-        HIPCHK(ctx, hipEventRecord(as.computed, ctx->stream));
-        HIPCHK(ctx, hipStreamWaitEvent(down, as.computed, 0));
+    if (direct) {
+        HIPCHK(ctx, hipEventRecord(as.downloaded, ctx->stream)); // (the results are in host memory when k_label is done)
+    } else {
+        // results come back on their own stream, so that the next ticket's kernels do not queue behind this download
+        const hipStream_t down = pipelined ? ctx->d2h_stream : ctx->stream;
+        if (pipelined) {
+            HIPCHK(ctx, hipEventRecord(as.computed, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(down, as.computed, 0));
+        }
+        HIPCHK(ctx, hipMemcpyAsync(as.h_counts, as.d_counts, 64 + n * 5, hipMemcpyDeviceToHost, down)); // counts + index + labels: one copy
+        HIPCHK(ctx, hipEventRecord(as.downloaded, down));
     }
-    HIPCHK(ctx, hipMemcpyAsync(as.h_counts, as.d_counts, 64 + n * 5, hipMemcpyDeviceToHost, down)); // counts + index + labels: one copy
-    HIPCHK(ctx, hipEventRecord(as.downloaded, down));
     if (plan && (plan->mask & ~EARLY_LAYERS)) { // the layers that are only final now (ground, groundpatch, points) follow the results: the host
         Arena a = ctx->arena;                   // assembles the returned cloud while they travel
         enqueue_layer_downloads(ctx, a, slot, plan->mask & ~EARLY_LAYERS, *plan, ctx->stream);
@@ -1836,16 +1847,19 @@ int gg_filter_cloud_wait(gg_context *ctx, int ticket, gg_point32 *out_cloud, siz
     const auto t_w1 = std::chrono::steady_clock::now();
     const size_t n = as.n;
     if (out_n) *out_n = (size_t)as.h_counts[0];
-    if (out_label && n) memcpy(out_label, as.h_labels, n);
-    if (out_index && n) memcpy(out_index, as.h_index, n * 4);
-    if (out_cloud) {
-        // the returned cloud (:173-189): the host owns the input, so it assembles the output from index + label
+    if (n && (out_label || out_index || out_cloud)) {
+        // the returned cloud (:173-189): the host owns the input, so it assembles the output from index + label -- every input point has
+        // its own position in the returned cloud (the pieces of the input write disjoint records); labels and index are copied out by
+        // the same threads
         const gg_point32 *cloud = as.cloud;
         const double *tf = as.has_tf ? as.tf : nullptr;
         const int32_t *h_index = as.h_index;
         const uint8_t *h_labels = as.h_labels;
-        // (every input point has its own position in the returned cloud: the two halves of the input write disjoint records)
-        ctx->helper.split(n, [&](size_t i0, size_t i1) { assemble_returned_cloud(cloud, h_index, h_labels, tf, out_cloud, i0, i1); });
+        ctx->helper.split(n, [&](size_t i0, size_t i1) {
+            if (out_label) memcpy(out_label + i0, h_labels + i0, i1 - i0);
+            if (out_index) memcpy(out_index + i0, h_index + i0, (i1 - i0) * 4);
+            if (out_cloud) assemble_returned_cloud(cloud, h_index, h_labels, tf, out_cloud, i0, i1);
+        });
     }
     if (host_timing) {
         ctx->host_t[2] += std::chrono::duration<double>(t_w1 - t_w0).count();
@@ -2176,6 +2190,7 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
     else if (!strcmp(key, "scan_parts")) ctx->arena.tune_scan_parts = value;
     else if (!strcmp(key, "scan_poll_cap")) ctx->arena.tune_scan_poll_cap = value;
+    else if (!strcmp(key, "results_direct")) ctx->results_direct = value; // (A/B: 0 = results into HBM and a copy behind k_label, as before round 5)
     else if (!strcmp(key, "halves_min_clouds")) ctx->halves_min_clouds = std::max(2, value); // (tests: GG_FLAG_CONCURRENT_HALVES on small batches)
     else if (!strcmp(key, "halves_no_fork")) ctx->probe_no_fork = value != 0; // (measurement only: the side stream does not wait for the caller's)
     else if (!strcmp(key, "scan_fault")) ctx->arena.tune_scan_fault = value;
