@@ -5,6 +5,7 @@
 
 #include <sched.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -106,15 +107,17 @@ class HostHelper {
         std::condition_variable cv, done_cv;
         std::function<void(int)> job;
         std::atomic<int> pending{0};
-        unsigned long epoch = 0;
-        bool quit = false;
+        std::atomic<unsigned long> epoch{0};
+        std::atomic<bool> quit{false};
         pid_t owner = 0;
+        int idle_spins = 4000; // ~60 us (GG_HOST_HELPER_SPINS: 0 = sleep at once; measured 0 / 1500 / 4000: fused call 0.598 / 0.589 / 0.576 ms)
     };
     void ensure_threads()
     {
         if (st_ && st_->owner == getpid()) return;
         st_ = new State(); // (first use, or a forked child: the parent's State is abandoned)
         st_->owner = getpid();
+        if (const char *e = getenv("GG_HOST_HELPER_SPINS")) st_->idle_spins = std::max(0, atoi(e));
         const int n = std::min(wanted_, usable_cpus() - 1);
         State *st = st_;
         for (int k = 0; k < n; ++k) st->threads.emplace_back([st, k] { loop(*st, k); }); // (epoch 0 is what they have seen so far)
@@ -122,16 +125,29 @@ class HostHelper {
     static void loop(State &st, int k)
     {
         unsigned long seen = 0;
-        std::unique_lock<std::mutex> lk(st.m);
         for (;;) {
-            st.cv.wait(lk, [&] { return st.epoch != seen; });
-            seen = st.epoch;
-            if (st.quit) return;
-            lk.unlock();
+            // a split often follows another within microseconds (the two pieces of a cloud being packed, the copy-out behind a short
+            // call): look for it with a short spin (~60 us) before sleeping on the condition variable -- a futex wake-up of seven
+            // threads is 10-20 us of the caller's critical path
+            bool found = false;
+            for (int spins = 0; spins < st.idle_spins && !found; ++spins) {
+                found = st.epoch.load(std::memory_order_acquire) != seen;
+#if defined(__x86_64__)
+                if (!found) __builtin_ia32_pause();
+#endif
+            }
+            if (!found) {
+                std::unique_lock<std::mutex> lk(st.m);
+                st.cv.wait(lk, [&] { return st.epoch.load(std::memory_order_acquire) != seen; });
+            }
+            seen = st.epoch.load(std::memory_order_acquire); // (the job was stored before the epoch moved; the next epoch cannot come before this job is done)
+            if (st.quit.load(std::memory_order_acquire)) return;
             st.job(k); // (the job stays valid until `pending` reaches 0: split() does not return before)
             const bool last = st.pending.fetch_sub(1, std::memory_order_acq_rel) == 1;
-            lk.lock();
-            if (last) st.done_cv.notify_all();
+            if (last) {
+                std::lock_guard<std::mutex> g(st.m); // (under the lock, after the decrement: no wake-up of a sleeping caller is lost)
+                st.done_cv.notify_all();
+            }
         }
     }
     State *st_ = nullptr;

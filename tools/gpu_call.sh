@@ -2,5 +2,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 200 python tools/direct_probe.py 2>&1 | tail -1 | tee gpurun_out/direct_probe.json
-timeout 900 python -m pytest tests -m gpu -x -q -k "not full_size" > gpurun_out/tests_direct.log 2>&1; grep -E "passed|failed|error" gpurun_out/tests_direct.log | tail -3
+for sp in 1500 0 4000 1500 0 4000; do
+GG_HOST_HELPER_SPINS=$sp timeout 200 python tools/direct_probe.py 2>&1 | tail -1 | tee -a gpurun_out/helper_spin.log
+done
+nproc
