@@ -86,6 +86,9 @@ struct gg_context {
     // gg_filter_cloud / _async / _layers: k_label writes counts, index and labels straight into the pinned host block (posted writes over
     // the link while the kernel runs) instead of into HBM with a copy behind the kernel: one transfer and one stream hop less per call
     int results_direct = 1;
+    int upload_pieces = 1; // the input cloud is packed and uploaded in this many pieces (the copy of one travels while the next is packed:
+                           // measured 1 / 2 / 3 / 4 pieces: 0.472 / 0.478 / 0.488 / 0.494 ms per synchronous call -- a piece's split and copy
+                           // call cost more than its overlap gives)
     bool probe_no_fork = false;
     hipEvent_t ring_done2[4]{};
     bool ring_used2[4]{};
@@ -1762,10 +1765,11 @@ static int enqueue_ticket(gg_context *ctx, int slot, const gg_point32 *cloud, si
 
     static const bool host_timing = getenv("GG_HOST_TIMING") != nullptr; // (tools: where does the host call spend its time)
     const auto t_pack0 = std::chrono::steady_clock::now();
-    // pack and upload in two pieces (each packed by all of the context's host threads): the copy of the first travels while the
+    // pack and upload in pieces (each packed by all of the context's host threads): the copy of the first travels while the
     // second is packed (and all of it overlaps the device work of the previous ticket)
-    for (int c = 0; c < 2; ++c) {
-        const size_t lo = n * c / 2, hi = n * (c + 1) / 2;
+    const int pieces = std::max(1, std::min(ctx->upload_pieces, 8));
+    for (int c = 0; c < pieces; ++c) {
+        const size_t lo = n * c / pieces, hi = n * (c + 1) / pieces;
         if (hi == lo) continue;
         ctx->helper.split(hi - lo, [&](size_t a0, size_t a1) { pack_points(cloud + lo + a0, as.h_pts + lo + a0, a1 - a0); });
         HIPCHK(ctx, hipMemcpyAsync(as.d_pts + lo, as.h_pts + lo, (hi - lo) * sizeof(gg_point16), hipMemcpyHostToDevice, pipelined ? ctx->h2d_stream : ctx->stream));
@@ -2190,6 +2194,7 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
     else if (!strcmp(key, "scan_parts")) ctx->arena.tune_scan_parts = value;
     else if (!strcmp(key, "scan_poll_cap")) ctx->arena.tune_scan_poll_cap = value;
+    else if (!strcmp(key, "upload_pieces")) ctx->upload_pieces = value;
     else if (!strcmp(key, "results_direct")) ctx->results_direct = value; // (A/B: 0 = results into HBM and a copy behind k_label, as before round 5)
     else if (!strcmp(key, "halves_min_clouds")) ctx->halves_min_clouds = std::max(2, value); // (tests: GG_FLAG_CONCURRENT_HALVES on small batches)
     else if (!strcmp(key, "halves_no_fork")) ctx->probe_no_fork = value != 0; // (measurement only: the side stream does not wait for the caller's)

@@ -20,5 +20,10 @@ for rep in range(2):
         seg.debug_set_tuning("results_direct", direct)
         res[f"sync_ms_direct{direct}_{rep}"] = h.best(lambda c: seg.filter_cloud(c, org, -1.73, reuse_buffers=True), seq)
         res[f"fused_all_layers_ms_direct{direct}_{rep}"] = h.best(lambda c: seg.filter_cloud_with_layers(c, org, -1.73, plain, reuse_buffers=True), seq[:32])
+seg.debug_set_tuning("results_direct", 1)
+for rep in range(2):
+    for pieces in (2, 1, 3, 4):
+        seg.debug_set_tuning("upload_pieces", pieces)
+        res[f"sync_ms_pieces{pieces}_{rep}"] = h.best(lambda c: seg.filter_cloud(c, org, -1.73, reuse_buffers=True), seq)
 seg.close()
 print(json.dumps(res))
