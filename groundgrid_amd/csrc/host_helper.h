@@ -22,12 +22,12 @@
 // Helper threads of a context for the host-buffer entry points: packing the input cloud and assembling the returned cloud are two
 // memory-bound loops of ~0.07 and ~0.12 ms per HDL-64E cloud on one core, a third of what a synchronous gg_filter_cloud costs
 // beyond its kernels.  A range is cut into equal parts, the caller's thread takes the first, the helpers the others.
-// GG_HOST_THREADS = threads per context including the caller's (default: 4, but never more than the CPUs this process may run
+// GG_HOST_THREADS = threads per context including the caller's (default: 8, but never more than the CPUs this process may run
 // on -- sched_getaffinity, so a cgroup / taskset limit counts; 1 = everything on the caller's thread).  The helpers are created
 // on the first split that is large enough to want them, not at gg_create (a context that only ever runs batches has none), and
 // a child process after fork() -- which inherits the object but not the threads -- starts its own.  The caller waits for the
 // parts with a short spin, then yields, then sleeps on the condition variable: a descheduled helper costs the caller a
-// context switch, not its time slice.
+// context switch, not its time slice.  An idle helper does the same from its side (loop()).
 class HostHelper {
   public:
     HostHelper() = default;
