@@ -17,6 +17,13 @@
 // branch-free; results are written fire-and-forget.  LDS: 24 KB for n = 364 (progress counters, corner values, joins, the
 // chains of the group-boundary rings), so several clouds share a CU and one cloud's waits are another's compute.
 //
+// Instruction count IS the time of a chain wavefront (a lone wavefront issues one instruction of any kind per ~5 cycles), so the step
+// loop is written around it (run_chain): whether a half step may run is one scalar compare against the last step the counters read
+// last are good for (ChainSync::cover inverts the closed-form needs where a counter is re-read); the trips of a group are compiled per
+// phase (TripKind: lanes still starting / lane 0 still reading the previous group's chain / joins only), the two long phases without
+// range tests; everything rare sits out of line (__builtin_expect), its polls as rolled loops; the wait for the join -- the sweep's
+// critical path, ring after ring -- reads one counter and goes on (wait_b).  DESIGN.md 4 "The chain wavefront's step" has the numbers.
+//
 // The same per-lane code runs on the host under a lock-step emulation (sweep_emul.hip, tests/test_sweep_emul_cpu.py).
 #include "gg_device.h"
 #include "sweep_core.h"
@@ -239,11 +246,12 @@ template <bool DBG> struct WaveClockT {
 #endif
 constexpr int SLEEP_LONG = GG_SWEEP_SLEEP_LONG;
 
+// A/B switches of run_chain (the defaults are what was measured best, profiles/r05e/sweep_ab_*.log)
 #ifndef GG_SWEEP_REC_AHEAD
-#define GG_SWEEP_REC_AHEAD 1
+#define GG_SWEEP_REC_AHEAD 1 // split steps: the chain wavefront reads its preparing wavefront's record a step early
 #endif
 #ifndef GG_SWEEP_BATCH_KINDS
-#define GG_SWEEP_BATCH_KINDS 2
+#define GG_SWEEP_BATCH_KINDS 2 // trip variants of the throughput launches: 1 = one loop, 2 = the first-step block peeled off, 3 = the phases of the latency launches (2.5x slower: instruction cache)
 #endif
 template <bool S, int B, int J> struct TripKind {
     static constexpr bool starts = S;
