@@ -40,7 +40,7 @@ SYMBOLS = [
     "gg_reset_map", "gg_reset_maps", "gg_set_map_position", "gg_move_map", "gg_get_map_position", "gg_set_layer", "gg_get_layer", "gg_get_layers", "gg_get_expected_points",
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
-    "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep",
+    "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep", "gg_debug_sweep_sync_selftest",
     "gg_batch_fence", "gg_device_error", "gg_filter_cloud_layers", "gg_host_register", "gg_host_unregister", "gg_run_stage", "gg_filter_cloud_pc2_out", "gg_get_gridmap_message",
     "gg_collective_available", "gg_comm_unique_id", "gg_comm_init_rank", "gg_comm_init_rank_for", "gg_comm_destroy", "gg_allgather_label_masks",
 ]

@@ -402,6 +402,43 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
 } // namespace sweep
 } // namespace gg
 
+namespace {
+// ChainSync's one-compare wait test against the closed forms it inverts (sweep_core.h cover()): every side and ring group of an n x n
+// map, every value each of the three counters can have (the other two complete), every wave-step of the group and a trip beyond
+template <int SIDE> long sync_mismatches(const Params &P)
+{
+    long bad = 0;
+    const LdsMap L = lds_layout(P.c, P.groups);
+    for (int group = 0; group < std::max(P.groups, 1); ++group) {
+        const int r0 = LANES * group + 1, nl = std::min(P.rings - (r0 - 1), (int)LANES);
+        if (nl <= 0) break;
+        const int t_last = group_last_step<SIDE>(r0, nl) + TRIP, top = r0 + nl + 2, bnd_top = chain_len<SIDE>(r0) + 2;
+        for (int which = 0; which < 3; ++which)
+            for (int have = 0; have <= (which == 2 ? bnd_top : top); ++have) {
+                ChainSync<SIDE> sy;
+                sy.init(r0, nl, group, P, L);
+                sy.have_corner = which == 0 ? have : top;
+                sy.have_join = which == 1 ? have : top;
+                sy.have_bnd = which == 2 ? have : bnd_top;
+                sy.cover();
+                for (int t = group_first_step(); t <= t_last; ++t) {
+                    sy.advance(t);
+                    bad += sy.ok_a() != sy.slow_ok_a();
+                    bad += sy.ok_b() != sy.slow_ok_b();
+                }
+            }
+    }
+    return bad;
+}
+} // namespace
+
+extern "C" long gg_debug_sweep_sync_selftest(int n)
+{
+    if (n < 8) return -1;
+    const Params P = gg::sweep::make_params(n, 0.33, 12.0f, 10.0);
+    return sync_mismatches<SIDE_A>(P) + sync_mismatches<SIDE_B>(P) + sync_mismatches<SIDE_C>(P) + sync_mismatches<SIDE_D>(P);
+}
+
 extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z, double decrease,
                                            unsigned seed, int late_loads, long *stats)
 {

@@ -460,6 +460,10 @@ int gg_abi_version(void);
  * Returns 0, or -10 if the wavefronts deadlock. */
 int gg_debug_emulate_ring_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z,
                                 double occupied_cells_decrease_factor, unsigned seed, int late_loads, long *stats);
+/* Testing hook, host only: the sweep's wait test -- one compare per half step against the last step the progress counters read last
+ * cover (csrc/sweep_core.h ChainSync::cover) -- held to the closed-form needs it inverts, for every side, ring group, counter value and
+ * wave-step of an n x n map.  Returns the number of disagreements (0), -1 for n < 8. */
+long gg_debug_sweep_sync_selftest(int n);
 
 #ifdef __cplusplus
 }

@@ -139,3 +139,12 @@ def test_split_steps_with_a_preparing_wavefront_per_side(lib, monkeypatch, lengt
             g, w, stats = emulate(lib, n, ref.resolution, ground, conf, -1.73, 5.0, seed, late)
             assert np.array_equal(g, ref.layer("ground")), (seed, late, np.argwhere(g != ref.layer("ground"))[:5].tolist())
             assert np.array_equal(w, ref.layer("groundpatch")), (seed, late)
+
+
+@pytest.mark.parametrize("n", [12, 30, 100, 130, 131, 258, 364, 727, 1000])
+def test_one_compare_wait_test_is_the_inverse_of_the_closed_form_needs(lib, n):
+    """k_sweep asks "may this half step run" with one scalar compare against the last step the cached counters cover; the closed forms
+    (which ring's corner, which join, how much of the previous group's chain a step needs) run only where a counter is re-read."""
+    lib.gg_debug_sweep_sync_selftest.restype = C.c_long
+    lib.gg_debug_sweep_sync_selftest.argtypes = [C.c_int]
+    assert lib.gg_debug_sweep_sync_selftest(n) == 0
