@@ -315,6 +315,39 @@ def test_one_cloud_per_call_replays_a_captured_graph_100_times():
     seg.close()
 
 
+def test_results_straight_into_host_memory_or_copied_and_input_in_pieces():
+    """The host calls let k_label write counts, index and labels into the pinned result block (results_direct, the default) or into HBM
+    with a copy behind the kernel; the input travels in one piece (the default) or several.  Every combination, synchronous calls and
+    the two-deep pipeline, ragged sizes and an empty cloud: the same bytes as the oracle."""
+    clouds = [synth.hdl64_cloud(seed=90 + k, n_az=140 + 61 * k) for k in range(4)] + [synth.empty_cloud(0), synth.hdl64_cloud(seed=95, n_az=33)[:5]]
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=max(len(c) for c in clouds) + 64)
+    ref = oracle.OracleMap(120.0, 0.33)
+    it = 0
+    for direct in (1, 0, 1):
+        for pieces in (1, 3, 8):
+            seg.debug_set_tuning("results_direct", direct)
+            seg.debug_set_tuning("upload_pieces", pieces)
+            for _ in range(3):
+                c = clouds[it % len(clouds)]
+                it += 1
+                out, labels, index = seg.filter_cloud(c, (0.1, 0.2, 0.0), -1.73, return_details=True)
+                r = ref.filter_cloud(c, (0.1, 0.2, 0.0), -1.73)
+                assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), (direct, pieces, it)
+                assert out.tobytes() == r["out_points"].tobytes(), (direct, pieces, it)
+            # two deep: the second ticket is issued before the first is waited for
+            a, b = clouds[it % len(clouds)], clouds[(it + 1) % len(clouds)]
+            it += 2
+            ta = seg.filter_cloud_async(a, (0.1, 0.2, 0.0), -1.73)
+            tb = seg.filter_cloud_async(b, (0.1, 0.2, 0.0), -1.73)
+            for t, c in ((ta, a), (tb, b)):
+                out = seg.filter_cloud_wait(t)
+                r = ref.filter_cloud(c, (0.1, 0.2, 0.0), -1.73)
+                assert out.tobytes() == r["out_points"].tobytes(), (direct, pieces, "async")
+    for name in oracle.LAYERS:
+        assert nan_equal(seg.map(0)[name], ref.layer(name)), name
+    seg.close()
+
+
 @pytest.mark.parametrize("registered", [False, True])
 def test_filter_cloud_with_layers_fused_call(registered):
     """gg_filter_cloud_layers: the returned cloud and all eleven layers of one call; the early layers travel while the sweep runs.

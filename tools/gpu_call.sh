@@ -2,6 +2,4 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for w in 0 1 2 3 0 1 2 3; do
-  GG_SWEEP_WAVES=$w MODES=cold timeout 300 python tools/ab_kernels.py 1024 6 waves$w 2>&1 | tail -1 | tee -a gpurun_out/ab_waves.log
-done
+timeout 600 python -m pytest tests/test_gpu_stages_wire.py -m gpu -x -q -k "results_straight or fused or graph" > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error|assert" gpurun_out/t.log | tail -5
