@@ -250,6 +250,9 @@ constexpr int SLEEP_LONG = GG_SWEEP_SLEEP_LONG;
 #ifndef GG_SWEEP_REC_AHEAD
 #define GG_SWEEP_REC_AHEAD 1 // split steps: the chain wavefront reads its preparing wavefront's record a step early
 #endif
+#ifndef GG_SWEEP_BATCH_RANGES
+#define GG_SWEEP_BATCH_RANGES 3 // throughput launches: 1 = the ranges of a step's rare blocks tested in every step, 3 = once per trip
+#endif
 #ifndef GG_SWEEP_BATCH_KINDS
 #define GG_SWEEP_BATCH_KINDS 2 // trip variants of the throughput launches: 1 = one loop, 2 = the first-step block peeled off, 3 = the phases of the latency launches (2.5x slower: instruction cache)
 #endif
@@ -286,6 +289,10 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
         auto trip = [&](const int tb, auto kind) __attribute__((always_inline)) {
             using K = decltype(kind);
             constexpr bool STARTS = K::starts;
+            // (kinds 3: the wave-uniform ranges of a step's rare blocks tested once per trip, not in every step)
+            const bool trip_bnd = K::bnd == 3 && group > 0 && tb + (int)TRIP - 1 >= 0 && tb < st.u_len0;
+            const bool trip_join = K::join == 3 && tb + (int)TRIP - 1 >= st.u_join_first && tb <= st.u_join_last;
+            const bool trip_pub = K::join == 3 && has_next != 0 && tb + (int)TRIP - 1 >= st.u_l3_last && tb < st.u_lend_last;
             PrepRec rec_ahead{};
 #pragma unroll
             for (int u = 0; u < TRIP; ++u) {
@@ -368,11 +375,11 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
                     st.template take<STARTS, K::bnd>(t, tmod, rec, x_in, group > 0, mem);
                     mem.set_counter(w_take, step_no + 1 + AHEAD); // (after the reads above: the DS queue is in order)
                 } else {
-                    st.template step_a<STARTS, K::bnd>(t, u % (int)PF, tmod, x_in, P, L, group > 0, mem);
+                    st.template step_a<STARTS, K::bnd>(t, u % (int)PF, tmod, x_in, P, L, K::bnd == 3 ? trip_bnd : group > 0, mem);
                 }
                 if (__builtin_expect(!sync.ok_b(), 0)) wait_b(join_read);
-                st.template step_b<STARTS, K::join>(t, tmod, P, L, (SPLIT ? scalar_here(has_next) : has_next) != 0, group, mem,
-                                                    SKEW != 1 || (SPLIT ? scalar_here(turn) : turn) == (u % 3), join_read); // (scalar_here: worth it for a lone wavefront only)
+                st.template step_b<STARTS, K::join>(t, tmod, P, L, K::join == 3 ? trip_pub : (SPLIT ? scalar_here(has_next) : has_next) != 0, group, mem,
+                                                    SKEW != 1 || (SPLIT ? scalar_here(turn) : turn) == (u % 3), join_read, trip_join); // (scalar_here: worth it for a lone wavefront only)
             }
         };
         if (SPLIT || GG_SWEEP_BATCH_KINDS >= 3) {
@@ -392,10 +399,10 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
             // place of its loops -- a third copy of the trip made the launch 2.5 times slower)
             int tb = t_first;
 #if GG_SWEEP_BATCH_KINDS >= 2
-            for (; tb <= t_last && tb <= st.u_start_last; tb += TRIP) trip(tb, TripKind<true, 1, 1>{});
-            for (; tb <= t_last; tb += TRIP) trip(tb, TripKind<false, 1, 1>{});
+            for (; tb <= t_last && tb <= st.u_start_last; tb += TRIP) trip(tb, TripKind<true, GG_SWEEP_BATCH_RANGES, GG_SWEEP_BATCH_RANGES>{});
+            for (; tb <= t_last; tb += TRIP) trip(tb, TripKind<false, GG_SWEEP_BATCH_RANGES, GG_SWEEP_BATCH_RANGES>{});
 #else
-            for (; tb <= t_last; tb += TRIP) trip(tb, TripKind<true, 1, 1>{});
+            for (; tb <= t_last; tb += TRIP) trip(tb, TripKind<true, GG_SWEEP_BATCH_RANGES, GG_SWEEP_BATCH_RANGES>{});
 #endif
         }
     }

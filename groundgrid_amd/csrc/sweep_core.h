@@ -536,6 +536,8 @@ template <int SIDE> struct ChainLane {
     //   STARTS = false   t > u_start_last: no lane takes its corner values any more
     //   BND    0 / 2     no step / every step reads the previous group's boundary chain (2: has_prev_group and 0 <= t < u_len0)
     //   JOIN   0 / 2     no step / every step can be a lane's join step (2: t >= u_join_first; past u_join_last the read is unused)
+    //   BND, JOIN = 3    the caller tested the ranges once for the trip: has_prev_group / trip_join / has_next_group ARE the answers (a
+    //                    step outside a range that its trip touches reads a value no lane selects, and publishes from no active lane)
     // (1 = test per step).  A range test is seven scalar instructions and a taken branch, the blocks meet the step at control-flow
     // joins that cost register copies, and a lone wavefront pays ~5 cycles for an instruction of any kind.
     template <bool STARTS = true, int BND = 1, class Mem>
@@ -549,7 +551,7 @@ template <int SIDE> struct ChainLane {
         // ---- LDS: what this lane could need (garbage until published; selected only when it is) -- but only in the
         //      (wave-uniform) ranges of steps in which some lane can be at that event
         WP c_bnd{0.f, 0.f};
-        if (BND == 2 || (BND == 1 && has_prev_group && t >= 0 && t < u_len0)) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
+        if (BND == 2 || (BND == 3 && has_prev_group) || (BND == 1 && has_prev_group && t >= 0 && t < u_len0)) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
         if (STARTS && tmod == 0 && t >= 0 && t <= u_start_last) { // a lane's first step (t = SKEW l): the corner values
             cs0 = mem.get(a_s0);
             cs1 = mem.get(a_s1);
@@ -598,7 +600,7 @@ template <int SIDE> struct ChainLane {
     {
         w_new_ = rec.w_new;
         WP c_bnd{0.f, 0.f};
-        if (BND == 2 || (BND == 1 && has_prev_group && t >= 0 && t < u_len0)) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
+        if (BND == 2 || (BND == 3 && has_prev_group) || (BND == 1 && has_prev_group && t >= 0 && t < u_len0)) c_bnd = mem.get(a_bnd + (l == 0 ? 2 * t : 0));
         if (STARTS && tmod == 0 && t >= 0 && t <= u_start_last) {
             cs0 = mem.get(a_s0);
             cs1 = mem.get(a_s1);
@@ -622,11 +624,12 @@ template <int SIDE> struct ChainLane {
     // join_turn: (wave-uniform) some lane of the group can end its chain at this step -- lane l ends at t + 1 = 3 l + lend of
     // lane 0 (SKEW = 1), i.e. in every third step only; see join_turn_of
     template <bool STARTS = true, int JOIN = 1, class Mem>
-    SW_HD void step_b(int t, int tmod, const Params &P, const LdsMap &L, bool has_next_group, int group, Mem &mem, bool join_turn = true, WP join_read = WP{0.f, 0.f})
+    SW_HD void step_b(int t, int tmod, const Params &P, const LdsMap &L, bool has_next_group, int group, Mem &mem, bool join_turn = true, WP join_read = WP{0.f, 0.f},
+                      bool trip_join = true)
     {
         // (JOIN = 2: the caller has read this lane's join slot -- early, so that the LDS round trip is over when the step gets here)
         WP x = xa;
-        if (JOIN == 2 || (JOIN == 1 && t >= u_join_first && t <= u_join_last)) {
+        if (JOIN == 2 || (JOIN == 3 && trip_join) || (JOIN == 1 && t >= u_join_first && t <= u_join_last)) {
             const WP c_join = JOIN == 2 ? join_read : mem.get(a_join);
             x = t + 2 == lend ? c_join : x; // s + 2 == len
         }
@@ -664,7 +667,7 @@ template <int SIDE> struct ChainLane {
         if (join_turn) mem.publish_if(t + 1 == lend && len > 0, l, L, a_pub, res, L.join_done + SIDE, r);
         // (uniform: only while the last lane runs.  Without STARTS t > u_start_last = u_l3_last when there is a next group, and past
         // u_lend_last no lane is active)
-        if (has_next_group && (!STARTS || (t >= u_l3_last && t < u_lend_last)))
+        if (has_next_group && (!STARTS || JOIN == 3 || (t >= u_l3_last && t < u_lend_last)))
             mem.publish(active ? pb_word + pb_step * t : pb_idle, res, active ? pb_cnt : pb_idle + 2, t - l3 + 1);
     }
 };
