@@ -2,9 +2,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/t.log 2>&1; grep -E "passed|failed" gpurun_out/t.log | tail -2
-for lib in rng1 new rng1 new; do
-  L=$GRAFT_REPO_ROOT/groundgrid_amd/variants/lib_$lib.so
-  [ $lib = new ] && L=$GRAFT_REPO_ROOT/groundgrid_amd/libgroundgrid_hip.so
-  GROUNDGRID_HIP_LIB=$L MODES=cold,warm timeout 300 python tools/ab_kernels.py 1024 8 $lib 2>&1 | tail -1 | tee -a gpurun_out/ab_ranges.log
-done
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/final_tests_full.log 2>&1; grep -E "passed|failed|error" gpurun_out/final_tests_full.log | tail -2 | tee gpurun_out/final_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; head -c 600 gpurun_out/final_bench.json
+( timeout 200 python tools/fuzz_more.py 1500 2500; timeout 200 python tools/fuzz_knobs.py 900 1500; timeout 200 python tools/fuzz_walk.py 400 520 ) 2>&1 | grep -E "done|FAILED" | tee gpurun_out/final_fuzz.log
