@@ -1037,7 +1037,10 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         CREATE_CHK(hipHostMalloc((void **)&as.h_counts, 64 + max_points * 5 + 64, hipHostMallocDefault)); // (the same block on the host)
         as.h_index = as.h_counts + 16;
         as.h_labels = nullptr;
-        CREATE_CHK(hipHostGetDevicePointer((void **)&as.hd_counts, as.h_counts, 0));
+        if (hipHostGetDevicePointer((void **)&as.hd_counts, as.h_counts, 0) != hipSuccess) { // (no device view of pinned memory: the results take the copy)
+            as.hd_counts = nullptr;
+            (void)hipGetLastError();
+        }
         CREATE_CHK(hipEventCreateWithFlags(&as.uploaded, hipEventDisableTiming));
         CREATE_CHK(hipEventCreateWithFlags(&as.computed, hipEventDisableTiming));
         CREATE_CHK(hipEventCreateWithFlags(&as.downloaded, hipEventDisableTiming));
