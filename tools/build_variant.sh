@@ -8,7 +8,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/gg_var_$name
 mkdir -p "$obj" "$root/groundgrid_amd/variants"
 cd "$root/groundgrid_amd/csrc"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -I../../include -I. -Wno-unused-result -Wno-unused-value $extra"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -I../../include -I. -Wno-unused-result -Wno-unused-value $extra"
 pids=()
 for f in gg_context sweep_emul k0_scroll k1_classify k_sort k2_reduce k3_patch k4_sweep k5_label k6_wire k7_stage; do
   /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o "$obj/$f.o" 2> "$obj/$f.log" & pids+=($!)
