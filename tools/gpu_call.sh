@@ -2,5 +2,6 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/final_tests_full.log 2>&1; grep -E "passed|failed|error" gpurun_out/final_tests_full.log | tail -2 | tee gpurun_out/final_tests.log
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee gpurun_out/final_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; head -c 2400 gpurun_out/final_bench.json
