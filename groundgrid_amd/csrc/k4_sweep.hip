@@ -256,6 +256,7 @@ constexpr int SLEEP_LONG = GG_SWEEP_SLEEP_LONG;
 #ifndef GG_SWEEP_BATCH_KINDS
 #define GG_SWEEP_BATCH_KINDS 2 // trip variants of the throughput launches: 1 = one loop, 2 = the first-step block peeled off, 3 = the phases of the latency launches (2.5x slower: instruction cache)
 #endif
+// what the six steps of a trip are compiled for (sweep_core.h ChainLane::step_a: STARTS, BND, JOIN)
 template <bool S, int B, int J> struct TripKind {
     static constexpr bool starts = S;
     static constexpr int bnd = B, join = J;
@@ -276,7 +277,7 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
         st.init(lane, r0, nl, group, P, L);
         const int t_first = group_first_step(), t_last = group_last_step<SIDE>(r0, nl);
         const int has_next = __builtin_amdgcn_readfirstlane(group + 1 < P.groups ? 1 : 0);
-        // PF steps per trip, no per-step condition: a step past t_last finds every lane idle (no loads, no stores, nothing
+        // TRIP steps per trip, no per-step condition: a step past t_last finds every lane idle (no loads, no stores, nothing
         // to wait for), and without a conditional around it the queue registers of a slot never meet a control-flow join --
         // a join makes the compiler copy freshly loaded registers, i.e. wait for the loads it has just issued
         ChainSync<SIDE> sync;
