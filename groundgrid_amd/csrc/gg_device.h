@@ -11,6 +11,16 @@
 
 namespace gg {
 
+// The kernels' measurement switches (env GG_K2_DEBUG / GG_K3_DEBUG / GG_K5_DEBUG -> Arena::k2_debug ...: early returns, skipped gathers or
+// stores, cycle counters; results void) exist only in libraries built with -DGG_INSTRUMENT (tools/build_variant.sh inst "-DGG_INSTRUMENT"):
+// the production kernels are compiled as if they were 0.
+#ifdef GG_INSTRUMENT
+#define GG_DEBUG_SWITCH(a, field) ((a).field)
+#else
+#define GG_DEBUG_SWITCH(a, field) 0
+#endif
+
+
 #define GG_DEV __device__ __forceinline__
 
 // libstdc++ std::min / std::max (NaN: return the first argument when the comparison is false)

@@ -160,7 +160,7 @@ struct Arena {
     int tune_k2_dense_share; // sixteenths of them that walk the dense list
     int k2_skip;             // measurement (GG_K2_SKIP): 1 = k_reduce leaves the light tiles out, 2 = the dense tiles
     unsigned flags;
-    int k2_debug;        // env GG_K2_DEBUG (measurement only, libraries built with -DGG_K2_INSTRUMENT: k2_reduce.hip k2_debug_of): 1 = k_reduce stops after the tile lookup, 2 = after step 1, 3 = after step 3,
+    int k2_debug;        // env GG_K2_DEBUG (measurement only, libraries built with -DGG_INSTRUMENT: gg_device.h GG_DEBUG_SWITCH): 1 = k_reduce stops after the tile lookup, 2 = after step 1, 3 = after step 3,
                          // 9 = per-phase cycle counters into k2_dbg (tools/k2_phases.py)
     unsigned long long *k2_dbg; // [64] when k2_debug == 9
     int k5_debug;        // env GG_K5_DEBUG (measurement only, results void), bits: 1 = no gathers (every lane reads element 0), 2 = no label / index stores,

@@ -64,13 +64,8 @@ constexpr RecipTable make_recip_table()
 __constant__ const RecipTable recip_table = make_recip_table();
 
 // The measurement switches of this file (env GG_K2_DEBUG, gg_internal.h k2_debug: early returns, per-phase cycle counters, work-group traces)
-// are compiled in only with -DGG_K2_INSTRUMENT (tools/build_variant.sh; tools/k2_phases.py, k2_trace.py need such a library): in the
+// are compiled in only with -DGG_INSTRUMENT (gg_device.h GG_DEBUG_SWITCH; tools/k2_phases.py, k2_trace.py need such a library): in the
 // production kernel they were a dozen scalar tests per tile, values kept alive across the whole kernel and its only scratch slot.
-#ifdef GG_K2_INSTRUMENT
-GG_DEV int k2_debug_of(const Arena &a) { return a.k2_debug; }
-#else
-GG_DEV constexpr int k2_debug_of(const Arena &) { return 0; }
-#endif
 // measurement only (GG_K2_DEBUG=9): counters of this work-group, k2_dbg[work-group][32]; few writers per slot
 GG_DEV void dbg_add(const Arena &a, int slot, unsigned long long v)
 {
@@ -381,7 +376,7 @@ GG_DEV void reduce_light_tiles(const Arena &a, const CloudParams &cp, const uint
     uint32_t *tile_live = a.tile_live + (size_t)cp.slot * a.tile_live_stride;
     const CellState reset = {0.0f, 0.0f, 0.0f, 0.0f, FLT_MIN, FLT_MAX};
     const float oz = cp.oz;
-    const bool timing = k2_debug_of(a) == 9;
+    const bool timing = GG_DEBUG_SWITCH(a, k2_debug) == 9;
     constexpr int RL = chains_of<MODE>();
 
     // the work list's entries say everything about a tile (gg_internal.h); the entry of the tile after this one is requested a
@@ -535,7 +530,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     // the tile's region of zcell starts on its own 64-byte line (a work-group reads back only lines it wrote itself)
     float *zc = a.zcell + (size_t)cp.slot * a.zcell_stride + (size_t)((start + 15u) & ~15u) + (size_t)rank * 32u;
     const uint32_t n = end - start;
-    const bool timing = k2_debug_of(a) == 9;
+    const bool timing = GG_DEBUG_SWITCH(a, k2_debug) == 9;
     unsigned long long tmark[6] = {0, 0, 0, 0, 0, 0};
     if (timing) tmark[0] = __builtin_readcyclecounter();
     const uint32_t Q = ((n + 255u) >> 8) << 6; // records per wave: a multiple of the window
@@ -569,7 +564,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     }
     __syncthreads();
     if (timing) tmark[1] = __builtin_readcyclecounter();
-    if (k2_debug_of(a) == 2) return;
+    if (GG_DEBUG_SWITCH(a, k2_debug) == 2) return;
     // ---- 2. thread = cell: totals, segment, the waves' shares, count class ----
     uint32_t kw[4], tot = 0u, rawc = 0u;
 #pragma unroll
@@ -648,7 +643,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
         }
     }
     __syncthreads(); // (the heights written above are read by other waves of this work-group below)
-    if (k2_debug_of(a) == 3) return;
+    if (GG_DEBUG_SWITCH(a, k2_debug) == 3) return;
     lds.cseg[tid] = seg; // (over the lane masks, which are all zero again)
     lds.ctot[tid] = tot;
     lds.craw[tid] = rawc;
@@ -664,7 +659,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
     if (!split) {
         const int cell = (int)lds.perm[tid];
         CellState st = reset;
-        run_cells<chains_of<MODE>(), 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st, k2_debug_of(a) == 4, k2_debug_of(a) == 7 ? zc : nullptr);
+        run_cells<chains_of<MODE>(), 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st, GG_DEBUG_SWITCH(a, k2_debug) == 4, GG_DEBUG_SWITCH(a, k2_debug) == 7 ? zc : nullptr);
         put_shared(cell);
         ex[1 * TILE_CELLS + cell] = st.mn;
         ex[2 * TILE_CELLS + cell] = st.m2;
@@ -678,18 +673,18 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
         const int cell = (int)lds.perm[lane];
         CellState st = reset;
         const float *zseg = zc + lds.cseg[cell];
-        const uint32_t np = k2_debug_of(a) == 8 ? 0u : lds.ctot[cell]; // (GG_K2_DEBUG=8, timing only: what the tile's 64 fullest cells cost)
+        const uint32_t np = GG_DEBUG_SWITCH(a, k2_debug) == 8 ? 0u : lds.ctot[cell]; // (GG_K2_DEBUG=8, timing only: what the tile's 64 fullest cells cost)
         if (wave == 0) {
-            run_cells<R_MEAN, 6>(zseg, np, oz, st, k2_debug_of(a) == 4, k2_debug_of(a) == 7 ? zc : nullptr);
+            run_cells<R_MEAN, 6>(zseg, np, oz, st, GG_DEBUG_SWITCH(a, k2_debug) == 4, GG_DEBUG_SWITCH(a, k2_debug) == 7 ? zc : nullptr);
             put_shared(cell);
             ex[2 * TILE_CELLS + cell] = st.m2;
             ex[4 * TILE_CELLS + cell] = st.mean;
         } else if (wave == 1) {
-            run_cells<R_GC, 6>(zseg, np, oz, st, k2_debug_of(a) == 4, k2_debug_of(a) == 7 ? zc : nullptr);
+            run_cells<R_GC, 6>(zseg, np, oz, st, GG_DEBUG_SWITCH(a, k2_debug) == 4, GG_DEBUG_SWITCH(a, k2_debug) == 7 ? zc : nullptr);
             ex[5 * TILE_CELLS + cell] = st.mx;
             ex[6 * TILE_CELLS + cell] = st.gc;
         } else {
-            run_cells<R_PDM | R_MN, 6>(zseg, np, oz, st, k2_debug_of(a) == 4, k2_debug_of(a) == 7 ? zc : nullptr);
+            run_cells<R_PDM | R_MN, 6>(zseg, np, oz, st, GG_DEBUG_SWITCH(a, k2_debug) == 4, GG_DEBUG_SWITCH(a, k2_debug) == 7 ? zc : nullptr);
             ex[1 * TILE_CELLS + cell] = st.mn;
             ex[7 * TILE_CELLS + cell] = st.pdm;
         }
@@ -697,7 +692,7 @@ GG_DEV void reduce_dense_tile(const Arena &a, const CloudParams &cp, const uint4
         for (int g = 1; g < 4; ++g) {
             const int cell = (int)lds.perm[g * 64 + lane];
             CellState st = reset;
-            run_cells<R_MEAN | R_GC | R_PDM | R_MN, 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st, k2_debug_of(a) == 4, k2_debug_of(a) == 7 ? zc : nullptr);
+            run_cells<R_MEAN | R_GC | R_PDM | R_MN, 3>(zc + lds.cseg[cell], lds.ctot[cell], oz, st, GG_DEBUG_SWITCH(a, k2_debug) == 4, GG_DEBUG_SWITCH(a, k2_debug) == 7 ? zc : nullptr);
             put_shared(cell);
             ex[1 * TILE_CELLS + cell] = st.mn;
             ex[2 * TILE_CELLS + cell] = st.m2;
@@ -785,10 +780,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const uint32_t item = xcd_contiguous_item(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
     const int cloud = (int)(item / gridDim.x);
     const int group = (int)(item % gridDim.x);
-    if (k2_debug_of(a) == 1) return;
-    const unsigned long long t_wg = (k2_debug_of(a) == 9 || k2_debug_of(a) == 5) ? __builtin_readcyclecounter() : k2_debug_of(a) == 6 ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (GG_DEBUG_SWITCH(a, k2_debug) == 1) return;
+    const unsigned long long t_wg = (GG_DEBUG_SWITCH(a, k2_debug) == 9 || GG_DEBUG_SWITCH(a, k2_debug) == 5) ? __builtin_readcyclecounter() : GG_DEBUG_SWITCH(a, k2_debug) == 6 ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long *census = nullptr; // (GG_K2_DEBUG=5, tools/k2_census.py: which CU runs how many work-groups at a time)
-    if (k2_debug_of(a) == 5 && threadIdx.x == 0) {
+    if (GG_DEBUG_SWITCH(a, k2_debug) == 5 && threadIdx.x == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_ID, XCC_ID
         census = a.k2_dbg + (size_t)(((xcc & 7u) << 7) | ((hw >> 8) & 0x7Fu)) * 8;
         atomicAdd(&census[0], 1ull);
@@ -797,7 +792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         atomicMin(&census[4], t_wg);
     }
     reduce_share<MODE>(a, params, lds, cloud, group, (int)gridDim.x, n_dense_groups);
-    if (k2_debug_of(a) == 6 && threadIdx.x == 0 && item < 65536u) { // (tools/k2_trace.py: one record per work-group)
+    if (GG_DEBUG_SWITCH(a, k2_debug) == 6 && threadIdx.x == 0 && item < 65536u) { // (tools/k2_trace.py: one record per work-group)
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         unsigned long long *rec = a.k2_dbg + (size_t)item * 4;
         rec[0] = t_wg;
@@ -811,7 +806,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         atomicAdd(&census[3], t_end - t_wg);
         atomicMax(&census[5], t_end);
     }
-    if (k2_debug_of(a) == 9 && threadIdx.x == 0) {
+    if (GG_DEBUG_SWITCH(a, k2_debug) == 9 && threadIdx.x == 0) {
         const int k = group < n_dense_groups ? 24 : 26;
         dbg_add(a, k, 1ull);
         dbg_add(a, k + 1, __builtin_readcyclecounter() - t_wg);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         }
     }
     __syncthreads();
-    if (a.k3_debug == 1) return;
+    if (GG_DEBUG_SWITCH(a, k3_debug) == 1) return;
     auto block_has_points = [&](int b) { // reads cover columns [PC b, PC b + LC)
         const int tc_lo = (PC * b) / TILE, tc_hi = min((PC * b + LC - 1) / TILE, tiles_c - 1);
         return (col_has_points[tc_lo] | col_has_points[tc_hi]) != 0u; // (LC <= TILE: at most two tile columns)
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         }
         const int S = near ? 3 : 5;
         // :364-365 (count and threshold are integer-valued floats: the comparison is the reference's binary64 one)
-        const bool pass = !(pointsblockSum < threshold) && a.k3_debug != 3;
+        const bool pass = !(pointsblockSum < threshold) && GG_DEBUG_SWITCH(a, k3_debug) != 3;
         produce.gidx = pass ? __float_as_int(cell_const.w) : 0; // the (ground, confidence) layer has its own element order (gp_layout.h)
         produce.old = gp2[produce.gidx];           // :360-361, used one block later
         produce.live = pass;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     PatchCarry c0, c1;
     c0.live = c1.live = false;
     while (b < n_blocks) {
-        if (a.k3_debug == 2) return;
+        if (GG_DEBUG_SWITCH(a, k3_debug) == 2) return;
         block_step(c0, c1);
         if (b >= n_blocks) break;
         block_step(c1, c0);

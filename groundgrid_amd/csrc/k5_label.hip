@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                 col = (int)(c0 >> 16) + (int)((key >> 4) & 15u);
             }
             cidx[j] = lab[j] ? (key >> KEY_TILE_SHIFT) * (uint32_t)PERCALL_BLOCK + (key & 255u) : 0u;
-            if (a.k5_debug & 1) cidx[j] = 0u, row = col = 0; // (measurement)
+            if (GG_DEBUG_SWITCH(a, k5_debug) & 1) cidx[j] = 0u, row = col = 0; // (measurement)
             gh[j] = gp2[gp_idx(a, row, col)].x; // :162
             var[j] = variance[cidx[j]]; // :165
             const float cx = cell0_x - ((float)row + 0.5f) * res_f, cy = cell0_y - ((float)col + 0.5f) * res_f;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                 const unsigned long long ngm = __ballot(ng);
                 const bool joins = ng && lane > 0 && ((ngm >> (lane - 1)) & 1ull) && c == c_prev; // continues the previous lane's run
                 const unsigned long long jm = __ballot(joins);
-                if (ng && !joins && !(a.k5_debug & 4)) {
+                if (ng && !joins && !(GG_DEBUG_SWITCH(a, k5_debug) & 4)) {
                     const unsigned long long after = lane == 63 ? 0ull : ~(jm >> (lane + 1)); // first 1 bit = first lane that does not join
                     const int run = 1 + (after ? __builtin_ctzll(after) : 63 - lane);
                     unsafeAtomicAdd(&points[c], (float)run);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_label(const Arena a, const CloudParams 
                                     ((uint32_t)__shfl_down((int)code, 3, 64) << 6);
                 if ((lane & 3) == 0 && p < (int)io.cloud_stride) masks[p >> 2] = (uint8_t)b4;
             }
-            if (valid[j] && !(a.k5_debug & 2)) {
+            if (valid[j] && !(GG_DEBUG_SWITCH(a, k5_debug) & 2)) {
                 if (labels) labels[p] = label;
                 if (out_index) out_index[p] = idx;
                 if (FMT == GG_POINT32 && out_cloud && idx >= 0) {

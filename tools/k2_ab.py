@@ -1,6 +1,6 @@
 """k_reduce per-launch time at a few batch sizes (HIP events inside the library), on the GPU box.  GG_K2_DEBUG=1/2/3 cuts the
 kernel short (results are then wrong: timing only).
-Needs a library built with the measurement switches: tools/build_variant.sh k2inst "-DGG_K2_INSTRUMENT", GROUNDGRID_HIP_LIB=groundgrid_amd/variants/lib_k2inst.so
+Needs a library built with the measurement switches: tools/build_variant.sh k2inst "-DGG_INSTRUMENT", GROUNDGRID_HIP_LIB=groundgrid_amd/variants/lib_k2inst.so
 (the production k_reduce is compiled without them since round 5)."""
 import os, sys
 import numpy as np, torch

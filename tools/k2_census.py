@@ -1,5 +1,5 @@
 """Which CUs ran k_reduce's work-groups, how many at a time and for how long (GG_K2_DEBUG=5), on the GPU box.
-Needs a library built with the measurement switches: tools/build_variant.sh k2inst "-DGG_K2_INSTRUMENT", GROUNDGRID_HIP_LIB=groundgrid_amd/variants/lib_k2inst.so
+Needs a library built with the measurement switches: tools/build_variant.sh k2inst "-DGG_INSTRUMENT", GROUNDGRID_HIP_LIB=groundgrid_amd/variants/lib_k2inst.so
 (the production k_reduce is compiled without them since round 5)."""
 import os, sys, ctypes as C
 os.environ["GG_K2_DEBUG"] = "5"

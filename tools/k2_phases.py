@@ -1,5 +1,5 @@
 """Where k_reduce's time goes (GG_K2_DEBUG=9: cycle counters summed over the tiles of one launch), on the GPU box.
-Needs a library built with the measurement switches: tools/build_variant.sh k2inst "-DGG_K2_INSTRUMENT", GROUNDGRID_HIP_LIB=groundgrid_amd/variants/lib_k2inst.so
+Needs a library built with the measurement switches: tools/build_variant.sh k2inst "-DGG_INSTRUMENT", GROUNDGRID_HIP_LIB=groundgrid_amd/variants/lib_k2inst.so
 (the production k_reduce is compiled without them since round 5)."""
 import os, sys, ctypes as C
 os.environ["GG_K2_DEBUG"] = "9"
