@@ -1,4 +1,5 @@
-"""k_patch per-launch time at a few batch sizes (HIP events inside the library), on the GPU box.  GG_K3_DEBUG=1/2/3 cuts the
+"""(GG_K3_DEBUG needs a library built with -DGG_INSTRUMENT: tools/build_variant.sh inst "-DGG_INSTRUMENT", GROUNDGRID_HIP_LIB=.../lib_inst.so)
+k_patch per-launch time at a few batch sizes (HIP events inside the library), on the GPU box.  GG_K3_DEBUG=1/2/3 cuts the
 kernel short (results are then wrong: timing only)."""
 import os, sys
 import numpy as np, torch
