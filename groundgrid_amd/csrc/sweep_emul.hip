@@ -560,3 +560,270 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
         }
     return rc;
 }
+
+// =====================================================================================================================
+// The pair sweep (sweep_pair.h) under the same kind of lock-step emulation: the preparation (records), then pair wavefronts
+// (lanes 0..31 side X, 32..63 side Y of 32 rings) and the two corner wavefronts of one or two work-groups, interleaved adversarially.
+// =====================================================================================================================
+#include "sweep_pair.h"
+
+namespace {
+namespace gp = gg::sweep::pair;
+
+struct PairHostMem { // one per emulated work-group
+    Cell *layer;
+    std::vector<int32_t> lds;
+    long stores = 0, lds_ops = 0;
+    bool fault = false; // a read of an entry nobody has published
+    float lds_f(int word)
+    {
+        ++lds_ops;
+        float v;
+        memcpy(&v, &lds[(size_t)word], 4);
+        return v;
+    }
+    void lds_put(int word, float v)
+    {
+        ++lds_ops;
+        memcpy(&lds[(size_t)word], &v, 4);
+    }
+    void lds_entry(int word, float v)
+    {
+        lds_put(word, v);
+        lds[(size_t)word + 1] = 1;
+    }
+    int lds_i(int word) { return lds[(size_t)word]; }
+    void lds_set(int word, int v) { lds[(size_t)word] = v; }
+    void store(bool valid, int cell, Cell v)
+    {
+        if (!valid) return;
+        ++stores;
+        layer[cell] = v;
+    }
+};
+
+struct Records {
+    std::vector<gp::VisitRec> visit;  // [total_steps][64]
+    std::vector<gp::CornerRec> corner; // [2][rings + 1]
+};
+
+template <int PAIR> struct PairWave : WaveBase {
+    const Params &P;
+    const gp::Plan &pl;
+    const gp::Lds &L;
+    PairHostMem &mem;
+    const Records &rec;
+    float centre_p;
+    int W, group, t, t_end;
+    gp::Group G;
+    gp::PairLane<PAIR> lane[64];
+    bool plan_mismatch = false;
+    PairWave(const Params &p, const gp::Plan &pl_, const gp::Lds &l, PairHostMem &m, const Records &r, float cp, int w, int W_)
+        : P(p), pl(pl_), L(l), mem(m), rec(r), centre_p(cp), W(W_), group(w - W_)
+    {
+        next_group();
+    }
+    void next_group()
+    {
+        group += W;
+        if (group >= pl.groups) return;
+        G = gp::group_of(PAIR, group, P.rings);
+        for (int k = 0; k < 64; ++k) {
+            lane[k].init(k, group, G, P, pl, L);
+            // the stride-64 store addressing against gp_index(), visit by visit
+            const gp::PairLane<PAIR> &c = lane[k];
+            const int side = c.is_x ? gp::side_x(PAIR) : gp::side_y(PAIR);
+            for (int s = 0; s < c.len; ++s) {
+                int x, y;
+                gp::side_xy(side, P.c, c.r, 0, gp::k0_of(side) + s, x, y);
+                if (c.st_base + 64 * (c.start + s) != gp_index(P.gl, x, y)) plan_mismatch = true;
+            }
+        }
+        t = G.t_first;
+        t_end = G.t_first + G.steps; // whole trips, like the device
+    }
+    bool done() const override { return group >= pl.groups; }
+    bool bad() const override { return plan_mismatch || mem.fault; }
+    bool try_step() override
+    {
+        if (done()) return false;
+        // what the step reads from other wavefronts must be there
+        for (int k = 0; k < 64; ++k) {
+            const gp::PairLane<PAIR> &c = lane[k];
+            if (c.first_at(t) && mem.lds_i(L.cnt_corner + c.cd) < c.r) return false;
+            if (c.imports_at(t, group) && mem.lds_i(c.import_entry(t) + 1) == 0) return false;
+            if (c.join_from_lds_at(t, group) && mem.lds_i(c.a_jl + 1) == 0) return false;
+        }
+        for (int k = 0; k < 64; ++k) lane[k].pre(t, mem);
+        float x_prev[64], j_perm[64];
+        for (int k = 0; k < 64; ++k) {
+            x_prev[k] = k ? lane[k - 1].h2 : 0.f;                                  // wave shift right by one (lane 32 gets side X's last lane: never used)
+            j_perm[k] = k < 32 ? (k ? lane[32 + k - 1].OP : 0.f) : lane[k - 32].OP; // X l <- Y l - 1, Y l <- X l
+        }
+        const size_t base = ((size_t)pl.base[PAIR][group] + (size_t)(t - G.t_first)) * 64;
+        for (int k = 0; k < 64; ++k) lane[k].step(t, group, rec.visit[base + k], x_prev[k], j_perm[k], centre_p, mem);
+        if (++t >= t_end) next_group();
+        return true;
+    }
+};
+
+template <int CD> struct PairCornerWave : WaveBase {
+    const Params &P;
+    const gp::Plan &pl;
+    const gp::Lds &L;
+    PairHostMem &mem;
+    const Records &rec;
+    float centre_p;
+    int r = 1;
+    gp::CornerLane<CD> lane[64];
+    float in_corner, in_x1 = 0.f;
+    PairCornerWave(const Params &p, const gp::Plan &pl_, const gp::Lds &l, PairHostMem &m, const Records &rc, float cp) : P(p), pl(pl_), L(l), mem(m), rec(rc), centre_p(cp), in_corner(cp) {}
+    bool done() const override { return r > P.rings; }
+    bool try_step() override
+    {
+        if (done()) return false;
+        if (CD && r == 1) {
+            if (mem.lds_i(L.b1 + 1) == 0) return false; // B_1(1) from the AB corner wavefront
+            in_x1 = mem.lds_f(L.b1);
+        }
+        const int k = (r - 1) % 64;
+        if (k == 0)
+            for (int j = 0; j < 64; ++j) {
+                const int ring = r + j;
+                lane[j].init(ring, P, rec.corner[(size_t)CD * (P.rings + 1) + (ring <= P.rings ? ring : P.rings)]);
+            }
+        float x1, y0;
+        lane[k].recur(true, in_corner, in_x1, P, L, mem, x1, y0);
+        if (!CD && r == 1) { // the one chain visit the other corner needs
+            const size_t idx = ((size_t)pl.base[gp::PAIR_BC][0] + (size_t)(0 - gp::group_of(gp::PAIR_BC, 0, P.rings).t_first)) * 64;
+            mem.lds_entry(L.b1, gp::b1_of_ring1(rec.visit[idx], x1, y0, centre_p));
+        }
+        in_corner = y0;
+        in_x1 = x1;
+        ++r;
+        return true;
+    }
+};
+
+} // namespace
+
+extern "C" int gg_debug_emulate_pair_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z, double decrease, unsigned seed, int n_wgs,
+                                           int waves_per_pair, long *stats)
+{
+    if (n < 8 || !gp2) return GG_ERR_INVALID;
+    const Params P = gg::sweep::make_params(n, resolution, min_dist_squared, decrease);
+    const gp::Plan pl = gp::make_plan(P.rings);
+    if (pl.groups <= 0) return GG_ERR_INVALID;
+    std::vector<Cell> sheared((size_t)P.gl.elems, Cell{0.f, 0.f});
+    for (int col = 0; col < n; ++col)
+        for (int row = 0; row < n; ++row) sheared[(size_t)gp_index(P.gl, row, col)] = Cell{gp2[2 * ((size_t)row + (size_t)col * n)], gp2[2 * ((size_t)row + (size_t)col * n) + 1]};
+    // ---- the preparation: every record from the OLD layer
+    Records rec;
+    const float poison = __builtin_nanf("");
+    gp::VisitRec none;
+    none.gvl = none.a = none.b = none.wn = none.o[0] = none.o[1] = none.o[2] = none.o[3] = none.o4 = none.xo = poison;
+    rec.visit.assign((size_t)pl.total_steps * 64, none);
+    auto load = [&](int x, int y) { return sheared[(size_t)gp_index(P.gl, x, y)]; };
+    long n_visits = 0;
+    for (int p = 0; p < 2; ++p)
+        for (int g = 0; g < pl.groups; ++g) {
+            const gp::Group G = gp::group_of(p, g, P.rings);
+            for (int t = G.t_first; t < G.t_first + G.steps; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const bool is_x = lane < 32;
+                    const int l = lane & 31, side = is_x ? gp::side_x(p) : gp::side_y(p);
+                    if (l >= G.nl) continue;
+                    const int r = G.r0 + l, s = t - (2 * l + gp::start0(p, is_x));
+                    if (s < 0 || s >= gp::len_of(side, r)) continue;
+                    rec.visit[((size_t)pl.base[p][g] + (size_t)(t - G.t_first)) * 64 + lane] = gp::make_visit_rec(P, p, is_x, r, s, load);
+                    ++n_visits;
+                }
+        }
+    rec.corner.resize(2 * (size_t)(P.rings + 1));
+    for (int r = 1; r <= P.rings; ++r) {
+        rec.corner[(size_t)r] = gp::make_corner_rec<0>(P, r, load);
+        rec.corner[(size_t)(P.rings + 1) + r] = gp::make_corner_rec<1>(P, r, load);
+    }
+    // ---- the sweep
+    sheared[(size_t)gp_index(P.gl, P.c, P.c)] = Cell{base_z, 1.0f}; // :405-411
+    const float centre_p = 1.0f * base_z;
+    if (n_wgs != 2) n_wgs = 1;
+    const gp::Lds L = gp::lds_of(P.c, pl, n_wgs == 1);
+    const int W = std::max(1, std::min(waves_per_pair > 0 ? waves_per_pair : pl.groups, pl.groups));
+    std::vector<PairHostMem> mems((size_t)n_wgs);
+    std::vector<WaveBase *> waves;
+    for (int wg = 0; wg < n_wgs; ++wg) {
+        PairHostMem &mem = mems[(size_t)wg];
+        mem.layer = sheared.data();
+        mem.lds.assign((size_t)L.words, 0);
+        for (int k = 0; k < 64; ++k) mem.lds[(size_t)L.scratch + 2 * k + 1] = 1;
+        for (int cd = 0; cd < 2; ++cd) mem.lds_put(gp::corner_word(L, P.c, cd, 0, 1), centre_p);
+        for (int w = 0; w < W; ++w) {
+            if (n_wgs == 1 || wg == 0) waves.push_back(new PairWave<gp::PAIR_AD>(P, pl, L, mem, rec, centre_p, w, W));
+            if (n_wgs == 1 || wg == 1) waves.push_back(new PairWave<gp::PAIR_BC>(P, pl, L, mem, rec, centre_p, w, W));
+        }
+        waves.push_back(new PairCornerWave<0>(P, pl, L, mem, rec, centre_p));
+        waves.push_back(new PairCornerWave<1>(P, pl, L, mem, rec, centre_p));
+    }
+    uint32_t rng = seed * 2654435761u + 12345u;
+    auto rnd = [&]() { return rng = rng * 1664525u + 1013904223u; };
+    long total_steps = 0, stalls = 0;
+    int rc = GG_OK;
+    for (;;) {
+        bool all_done = true, progress = false;
+        for (auto *w : waves) all_done &= w->done();
+        if (all_done) break;
+        if (seed == 0) {
+            for (auto *w : waves)
+                if (w->try_step()) {
+                    progress = true;
+                    ++total_steps;
+                } else if (!w->done())
+                    ++stalls;
+        } else {
+            for (int tries = 0; tries < 4 * (int)waves.size() && !progress; ++tries) {
+                WaveBase *w = waves[(rnd() >> 8) % waves.size()];
+                const uint32_t mode = (rnd() >> 8) % 8;
+                int burst = mode == 0 ? 1 << 30 : mode < 4 ? 1 + (int)((rnd() >> 8) % 64) : 1;
+                while (burst-- > 0 && w->try_step()) {
+                    progress = true;
+                    ++total_steps;
+                }
+                if (!progress && !w->done()) ++stalls;
+            }
+            if (!progress)
+                for (auto *w : waves)
+                    if (w->try_step()) {
+                        progress = true;
+                        ++total_steps;
+                        break;
+                    }
+        }
+        if (!progress) {
+            rc = -10; // deadlock
+            break;
+        }
+    }
+    if (stats) {
+        stats[0] = total_steps;
+        stats[1] = stalls;
+        stats[2] = n_visits;
+        stats[3] = 0;
+        for (const PairHostMem &m : mems) stats[3] += m.stores;
+        stats[4] = (long)L.words * 4;
+        stats[5] = (long)waves.size();
+        stats[6] = pl.total_steps;
+        stats[7] = pl.groups;
+    }
+    for (auto *w : waves) {
+        if (w->bad() && rc == GG_OK) rc = -11;
+        delete w;
+    }
+    for (int col = 0; col < n; ++col)
+        for (int row = 0; row < n; ++row) {
+            const Cell v = sheared[(size_t)gp_index(P.gl, row, col)];
+            gp2[2 * ((size_t)row + (size_t)col * n)] = v.g;
+            gp2[2 * ((size_t)row + (size_t)col * n) + 1] = v.w;
+        }
+    return rc;
+}
