@@ -634,6 +634,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
         Arena a2 = a; // the words kernels of one launch synchronise through: the second half has its own
         a2.front_sync = a.front_sync2;
         a2.sweep_sync = a.sweep_sync2;
+        a2.sweep_rec_clouds = 0; // (one scratch region: the side stream's half keeps k_sweep)
         a2.scan_sync = a.scan_sync + (size_t)n_first * SCAN_SYNC_WORDS;
         HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * n_first, hipMemcpyHostToDevice, s));
         HIPCHK(ctx, hipMemcpyAsync(dp + n_first, hp + n_first, sizeof(CloudParams) * (nb - n_first), hipMemcpyHostToDevice, ctx->half_stream));
@@ -814,6 +815,9 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.tune_sweep_waves = getenv("GG_SWEEP_WAVES") ? atoi(getenv("GG_SWEEP_WAVES")) : 0;
     a.tune_sweep_gpw = getenv("GG_SWEEP_GPW") ? atoi(getenv("GG_SWEEP_GPW")) : 0;
     a.tune_sweep_split = getenv("GG_SWEEP_SPLIT") ? atoi(getenv("GG_SWEEP_SPLIT")) : 0;
+    a.tune_sweep_pair = getenv("GG_SWEEP_PAIR") ? atoi(getenv("GG_SWEEP_PAIR")) : 0;
+    a.tune_sweep_pair_wgs = getenv("GG_SWEEP_PAIR_WGS") ? atoi(getenv("GG_SWEEP_PAIR_WGS")) : 0;
+    a.tune_sweep_pair_waves = getenv("GG_SWEEP_PAIR_WAVES") ? atoi(getenv("GG_SWEEP_PAIR_WAVES")) : 0;
     a.tune_front = getenv("GG_FRONT") ? atoi(getenv("GG_FRONT")) : 0;
     a.tune_k2_per_cloud = getenv("GG_K2_PER_CLOUD") ? atoi(getenv("GG_K2_PER_CLOUD")) : 0;
     a.tune_k2_dense_share = getenv("GG_K2_DENSE_SHARE") ? atoi(getenv("GG_K2_DENSE_SHARE")) : 0;
@@ -890,6 +894,9 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_scansync = carve((size_t)n_slots * SCAN_SYNC_WORDS * 8);
     a.sweep_xchg_stride = align_up(std::max<size_t>(gg::sweep_xchg_entries(ctx->sweep_params), 1) * 16, A) / 8;
     const size_t o_xchg = carve((size_t)n_slots * a.sweep_xchg_stride * 8);
+    a.sweep_rec_stride = gg::sweep_pair_rec_floats(ctx->sweep_params);
+    a.sweep_rec_clouds = a.sweep_rec_stride ? std::min(n_slots, SWEEP_PAIR_MAX_CLOUDS) : 0;
+    const size_t o_srec = carve(std::max<size_t>((size_t)a.sweep_rec_clouds * a.sweep_rec_stride * 4, 64));
     const size_t o_params = carve((size_t)PARAM_RING * n_slots * sizeof(CloudParams));
     const size_t o_gparams = carve(sizeof(CloudParams));
     const size_t o_spts = carve(max_points * sizeof(gg_point16));
@@ -912,6 +919,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t gp_valid_words = ((size_t)a.gpl.elems + 31) / 32;
     const size_t o_gpvalid = carve(gp_valid_words * 4);
     const size_t o_dbg = carve(64 * 8); // sweep timing
+    const size_t o_pdbg = carve(2048 * 8); // pair sweep timing
     const bool k2_timing = getenv("GG_K2_DEBUG") && (atoi(getenv("GG_K2_DEBUG")) == 9 || atoi(getenv("GG_K2_DEBUG")) == 5 || atoi(getenv("GG_K2_DEBUG")) == 6);
     const size_t o_k2dbg = carve(k2_timing ? (size_t)K2_DBG_WGS * 32 * 8 : 64);
     ctx->arena_bytes = off;
@@ -959,6 +967,8 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
         a.dev_error = (uint32_t *)dptr;
     }
     a.sweep_xchg = (unsigned long long *)(base + o_xchg);
+    a.sweep_rec = a.sweep_rec_clouds ? (float *)(base + o_srec) : nullptr;
+    a.pair_dbg = getenv("GG_PAIR_TIMING") ? (unsigned long long *)(base + o_pdbg) : nullptr;
     a.flags = 0;
     a.k2_debug = getenv("GG_K2_DEBUG") ? atoi(getenv("GG_K2_DEBUG")) : 0;
     a.k2_dbg = (unsigned long long *)(base + o_k2dbg);
@@ -2193,6 +2203,9 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     if (!strcmp(key, "sweep_waves")) ctx->arena.tune_sweep_waves = value;
     else if (!strcmp(key, "sweep_gpw")) ctx->arena.tune_sweep_gpw = value;
     else if (!strcmp(key, "sweep_split")) ctx->arena.tune_sweep_split = value;
+    else if (!strcmp(key, "sweep_pair")) ctx->arena.tune_sweep_pair = value;
+    else if (!strcmp(key, "sweep_pair_wgs")) ctx->arena.tune_sweep_pair_wgs = value;
+    else if (!strcmp(key, "sweep_pair_waves")) ctx->arena.tune_sweep_pair_waves = value;
     else if (!strcmp(key, "front")) ctx->arena.tune_front = std::min(value, 3);
     else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
     else if (!strcmp(key, "scan_parts")) ctx->arena.tune_scan_parts = value;
@@ -2216,6 +2229,15 @@ extern "C" int gg_debug_sweep_timing(gg_context *ctx, unsigned long long out[64]
 {
     if (!ctx || !out || !ctx->d_sweep_dbg) return GG_ERR_INVALID;
     if (hipMemcpy(out, ctx->d_sweep_dbg, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
+    return GG_OK;
+}
+
+// tools only: what the pair sweep's wavefronts of the last launch's cloud 0 recorded (GG_PAIR_TIMING=1 at gg_create; tools/pair_timing.py)
+extern "C" int gg_debug_pair_timing(gg_context *ctx, unsigned long long out[2048])
+{
+    if (!ctx || !out || !ctx->arena.pair_dbg) return GG_ERR_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return GG_ERR_HIP;
+    if (hipMemcpy(out, ctx->arena.pair_dbg, 2048 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GG_ERR_HIP;
     return GG_OK;
 }
 

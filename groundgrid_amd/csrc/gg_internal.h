@@ -139,6 +139,9 @@ struct Arena {
     uint32_t *front_sync2, *sweep_sync2; // the same two regions once more, for the half of a batch that runs on the library's side stream
     uint32_t *sweep_sync; // [4] ticket counter, finished work-groups, epoch of k_sweep launches with several work-groups per cloud (k4_sweep.hip)
     unsigned long long *sweep_xchg; size_t sweep_xchg_stride; // [slot] exchange region between the work-groups of one sweep (sweep_core.h "Parts"), in 64-bit words
+    float *sweep_rec; size_t sweep_rec_stride; int sweep_rec_clouds; // scratch of the pair sweep (k4p_sweep_pair.hip): the records of up to
+                                                                     // sweep_rec_clouds clouds of ONE launch (cloud b of the launch at sweep_rec + b * stride floats)
+    unsigned long long *pair_dbg; // tools (GG_PAIR_TIMING=1 at gg_create): cycle counters of the pair sweep's wavefronts, cloud 0 of a launch; else nullptr
     int n_slots; // independent map states of the context
     int PW;    // points per wave-chunk
     int NCH;   // chunks per cloud (capacity)
@@ -148,6 +151,9 @@ struct Arena {
     int tune_sweep_waves;   // chain wavefronts per side of k_sweep
     int tune_sweep_gpw;     // ring groups per work-group of k_sweep (sweep_core.h "Parts"); default min(groups, 3)
     int tune_sweep_split;   // k_sweep "split steps": 0 = when a launch has one ring group per work-group and at most 256 work-groups, 1 = whenever gpw == 1, 2 = never
+    int tune_sweep_pair;    // the pair sweep (sweep_pair.h) for launches of at most sweep_rec_clouds clouds: 0 = yes, 2 = never (k_sweep always)
+    int tune_sweep_pair_wgs; // work-groups per cloud of the pair sweep: 0 / 2 = one per pair of sides (two CUs), 1 = both pairs in one
+    int tune_sweep_pair_waves; // chain wavefronts per pair (0 = one per 32-ring group, as many as fit)
     int tune_sweep_poll_cap; // tests: polls after which k_sweep's waits give up (0 = about a second)
     int tune_sweep_fault;   // tests: sweep::Params::debug_fault
     int tune_scan_fault;    // tests: 1 = the first part of a cloud's scan never publishes its sums (the waits of the others run out: GG_DEVERR_SCAN_WAIT)
@@ -284,6 +290,9 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
 } // namespace sweep
 void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s,
                   unsigned long long *dbg = nullptr); // k4_sweep.hip; dbg: 16 x 4 cycle counters of cloud 0's wavefronts (tools)
+bool launch_sweep_pair(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4p_sweep_pair.hip; false: not this launch
+size_t sweep_pair_rec_floats(const sweep::Params &P); // scratch floats per cloud of a launch (0: the geometry cannot take the pair sweep)
+constexpr int SWEEP_PAIR_MAX_CLOUDS = 16;              // launches of more clouds keep k_sweep
 size_t sweep_lds_bytes(const sweep::Params &P);
 size_t sweep_xchg_entries(const sweep::Params &P);
 void launch_label(const Arena &a, const CloudParams *d_params, const BatchIO &io, int n_clouds, int max_n, hipStream_t s);

@@ -85,4 +85,33 @@ GPL_HD int gp_index(const GpLayout &L, int row, int col)
     return 1 + ((side * L.G + g) * L.VS + v + GP_SHEAR * l) * 64 + l;
 }
 
+// the inverse: which cell element `e` holds (false: the centre's slot 0 is cell (c, c); padding elements hold no cell)
+GPL_HD bool gp_cell_of(const GpLayout &L, int e, int &row, int &col)
+{
+    if (e == 0) {
+        row = col = L.c;
+        return true;
+    }
+    if (e < 0 || e >= L.elems) return false;
+    const int q = e - 1, l = q & 63, rest = q >> 6;
+    const int vs = rest % L.VS, sg = rest / L.VS, g = sg % L.G, side = sg / L.G;
+    const int r = 64 * g + l + 1, v = vs - GP_SHEAR * l;
+    if (side > 3 || v < 0 || v >= L.n) return false;
+    if (side == 0) {
+        row = L.c - r;
+        col = v;
+    } else if (side == 2) {
+        row = L.c + r;
+        col = L.n - 1 - v;
+    } else if (side == 1) {
+        col = L.c - r;
+        row = v;
+    } else {
+        col = L.c + r;
+        row = L.n - 1 - v;
+    }
+    if (row < 0 || row >= L.n || col < 0 || col >= L.n) return false;
+    return gp_index(L, row, col) == e; // (the side's own range of v: the other positions of the plane are padding)
+}
+
 } // namespace gg

@@ -756,6 +756,8 @@ size_t sweep_xchg_entries(const Params &P) { return (size_t)xchg_entries(P.group
 void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_params, int n_clouds, hipStream_t s, unsigned long long *dbg)
 {
     if (n_clouds == 0 || P_in.rings <= 0) return;
+    // latency launches: the pair sweep (sweep_pair.h) -- both sides of a ring hand-over in one wavefront, old values from records
+    if (!dbg && a.tune_sweep_pair != 2 && a.tune_sweep_fault == 0 && launch_sweep_pair(a, P_in, d_params, n_clouds, s)) return;
     Params P = P_in;
     // Work-groups ("parts", sweep_core.h) per cloud.  The sweep of one cloud is a dependency chain, so a launch that leaves CUs idle
     // spreads every cloud over as many work-groups as there are CUs to take them (measured, k_sweep per launch: n = 1000, 1 / 8

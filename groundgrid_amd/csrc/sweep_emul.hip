@@ -572,6 +572,12 @@ namespace gp = gg::sweep::pair;
 
 struct PairHostMem { // one per emulated work-group
     Cell *layer;
+    std::vector<float> *out; // the chains' result stream (shared by the work-groups of a cloud)
+    void emit(int slot, float g)
+    {
+        ++stores;
+        (*out)[(size_t)slot] = g;
+    }
     std::vector<int32_t> lds;
     long stores = 0, lds_ops = 0;
     bool fault = false; // a read of an entry nobody has published
@@ -637,6 +643,8 @@ template <int PAIR> struct PairWave : WaveBase {
                 int x, y;
                 gp::side_xy(side, P.c, c.r, 0, gp::k0_of(side) + s, x, y);
                 if (c.st_base + 64 * (c.start + s) != gp_index(P.gl, x, y)) plan_mismatch = true;
+                int slot = -1;
+                if (!gp::chain_slot_of_cell(P, pl, x, y, slot) || slot != c.out_base + 64 * (c.start + s)) plan_mismatch = true; // the finish finds this visit's height
             }
         }
         t = G.t_first;
@@ -658,7 +666,7 @@ template <int PAIR> struct PairWave : WaveBase {
         float x_prev[64], j_perm[64];
         for (int k = 0; k < 64; ++k) {
             x_prev[k] = k ? lane[k - 1].h2 : 0.f;                                  // wave shift right by one (lane 32 gets side X's last lane: never used)
-            j_perm[k] = k < 32 ? (k ? lane[32 + k - 1].OP : 0.f) : lane[k - 32].OP; // X l <- Y l - 1, Y l <- X l
+            j_perm[k] = k < 32 ? (k ? lane[32 + k - 1].h1 : 0.f) : lane[k - 32].h1; // X l <- Y l - 1, Y l <- X l
         }
         const size_t base = ((size_t)pl.base[PAIR][group] + (size_t)(t - G.t_first)) * 64;
         for (int k = 0; k < 64; ++k) lane[k].step(t, group, rec.visit[base + k], x_prev[k], j_perm[k], centre_p, mem);
@@ -747,6 +755,7 @@ extern "C" int gg_debug_emulate_pair_sweep(int n, double resolution, float min_d
     // ---- the sweep
     sheared[(size_t)gp_index(P.gl, P.c, P.c)] = Cell{base_z, 1.0f}; // :405-411
     const float centre_p = 1.0f * base_z;
+    std::vector<float> out((size_t)pl.total_steps * 64, poison);
     if (n_wgs != 2) n_wgs = 1;
     const gp::Lds L = gp::lds_of(P.c, pl, n_wgs == 1);
     const int W = std::max(1, std::min(waves_per_pair > 0 ? waves_per_pair : pl.groups, pl.groups));
@@ -755,6 +764,7 @@ extern "C" int gg_debug_emulate_pair_sweep(int n, double resolution, float min_d
     for (int wg = 0; wg < n_wgs; ++wg) {
         PairHostMem &mem = mems[(size_t)wg];
         mem.layer = sheared.data();
+        mem.out = &out;
         mem.lds.assign((size_t)L.words, 0);
         for (int k = 0; k < 64; ++k) mem.lds[(size_t)L.scratch + 2 * k + 1] = 1;
         for (int cd = 0; cd < 2; ++cd) mem.lds_put(gp::corner_word(L, P.c, cd, 0, 1), centre_p);
@@ -804,6 +814,18 @@ extern "C" int gg_debug_emulate_pair_sweep(int n, double resolution, float min_d
             break;
         }
     }
+    // ---- the finish: the streamed heights into the layer, with the cells' own new confidences (element by element, like the device:
+    //      the layout's inverse map must name every cell exactly once)
+    long finished = 0, cells_seen = 0;
+    for (int e = 0; e < P.gl.elems; ++e) {
+        int x, y, slot;
+        if (!gg::gp_cell_of(P.gl, e, x, y)) continue;
+        ++cells_seen;
+        if (!gp::chain_slot_of_cell(P, pl, x, y, slot)) continue;
+        sheared[(size_t)e] = gp::finished_cell(P, x, y, sheared[(size_t)e].w, out[(size_t)slot]);
+        ++finished;
+    }
+    if ((finished != n_visits || cells_seen != (long)n * n) && rc == GG_OK) rc = -12;
     if (stats) {
         stats[0] = total_steps;
         stats[1] = stalls;

@@ -38,7 +38,9 @@ namespace gg {
 namespace sweep {
 namespace pair {
 
-enum { HALF = 32, PAIR_AD = 0, PAIR_BC = 1, MAX_GROUPS = 72 /* n <= 4600 */, PTRIP = 6, PPF = 3 };
+// PTRIP: a group's wave-steps are rounded up to whole trips of the device's unrolled loop; PPF: how many wave-steps ahead the device requests
+// a step's record (its queue slot is a constant of the unrolled loop: PPF divides PTRIP; smaller queues -- 6, 4, 3 -- divide it too)
+enum { HALF = 32, PAIR_AD = 0, PAIR_BC = 1, MAX_GROUPS = 72 /* n <= 4600 */, PTRIP = 12, PPF = 12 };
 static_assert(PTRIP % PPF == 0, "a record slot is a constant of the unrolled loop");
 
 SW_HD constexpr int len_of(int side, int r) { return side == SIDE_A ? 2 * r - 2 : side == SIDE_D ? 2 * r : 2 * r - 1; }
@@ -340,7 +342,8 @@ template <int CD, class Load> SW_HD CornerRec make_corner_rec(const Params &P, i
 //   void  lds_put(int word, float v)
 //   void  lds_entry(int word, float v)    (v, tag 1) as ONE 8-byte write
 //   int   lds_i(int word)  /  void lds_set(int word, int v)
-//   void  store(bool valid, int cell, Cell v)     the layer (fire and forget)
+//   void  store(bool valid, int cell, Cell v)     the layer (fire and forget; the corner wavefronts only)
+//   void  emit(int slot, float g)                 the chain's height of wave-step t, lane: slot = (record block of the step) * 64 + lane
 // ---------------------------------------------------------------------------------------------------------------------
 
 // one lane of a pair wavefront
@@ -348,15 +351,17 @@ template <int PAIR> struct PairLane {
     // constants
     bool is_x, live, jl_lane; // half; the lane has a ring; X lane 0: its join comes from LDS (the group inside, or the centre for ring 1)
     int l, r, len, start;
-    int st_base;            // layer element of the cell visited at wave-step t = st_base + 64 t
+    int st_base;            // layer element of the cell visited at wave-step t = st_base + 64 t (the emulation holds finish_cell's inverse map to it)
+    int out_base;           // where the height of wave-step t goes in the result stream: out_base + 64 t
     int a_s0, a_s1, a_pred; // LDS words of S[0], S[1] and the first predecessor (corner table)
     int a_bnd;              // lane 0 of a half, group > 0: (value, tag) of wave-step t = a_bnd + 2 t while the step imports (others: never)
     int a_jl;               // X lane 0: LDS entry (value, tag) of the join
     int pb;                 // last lane of a half when a group follows: wave-step t's result goes to entry pb + 2 t (others: -1)
     int scr;                // the lane's scratch entry (tag preset)
     int cd;                 // which corner wavefront the lane's first step waits for
-    // state: the inner line S[s], S[s+1], S[s+2]; the predecessor's product; the last two results (lane l + 1 reads the older one)
-    float I0, I1, I2, OP, h1, h2;
+    // state: the inner line S[s], S[s+1], S[s+2]; the last two results.  h1 is the predecessor's product of the next visit, the join the
+    // partner lane takes one step after this chain's end, and -- a step later, as h2 -- what lane l + 1 reads as its S[s + 2]
+    float I0, I1, I2, h1, h2;
 
     SW_HD void init(int lane, int group, const Group &G, const Params &P, const Plan &pl, const Lds &L)
     {
@@ -371,6 +376,7 @@ template <int PAIR> struct PairLane {
         int x, y;
         side_xy(side, P.c, r, 0, 1, x, y);
         st_base = gp_index(P.gl, x, y) + 64 * (k0_of(side) - 1 - start);
+        out_base = (pl.base[PAIR][group] - G.t_first) * 64 + lane;
         cd = (side == SIDE_A || side == SIDE_B) ? 0 : 1;
         if (side == SIDE_A) { // S[0] = B_0(r-1), S[1] = A_1(r-1), predecessor A_1(r)
             a_s0 = corner_word(L, P.c, cd, r - 1, 1);
@@ -398,7 +404,7 @@ template <int PAIR> struct PairLane {
         if (jl_lane && group > 0) a_jl = pair_base + 2 * L.bnd_half + 2 * (pl.bnd_off[group - 1] + len_of(side_y(PAIR), G.r0 - 1) - 1);
         // export: the last lane of a half, when a group follows
         pb = (l == (int)HALF - 1 && group + 1 < pl.groups) ? half_base + 2 * (pl.bnd_off[group] - start) : -1;
-        I0 = I1 = I2 = OP = h1 = h2 = 0.f;
+        I0 = I1 = I2 = h1 = h2 = 0.f;
     }
     // what wave-step t of this lane reads from other wavefronts (the wavefront may run the step once all of it is there)
     SW_HD bool first_at(int t) const { return live && t == start; } // (ring 1 of side A has no chain, but its "first step" still takes A_1(1): D's join)
@@ -406,12 +412,12 @@ template <int PAIR> struct PairLane {
     SW_HD bool join_from_lds_at(int t, int group) const { return jl_lane && group > 0 && t - start + 2 == len; }
     SW_HD int import_entry(int t) const { return a_bnd + 2 * t; }
 
-    // 1. the first step takes the predecessor from the corner table -- BEFORE the wavefront exchanges OP (see first_at)
+    // 1. the first step takes the predecessor from the corner table -- BEFORE the wavefront exchanges h1 (see first_at)
     template <class Mem> SW_HD void pre(int t, Mem &mem)
     {
-        if (first_at(t)) OP = mem.lds_f(a_pred);
+        if (first_at(t)) h1 = mem.lds_f(a_pred);
     }
-    // 2. the visit.  x_prev = h2 of lane - 1, j_perm = OP of the partner lane (X l <- Y l - 1, Y l <- X l), both as they were after pre();
+    // 2. the visit.  x_prev = h2 of lane - 1, j_perm = h1 of the partner lane (X l <- Y l - 1, Y l <- X l), both as they were after pre();
     //    centre_p = the centre cell's product (the join of ring 1 of side B)
     template <class Mem> SW_HD void step(int t, int group, const VisitRec &R, float x_prev, float j_perm, float centre_p, Mem &mem)
     {
@@ -430,18 +436,57 @@ template <int PAIR> struct PairLane {
             if (len != 1) I1 = mem.lds_f(a_s1); // (a chain of one visit: S[1] is the join, taken a step ago)
         }
         const bool active = (unsigned)s < (unsigned)len;
-        const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR>(is_x, R, I0, I1, I2, OP));
+        const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR>(is_x, R, I0, I1, I2, h1));
         const float res = R.wn * g;
 #if !defined(__HIP_DEVICE_COMPILE__)
-        if (getenv("GG_PAIR_DBG") && active && r == atoi(getenv("GG_PAIR_DBG")) && s < 3) fprintf(stderr, "pair %d x %d r %d s %d t %d: I %g %g %g OP %g | gvl %g a %g b %g wn %g o %g %g %g %g %g xo %g -> g %g\n", PAIR, (int)is_x, r, s, t, I0, I1, I2, OP, R.gvl, R.a, R.b, R.wn, R.o[0], R.o[1], R.o[2], R.o[3], R.o4, R.xo, g);
+        if (getenv("GG_PAIR_DBG") && active && r == atoi(getenv("GG_PAIR_DBG")) && s < 3) fprintf(stderr, "pair %d x %d r %d s %d t %d: I %g %g %g pred %g | gvl %g a %g b %g wn %g o %g %g %g %g %g xo %g -> g %g\n", PAIR, (int)is_x, r, s, t, I0, I1, I2, h1, R.gvl, R.a, R.b, R.wn, R.o[0], R.o[1], R.o[2], R.o[3], R.o4, R.xo, g);
 #endif
-        mem.store(active, st_base + 64 * t, Cell{g, R.wn});
-        OP = active ? res : OP;
+        // the height goes to the result stream, 64 lanes = 64 consecutive floats (the lanes' cells lie in 64 different lines of the layer: a
+        // scattered store costs the CU's memory front end more than the rest of the step); finish_cell() puts it into the layer
+        if (active) mem.emit(out_base + 64 * t, g);
         h2 = h1;
         h1 = res;
         if (pb >= 0 && active) mem.lds_entry(pb + 2 * t, res);
     }
 };
+
+// The chain visit that rewrites cell (x, y), if one does (the centre, the cells of the corner wavefronts -- the two diagonal corners and the
+// second cell of sides A and C -- and the three border lines are not chain cells): where its height sits in the result stream.
+SW_HD bool chain_slot_of_cell(const Params &P, const Plan &pl, int x, int y, int &slot)
+{
+    const int dx = x - P.c, dy = y - P.c;
+    const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, r = ax > ay ? ax : ay;
+    if (r == 0 || r > P.rings) return false;
+    const int rp = P.c - r, R = P.c + r;
+    int side, k;
+    if (dx == -r && dy < r) {
+        side = SIDE_A;
+        k = y - rp;
+    } else if (dx == r) {
+        side = SIDE_C;
+        k = R - y;
+    } else if (dy == -r) {
+        side = SIDE_B;
+        k = x - rp;
+    } else {
+        side = SIDE_D;
+        k = R - x;
+    }
+    const int s = k - k0_of(side);
+    if (s < 0 || s >= len_of(side, r)) return false;
+    const int pair = (side == SIDE_A || side == SIDE_D) ? (int)PAIR_AD : (int)PAIR_BC;
+    const bool is_x = side == SIDE_A || side == SIDE_B;
+    const int g = (r - 1) / HALF, l = (r - 1) % HALF;
+    const int t = s + 2 * l + start0(pair, is_x);
+    slot = (pl.base[pair][g] + t - (-1)) * 64 + l + (is_x ? 0 : (int)HALF); // (t_first = -1)
+    return true;
+}
+// ... and what the cell holds after the sweep: the streamed height, its own decayed confidence (:463-464; a chain cell is visited once)
+SW_HD Cell finished_cell(const Params &P, int x, int y, float w_old, float g_new)
+{
+    const int dx = x - P.c, dy = y - P.c;
+    return Cell{g_new, decayed_confidence(w_old, dx * dx + dy * dy >= P.r2min, P)};
+}
 
 // one lane of a corner wavefront: lane = ring within a batch of 64, the three dependent visits run ring after ring (every lane executes
 // them with its own record, the lane whose ring it is holds the meaningful operands)
