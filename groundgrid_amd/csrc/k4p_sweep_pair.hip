@@ -32,10 +32,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
 
-// records of one cloud inside the scratch region (floats): per wave-step a block of 640 floats -- 64 x (gvl, a, b, wn), 64 x o[0..3],
-// 64 x (o4, xo): three coalesced loads per lane at one scalar offset -- for total_steps + PPF + 1 wave-steps (the queue reads PPF steps
+// records of one cloud inside the scratch region (floats): per wave-step a block of 512 floats -- 64 x (gvl, a, b, wn), 64 x (nN, nU, xo,
+// spare): two coalesced 16-byte loads per lane at one scalar offset -- for total_steps + PPF + 1 wave-steps (the queue reads PPF steps
 // past the end), then 32 planes [2][ring_pad] of the corner records
-enum { STEP_FLOATS = 640 };
+enum { STEP_FLOATS = 512 };
 struct RecLayout {
     size_t corner, ring_pad, out, floats; // (out: the chains' result stream, one float per record)
 };
@@ -79,12 +79,11 @@ __global__ __launch_bounds__(256) void k_sweep_records(const Arena a, const Para
         const bool is_x = lane < (int)sp::HALF;
         const int l = lane & (sp::HALF - 1), side = is_x ? sp::side_x(p) : sp::side_y(p);
         const int r = G.r0 + l, s = t - (2 * l + sp::start0(p, is_x));
-        if (l >= G.nl || s < 0 || s >= sp::len_of(side, r)) return; // (no visit: the chain lane is idle at this step and uses nothing of the record)
+        if (l >= G.nl || s < -(int)sp::WARMUP || s >= sp::len_of(side, r)) return; // (the chain lane is idle at this step and uses nothing of the record)
         const sp::VisitRec R = sp::make_visit_rec(P, p, is_x, r, s, load);
         float *blk = rec + (size_t)step * STEP_FLOATS;
-        reinterpret_cast<float4 *>(blk)[lane] = make_float4(R.gvl, R.a, R.b, R.wn);
-        reinterpret_cast<float4 *>(blk + 256)[lane] = make_float4(R.o[0], R.o[1], R.o[2], R.o[3]);
-        reinterpret_cast<float2 *>(blk + 512)[lane] = make_float2(R.o4, R.xo);
+        if (s >= 0) reinterpret_cast<float4 *>(blk)[lane] = make_float4(R.gvl, R.a, R.b, R.wn);
+        reinterpret_cast<float4 *>(blk + 256)[lane] = make_float4(R.nN, R.nU, R.xo, 0.f);
         return;
     }
     const size_t k = e - n_visit;
@@ -149,9 +148,12 @@ GG_DEV float partner_both(float h1)
     return __int_as_float(__builtin_amdgcn_update_dpp((int)sw[0], (int)sw[1], 0x138 /* wave_shr:1 */, 0x3 /* rows 0, 1 */, 0xF, false));
 }
 
+// Timing experiments only (tools/build_pair_variant.sh; results void): what a step costs without one of its parts
+//   -DGG_PAIR_X_NODIV    a multiplication instead of the IEEE division       -DGG_PAIR_X_NOSTORE  no store into the result stream
+//   -DGG_PAIR_X_NOLDS    no import / export / join through LDS (nor waits)    -DGG_PAIR_X_NOLOAD   the record queue is never refilled
+//   -DGG_PAIR_X_NOPERM   no exchange of the halves' last results
 template <int PF> struct RecQueue {
     u32x4 q0[PF], q1[PF];
-    u32x2 q2[PF];
 };
 // the three parts of wave-step `step`'s record block for this lane (voff = lane * 16)
 template <int PF> GG_DEV void rec_request(RecQueue<PF> &Q, int slot, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int step)
@@ -159,12 +161,11 @@ template <int PF> GG_DEV void rec_request(RecQueue<PF> &Q, int slot, __amdgpu_bu
     const uint32_t soff = (uint32_t)step * (uint32_t)(STEP_FLOATS * 4);
     Q.q0[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     Q.q1[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, soff, 0);
-    Q.q2[slot] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (voff >> 1) + 2048u, soff, 0);
 }
 
 // Which of a lane's rare events a wave-step can hold follows from t mod 4 alone: X(r) ends at 4 l + 2 r0 + b - 1 (r0 = 1 mod 32), so the
 // join step of side X (the step before its last) falls on t = b (mod 4), its last step one later, side Y's two steps later.  A trip of the
-// unrolled loop is 12 steps from t = -1 (mod 12): the residue is a constant of every step.
+// unrolled loop is 12 steps from t = -2 (mod 12): the residue is a constant of every step.
 template <int PAIR> struct Residue {
     static constexpr int x_join = PAIR == sp::PAIR_AD ? 2 : 3, x_last = (x_join + 1) & 3, y_join = (x_join + 2) & 3, y_last = (x_join + 3) & 3;
 };
@@ -185,7 +186,12 @@ enum { PAIR_TRIP = 12 };
 // atomics in program order and sank a plain prefetch to just before the next LDS operation; between `issue` and `wait` the destination
 // is touched by nothing.)
 GG_DEV void entry_issue(uint32_t addr, u32x2 &dst) { asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); }
-GG_DEV void entry_wait(u32x2 &dst) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dst)::"memory"); }
+// (NEWER: LDS operations the wavefront has issued since -- the step's publish; the queue returns in order)
+template <int NEWER> GG_DEV void entry_wait(u32x2 &dst)
+{
+    if (NEWER == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dst)::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(dst)::"memory");
+}
 
 template <int PAIR, int PF>
 GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, PairMem &mem, __amdgpu_buffer_rsrc_t rec, __amdgpu_buffer_rsrc_t out, int w, int W, int lane, float centre_p,
@@ -232,10 +238,15 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
         const uint32_t scr_a = lds0 + 4u * (uint32_t)st.scr;
         auto trip = [&](const int tb, auto kind) __attribute__((always_inline)) {
             using K = decltype(kind);
+#ifdef GG_PAIR_X_NOLDS
+            constexpr int kimp = 0, kexp = 0;
+#else
+            constexpr int kimp = K::imp, kexp = K::exp;
+#endif
             u32x2 ent_q{0u, 0u};
             uint32_t imp_cur = imp_a + imp_k * (uint32_t)tb, exp_cur = exp_a + exp_k * (uint32_t)tb;
-            auto imp_addr = [&](int t) { return (K::imp == 2 || (unsigned)(t - imp_lo) < (unsigned)imp_n) ? imp_cur : scr_a; };
-            if (K::imp >= 2) entry_issue(imp_addr(tb), ent_q);
+            auto imp_addr = [&](int t) { return (kimp == 2 || (unsigned)(t - imp_lo) < (unsigned)imp_n) ? imp_cur : scr_a; };
+            if (kimp >= 2) entry_issue(imp_addr(tb), ent_q);
             // scalar byte offsets of the step's record block (+ PF steps: the request) and of its row of the result stream
             uint32_t rec_soff = (uint32_t)(step0 + (tb - G.t_first) + PF) * (uint32_t)(STEP_FLOATS * 4);
             uint32_t out_soff = (uint32_t)(step0 + (tb - G.t_first)) * 256u;
@@ -261,16 +272,16 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
 #pragma unroll
             for (int u = 0; u < (int)PAIR_TRIP; ++u) {
                 const int t = tb + u;
-                const int slot = u % PF, res4 = (u + 3) & 3; // t = -1 + u (mod 4)
-                const bool t_even = (u & 1) != 0;            // (lanes start at even t only)
+                const int slot = u % PF, res4 = (u + 2) & 3; // t = -2 + u (mod 4)
+                const bool t_even = (u & 1) == 0;            // (lanes start at even t only)
                 // ---- the record of this step (queued PF steps ago), the next request into its place
                 sp::VisitRec R;
                 R.gvl = __uint_as_float(Q.q0[slot].x), R.a = __uint_as_float(Q.q0[slot].y), R.b = __uint_as_float(Q.q0[slot].z), R.wn = __uint_as_float(Q.q0[slot].w);
-                R.o[0] = __uint_as_float(Q.q1[slot].x), R.o[1] = __uint_as_float(Q.q1[slot].y), R.o[2] = __uint_as_float(Q.q1[slot].z), R.o[3] = __uint_as_float(Q.q1[slot].w);
-                R.o4 = __uint_as_float(Q.q2[slot].x), R.xo = __uint_as_float(Q.q2[slot].y);
+                R.nN = __uint_as_float(Q.q1[slot].x), R.nU = __uint_as_float(Q.q1[slot].y), R.xo = __uint_as_float(Q.q1[slot].z), R.spare = 0.f;
+#ifndef GG_PAIR_X_NOLOAD
                 Q.q0[slot] = __builtin_amdgcn_raw_buffer_load_b128(rec, voff, rec_soff, 0);
                 Q.q1[slot] = __builtin_amdgcn_raw_buffer_load_b128(rec, voff + 1024u, rec_soff, 0);
-                Q.q2[slot] = __builtin_amdgcn_raw_buffer_load_b64(rec, (voff >> 1) + 2048u, rec_soff, 0);
+#endif
                 rec_soff += (uint32_t)(STEP_FLOATS * 4);
                 // ---- first steps: the corner values
                 bool first = false;
@@ -297,8 +308,9 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
                 }
                 // ---- S[s + 2]: lane - 1's result of two steps ago; the first lane of a half reads the group inside
                 float x = pair_wave_shr1(st.h2);
-                if (K::imp >= 2) {
-                    entry_wait(ent_q); // (requested a step ago)
+                if (kimp >= 2) {
+                    if (u >= 1 && kexp >= 2) entry_wait<1>(ent_q); // (requested a step ago; the one LDS operation since is that step's publish)
+                    else entry_wait<0>(ent_q);
                     u32x2 ent = ent_q;
                     if (__builtin_expect(__any(ent.y == 0u), 0)) { // (rare) the group inside is less than a step ahead
                         const unsigned long long w0 = dbg ? __builtin_readcyclecounter() : 0ull;
@@ -311,11 +323,11 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
                         } while (__any(ent.y == 0u));
                         if (dbg) wait_import += __builtin_readcyclecounter() - w0, ++n_wait;
                     }
-                    const bool mine = K::imp == 2 ? l0 : (unsigned)(t - imp_lo) < (unsigned)imp_n;
+                    const bool mine = kimp == 2 ? l0 : (unsigned)(t - imp_lo) < (unsigned)imp_n;
                     imp_cur += imp_k;
                     if (u + 1 < (int)PAIR_TRIP) entry_issue(imp_addr(t + 1), ent_q);
                     x = mine ? __uint_as_float(ent.x) : x;
-                } else if (K::imp == 1 && t < imp_any_hi) { // (uniform)
+                } else if (kimp == 1 && t < imp_any_hi) { // (uniform)
                     const bool imp = st.imports_at(t, group);
                     const int word = imp ? st.import_entry(t) : st.scr;
                     uint64_t ent = mem.lds_entry_get(word);
@@ -327,8 +339,12 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
                 }
                 // ---- the join / the far end: one kind of event per residue of t
                 if (res4 == Residue<PAIR>::x_join || res4 == Residue<PAIR>::y_join) {
+#ifdef GG_PAIR_X_NOPERM
+                    float j = st.h2;
+#else
                     float j = res4 == Residue<PAIR>::x_join ? partner_for_x(st.h1) : partner_for_y(st.h1);
-                    if (K::imp == 1 && res4 == Residue<PAIR>::x_join) {
+#endif
+                    if (kimp == 1 && res4 == Residue<PAIR>::x_join) {
                         if (l0 && is_x) j = centre_p; // (group 0: the join of ring 1 of side B is the centre cell)
                         if (t == t_jl) {              // (uniform) X lane 0: Y's last value of the ring inside
                             const int word = st.jl_lane ? st.a_jl : st.scr;
@@ -355,17 +371,20 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
                     st.I1 = first ? cs1 : st.I1; // (chains of one visit -- ring 1 -- start in the generic trip)
                 }
                 // ---- the visit; its height goes to the result stream, 64 lanes = 256 contiguous bytes (idle lanes write a slot nobody reads)
-                const float g = sp::height_of(R.gvl, R.a, R.b, sp::window_sum<PAIR>(is_x, R, st.I0, st.I1, st.I2, st.h1));
+                st.O.shift(R);
+                const float g = sp::height_of(R.gvl, R.a, R.b, sp::window_sum<PAIR>(is_x, st.O, st.I0, st.I1, st.I2, st.h1));
                 const float res = R.wn * g;
+#ifndef GG_PAIR_X_NOSTORE
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g), out, (uint32_t)lane * 4u, out_soff, 0);
+#endif
                 out_soff += 256u;
                 st.h2 = st.h1;
                 st.h1 = res;
-                if (K::exp == 2) {
+                if (kexp == 2) {
                     mem.lds_entry_at(exp_cur, res);
-                } else if (K::exp == 3) {
+                } else if (kexp == 3) {
                     mem.lds_entry_at((unsigned)(t - exp_lo) < (unsigned)exp_n ? exp_cur : scr_a, res);
-                } else if (K::exp == 1 && t >= exp_any_lo && t < exp_any_hi) { // (uniform)
+                } else if (kexp == 1 && t >= exp_any_lo && t < exp_any_hi) { // (uniform)
                     const bool active = (unsigned)(t - st.start) < (unsigned)st.len;
                     mem.lds_entry((st.pb >= 0 && active) ? st.pb + 2 * t : st.scr, res);
                 }
@@ -377,6 +396,7 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
             const bool no_start = tb > t_start_last, has_jl = t_jl >= tb && t_jl < te;
             const bool imp2 = !has_prev || (tb >= imp_all_lo && te <= imp_all_hi), imp0 = tb >= imp_any_hi && tb > t_jl; // (no group inside: every lane reads its scratch word)
             const bool exp2 = !has_next || (tb >= exp_all_lo && te <= exp_all_hi);
+            static_assert((int)sp::WARMUP == 2, "the residues and the parity of the first steps count from t = -2");
             if (has_jl || (group == 0 && tb == G.t_first)) trip(tb, PairKind<1, 1, 1>{}); // ring 1 (chains of one visit, the centre as a join); X lane 0's join from LDS
             else if (!no_start) trip(tb, PairKind<2, 3, 3>{});
             else if (imp0 && exp2) trip(tb, PairKind<0, 0, 2>{});
@@ -423,13 +443,14 @@ GG_DEV void run_pair_corner(const Params &P, const sp::Plan &pl, const sp::Lds &
             in_x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), l));
             if (!CD && r0 + l == 1) { // the one chain visit the CD corner needs: B_1(1) = pair B/C, group 0, lane 0, wave-step 0
                 const float *blk = rec + ((size_t)pl.base[sp::PAIR_BC][0] + (size_t)(0 - sp::group_of(sp::PAIR_BC, 0, P.rings).t_first)) * STEP_FLOATS;
-                const float4 v0 = reinterpret_cast<const float4 *>(blk)[0], v1 = reinterpret_cast<const float4 *>(blk + 256)[0];
-                const float2 v2 = reinterpret_cast<const float2 *>(blk + 512)[0];
-                sp::VisitRec B;
-                B.gvl = v0.x, B.a = v0.y, B.b = v0.z, B.wn = v0.w;
-                B.o[0] = v1.x, B.o[1] = v1.y, B.o[2] = v1.z, B.o[3] = v1.w;
-                B.o4 = v2.x, B.xo = v2.y;
-                const float b1 = sp::b1_of_ring1(B, in_x1, in_corner, centre_p);
+                auto rec_of = [&](int back) { // lane 0's record of wave-step 0 - back
+                    const float4 v0 = reinterpret_cast<const float4 *>(blk - (size_t)back * STEP_FLOATS)[0], v1 = reinterpret_cast<const float4 *>(blk - (size_t)back * STEP_FLOATS + 256)[0];
+                    sp::VisitRec B;
+                    B.gvl = v0.x, B.a = v0.y, B.b = v0.z, B.wn = v0.w;
+                    B.nN = v1.x, B.nU = v1.y, B.xo = v1.z, B.spare = 0.f;
+                    return B;
+                };
+                const float b1 = sp::b1_of_ring1(rec_of(2), rec_of(1), rec_of(0), in_x1, in_corner, centre_p);
                 if (lane == 0) mem.lds_entry(L.b1, b1);
             }
         }
@@ -539,15 +560,15 @@ bool launch_sweep_pair(const Arena &a, const Params &P, const CloudParams *d_par
     // this kernel); bigger work-groups get 128 registers and a queue of 6
     const int waves = (both ? 2 * W : W) + 2;
     const bool small = waves <= 8;
-    const void *fn = both ? (small ? (const void *)k_sweep_pair<true, 6, 512> : (const void *)k_sweep_pair<true, 3, 1024>)
-                          : (small ? (const void *)k_sweep_pair<false, 6, 512> : (const void *)k_sweep_pair<false, 3, 1024>);
+    const void *fn = both ? (small ? (const void *)k_sweep_pair<true, 12, 512> : (const void *)k_sweep_pair<true, 3, 1024>)
+                          : (small ? (const void *)k_sweep_pair<false, 12, 512> : (const void *)k_sweep_pair<false, 3, 1024>);
     if (lds > 64 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); // (idempotent; big maps only)
     const size_t n_rec = (size_t)pl.total_steps * 64 + 2 * (size_t)P.rings;
     hipLaunchKernelGGL(k_sweep_records, dim3((unsigned)((n_rec + 255) / 256), (unsigned)n_clouds), dim3(256), 0, s, a, P, pl, d_params);
     const dim3 grid(both ? n_clouds : 2 * n_clouds), block(waves * 64);
-    if (both && small) hipLaunchKernelGGL((k_sweep_pair<true, 6, 512>), grid, block, lds, s, a, P, pl, d_params, W);
+    if (both && small) hipLaunchKernelGGL((k_sweep_pair<true, 12, 512>), grid, block, lds, s, a, P, pl, d_params, W);
     else if (both) hipLaunchKernelGGL((k_sweep_pair<true, 3, 1024>), grid, block, lds, s, a, P, pl, d_params, W);
-    else if (small) hipLaunchKernelGGL((k_sweep_pair<false, 6, 512>), grid, block, lds, s, a, P, pl, d_params, W);
+    else if (small) hipLaunchKernelGGL((k_sweep_pair<false, 12, 512>), grid, block, lds, s, a, P, pl, d_params, W);
     else hipLaunchKernelGGL((k_sweep_pair<false, 3, 1024>), grid, block, lds, s, a, P, pl, d_params, W);
     hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)((P.gl.elems + 255) / 256), (unsigned)n_clouds), dim3(256), 0, s, a, P, pl, d_params);
     return true;

@@ -704,7 +704,7 @@ template <int CD> struct PairCornerWave : WaveBase {
         lane[k].recur(true, in_corner, in_x1, P, L, mem, x1, y0);
         if (!CD && r == 1) { // the one chain visit the other corner needs
             const size_t idx = ((size_t)pl.base[gp::PAIR_BC][0] + (size_t)(0 - gp::group_of(gp::PAIR_BC, 0, P.rings).t_first)) * 64;
-            mem.lds_entry(L.b1, gp::b1_of_ring1(rec.visit[idx], x1, y0, centre_p));
+            mem.lds_entry(L.b1, gp::b1_of_ring1(rec.visit[idx - 128], rec.visit[idx - 64], rec.visit[idx], x1, y0, centre_p));
         }
         in_corner = y0;
         in_x1 = x1;
@@ -729,7 +729,7 @@ extern "C" int gg_debug_emulate_pair_sweep(int n, double resolution, float min_d
     Records rec;
     const float poison = __builtin_nanf("");
     gp::VisitRec none;
-    none.gvl = none.a = none.b = none.wn = none.o[0] = none.o[1] = none.o[2] = none.o[3] = none.o4 = none.xo = poison;
+    none.gvl = none.a = none.b = none.wn = none.nN = none.nU = none.xo = none.spare = poison;
     rec.visit.assign((size_t)pl.total_steps * 64, none);
     auto load = [&](int x, int y) { return sheared[(size_t)gp_index(P.gl, x, y)]; };
     long n_visits = 0;
@@ -742,9 +742,9 @@ extern "C" int gg_debug_emulate_pair_sweep(int n, double resolution, float min_d
                     const int l = lane & 31, side = is_x ? gp::side_x(p) : gp::side_y(p);
                     if (l >= G.nl) continue;
                     const int r = G.r0 + l, s = t - (2 * l + gp::start0(p, is_x));
-                    if (s < 0 || s >= gp::len_of(side, r)) continue;
+                    if (s < -(int)gp::WARMUP || s >= gp::len_of(side, r)) continue;
                     rec.visit[((size_t)pl.base[p][g] + (size_t)(t - G.t_first)) * 64 + lane] = gp::make_visit_rec(P, p, is_x, r, s, load);
-                    ++n_visits;
+                    n_visits += s >= 0;
                 }
         }
     rec.corner.resize(2 * (size_t)(P.rings + 1));

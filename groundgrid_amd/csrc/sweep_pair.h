@@ -16,8 +16,9 @@
 // Second change: nothing on the chain reads the layer.  Everything a visit needs that does not depend on NEW heights is known before the
 // sweep starts -- all nine confidences of its window (a cell's new confidence is a function of its old one and its position: :463-464),
 // hence gvlSum (:457), the factors (1 - occupied) and occupied * height of :460, and the products w * g of the five OLD window cells.
-// A preparation kernel (k_sweep_records: one thread per visit, no dependences) leaves one VisitRec per visit in the order the chain
-// wavefronts walk them, 64 lanes = 64 consecutive records; the chain adds the four NEW products to the tree (:458), divides, blends and
+// A preparation kernel (k_sweep_records: one thread per visit, no dependences) leaves one 32-byte VisitRec per wave-step and lane in the
+// order the chain wavefronts walk them, 64 lanes = 64 consecutive records (the OLD products arrive one window column per step, like a
+// stream; the window itself is five registers); the chain adds the four NEW products to the tree (:458), divides, blends and
 // multiplies: per visit 8 additions, an IEEE division, 2 multiplications and an addition -- the reference's float operations in the
 // reference's order (the trees are Eigen's unrolled 3x3 reduction in the side's own column-major window order, the new confidence is
 // decayed_confidence() of sweep_core.h).  The snapshot also removes every write-after-read hazard on the in-place layer: the sweep kernel
@@ -91,35 +92,65 @@ static_assert(tree_pos<SIDE_A>(1, 0) == 1 && tree_pos<SIDE_D>(0, 1) == 1 && tree
 static_assert(tree_pos<SIDE_A>(0, 1) == 5 && tree_pos<SIDE_D>(1, 0) == 5 && tree_pos<SIDE_B>(0, 1) == 7 && tree_pos<SIDE_C>(1, 0) == 7, "I1 of X = OP of Y");
 static_assert(tree_pos<SIDE_A>(0, 2) == 8 && tree_pos<SIDE_D>(0, 2) == 0 && tree_pos<SIDE_B>(0, 2) == 8 && tree_pos<SIDE_C>(0, 2) == 0, "I2: 8 for X, 0 for Y");
 
-// what the preparation leaves per chain visit (40 bytes, three arrays: 16 + 16 + 8 per record)
+// What the preparation leaves per lane and wave-step (32 bytes = two 16-byte loads).  The OLD part of a window is a stream: step s
+// brings the column behind the visited cell's successor side -- the own line's cell at along-position k0 + s + 1 and the outer line's --
+// and the window of OLD products (S N on the own line, U0 U1 U2 on the outer one) shifts by one; steps s = -2, -1 of a chain carry the two
+// columns the first visit finds already there.
 struct VisitRec {
     float gvl;        // :457 gvlSum = (window confidences).sum() + FLT_MIN, every neighbour visited earlier with its NEW confidence
     float a, b;       // :460 (1 - occupied), occupied * height of the visited cell (both OLD)
     float wn;         // :464 the visited cell's new confidence
-    float o[4];       // products w * g of the OLD window cells at the pair's COMMON tree positions
-    float o4;         // ... and at the FLEX position (0 for X, 8 for Y)
+    float nN, nU;     // products w * g of the arriving column's OLD cells: own line (the next successor), outer line
     float xo;         // last visit of a chain: the product of the inner line's successor cell, which is still OLD there (S[len + 1])
+    float spare;
+};
+enum { WARMUP = 2 }; // steps before a chain's first visit that only shift the window
+
+// the OLD products of a window (own line: self, successor; outer line: predecessor side, middle, successor side)
+struct OldWindow {
+    float S, N, U0, U1, U2;
+    SW_HD void shift(const VisitRec &R)
+    {
+        S = N;
+        N = R.nN;
+        U0 = U1;
+        U1 = U2;
+        U2 = R.nU;
+    }
 };
 
-// :458 (products).sum() in Eigen's order for a lane of either half
-template <int PAIR> SW_HD float window_sum(bool is_x, const VisitRec &R, float I0, float I1, float I2, float OP)
+// :458 (products).sum() in Eigen's order for a lane of either half.  COMMON positions: X (U1 . . N), Y (N . . U1) with (S, U2) between
+// them for the pair A/D and (U2, S) for B/C; FLEX = U0.
+template <int PAIR> SW_HD float window_sum(bool is_x, const OldWindow &O, float I0, float I1, float I2, float OP)
 {
     float e[9];
-    e[Slots<PAIR>::c0] = R.o[0];
-    e[Slots<PAIR>::c1] = R.o[1];
-    e[Slots<PAIR>::c2] = R.o[2];
-    e[Slots<PAIR>::c3] = R.o[3];
+    e[Slots<PAIR>::c0] = is_x ? O.U1 : O.N;
+    e[Slots<PAIR>::c1] = PAIR == PAIR_AD ? O.S : O.U2;
+    e[Slots<PAIR>::c2] = PAIR == PAIR_AD ? O.U2 : O.S;
+    e[Slots<PAIR>::c3] = is_x ? O.N : O.U1;
     e[Slots<PAIR>::i0] = I0;
     e[Slots<PAIR>::op_x] = is_x ? OP : I1;
     e[Slots<PAIR>::i1_x] = is_x ? I1 : OP;
-    e[0] = is_x ? R.o4 : I2;
-    e[8] = is_x ? I2 : R.o4;
+    e[0] = is_x ? O.U0 : I2;
+    e[8] = is_x ? I2 : O.U0;
     return sw_tree9(e);
 }
+static_assert(tree_pos<SIDE_A>(2, 1) == Slots<PAIR_AD>::c0 && tree_pos<SIDE_A>(1, 1) == Slots<PAIR_AD>::c1 && tree_pos<SIDE_A>(2, 2) == Slots<PAIR_AD>::c2 &&
+                  tree_pos<SIDE_A>(1, 2) == Slots<PAIR_AD>::c3 && tree_pos<SIDE_A>(2, 0) == 0, "A: U1 S U2 N, U0 at 0");
+static_assert(tree_pos<SIDE_D>(1, 2) == Slots<PAIR_AD>::c0 && tree_pos<SIDE_D>(1, 1) == Slots<PAIR_AD>::c1 && tree_pos<SIDE_D>(2, 2) == Slots<PAIR_AD>::c2 &&
+                  tree_pos<SIDE_D>(2, 1) == Slots<PAIR_AD>::c3 && tree_pos<SIDE_D>(2, 0) == 8, "D: N S U2 U1, U0 at 8");
+static_assert(tree_pos<SIDE_B>(2, 1) == Slots<PAIR_BC>::c0 && tree_pos<SIDE_B>(2, 2) == Slots<PAIR_BC>::c1 && tree_pos<SIDE_B>(1, 1) == Slots<PAIR_BC>::c2 &&
+                  tree_pos<SIDE_B>(1, 2) == Slots<PAIR_BC>::c3 && tree_pos<SIDE_B>(2, 0) == 0, "B: U1 U2 S N, U0 at 0");
+static_assert(tree_pos<SIDE_C>(1, 2) == Slots<PAIR_BC>::c0 && tree_pos<SIDE_C>(2, 2) == Slots<PAIR_BC>::c1 && tree_pos<SIDE_C>(1, 1) == Slots<PAIR_BC>::c2 &&
+                  tree_pos<SIDE_C>(2, 1) == Slots<PAIR_BC>::c3 && tree_pos<SIDE_C>(2, 0) == 8, "C: N U2 S U1, U0 at 8");
 // :458 / :460 from the tree sum
 SW_HD float height_of(float gvl, float a, float b, float sum)
 {
+#ifdef GG_PAIR_X_NODIV
+    const float avg = sum * gvl; // (timing experiment: k4p_sweep_pair.hip)
+#else
     const float avg = sum / gvl;
+#endif
     return a * avg + b;
 }
 
@@ -128,7 +159,7 @@ SW_HD float height_of(float gvl, float a, float b, float sum)
 // ---------------------------------------------------------------------------------------------------------------------
 struct Group {
     int r0, nl;          // first ring, rings (<= 32)
-    int t_first, t_last; // wave-steps of the group (t_first = -1: a chain of one visit takes its join at "step -1")
+    int t_first, t_last; // wave-steps of the group (t_first = -2: the first lane's window warms up two steps before its first visit)
     int steps;           // t_last - t_first + 1 rounded up to whole trips
 };
 SW_HD Group group_of(int pair, int g, int rings)
@@ -136,7 +167,7 @@ SW_HD Group group_of(int pair, int g, int rings)
     Group G;
     G.r0 = HALF * g + 1;
     G.nl = rings - (G.r0 - 1) < (int)HALF ? rings - (G.r0 - 1) : (int)HALF;
-    G.t_first = -1;
+    G.t_first = -(int)WARMUP;
     G.t_last = 2 * (G.nl - 1) + start0(pair, false) + len_of(side_y(pair), G.r0 + G.nl - 1) - 1; // Y of the last ring ends last
     const int n = G.t_last - G.t_first + 1;
     G.steps = (n + PTRIP - 1) / PTRIP * PTRIP;
@@ -220,17 +251,24 @@ SW_HD float final_confidence(const Params &P, int x, int y, float w_old)
     return w;
 }
 
+// the record of step s of chain (side, ring r), s in [-WARMUP, len)
 template <class Load> SW_HD VisitRec make_visit_rec(const Params &P, int pair, bool is_x, int r, int s, Load load)
 {
     const int side = is_x ? side_x(pair) : side_y(pair);
     const int len = len_of(side, r), k = k0_of(side) + s;
-    const bool ad = pair == PAIR_AD;
-    const int common[4] = {ad ? 3 : 1, ad ? 4 : 2, ad ? 6 : 4, ad ? 7 : 5};
-    const int flex = is_x ? 0 : 8;
-    float w[9];
     VisitRec R;
-    R.o[0] = R.o[1] = R.o[2] = R.o[3] = R.o4 = R.xo = 0.f;
-    R.a = R.b = R.wn = 0.f;
+    R.gvl = R.a = R.b = R.wn = R.xo = R.spare = 0.f;
+    {   // the arriving column of OLD cells: along-position k + 1 of the own and of the outer line
+        int x, y;
+        side_xy(side, P.c, r, 0, k + 1, x, y);
+        const Cell own = load(x, y);
+        side_xy(side, P.c, r, 1, k + 1, x, y);
+        const Cell outer = load(x, y);
+        R.nN = own.w * own.g;
+        R.nU = outer.w * outer.g;
+    }
+    if (s < 0) return R; // (a warm-up step: no visit)
+    float w[9];
     for (int line = 0; line < 3; ++line)     // 0 inner, 1 own, 2 outer
         for (int pos = 0; pos < 3; ++pos) { // 0 predecessor, 1 self, 2 successor
             int x, y;
@@ -238,15 +276,8 @@ template <class Load> SW_HD VisitRec make_visit_rec(const Params &P, int pair, b
             const Cell v = load(x, y);
             const bool last_succ = line == 0 && pos == 2 && s == len - 1; // S[len + 1]: belongs to a chain that has not got there yet
             const bool is_new = (line == 0 && !last_succ) || (line == 1 && pos == 0);
-            const int q = tree_pos_of(side, line, pos);
-            w[q] = is_new ? final_confidence(P, x, y, v.w) : v.w;
-            const float p_old = v.w * v.g;
-            if (last_succ) R.xo = p_old;
-            if (!is_new && !last_succ) {
-                if (q == flex) R.o4 = p_old;
-                for (int i = 0; i < 4; ++i)
-                    if (q == common[i]) R.o[i] = p_old;
-            }
+            w[tree_pos_of(side, line, pos)] = is_new ? final_confidence(P, x, y, v.w) : v.w;
+            if (last_succ) R.xo = v.w * v.g;
             if (line == 1 && pos == 1) {
                 R.a = 1.0f - v.w; // :460
                 R.b = v.w * v.g;
@@ -362,6 +393,7 @@ template <int PAIR> struct PairLane {
     // state: the inner line S[s], S[s+1], S[s+2]; the last two results.  h1 is the predecessor's product of the next visit, the join the
     // partner lane takes one step after this chain's end, and -- a step later, as h2 -- what lane l + 1 reads as its S[s + 2]
     float I0, I1, I2, h1, h2;
+    OldWindow O; // the window's OLD products (a column arrives per step: VisitRec)
 
     SW_HD void init(int lane, int group, const Group &G, const Params &P, const Plan &pl, const Lds &L)
     {
@@ -405,6 +437,7 @@ template <int PAIR> struct PairLane {
         // export: the last lane of a half, when a group follows
         pb = (l == (int)HALF - 1 && group + 1 < pl.groups) ? half_base + 2 * (pl.bnd_off[group] - start) : -1;
         I0 = I1 = I2 = h1 = h2 = 0.f;
+        O.S = O.N = O.U0 = O.U1 = O.U2 = 0.f;
     }
     // what wave-step t of this lane reads from other wavefronts (the wavefront may run the step once all of it is there)
     SW_HD bool first_at(int t) const { return live && t == start; } // (ring 1 of side A has no chain, but its "first step" still takes A_1(1): D's join)
@@ -436,10 +469,11 @@ template <int PAIR> struct PairLane {
             if (len != 1) I1 = mem.lds_f(a_s1); // (a chain of one visit: S[1] is the join, taken a step ago)
         }
         const bool active = (unsigned)s < (unsigned)len;
-        const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR>(is_x, R, I0, I1, I2, h1));
+        O.shift(R); // (the record's column is this visit's successor column)
+        const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR>(is_x, O, I0, I1, I2, h1));
         const float res = R.wn * g;
 #if !defined(__HIP_DEVICE_COMPILE__)
-        if (getenv("GG_PAIR_DBG") && active && r == atoi(getenv("GG_PAIR_DBG")) && s < 3) fprintf(stderr, "pair %d x %d r %d s %d t %d: I %g %g %g pred %g | gvl %g a %g b %g wn %g o %g %g %g %g %g xo %g -> g %g\n", PAIR, (int)is_x, r, s, t, I0, I1, I2, h1, R.gvl, R.a, R.b, R.wn, R.o[0], R.o[1], R.o[2], R.o[3], R.o4, R.xo, g);
+        if (getenv("GG_PAIR_DBG") && active && r == atoi(getenv("GG_PAIR_DBG")) && s < 3) fprintf(stderr, "pair %d x %d r %d s %d t %d: I %g %g %g pred %g | gvl %g a %g b %g wn %g o %g %g %g %g %g xo %g -> g %g\n", PAIR, (int)is_x, r, s, t, I0, I1, I2, h1, R.gvl, R.a, R.b, R.wn, O.S, O.N, O.U0, O.U1, O.U2, R.xo, g);
 #endif
         // the height goes to the result stream, 64 lanes = 64 consecutive floats (the lanes' cells lie in 64 different lines of the layer: a
         // scattered store costs the CU's memory front end more than the rest of the step); finish_cell() puts it into the layer
@@ -478,7 +512,7 @@ SW_HD bool chain_slot_of_cell(const Params &P, const Plan &pl, int x, int y, int
     const bool is_x = side == SIDE_A || side == SIDE_B;
     const int g = (r - 1) / HALF, l = (r - 1) % HALF;
     const int t = s + 2 * l + start0(pair, is_x);
-    slot = (pl.base[pair][g] + t - (-1)) * 64 + l + (is_x ? 0 : (int)HALF); // (t_first = -1)
+    slot = (pl.base[pair][g] + t + (int)WARMUP) * 64 + l + (is_x ? 0 : (int)HALF); // (t_first = -WARMUP)
     return true;
 }
 // ... and what the cell holds after the sweep: the streamed height, its own decayed confidence (:463-464; a chain cell is visited once)
@@ -540,9 +574,12 @@ template <int CD> struct CornerLane {
     }
 };
 // B_1 of ring 1 from the AB corner's results (A_1(1), B_0(1)) and the record of that visit (pair B/C, group 0, lane 0, wave-step 0)
-SW_HD float b1_of_ring1(const VisitRec &R, float a1p, float b0p, float centre_p)
+// (W2, W1: that lane's records of steps -2 and -1 -- its window's first two columns)
+SW_HD float b1_of_ring1(const VisitRec &W2, const VisitRec &W1, const VisitRec &R, float a1p, float b0p, float centre_p)
 {
-    const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR_BC>(true, R, a1p, centre_p, R.xo, b0p));
+    OldWindow O;
+    O.S = W1.nN, O.N = R.nN, O.U0 = W2.nU, O.U1 = W1.nU, O.U2 = R.nU;
+    const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR_BC>(true, O, a1p, centre_p, R.xo, b0p));
     return R.wn * g;
 }
 
