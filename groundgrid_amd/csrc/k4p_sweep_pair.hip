@@ -105,6 +105,11 @@ struct PairMem {
     GG_DEV uint32_t lds_base() const { return (uint32_t)(uintptr_t)lds; }
     GG_DEV float lds_f(int word) const { return __int_as_float(__hip_atomic_load(lds + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
     GG_DEV void lds_put(int word, float v) const { __hip_atomic_store(lds + word, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    GG_DEV void lds_put2(int word, float v0, float v1) const
+    {
+        const uint64_t u = (uint64_t)__float_as_uint(v0) | ((uint64_t)__float_as_uint(v1) << 32);
+        __hip_atomic_store((lds_u64 *)(lds + word), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     GG_DEV void lds_entry(int word, float v) const
     {
         const uint64_t u = (uint64_t)__float_as_uint(v) | (1ull << 32);
@@ -249,7 +254,8 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
             if (kimp >= 2) entry_issue(imp_addr(tb), ent_q);
             // scalar byte offsets of the step's record block (+ PF steps: the request) and of its row of the result stream
             uint32_t rec_soff = (uint32_t)(step0 + (tb - G.t_first) + PF) * (uint32_t)(STEP_FLOATS * 4);
-            uint32_t out_soff = (uint32_t)(step0 + (tb - G.t_first)) * 256u;
+            uint32_t out_soff = (uint32_t)(step0 + (tb - G.t_first)) * 256u; // (a row of the result stream = 4 steps x 64 lanes x 4 bytes)
+            u32x4 g4{0u, 0u, 0u, 0u};
             float cs0 = 0.f, cs1 = 0.f, cpred = 0.f;
             if (K::starts == 2) { // the corner values of the lanes that start in [tb, tb + 12): once, up front
                 const int te = tb + (int)PAIR_TRIP;
@@ -370,14 +376,25 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
                     st.I0 = first ? cs0 : st.I0;
                     st.I1 = first ? cs1 : st.I1; // (chains of one visit -- ring 1 -- start in the generic trip)
                 }
-                // ---- the visit; its height goes to the result stream, 64 lanes = 256 contiguous bytes (idle lanes write a slot nobody reads)
+                // ---- the visit; its height goes to the result stream (idle lanes write slots nobody reads)
                 st.O.shift(R);
                 const float g = sp::height_of(R.gvl, R.a, R.b, sp::window_sum<PAIR>(is_x, st.O, st.I0, st.I1, st.I2, st.h1));
                 const float res = R.wn * g;
+                g4[u & 3] = __float_as_uint(g);
+                if ((u & 3) == 3) { // four steps of a lane = 16 contiguous bytes, one store (sweep_pair.h out_slot)
 #ifndef GG_PAIR_X_NOSTORE
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g), out, (uint32_t)lane * 4u, out_soff, 0);
+#ifdef GG_PAIR_X_STORE4
+                    for (int k4 = 0; k4 < 4; ++k4) __builtin_amdgcn_raw_buffer_store_b32(g4[k4], out, (uint32_t)lane * 16u + 4u * k4, out_soff, 0);
+#else
+                    // (the row's offset goes into the VECTOR offset on purpose.  A 16-byte buffer store whose offset sits in a scalar register
+                    // is still reading its data registers when the next instruction issues -- a select that reused g4's first register
+                    // put LDS addresses into the stream, on some boxes, in some lanes -- and the compiler only keeps writers away from the
+                    // data of stores WITHOUT a scalar offset register: tools/pair_race.py found it)
+                    __builtin_amdgcn_raw_buffer_store_b128(g4, out, (uint32_t)lane * 16u + out_soff, 0, 0);
 #endif
-                out_soff += 256u;
+#endif
+                    out_soff += 1024u;
+                }
                 st.h2 = st.h1;
                 st.h1 = res;
                 if (kexp == 2) {
@@ -437,10 +454,15 @@ GG_DEV void run_pair_corner(const Params &P, const sp::Plan &pl, const sp::Lds &
                 }
                 in_x1 = __uint_as_float((uint32_t)ent);
             }
-            float x1, y0;
-            st.recur(lane == l, in_corner, in_x1, P, L, mem, x1, y0);
+            float x1g, x1, y0g, y0;
+            st.visits(in_corner, in_x1, x1g, x1, y0g, y0);
+            st.keep(lane == l, x1g, y0g);
+#ifdef GG_PAIR_X_FLUSHEACH
+            st.flush(lane == l, mem);
+#endif
             in_corner = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y0), l));
             in_x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), l));
+            if (lane == 0) sp::CornerLane<CD>::publish(r0 + l, in_x1, in_corner, P, L, mem); // (uniform values: one lane writes)
             if (!CD && r0 + l == 1) { // the one chain visit the CD corner needs: B_1(1) = pair B/C, group 0, lane 0, wave-step 0
                 const float *blk = rec + ((size_t)pl.base[sp::PAIR_BC][0] + (size_t)(0 - sp::group_of(sp::PAIR_BC, 0, P.rings).t_first)) * STEP_FLOATS;
                 auto rec_of = [&](int back) { // lane 0's record of wave-step 0 - back
@@ -454,6 +476,7 @@ GG_DEV void run_pair_corner(const Params &P, const sp::Plan &pl, const sp::Lds &
                 if (lane == 0) mem.lds_entry(L.b1, b1);
             }
         }
+        st.flush(lane < nl, mem); // the batch's cells, one store per lane
         if (dbg && lane == 0 && r0 / 64 < 8) dbg[3 + 2 * (r0 / 64)] = __builtin_readcyclecounter(); // (... and its rings are done)
     }
 }
@@ -489,7 +512,15 @@ __global__ __launch_bounds__(THREADS) void k_sweep_pair(const Arena a, const Par
     unsigned long long *dbg = (a.pair_dbg && cloud == 0) ? a.pair_dbg + ((size_t)which * 16 + wave) * 32 : nullptr;
     if (dbg && lane == 0) dbg[0] = __builtin_readcyclecounter();
     if (wave < n_chain) {
-        const int p = BOTH ? (wave & 1) : which, w = BOTH ? (wave >> 1) : wave;
+        // wavefront ids go to the CU's four SIMDs round-robin.  The corner wavefronts (ids n_chain, n_chain + 1) work while the inner groups
+        // do; the two chain wavefronts that share their SIMDs take the LAST groups, which start when the corners are nearly done
+        int p = BOTH ? (wave & 1) : which, w = BOTH ? (wave >> 1) : wave;
+#ifndef GG_PAIR_X_NOREMAP
+        if (!BOTH && W >= 4 && ((n_chain & 3) == 2)) { // ids 2, 3 share SIMDs with the corners (n_chain = 2 mod 4): swap them with the last two
+            if (w == 2 || w == 3) w = W - 4 + w;         // ... wavefronts of the pair
+            else if (w >= W - 2) w = w - (W - 4);
+        }
+#endif
         const __amdgpu_buffer_rsrc_t rrec = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rec), 0, (int)(RL.corner * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rec) + RL.out, 0, (int)((RL.floats - RL.out) * 4), 0x00020000);
         if (p == 0) run_pair<sp::PAIR_AD, PF>(P, pl, L, mem, rrec, rout, w, W, lane, centre_p, dbg);

@@ -593,6 +593,12 @@ struct PairHostMem { // one per emulated work-group
         ++lds_ops;
         memcpy(&lds[(size_t)word], &v, 4);
     }
+    void lds_put2(int word, float v0, float v1)
+    {
+        if (word & 1) fault = true; // (one 8-byte write on the device)
+        lds_put(word, v0);
+        lds_put(word + 1, v1);
+    }
     void lds_entry(int word, float v)
     {
         lds_put(word, v);
@@ -644,7 +650,7 @@ template <int PAIR> struct PairWave : WaveBase {
                 gp::side_xy(side, P.c, c.r, 0, gp::k0_of(side) + s, x, y);
                 if (c.st_base + 64 * (c.start + s) != gp_index(P.gl, x, y)) plan_mismatch = true;
                 int slot = -1;
-                if (!gp::chain_slot_of_cell(P, pl, x, y, slot) || slot != c.out_base + 64 * (c.start + s)) plan_mismatch = true; // the finish finds this visit's height
+                if (!gp::chain_slot_of_cell(P, pl, x, y, slot) || slot != gp::out_slot(c.out_step0 + c.start + s, c.lane_)) plan_mismatch = true; // the finish finds this visit's height
             }
         }
         t = G.t_first;
@@ -700,8 +706,11 @@ template <int CD> struct PairCornerWave : WaveBase {
                 const int ring = r + j;
                 lane[j].init(ring, P, rec.corner[(size_t)CD * (P.rings + 1) + (ring <= P.rings ? ring : P.rings)]);
             }
-        float x1, y0;
-        lane[k].recur(true, in_corner, in_x1, P, L, mem, x1, y0);
+        float x1g, x1, y0g, y0;
+        lane[k].visits(in_corner, in_x1, x1g, x1, y0g, y0);
+        lane[k].keep(true, x1g, y0g);
+        lane[k].flush(true, mem);
+        gp::CornerLane<CD>::publish(r, x1, y0, P, L, mem);
         if (!CD && r == 1) { // the one chain visit the other corner needs
             const size_t idx = ((size_t)pl.base[gp::PAIR_BC][0] + (size_t)(0 - gp::group_of(gp::PAIR_BC, 0, P.rings).t_first)) * 64;
             mem.lds_entry(L.b1, gp::b1_of_ring1(rec.visit[idx - 128], rec.visit[idx - 64], rec.visit[idx], x1, y0, centre_p));

@@ -204,6 +204,10 @@ inline Plan make_plan(int rings)
     return pl;
 }
 
+// Where the height of (wave-step record `step`, lane) sits in the result stream: four consecutive steps of a lane are 16 contiguous
+// bytes (the device stores them with one instruction), 64 lanes x 16 bytes a row.
+SW_HD int out_slot(int step, int lane) { return (((step >> 2) * 64 + lane) << 2) + (step & 3); }
+
 // LDS image of one work-group (4-byte words).  Boundary entries are (value, tag) pairs: tag != 0 = published.
 struct Lds {
     int cnt_corner; // [2] rings finished by the AB / CD corner wavefront
@@ -370,7 +374,7 @@ template <int CD, class Load> SW_HD CornerRec make_corner_rec(const Params &P, i
 // ---------------------------------------------------------------------------------------------------------------------
 // Memory back end of the chain / corner code (device: k4p_sweep_pair.hip PairMem; host: sweep_emul.hip PairHostMem)
 //   float lds_f(int word)                 read a float another wavefront may have written
-//   void  lds_put(int word, float v)
+//   void  lds_put(int word, float v)  /  lds_put2(int word, float v0, float v1)   (two consecutive words, 8-byte aligned, one write)
 //   void  lds_entry(int word, float v)    (v, tag 1) as ONE 8-byte write
 //   int   lds_i(int word)  /  void lds_set(int word, int v)
 //   void  store(bool valid, int cell, Cell v)     the layer (fire and forget; the corner wavefronts only)
@@ -383,7 +387,7 @@ template <int PAIR> struct PairLane {
     bool is_x, live, jl_lane; // half; the lane has a ring; X lane 0: its join comes from LDS (the group inside, or the centre for ring 1)
     int l, r, len, start;
     int st_base;            // layer element of the cell visited at wave-step t = st_base + 64 t (the emulation holds finish_cell's inverse map to it)
-    int out_base;           // where the height of wave-step t goes in the result stream: out_base + 64 t
+    int out_step0, lane_;   // the height of wave-step t goes to out_slot(out_step0 + t, lane_) of the result stream
     int a_s0, a_s1, a_pred; // LDS words of S[0], S[1] and the first predecessor (corner table)
     int a_bnd;              // lane 0 of a half, group > 0: (value, tag) of wave-step t = a_bnd + 2 t while the step imports (others: never)
     int a_jl;               // X lane 0: LDS entry (value, tag) of the join
@@ -408,7 +412,8 @@ template <int PAIR> struct PairLane {
         int x, y;
         side_xy(side, P.c, r, 0, 1, x, y);
         st_base = gp_index(P.gl, x, y) + 64 * (k0_of(side) - 1 - start);
-        out_base = (pl.base[PAIR][group] - G.t_first) * 64 + lane;
+        out_step0 = pl.base[PAIR][group] - G.t_first;
+        lane_ = lane;
         cd = (side == SIDE_A || side == SIDE_B) ? 0 : 1;
         if (side == SIDE_A) { // S[0] = B_0(r-1), S[1] = A_1(r-1), predecessor A_1(r)
             a_s0 = corner_word(L, P.c, cd, r - 1, 1);
@@ -477,7 +482,7 @@ template <int PAIR> struct PairLane {
 #endif
         // the height goes to the result stream, 64 lanes = 64 consecutive floats (the lanes' cells lie in 64 different lines of the layer: a
         // scattered store costs the CU's memory front end more than the rest of the step); finish_cell() puts it into the layer
-        if (active) mem.emit(out_base + 64 * t, g);
+        if (active) mem.emit(out_slot(out_step0 + t, lane_), g);
         h2 = h1;
         h1 = res;
         if (pb >= 0 && active) mem.lds_entry(pb + 2 * t, res);
@@ -512,7 +517,7 @@ SW_HD bool chain_slot_of_cell(const Params &P, const Plan &pl, int x, int y, int
     const bool is_x = side == SIDE_A || side == SIDE_B;
     const int g = (r - 1) / HALF, l = (r - 1) % HALF;
     const int t = s + 2 * l + start0(pair, is_x);
-    slot = (pl.base[pair][g] + t + (int)WARMUP) * 64 + l + (is_x ? 0 : (int)HALF); // (t_first = -WARMUP)
+    slot = out_slot(pl.base[pair][g] + t + (int)WARMUP, l + (is_x ? 0 : (int)HALF)); // (t_first = -WARMUP)
     return true;
 }
 // ... and what the cell holds after the sweep: the streamed height, its own decayed confidence (:463-464; a chain cell is visited once)
@@ -550,27 +555,38 @@ template <int CD> struct CornerLane {
         }
         return sw_tree9(e);
     }
-    // ring r's visits, given in_corner = Y_0 of ring r - 1 (ring 0: the centre) and in_x1 = X_1 of ring r - 1 (ring 1 of CD: B_1(1))
-    template <class Mem> SW_HD void recur(bool mine, float in_corner, float in_x1_ring, const Params &P, const Lds &L, Mem &mem, float &x1_out, float &y0_out)
+    // ring r's three visits, given in_corner = Y_0 of ring r - 1 (ring 0: the centre) and in_x1 = X_1 of ring r - 1 (ring 1 of CD: B_1(1)):
+    // heights and products of X_1 and of the revisit Y_0
+    SW_HD void visits(float in_corner, float in_x1_ring, float &x1g, float &x1p, float &y0g, float &y0p) const
     {
         using S = CornerSlots<CD>;
         const float in_x1 = (r == 1 && !CD) ? R.oin : in_x1_ring;
         const float x0g = height_of(R.gvl[0], R.a[0], R.b[0], tree_with<8>(R.o0, S::x0_in, in_corner, -1, 0.f, -1, 0.f));
         const float x0p = R.wn[0] * x0g;
-        const float x1g = height_of(R.gvl[1], R.a[1], R.b[1], tree_with<6>(R.o1, S::x1_x0, x0p, S::x1_in, in_corner, S::x1_x1, in_x1));
-        const float x1p = R.wn[1] * x1g;
+        x1g = height_of(R.gvl[1], R.a[1], R.b[1], tree_with<6>(R.o1, S::x1_x0, x0p, S::x1_in, in_corner, S::x1_x1, in_x1));
+        x1p = R.wn[1] * x1g;
         // the revisit: occupied * height = the first visit's confidence times the height it left = its product, the same two floats
-        const float y0g = height_of(R.gvl[2], R.a[2], x0p, tree_with<6>(R.o2, S::y0_x0, x0p, S::y0_x1, x1p, S::y0_in, in_corner));
-        const float y0p = R.wn[2] * y0g;
-        mem.store(mine, e00, Cell{y0g, R.wn[2]});
-        mem.store(mine, e0m1, Cell{x1g, R.wn[1]});
-        if (mine) {
-            mem.lds_put(corner_word(L, P.c, CD, r, 0), x1p);
-            mem.lds_put(corner_word(L, P.c, CD, r, 1), y0p);
-            mem.lds_set(L.cnt_corner + CD, r); // (after the values: one wavefront's LDS operations execute in order)
-        }
-        x1_out = x1p;
-        y0_out = y0p;
+        y0g = height_of(R.gvl[2], R.a[2], x0p, tree_with<6>(R.o2, S::y0_x0, x0p, S::y0_x1, x1p, S::y0_in, in_corner));
+        y0p = R.wn[2] * y0g;
+    }
+    // the two cells of the ring: kept by the lane whose ring it is, stored once per batch of rings (nothing reads the layer meanwhile)
+    float kx1g = 0.f, ky0g = 0.f;
+    SW_HD void keep(bool mine, float x1g, float y0g)
+    {
+        kx1g = mine ? x1g : kx1g;
+        ky0g = mine ? y0g : ky0g;
+    }
+    template <class Mem> SW_HD void flush(bool done, Mem &mem) const
+    {
+        mem.store(live && done, e00, Cell{ky0g, R.wn[2]});
+        mem.store(live && done, e0m1, Cell{kx1g, R.wn[1]});
+    }
+    // what the chains of ring r (and r + 1) take at their first steps: the two products, then the ring count (one wavefront's LDS
+    // operations execute in order)
+    template <class Mem> SW_HD static void publish(int ring, float x1p, float y0p, const Params &P, const Lds &L, Mem &mem)
+    {
+        mem.lds_put2(corner_word(L, P.c, CD, ring, 0), x1p, y0p);
+        mem.lds_set(L.cnt_corner + CD, ring);
     }
 };
 // B_1 of ring 1 from the AB corner's results (A_1(1), B_0(1)) and the record of that visit (pair B/C, group 0, lane 0, wave-step 0)

@@ -1,8 +1,6 @@
-# scratch: what the next gpurun call runs (edited per call)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for v in base nodiv nolds nostore noload noperm none4; do
-  if [ $v = base ]; then unset GROUNDGRID_HIP_LIB; else export GROUNDGRID_HIP_LIB=$GRAFT_REPO_ROOT/groundgrid_amd/variants/lib_$v.so; fi
-  echo "== $v"
-  timeout 300 python tools/pair_timing.py 2>&1 | grep "wg 1" | grep "wave  [0567]"
-done 2>&1 | tee gpurun_out/pair_variants.log
+timeout 900 python tools/pair_race.py 12 30 2>&1 | grep -v amdgpu.ids | cut -c1-600 | sort | uniq -c | tee gpurun_out/pair_race.log
+timeout 300 python tools/pair_timing.py 2>&1 | grep "wg 1" | tee gpurun_out/pair_timing.log
+timeout 600 python tools/pair_ab.py 1 2>&1 | tee gpurun_out/pair_ab.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/tests.log

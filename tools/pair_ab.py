@@ -34,6 +34,20 @@ def run(length, res, cloud, batch, knobs, steps=20, check=False):
         g = seg.map(batch - 1)["ground"]
         w = seg.map(batch - 1)["groundpatch"]
         ok = bool(np.array_equal(g, ref.layer("ground"), equal_nan=True) and np.array_equal(w, ref.layer("groundpatch"), equal_nan=True))
+        if not ok and os.environ.get("PAIR_AB_VERBOSE"):
+            n = g.shape[0]; c = n // 2 - 1
+            bad = np.argwhere(~((g == ref.layer("ground")) | (np.isnan(g) & np.isnan(ref.layer("ground")))))
+            from collections import Counter
+            cnt = Counter(); first = {}
+            for x, y in bad.tolist():
+                dx, dy = x - c, y - c; r = max(abs(dx), abs(dy))
+                if dx == -r and dy < r: side, k = 'A', y - (c - r)
+                elif dx == r: side, k = 'C', (c + r) - y
+                elif dy == -r: side, k = 'B', x - (c - r)
+                else: side, k = 'D', (c + r) - x
+                cnt[(r, side)] += 1; first[(r, side)] = min(first.get((r, side), 10**9), k)
+            print("   ground differs in", len(bad), "cells; w differs in", int((w != ref.layer("groundpatch")).sum()), "; by (ring, side): count, first position:",
+                  [(k, cnt[k], first[k]) for k in sorted(cnt)][:24], flush=True)
     seg.close()
     return {"ms_per_step": round(dt * 1e3, 4), "k_sweep": kt.get("k_sweep"), "parity": ok}
 
