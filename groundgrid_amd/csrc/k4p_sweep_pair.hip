@@ -32,20 +32,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) int lds_int;
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
 
-// records of one cloud inside the scratch region (floats): per wave-step a block of 512 floats -- 64 x (gvl, a, b, wn), 64 x (nN, nU, xo,
-// spare): two coalesced 16-byte loads per lane at one scalar offset -- for total_steps + PPF + 1 wave-steps (the queue reads PPF steps
-// past the end), then 32 planes [2][ring_pad] of the corner records
-enum { STEP_FLOATS = 512 };
+// records of one cloud inside the scratch region (floats): quad blocks of 1280 floats (sweep_pair.h quad_word: four wave-steps x 64 lanes
+// as five 16-byte words per lane) for total_steps / 4 + 4 quads (the queue reads three quads ahead), then 32 planes [2][ring_pad] of the
+// corner records, then the result stream
 struct RecLayout {
     size_t corner, ring_pad, out, floats; // (out: the chains' result stream, one float per record)
 };
 static __host__ __device__ RecLayout rec_layout(const sp::Plan &pl, int rings)
 {
     RecLayout R;
-    R.corner = ((size_t)pl.total_steps + sp::PPF + 1) * STEP_FLOATS;
+    R.corner = ((size_t)pl.total_steps / 4 + 4) * sp::QUAD_BLOCK_FLOATS;
     R.ring_pad = ((size_t)rings + 1 + 63) / 64 * 64 + 64;
     R.out = R.corner + (size_t)sp::CORNER_REC_FLOATS * 2 * R.ring_pad;
-    R.floats = R.out + ((size_t)pl.total_steps + 1) * 64;
+    R.floats = R.out + ((size_t)pl.total_steps + 4) * 64;
     return R;
 }
 size_t sweep_pair_rec_floats(const Params &P)
@@ -69,21 +68,24 @@ __global__ __launch_bounds__(256) void k_sweep_records(const Arena a, const Para
         return Cell{v.x, v.y};
     };
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t n_visit = (size_t)pl.total_steps * 64;
+    const size_t n_visit = (size_t)pl.total_steps / 4 * 64; // one thread per (quad of wave-steps, lane): the four windows share their cells
     if (e < n_visit) {
-        const int step = (int)(e >> 6), lane = (int)(e & 63);
+        // (a wavefront = one half -- one side of the spiral: no divergence on it -- of two consecutive quads)
+        const int half = (int)(e >> 6) & 1, lane = half * (int)sp::HALF + (int)(e & 31);
+        const int step = ((int)(e >> 7) * 2 + ((int)(e >> 5) & 1)) * 4;
         int p = step >= pl.base[1][0] ? 1 : 0, g = 0;
         while (g + 1 < pl.groups && step >= pl.base[p][g + 1]) ++g; // (wave-uniform)
         const sp::Group G = sp::group_of(p, g, P.rings);
-        const int t = G.t_first + (step - pl.base[p][g]);
+        const int t0 = G.t_first + (step - pl.base[p][g]);
         const bool is_x = lane < (int)sp::HALF;
         const int l = lane & (sp::HALF - 1), side = is_x ? sp::side_x(p) : sp::side_y(p);
-        const int r = G.r0 + l, s = t - (2 * l + sp::start0(p, is_x));
-        if (l >= G.nl || s < -(int)sp::WARMUP || s >= sp::len_of(side, r)) return; // (the chain lane is idle at this step and uses nothing of the record)
-        const sp::VisitRec R = sp::make_visit_rec(P, p, is_x, r, s, load);
-        float *blk = rec + (size_t)step * STEP_FLOATS;
-        if (s >= 0) reinterpret_cast<float4 *>(blk)[lane] = make_float4(R.gvl, R.a, R.b, R.wn);
-        reinterpret_cast<float4 *>(blk + 256)[lane] = make_float4(R.nN, R.nU, R.xo, 0.f);
+        const int r = G.r0 + l, len = sp::len_of(side, r), s0 = t0 - (2 * l + sp::start0(p, is_x));
+        if (l >= G.nl || s0 + 3 < -(int)sp::WARMUP || s0 > len) return; // (the chain lane is idle at these steps and uses nothing of the records)
+        float q[sp::QUAD_FLOATS];
+        sp::make_visit_quad(P, p, is_x, r, s0, load, q);
+        // (steps of the quad outside [-WARMUP, len] come out as zeros: nobody reads them)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) reinterpret_cast<float4 *>(rec + sp::quad_word(step, lane, c))[0] = make_float4(q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]);
         return;
     }
     const size_t k = e - n_visit;
@@ -157,15 +159,29 @@ GG_DEV float partner_both(float h1)
 //   -DGG_PAIR_X_NODIV    a multiplication instead of the IEEE division       -DGG_PAIR_X_NOSTORE  no store into the result stream
 //   -DGG_PAIR_X_NOLDS    no import / export / join through LDS (nor waits)    -DGG_PAIR_X_NOLOAD   the record queue is never refilled
 //   -DGG_PAIR_X_NOPERM   no exchange of the halves' last results
-template <int PF> struct RecQueue {
-    u32x4 q0[PF], q1[PF];
+// three quads of records in flight per lane (sweep_pair.h quad_word): slot j of a trip holds the trip's j-th quad.  A slot is refilled
+// while the NEXT quad runs, one 16-byte word per step (two in the first: a burst of five loads behind one step stalled the wavefront at
+// the memory pipeline's door) -- every word at least 7 steps before its first use
+struct RecQueue {
+    u32x4 c[3][5];
 };
-// the three parts of wave-step `step`'s record block for this lane (voff = lane * 16)
-template <int PF> GG_DEV void rec_request(RecQueue<PF> &Q, int slot, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int step)
+GG_DEV void quad_request(RecQueue &Q, int slot, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t quad_soff)
 {
-    const uint32_t soff = (uint32_t)step * (uint32_t)(STEP_FLOATS * 4);
-    Q.q0[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
-    Q.q1[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, soff, 0);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) Q.c[slot][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u * (uint32_t)k, quad_soff, 0);
+}
+GG_DEV void word_request(RecQueue &Q, int slot, int k, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t quad_soff)
+{
+    Q.c[slot][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u * (uint32_t)k, quad_soff, 0);
+}
+// the record of step u of the trip (u = 12: the next trip's first, already in slot 0)
+GG_DEV sp::VisitRec quad_rec(const RecQueue &Q, int u)
+{
+    const int slot = (u >> 2) % 3, i = u & 3;
+    sp::VisitRec R;
+    R.gvl = __uint_as_float(Q.c[slot][i].x), R.a = __uint_as_float(Q.c[slot][i].y), R.b = __uint_as_float(Q.c[slot][i].z), R.wn = __uint_as_float(Q.c[slot][i].w);
+    R.nU = __uint_as_float(Q.c[slot][4][i]);
+    return R;
 }
 
 // Which of a lane's rare events a wave-step can hold follows from t mod 4 alone: X(r) ends at 4 l + 2 r0 + b - 1 (r0 = 1 mod 32), so the
@@ -204,18 +220,21 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
 {
     unsigned long long wait_corner = 0, wait_import = 0, n_wait = 0; // (tools: GG_PAIR_TIMING)
     int gi = 0;
-    static_assert((int)sp::PTRIP == (int)PAIR_TRIP && PAIR_TRIP % PF == 0 && PF <= (int)sp::PPF, "a record's queue slot and a step's residue are constants of the unrolled loop");
+    static_assert((int)sp::PTRIP == (int)PAIR_TRIP && PAIR_TRIP == 3 * (int)sp::QUAD, "a trip is three quads of records; a step's residue and queue slot are constants of the unrolled loop");
+    (void)PF;
     sp::PairLane<PAIR> st;
     const bool is_x = lane < (int)sp::HALF;
     for (int group_ = w; group_ < pl.groups; group_ += W) {
         const int group = __builtin_amdgcn_readfirstlane(group_); // (wave-uniform, and the compiler must know: it becomes scalar offsets)
         const sp::Group G = sp::group_of(PAIR, group, P.rings);
         st.init(lane, group, G, P, pl, L);
-        const int step0 = __builtin_amdgcn_readfirstlane(pl.base[PAIR][group]); // first record block of the group
+        const int step0 = __builtin_amdgcn_readfirstlane(pl.base[PAIR][group]); // first wave-step record of the group
         const uint32_t voff = (uint32_t)lane * 16u;
-        RecQueue<PF> Q;
+        constexpr uint32_t QUAD_BYTES = (uint32_t)sp::QUAD_BLOCK_FLOATS * 4u;
+        RecQueue Q;
 #pragma unroll
-        for (int k = 0; k < PF; ++k) rec_request(Q, k, rec, voff, step0 + k);
+        for (int k = 0; k < 2; ++k) quad_request(Q, k, rec, voff, (uint32_t)(step0 / 4 + k) * QUAD_BYTES); // (the third slot fills during the first quad)
+        Q.c[2][0] = Q.c[2][1] = Q.c[2][2] = Q.c[2][3] = Q.c[2][4] = u32x4{0u, 0u, 0u, 0u};
         // ---- per-lane constants of the fast trips
         const uint32_t lds0 = mem.lds_base();
         const bool l0 = st.l == 0;
@@ -252,8 +271,9 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
             uint32_t imp_cur = imp_a + imp_k * (uint32_t)tb, exp_cur = exp_a + exp_k * (uint32_t)tb;
             auto imp_addr = [&](int t) { return (kimp == 2 || (unsigned)(t - imp_lo) < (unsigned)imp_n) ? imp_cur : scr_a; };
             if (kimp >= 2) entry_issue(imp_addr(tb), ent_q);
-            // scalar byte offsets of the step's record block (+ PF steps: the request) and of its row of the result stream
-            uint32_t rec_soff = (uint32_t)(step0 + (tb - G.t_first) + PF) * (uint32_t)(STEP_FLOATS * 4);
+            // scalar byte offsets of the quad block two quads ahead (the refill of the slot behind the running quad) and of the step's row of
+            // the result stream
+            uint32_t rec_soff = (uint32_t)((step0 + (tb - G.t_first)) / 4 + 2) * QUAD_BYTES;
             uint32_t out_soff = (uint32_t)(step0 + (tb - G.t_first)) * 256u; // (a row of the result stream = 4 steps x 64 lanes x 4 bytes)
             u32x4 g4{0u, 0u, 0u, 0u};
             float cs0 = 0.f, cs1 = 0.f, cpred = 0.f;
@@ -278,17 +298,18 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
 #pragma unroll
             for (int u = 0; u < (int)PAIR_TRIP; ++u) {
                 const int t = tb + u;
-                const int slot = u % PF, res4 = (u + 2) & 3; // t = -2 + u (mod 4)
-                const bool t_even = (u & 1) == 0;            // (lanes start at even t only)
-                // ---- the record of this step (queued PF steps ago), the next request into its place
-                sp::VisitRec R;
-                R.gvl = __uint_as_float(Q.q0[slot].x), R.a = __uint_as_float(Q.q0[slot].y), R.b = __uint_as_float(Q.q0[slot].z), R.wn = __uint_as_float(Q.q0[slot].w);
-                R.nN = __uint_as_float(Q.q1[slot].x), R.nU = __uint_as_float(Q.q1[slot].y), R.xo = __uint_as_float(Q.q1[slot].z), R.spare = 0.f;
+                const int res4 = (u + 2) & 3;     // t = -2 + u (mod 4)
+                const bool t_even = (u & 1) == 0; // (lanes start at even t only)
+                // ---- the records of this step and of the next (requested at least 8 steps ago)
+                const sp::VisitRec R = quad_rec(Q, u), Rn = quad_rec(Q, u + 1);
 #ifndef GG_PAIR_X_NOLOAD
-                Q.q0[slot] = __builtin_amdgcn_raw_buffer_load_b128(rec, voff, rec_soff, 0);
-                Q.q1[slot] = __builtin_amdgcn_raw_buffer_load_b128(rec, voff + 1024u, rec_soff, 0);
+                {   // refill the slot of the quad that ended before this one: words 0 and 4 first (the next quad's first step needs them), then 1, 2, 3
+                    const int fs = ((u >> 2) + 2) % 3, fi = u & 3;
+                    if (fi == 0) word_request(Q, fs, 4, rec, voff, rec_soff);
+                    word_request(Q, fs, fi, rec, voff, rec_soff);
+                    if (fi == 3) rec_soff += QUAD_BYTES;
+                }
 #endif
-                rec_soff += (uint32_t)(STEP_FLOATS * 4);
                 // ---- first steps: the corner values
                 bool first = false;
                 if (K::starts == 1 && t >= 0 && t <= t_start_last) { // (uniform) the generic trip: read where a lane starts, poll if the cached counters do not cover it
@@ -364,7 +385,7 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
                     }
                     x = t + 2 == endm ? j : x;
                 } else {
-                    x = t + 1 == endm ? R.xo : x;
+                    x = t + 1 == endm ? Rn.gvl : x; // (an OLD cell at the far end: it travels in the record behind the chain's last)
                 }
                 st.I0 = st.I1;
                 st.I1 = st.I2;
@@ -377,11 +398,13 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
                     st.I1 = first ? cs1 : st.I1; // (chains of one visit -- ring 1 -- start in the generic trip)
                 }
                 // ---- the visit; its height goes to the result stream (idle lanes write slots nobody reads)
-                st.O.shift(R);
-                const float g = sp::height_of(R.gvl, R.a, R.b, sp::window_sum<PAIR>(is_x, st.O, st.I0, st.I1, st.I2, st.h1));
+                const sp::OldWindow O{R.b, Rn.b, st.U1, st.U2, R.nU};
+                st.U1 = st.U2;
+                st.U2 = R.nU;
+                const float g = sp::height_of(R.gvl, R.a, R.b, sp::window_sum<PAIR>(is_x, O, st.I0, st.I1, st.I2, st.h1));
                 const float res = R.wn * g;
                 g4[u & 3] = __float_as_uint(g);
-                if ((u & 3) == 3) { // four steps of a lane = 16 contiguous bytes, one store (sweep_pair.h out_slot)
+                if ((u & 3) == 3) { // four heights of a lane = 16 contiguous bytes, one store
 #ifndef GG_PAIR_X_NOSTORE
 #ifdef GG_PAIR_X_STORE4
                     for (int k4 = 0; k4 < 4; ++k4) __builtin_amdgcn_raw_buffer_store_b32(g4[k4], out, (uint32_t)lane * 16u + 4u * k4, out_soff, 0);
@@ -464,15 +487,8 @@ GG_DEV void run_pair_corner(const Params &P, const sp::Plan &pl, const sp::Lds &
             in_x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), l));
             if (lane == 0) sp::CornerLane<CD>::publish(r0 + l, in_x1, in_corner, P, L, mem); // (uniform values: one lane writes)
             if (!CD && r0 + l == 1) { // the one chain visit the CD corner needs: B_1(1) = pair B/C, group 0, lane 0, wave-step 0
-                const float *blk = rec + ((size_t)pl.base[sp::PAIR_BC][0] + (size_t)(0 - sp::group_of(sp::PAIR_BC, 0, P.rings).t_first)) * STEP_FLOATS;
-                auto rec_of = [&](int back) { // lane 0's record of wave-step 0 - back
-                    const float4 v0 = reinterpret_cast<const float4 *>(blk - (size_t)back * STEP_FLOATS)[0], v1 = reinterpret_cast<const float4 *>(blk - (size_t)back * STEP_FLOATS + 256)[0];
-                    sp::VisitRec B;
-                    B.gvl = v0.x, B.a = v0.y, B.b = v0.z, B.wn = v0.w;
-                    B.nN = v1.x, B.nU = v1.y, B.xo = v1.z, B.spare = 0.f;
-                    return B;
-                };
-                const float b1 = sp::b1_of_ring1(rec_of(2), rec_of(1), rec_of(0), in_x1, in_corner, centre_p);
+                const int st0 = pl.base[sp::PAIR_BC][0] + (0 - sp::group_of(sp::PAIR_BC, 0, P.rings).t_first); // lane 0's wave-step 0
+                const float b1 = sp::b1_of_ring1(sp::rec_at(rec, st0 - 2, 0), sp::rec_at(rec, st0 - 1, 0), sp::rec_at(rec, st0, 0), sp::rec_at(rec, st0 + 1, 0), in_x1, in_corner, centre_p);
                 if (lane == 0) mem.lds_entry(L.b1, b1);
             }
         }
@@ -594,7 +610,7 @@ bool launch_sweep_pair(const Arena &a, const Params &P, const CloudParams *d_par
     const void *fn = both ? (small ? (const void *)k_sweep_pair<true, 12, 512> : (const void *)k_sweep_pair<true, 3, 1024>)
                           : (small ? (const void *)k_sweep_pair<false, 12, 512> : (const void *)k_sweep_pair<false, 3, 1024>);
     if (lds > 64 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); // (idempotent; big maps only)
-    const size_t n_rec = (size_t)pl.total_steps * 64 + 2 * (size_t)P.rings;
+    const size_t n_rec = (size_t)pl.total_steps / 4 * 64 + 2 * (size_t)P.rings;
     hipLaunchKernelGGL(k_sweep_records, dim3((unsigned)((n_rec + 255) / 256), (unsigned)n_clouds), dim3(256), 0, s, a, P, pl, d_params);
     const dim3 grid(both ? n_clouds : 2 * n_clouds), block(waves * 64);
     if (both && small) hipLaunchKernelGGL((k_sweep_pair<true, 12, 512>), grid, block, lds, s, a, P, pl, d_params, W);

@@ -615,7 +615,7 @@ struct PairHostMem { // one per emulated work-group
 };
 
 struct Records {
-    std::vector<gp::VisitRec> visit;  // [total_steps][64]
+    std::vector<float> visit;          // quad blocks (sweep_pair.h quad_word), total_steps / 4 + 1 of them
     std::vector<gp::CornerRec> corner; // [2][rings + 1]
 };
 
@@ -674,8 +674,8 @@ template <int PAIR> struct PairWave : WaveBase {
             x_prev[k] = k ? lane[k - 1].h2 : 0.f;                                  // wave shift right by one (lane 32 gets side X's last lane: never used)
             j_perm[k] = k < 32 ? (k ? lane[32 + k - 1].h1 : 0.f) : lane[k - 32].h1; // X l <- Y l - 1, Y l <- X l
         }
-        const size_t base = ((size_t)pl.base[PAIR][group] + (size_t)(t - G.t_first)) * 64;
-        for (int k = 0; k < 64; ++k) lane[k].step(t, group, rec.visit[base + k], x_prev[k], j_perm[k], centre_p, mem);
+        const int step = pl.base[PAIR][group] + (t - G.t_first);
+        for (int k = 0; k < 64; ++k) lane[k].step(t, group, gp::rec_at(rec.visit.data(), step, k), gp::rec_at(rec.visit.data(), step + 1, k), x_prev[k], j_perm[k], centre_p, mem);
         if (++t >= t_end) next_group();
         return true;
     }
@@ -712,8 +712,9 @@ template <int CD> struct PairCornerWave : WaveBase {
         lane[k].flush(true, mem);
         gp::CornerLane<CD>::publish(r, x1, y0, P, L, mem);
         if (!CD && r == 1) { // the one chain visit the other corner needs
-            const size_t idx = ((size_t)pl.base[gp::PAIR_BC][0] + (size_t)(0 - gp::group_of(gp::PAIR_BC, 0, P.rings).t_first)) * 64;
-            mem.lds_entry(L.b1, gp::b1_of_ring1(rec.visit[idx - 128], rec.visit[idx - 64], rec.visit[idx], x1, y0, centre_p));
+            const int st0 = pl.base[gp::PAIR_BC][0] + (0 - gp::group_of(gp::PAIR_BC, 0, P.rings).t_first); // lane 0's wave-step 0
+            const float *v = rec.visit.data();
+            mem.lds_entry(L.b1, gp::b1_of_ring1(gp::rec_at(v, st0 - 2, 0), gp::rec_at(v, st0 - 1, 0), gp::rec_at(v, st0, 0), gp::rec_at(v, st0 + 1, 0), x1, y0, centre_p));
         }
         in_corner = y0;
         in_x1 = x1;
@@ -737,23 +738,30 @@ extern "C" int gg_debug_emulate_pair_sweep(int n, double resolution, float min_d
     // ---- the preparation: every record from the OLD layer
     Records rec;
     const float poison = __builtin_nanf("");
-    gp::VisitRec none;
-    none.gvl = none.a = none.b = none.wn = none.nN = none.nU = none.xo = none.spare = poison;
-    rec.visit.assign((size_t)pl.total_steps * 64, none);
+    rec.visit.assign(((size_t)pl.total_steps / 4 + 1) * gp::QUAD_BLOCK_FLOATS, poison);
     auto load = [&](int x, int y) { return sheared[(size_t)gp_index(P.gl, x, y)]; };
     long n_visits = 0;
     for (int p = 0; p < 2; ++p)
         for (int g = 0; g < pl.groups; ++g) {
             const gp::Group G = gp::group_of(p, g, P.rings);
-            for (int t = G.t_first; t < G.t_first + G.steps; ++t)
+            for (int t0 = G.t_first; t0 < G.t_first + G.steps; t0 += gp::QUAD)
                 for (int lane = 0; lane < 64; ++lane) {
                     const bool is_x = lane < 32;
                     const int l = lane & 31, side = is_x ? gp::side_x(p) : gp::side_y(p);
-                    if (l >= G.nl) continue;
-                    const int r = G.r0 + l, s = t - (2 * l + gp::start0(p, is_x));
-                    if (s < -(int)gp::WARMUP || s >= gp::len_of(side, r)) continue;
-                    rec.visit[((size_t)pl.base[p][g] + (size_t)(t - G.t_first)) * 64 + lane] = gp::make_visit_rec(P, p, is_x, r, s, load);
-                    n_visits += s >= 0;
+                    if (l >= G.nl) continue; // (a lane without a ring: its records stay poison)
+                    const int r = G.r0 + l, len = gp::len_of(side, r), s0 = t0 - (2 * l + gp::start0(p, is_x));
+                    if (s0 + 3 < -(int)gp::WARMUP || s0 > len) continue;
+                    float q[gp::QUAD_FLOATS];
+                    gp::make_visit_quad(P, p, is_x, r, s0, load, q);
+                    const int step = pl.base[p][g] + (t0 - G.t_first);
+                    for (int i = 0; i < 4; ++i) {
+                        const int s = s0 + i;
+                        if (s < -(int)gp::WARMUP || s > len) continue; // (steps outside the chain: poison, like the device's untouched memory)
+                        float *w = rec.visit.data() + gp::quad_word(step + i, lane, i);
+                        w[0] = q[4 * i], w[1] = q[4 * i + 1], w[2] = q[4 * i + 2], w[3] = q[4 * i + 3];
+                        rec.visit[(size_t)gp::quad_word(step + i, lane, 4) + i] = q[16 + i];
+                        n_visits += s >= 0 && s < len;
+                    }
                 }
         }
     rec.corner.resize(2 * (size_t)(P.rings + 1));

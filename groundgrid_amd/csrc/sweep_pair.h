@@ -35,6 +35,12 @@
 
 #include "sweep_core.h"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SW_UNROLL _Pragma("unroll")
+#else
+#define SW_UNROLL
+#endif
+
 namespace gg {
 namespace sweep {
 namespace pair {
@@ -92,31 +98,32 @@ static_assert(tree_pos<SIDE_A>(1, 0) == 1 && tree_pos<SIDE_D>(0, 1) == 1 && tree
 static_assert(tree_pos<SIDE_A>(0, 1) == 5 && tree_pos<SIDE_D>(1, 0) == 5 && tree_pos<SIDE_B>(0, 1) == 7 && tree_pos<SIDE_C>(1, 0) == 7, "I1 of X = OP of Y");
 static_assert(tree_pos<SIDE_A>(0, 2) == 8 && tree_pos<SIDE_D>(0, 2) == 0 && tree_pos<SIDE_B>(0, 2) == 8 && tree_pos<SIDE_C>(0, 2) == 0, "I2: 8 for X, 0 for Y");
 
-// What the preparation leaves per lane and wave-step (32 bytes = two 16-byte loads).  The OLD part of a window is a stream: step s
-// brings the column behind the visited cell's successor side -- the own line's cell at along-position k0 + s + 1 and the outer line's --
-// and the window of OLD products (S N on the own line, U0 U1 U2 on the outer one) shifts by one; steps s = -2, -1 of a chain carry the two
-// columns the first visit finds already there.
+// What the preparation leaves per lane and wave-step (20 bytes; four steps of a lane are packed as five 16-byte words, the chain loads
+// five words per four steps).  The OLD part of a window is a stream: the own line's products are the `b` of the steps themselves (self =
+// this step's, successor = the next step's), the outer line's arrive one per step (nU = the cell beside the successor) and are kept for
+// three steps; steps s = -2, -1 of a chain carry the two outer cells its first visit finds already there, and step s = len -- one past
+// the chain -- carries what the LAST visit still needs: the own line's cell behind it (b) and, in `gvl`, the product of the inner line's
+// successor cell, which is still OLD there (S[len + 1]).
 struct VisitRec {
     float gvl;        // :457 gvlSum = (window confidences).sum() + FLT_MIN, every neighbour visited earlier with its NEW confidence
     float a, b;       // :460 (1 - occupied), occupied * height of the visited cell (both OLD)
     float wn;         // :464 the visited cell's new confidence
-    float nN, nU;     // products w * g of the arriving column's OLD cells: own line (the next successor), outer line
-    float xo;         // last visit of a chain: the product of the inner line's successor cell, which is still OLD there (S[len + 1])
-    float spare;
+    float nU;         // product w * g of the arriving OLD cell of the outer line
 };
-enum { WARMUP = 2 }; // steps before a chain's first visit that only shift the window
+enum { WARMUP = 2, QUAD = 4, QUAD_FLOATS = 20, QUAD_BLOCK_FLOATS = 64 * QUAD_FLOATS }; // a quad block: [chunk 0..3 = step (gvl a b wn)][chunk 4 = nU x 4] x 64 lanes x 16 bytes
+SW_HD int quad_word(int step, int lane, int chunk) { return (step >> 2) * QUAD_BLOCK_FLOATS + chunk * 256 + lane * 4; } // (float index of a 16-byte word)
+SW_HD VisitRec rec_at(const float *stream, int step, int lane)
+{
+    const float *q = stream + quad_word(step, lane, step & 3);
+    VisitRec R;
+    R.gvl = q[0], R.a = q[1], R.b = q[2], R.wn = q[3];
+    R.nU = stream[quad_word(step, lane, 4) + (step & 3)];
+    return R;
+}
 
 // the OLD products of a window (own line: self, successor; outer line: predecessor side, middle, successor side)
 struct OldWindow {
     float S, N, U0, U1, U2;
-    SW_HD void shift(const VisitRec &R)
-    {
-        S = N;
-        N = R.nN;
-        U0 = U1;
-        U1 = U2;
-        U2 = R.nU;
-    }
 };
 
 // :458 (products).sum() in Eigen's order for a lane of either half.  COMMON positions: X (U1 . . N), Y (N . . U1) with (S, U2) between
@@ -169,7 +176,7 @@ SW_HD Group group_of(int pair, int g, int rings)
     G.nl = rings - (G.r0 - 1) < (int)HALF ? rings - (G.r0 - 1) : (int)HALF;
     G.t_first = -(int)WARMUP;
     G.t_last = 2 * (G.nl - 1) + start0(pair, false) + len_of(side_y(pair), G.r0 + G.nl - 1) - 1; // Y of the last ring ends last
-    const int n = G.t_last - G.t_first + 1;
+    const int n = G.t_last - G.t_first + 2; // (+ 1: the record behind the last chain's end)
     G.steps = (n + PTRIP - 1) / PTRIP * PTRIP;
     return G;
 }
@@ -255,42 +262,65 @@ SW_HD float final_confidence(const Params &P, int x, int y, float w_old)
     return w;
 }
 
-// the record of step s of chain (side, ring r), s in [-WARMUP, len)
-template <class Load> SW_HD VisitRec make_visit_rec(const Params &P, int pair, bool is_x, int r, int s, Load load)
+// the records of steps s0 .. s0 + 3 of chain (side, ring r) as one quad (20 floats: four x (gvl a b wn), then four nU); steps outside
+// [-WARMUP, len] stay zero.  The four windows share their cells: six columns of three are loaded once.
+template <int SIDE, class Load> SW_HD void make_visit_quad_of(const Params &P, int r, int s0, Load load, float (&out)[QUAD_FLOATS])
 {
-    const int side = is_x ? side_x(pair) : side_y(pair);
-    const int len = len_of(side, r), k = k0_of(side) + s;
-    VisitRec R;
-    R.gvl = R.a = R.b = R.wn = R.xo = R.spare = 0.f;
-    {   // the arriving column of OLD cells: along-position k + 1 of the own and of the outer line
-        int x, y;
-        side_xy(side, P.c, r, 0, k + 1, x, y);
-        const Cell own = load(x, y);
-        side_xy(side, P.c, r, 1, k + 1, x, y);
-        const Cell outer = load(x, y);
-        R.nN = own.w * own.g;
-        R.nU = outer.w * outer.g;
-    }
-    if (s < 0) return R; // (a warm-up step: no visit)
-    float w[9];
-    for (int line = 0; line < 3; ++line)     // 0 inner, 1 own, 2 outer
-        for (int pos = 0; pos < 3; ++pos) { // 0 predecessor, 1 self, 2 successor
+    constexpr int side = SIDE;
+    const int len = len_of(side, r), k0 = k0_of(side);
+    SW_UNROLL
+    for (int i = 0; i < (int)QUAD_FLOATS; ++i) out[i] = 0.f;
+    // column j = along-position k0 + s0 - 1 + j of the inner / own / outer line (every index below is a constant once the loops are unrolled:
+    // the arrays are registers)
+    float in_w[6], in_p[6], in_f[6], own_w[6], own_p[6], own_f[6], out_w[6], out_p[6];
+    SW_UNROLL
+    for (int j = 0; j < 6; ++j) {
+        const int pos = k0 + s0 - 1 + j;
+    SW_UNROLL
+        for (int line = -1; line <= 1; ++line) {
             int x, y;
-            side_xy(side, P.c, r, line - 1, k + pos - 1, x, y);
+            side_xy(side, P.c, r, line, pos, x, y);
+            x = x < 0 ? 0 : x >= P.n ? P.n - 1 : x; // (columns beyond the chain's ends are never used; keep the loads inside the map)
+            y = y < 0 ? 0 : y >= P.n ? P.n - 1 : y;
             const Cell v = load(x, y);
-            const bool last_succ = line == 0 && pos == 2 && s == len - 1; // S[len + 1]: belongs to a chain that has not got there yet
-            const bool is_new = (line == 0 && !last_succ) || (line == 1 && pos == 0);
-            w[tree_pos_of(side, line, pos)] = is_new ? final_confidence(P, x, y, v.w) : v.w;
-            if (last_succ) R.xo = v.w * v.g;
-            if (line == 1 && pos == 1) {
-                R.a = 1.0f - v.w; // :460
-                R.b = v.w * v.g;
-                const int dx = x - P.c, dy = y - P.c;
-                R.wn = decayed_confidence(v.w, dx * dx + dy * dy >= P.r2min, P); // :463-464
-            }
+            const float p = v.w * v.g;
+            if (line == -1) in_w[j] = v.w, in_p[j] = p, in_f[j] = final_confidence(P, x, y, v.w);
+            else if (line == 0) own_w[j] = v.w, own_p[j] = p, own_f[j] = final_confidence(P, x, y, v.w);
+            else out_w[j] = v.w, out_p[j] = p;
         }
-    R.gvl = sw_tree9(w) + FLT_MIN; // :457
-    return R;
+    }
+    SW_UNROLL
+    for (int i = 0; i < (int)QUAD; ++i) {
+        const int s = s0 + i; // its visited cell is column i + 1
+        const bool in_range = s >= -(int)WARMUP && s <= len, visit = s >= 0 && s < len, past = s == len;
+        float w[9];
+        w[tree_pos<SIDE>(0, 0)] = in_f[i];
+        w[tree_pos<SIDE>(0, 1)] = in_f[i + 1];
+        w[tree_pos<SIDE>(0, 2)] = s == len - 1 ? in_w[i + 2] : in_f[i + 2]; // S[len + 1] belongs to a chain that has not got there yet
+        w[tree_pos<SIDE>(1, 0)] = own_f[i];
+        w[tree_pos<SIDE>(1, 1)] = own_w[i + 1];
+        w[tree_pos<SIDE>(1, 2)] = own_w[i + 2];
+        w[tree_pos<SIDE>(2, 0)] = out_w[i];
+        w[tree_pos<SIDE>(2, 1)] = out_w[i + 1];
+        w[tree_pos<SIDE>(2, 2)] = out_w[i + 2];
+        const float gvl = sw_tree9(w) + FLT_MIN; // :457
+        // (unconditional stores of selected values: the quad stays in registers on the device)
+        out[4 * i + 0] = visit ? gvl : past ? in_p[i + 1] : 0.f; // ... one past the chain: what the last visit needs of its successor column
+        out[4 * i + 1] = visit ? 1.0f - own_w[i + 1] : 0.f;       // :460
+        out[4 * i + 2] = (visit || past) ? own_p[i + 1] : 0.f;
+        out[4 * i + 3] = visit ? own_f[i + 1] : 0.f;               // :463-464 (a chain cell is visited once: its final confidence)
+        out[16 + i] = in_range ? out_p[i + 2] : 0.f;               // nU: the outer line's cell beside the successor
+    }
+}
+template <class Load> SW_HD void make_visit_quad(const Params &P, int pair, bool is_x, int r, int s0, Load load, float (&out)[QUAD_FLOATS])
+{
+    if (pair == PAIR_AD) {
+        if (is_x) make_visit_quad_of<SIDE_A>(P, r, s0, load, out);
+        else make_visit_quad_of<SIDE_D>(P, r, s0, load, out);
+    } else {
+        if (is_x) make_visit_quad_of<SIDE_B>(P, r, s0, load, out);
+        else make_visit_quad_of<SIDE_C>(P, r, s0, load, out);
+    }
 }
 
 // The three corner visits of ring r: X_0 = (z, z), X_1 = (z, z - o), Y_0 = (z, z) again (z = c - r, o = -1 for AB; z = c + r, o = +1 for
@@ -317,10 +347,12 @@ template <int CD, class Load> SW_HD CornerRec make_corner_rec(const Params &P, i
     const bool decay0 = 2 * r * r >= P.r2min;
     const Cell c00 = load(z, z);
     const float x0w = decayed_confidence(c00.w, decay0, P);
+    SW_UNROLL
     for (int v = 0; v < 3; ++v) {
         const int ca = 0, cb = v == 1 ? -1 : 0;
         float w[9];
         int n_old = 0;
+        SW_UNROLL
         for (int q = 0; q < 9; ++q) { // increasing tree position: (a, b) of position q around (ca, cb)
             const int da = q % 3 - 1, db = q / 3 - 1;
             const int a = CD ? ca + da : ca - da, b = CD ? cb + db : cb - db;
@@ -397,7 +429,7 @@ template <int PAIR> struct PairLane {
     // state: the inner line S[s], S[s+1], S[s+2]; the last two results.  h1 is the predecessor's product of the next visit, the join the
     // partner lane takes one step after this chain's end, and -- a step later, as h2 -- what lane l + 1 reads as its S[s + 2]
     float I0, I1, I2, h1, h2;
-    OldWindow O; // the window's OLD products (a column arrives per step: VisitRec)
+    float U1, U2; // the outer line's products of the last two steps (the window's OLD part: VisitRec)
 
     SW_HD void init(int lane, int group, const Group &G, const Params &P, const Plan &pl, const Lds &L)
     {
@@ -442,7 +474,7 @@ template <int PAIR> struct PairLane {
         // export: the last lane of a half, when a group follows
         pb = (l == (int)HALF - 1 && group + 1 < pl.groups) ? half_base + 2 * (pl.bnd_off[group] - start) : -1;
         I0 = I1 = I2 = h1 = h2 = 0.f;
-        O.S = O.N = O.U0 = O.U1 = O.U2 = 0.f;
+        U1 = U2 = 0.f;
     }
     // what wave-step t of this lane reads from other wavefronts (the wavefront may run the step once all of it is there)
     SW_HD bool first_at(int t) const { return live && t == start; } // (ring 1 of side A has no chain, but its "first step" still takes A_1(1): D's join)
@@ -455,9 +487,9 @@ template <int PAIR> struct PairLane {
     {
         if (first_at(t)) h1 = mem.lds_f(a_pred);
     }
-    // 2. the visit.  x_prev = h2 of lane - 1, j_perm = h1 of the partner lane (X l <- Y l - 1, Y l <- X l), both as they were after pre();
-    //    centre_p = the centre cell's product (the join of ring 1 of side B)
-    template <class Mem> SW_HD void step(int t, int group, const VisitRec &R, float x_prev, float j_perm, float centre_p, Mem &mem)
+    // 2. the visit.  R, Rn = the records of this and of the next wave-step; x_prev = h2 of lane - 1, j_perm = h1 of the partner lane (X l <- Y
+    //    l - 1, Y l <- X l), both as they were after pre(); centre_p = the centre cell's product (the join of ring 1 of side B)
+    template <class Mem> SW_HD void step(int t, int group, const VisitRec &R, const VisitRec &Rn, float x_prev, float j_perm, float centre_p, Mem &mem)
     {
         const int s = t - start;
         float x = x_prev;                                             // S[s + 2]: step s of the ring inside (lane - 1, two steps ago) ...
@@ -465,7 +497,7 @@ template <int PAIR> struct PairLane {
         float j = j_perm;
         if (jl_lane) j = group > 0 ? mem.lds_f(a_jl) : centre_p;
         x = s + 2 == len ? j : x;    // the join
-        x = s + 1 == len ? R.xo : x; // an OLD cell at the far end
+        x = s + 1 == len ? Rn.gvl : x; // an OLD cell at the far end (it travels in the record behind the chain's last)
         I0 = I1;
         I1 = I2;
         I2 = x;
@@ -474,11 +506,13 @@ template <int PAIR> struct PairLane {
             if (len != 1) I1 = mem.lds_f(a_s1); // (a chain of one visit: S[1] is the join, taken a step ago)
         }
         const bool active = (unsigned)s < (unsigned)len;
-        O.shift(R); // (the record's column is this visit's successor column)
+        const OldWindow O{R.b, Rn.b, U1, U2, R.nU};
+        U1 = U2;
+        U2 = R.nU;
         const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR>(is_x, O, I0, I1, I2, h1));
         const float res = R.wn * g;
 #if !defined(__HIP_DEVICE_COMPILE__)
-        if (getenv("GG_PAIR_DBG") && active && r == atoi(getenv("GG_PAIR_DBG")) && s < 3) fprintf(stderr, "pair %d x %d r %d s %d t %d: I %g %g %g pred %g | gvl %g a %g b %g wn %g o %g %g %g %g %g xo %g -> g %g\n", PAIR, (int)is_x, r, s, t, I0, I1, I2, h1, R.gvl, R.a, R.b, R.wn, O.S, O.N, O.U0, O.U1, O.U2, R.xo, g);
+        if (getenv("GG_PAIR_DBG") && active && r == atoi(getenv("GG_PAIR_DBG")) && s < 3) fprintf(stderr, "pair %d x %d r %d s %d t %d: I %g %g %g pred %g | gvl %g a %g b %g wn %g o %g %g %g %g %g xo %g -> g %g\n", PAIR, (int)is_x, r, s, t, I0, I1, I2, h1, R.gvl, R.a, R.b, R.wn, O.S, O.N, O.U0, O.U1, O.U2, Rn.gvl, g);
 #endif
         // the height goes to the result stream, 64 lanes = 64 consecutive floats (the lanes' cells lie in 64 different lines of the layer: a
         // scattered store costs the CU's memory front end more than the rest of the step); finish_cell() puts it into the layer
@@ -590,12 +624,11 @@ template <int CD> struct CornerLane {
     }
 };
 // B_1 of ring 1 from the AB corner's results (A_1(1), B_0(1)) and the record of that visit (pair B/C, group 0, lane 0, wave-step 0)
-// (W2, W1: that lane's records of steps -2 and -1 -- its window's first two columns)
-SW_HD float b1_of_ring1(const VisitRec &W2, const VisitRec &W1, const VisitRec &R, float a1p, float b0p, float centre_p)
+// (W2, W1, R, Rn: that lane's records of wave-steps -2 .. 1)
+SW_HD float b1_of_ring1(const VisitRec &W2, const VisitRec &W1, const VisitRec &R, const VisitRec &Rn, float a1p, float b0p, float centre_p)
 {
-    OldWindow O;
-    O.S = W1.nN, O.N = R.nN, O.U0 = W2.nU, O.U1 = W1.nU, O.U2 = R.nU;
-    const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR_BC>(true, O, a1p, centre_p, R.xo, b0p));
+    const OldWindow O{R.b, Rn.b, W2.nU, W1.nU, R.nU};
+    const float g = height_of(R.gvl, R.a, R.b, window_sum<PAIR_BC>(true, O, a1p, centre_p, Rn.gvl, b0p)); // (a chain of one visit: S[2] is the OLD far end)
     return R.wn * g;
 }
 
