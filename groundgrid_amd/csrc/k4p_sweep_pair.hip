@@ -598,25 +598,22 @@ bool launch_sweep_pair(const Arena &a, const Params &P, const CloudParams *d_par
     const sp::Lds L = sp::lds_of(P.c, pl, both);
     const size_t lds = (size_t)L.words * 4;
     if (lds > 158 * 1024) return false;
-    const int max_w = both ? 7 : 14;
+    // at most 8 wavefronts per work-group: 256 registers per lane hold the record queue and a trip's five variants without spilling (the
+    // 16-wavefront shape spilled 250 registers and was slower than fewer wavefronts taking several groups in turn: n = 1000, one cloud,
+    // 14 wavefronts per pair 0.54 ms, 6 wavefronts 0.43 ms)
+    const int max_w = both ? 3 : 6;
     int W = std::min(pl.groups, max_w);
     if (a.tune_sweep_pair_waves > 0) W = std::max(1, std::min(W, a.tune_sweep_pair_waves));
     const RecLayout RL = rec_layout(pl, P.rings);
     if (RL.floats > a.sweep_rec_stride) return false;
-    // up to 8 wavefronts per work-group leave 256 registers per lane: records are requested 12 steps ahead (memory latency is ~8 steps of
-    // this kernel); bigger work-groups get 128 registers and a queue of 6
     const int waves = (both ? 2 * W : W) + 2;
-    const bool small = waves <= 8;
-    const void *fn = both ? (small ? (const void *)k_sweep_pair<true, 12, 512> : (const void *)k_sweep_pair<true, 3, 1024>)
-                          : (small ? (const void *)k_sweep_pair<false, 12, 512> : (const void *)k_sweep_pair<false, 3, 1024>);
+    const void *fn = both ? (const void *)k_sweep_pair<true, 12, 512> : (const void *)k_sweep_pair<false, 12, 512>;
     if (lds > 64 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); // (idempotent; big maps only)
     const size_t n_rec = (size_t)pl.total_steps / 4 * 64 + 2 * (size_t)P.rings;
     hipLaunchKernelGGL(k_sweep_records, dim3((unsigned)((n_rec + 255) / 256), (unsigned)n_clouds), dim3(256), 0, s, a, P, pl, d_params);
     const dim3 grid(both ? n_clouds : 2 * n_clouds), block(waves * 64);
-    if (both && small) hipLaunchKernelGGL((k_sweep_pair<true, 12, 512>), grid, block, lds, s, a, P, pl, d_params, W);
-    else if (both) hipLaunchKernelGGL((k_sweep_pair<true, 3, 1024>), grid, block, lds, s, a, P, pl, d_params, W);
-    else if (small) hipLaunchKernelGGL((k_sweep_pair<false, 12, 512>), grid, block, lds, s, a, P, pl, d_params, W);
-    else hipLaunchKernelGGL((k_sweep_pair<false, 3, 1024>), grid, block, lds, s, a, P, pl, d_params, W);
+    if (both) hipLaunchKernelGGL((k_sweep_pair<true, 12, 512>), grid, block, lds, s, a, P, pl, d_params, W);
+    else hipLaunchKernelGGL((k_sweep_pair<false, 12, 512>), grid, block, lds, s, a, P, pl, d_params, W);
     hipLaunchKernelGGL(k_sweep_finish, dim3((unsigned)((P.gl.elems + 255) / 256), (unsigned)n_clouds), dim3(256), 0, s, a, P, pl, d_params);
     return true;
 }

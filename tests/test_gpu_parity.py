@@ -1338,3 +1338,48 @@ def test_random_scenes_fuzz(seed):
     cloud = synth.make_cloud(pts + np.array([pos[0], pos[1], 0.0], np.float32), ring=rng.integers(0, 64, len(pts)))
     run_pair(cloud, length=length, resolution=resolution, pos=pos, origin=origin, base_z=float(rng.uniform(-2.0, -1.4)), frames=3,
              odom_z=float(rng.uniform(-0.5, 0.5)))
+
+
+@pytest.mark.parametrize("wgs,waves", [(2, 0), (1, 0), (2, 1), (2, 3), (1, 2)])
+@pytest.mark.parametrize("length,resolution,batch", [(4.0, 0.33, 2), (22.0, 0.33, 3), (23.0, 0.33, 1), (61.0, 0.25, 5), (120.0, 0.33, 1), (120.0, 0.33, 16), (240.0, 0.33, 2)])
+def test_pair_sweep_shapes(length, resolution, batch, wgs, waves):
+    """Launches of at most 16 clouds sweep with k_sweep_pair (sweep_pair.h: both sides of a ring hand-over in one wavefront, OLD values
+    from k_sweep_records, heights through a result stream and k_sweep_finish): one work-group per cloud with both pairs of sides or two
+    with one pair each, one wavefront per 32-ring group or fewer (a wavefront then takes several groups in turn), maps from a single
+    ring group (12 x 12) to 23 groups (727 x 727: the 128-register variant of the kernel).  Three frames, labels of every cloud and all
+    layers of some against the oracle."""
+    import torch
+
+    clouds = _rotated_clouds(batch, length)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
+    seg.debug_set_tuning("sweep_pair_wgs", wgs)
+    seg.debug_set_tuning("sweep_pair_waves", waves)
+    refs = [oracle.OracleMap(length, resolution) for _ in clouds]
+    pts = _batch_inputs(16, clouds, stride)
+    out = None
+    for frame in range(3):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((batch, 3), np.float32), np.full(batch, -1.73 + 0.01 * frame), out=out)
+        torch.cuda.synchronize()
+        labels = out.labels.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, ORIGIN0, -1.73 + 0.01 * frame)
+            assert np.array_equal(labels[b, : len(c)], r["label"]), (frame, b)
+            if b in (0, 1, batch // 2, batch - 1):
+                assert_same_state(seg.map(b), refs[b], f"frame {frame} cloud {b}")
+    seg.close()
+
+
+def test_pair_sweep_and_k_sweep_leave_the_same_map():
+    """The two sweeps are interchangeable launch by launch: a map swept alternately by either (the pair sweep switched off for every
+    other frame) stays bit-identical to the oracle's."""
+    cloud = synth.hdl64_cloud(seed=77, n_az=900)
+    seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=1, max_points=len(cloud))
+    ref = oracle.OracleMap(120.0, 0.33)
+    for frame in range(6):
+        seg.debug_set_tuning("sweep_pair", 2 if frame % 2 else 0)
+        _, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, return_details=True)
+        r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+        assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), frame
+        assert_same_state(seg.map(0), ref, f"frame {frame}")
+    seg.close()
