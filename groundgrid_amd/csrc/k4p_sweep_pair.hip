@@ -371,9 +371,9 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
 #else
                     float j = res4 == Residue<PAIR>::x_join ? partner_for_x(st.h1) : partner_for_y(st.h1);
 #endif
-                    if (kimp == 1 && res4 == Residue<PAIR>::x_join) {
-                        if (l0 && is_x) j = centre_p; // (group 0: the join of ring 1 of side B is the centre cell)
-                        if (t == t_jl) {              // (uniform) X lane 0: Y's last value of the ring inside
+                    if ((kimp == 1 || kimp == 3) && res4 == Residue<PAIR>::x_join) {
+                        if (kimp == 1 && l0 && is_x) j = centre_p; // (group 0: the join of ring 1 of side B is the centre cell)
+                        if (t == t_jl) {                           // (uniform, once per group) X lane 0: Y's last value of the ring inside
                             const int word = st.jl_lane ? st.a_jl : st.scr;
                             uint64_t ent = mem.lds_entry_get(word);
                             while (__builtin_expect(__any((uint32_t)(ent >> 32) == 0u), 0)) {
@@ -437,7 +437,8 @@ GG_DEV void run_pair(const Params &P, const sp::Plan &pl, const sp::Lds &L, Pair
             const bool imp2 = !has_prev || (tb >= imp_all_lo && te <= imp_all_hi), imp0 = tb >= imp_any_hi && tb > t_jl; // (no group inside: every lane reads its scratch word)
             const bool exp2 = !has_next || (tb >= exp_all_lo && te <= exp_all_hi);
             static_assert((int)sp::WARMUP == 2, "the residues and the parity of the first steps count from t = -2");
-            if (has_jl || (group == 0 && tb == G.t_first)) trip(tb, PairKind<1, 1, 1>{}); // ring 1 (chains of one visit, the centre as a join); X lane 0's join from LDS
+            (void)has_jl; // (the ranged kinds take X lane 0's join from LDS where it falls; a trip of all-importing steps ends before it)
+            if (group == 0 && tb == G.t_first) trip(tb, PairKind<1, 1, 1>{}); // ring 1: chains of one visit, the centre as a join
             else if (!no_start) trip(tb, PairKind<2, 3, 3>{});
             else if (imp0 && exp2) trip(tb, PairKind<0, 0, 2>{});
             else if (imp2 && exp2) trip(tb, PairKind<0, 2, 2>{});
