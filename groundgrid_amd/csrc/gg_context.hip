@@ -80,8 +80,18 @@ struct gg_context {
     // GG_FLAG_CONCURRENT_HALVES: the clouds (and map re-initialisations) of the upper half of the slots run on half_stream; half_done is
     // recorded there behind each of them, half_fork on the caller's stream in front (the side stream sees what the caller enqueued before)
     hipStream_t half_stream = nullptr;
+    bool layer_copy_failed = false; // a download of the fused filter + layers call could not be enqueued (reported by the call)
     hipEvent_t half_fork = nullptr, half_done = nullptr;
     bool have_half_event = false;
+    // Output rows are indexed by a cloud's position in the batch, its half by its slot: two divided batches that are not joined (same caller
+    // stream) may write the same row of the same buffer from different streams.  The last few divided batches' output ranges and
+    // row-to-half maps are remembered; a batch that shares a range with one of them under another map joins first (enqueue_batch).
+    struct HalvesRecord {
+        const uint8_t *lo[6] = {}, *hi[6] = {};
+        uint64_t map_hash = 0;
+    };
+    HalvesRecord halves_hist[4];
+    int halves_hist_n = 0;
     int halves_min_clouds = 256;
     // gg_filter_cloud / _async / _layers: k_label writes counts, index and labels straight into the pinned host block (posted writes over
     // the link while the kernel runs) instead of into HBM with a copy behind the kernel: one transfer and one stream hop less per call
@@ -389,7 +399,7 @@ void enqueue_layer_downloads(gg_context *ctx, const Arena &a, int slot, unsigned
     int k = 0;
     for (int l = 0; l < GG_NUM_LAYERS; ++l) {
         if (!((mask >> l) & 1u)) continue;
-        hipMemcpyAsync(plan.dst[l], base + (size_t)k * plane, (size_t)a.g.C * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (hipMemcpyAsync(plan.dst[l], base + (size_t)k * plane, (size_t)a.g.C * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) ctx->layer_copy_failed = true;
         ++k;
     }
 }
@@ -600,8 +610,43 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
     if (ctx->have_batch_event && ctx->last_batch_stream != s && !ctx->probe_unordered_streams) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->batch_event, 0));
     // ... and after the second half of earlier batches -- unless this one is divided the same way: a slot is only ever touched from its
     // half's stream, so the halves of consecutive batches on one caller stream need not meet
-    if (!(split && ctx->last_batch_stream == s))
+    bool joined = false;
+    if (!(split && ctx->last_batch_stream == s)) {
         if (const int rc = stream_waits_for_second_half(ctx, s)) return rc;
+        joined = true;
+    }
+    if (split) {
+        // ... but the halves of consecutive batches DO meet in the output buffers when a row changes its half (rows follow the batch
+        // position, halves the slot): join the two streams once, in both directions, before such a batch
+        gg_context::HalvesRecord now;
+        const size_t per = b->cloud_stride;
+        const uint8_t *p6[6] = {(const uint8_t *)b->d_labels, (const uint8_t *)b->d_out_index, (const uint8_t *)b->d_out_clouds, (const uint8_t *)b->d_out_counts,
+                                (const uint8_t *)b->d_label_masks, (const uint8_t *)b->d_out_pc2};
+        const size_t bytes6[6] = {(size_t)nb * per, (size_t)nb * per * 4, (size_t)nb * per * sizeof(gg_point32), (size_t)nb * 64, (size_t)nb * ((per + 3) / 4), (size_t)nb * per * 18};
+        for (int k = 0; k < 6; ++k) now.lo[k] = p6[k], now.hi[k] = p6[k] ? p6[k] + bytes6[k] : nullptr;
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < nb; ++i) h = (h ^ (uint64_t)(second_half_slot(ctx, b->slots ? b->slots[i] : b->first_slot + i) ? 2 * i + 1 : 2 * i)) * 1099511628211ull;
+        now.map_hash = h ^ (uint64_t)nb;
+        bool clash = false;
+        for (int r = 0; r < ctx->halves_hist_n && !joined && !clash; ++r) {
+            const gg_context::HalvesRecord &o = ctx->halves_hist[r];
+            if (o.map_hash == now.map_hash) continue; // every row on the stream it was on: ordered by the streams themselves
+            for (int x = 0; x < 6 && !clash; ++x)
+                for (int y = 0; y < 6 && !clash; ++y) clash = now.lo[x] && o.lo[y] && now.lo[x] < o.hi[y] && o.lo[y] < now.hi[x];
+        }
+        if (clash) {
+            if (const int rc = stream_waits_for_second_half(ctx, s)) return rc;
+            if (ctx->have_batch_event) HIPCHK(ctx, hipStreamWaitEvent(ctx->half_stream, ctx->batch_event, 0));
+            joined = true;
+        }
+        if (joined) ctx->halves_hist_n = 0; // (everything before is ordered on both streams now)
+        if (ctx->halves_hist_n == 4) {
+            for (int r = 1; r < 4; ++r) ctx->halves_hist[r - 1] = ctx->halves_hist[r];
+            ctx->halves_hist_n = 3;
+        }
+        ctx->halves_hist[ctx->halves_hist_n++] = now;
+    } else if (joined)
+        ctx->halves_hist_n = 0;
     if (ctx->gather_lo) { // an all-gather still reads label masks: a batch on another stream that rewrites them waits for it
         auto overlaps = [&](const uint8_t *p, size_t bytes) { return p && p < ctx->gather_hi && p + bytes > ctx->gather_lo; };
         const size_t per_cloud = b->cloud_stride;
@@ -635,7 +680,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
         a2.front_sync = a.front_sync2;
         a2.sweep_sync = a.sweep_sync2;
         a2.sweep_rec_clouds = 0; // (one scratch region: the side stream's half keeps k_sweep)
-        a2.scan_sync = a.scan_sync + (size_t)n_first * SCAN_SYNC_WORDS;
+        a2.scan_sync = a.scan_sync2; // (its own region: the halves of consecutive divided batches need not be the same size)
         HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * n_first, hipMemcpyHostToDevice, s));
         HIPCHK(ctx, hipMemcpyAsync(dp + n_first, hp + n_first, sizeof(CloudParams) * (nb - n_first), hipMemcpyHostToDevice, ctx->half_stream));
         launch_sequence(ctx, a, dp, io, n_first, max_n[0], s, nullptr, hp[0].slot, false);
@@ -892,6 +937,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_fsync2 = carve(((size_t)2 * n_slots + 16) * 4);
     const size_t o_ssync2 = carve(64);
     const size_t o_scansync = carve((size_t)n_slots * SCAN_SYNC_WORDS * 8);
+    const size_t o_scansync2 = carve((size_t)n_slots * SCAN_SYNC_WORDS * 8);
     a.sweep_xchg_stride = align_up(std::max<size_t>(gg::sweep_xchg_entries(ctx->sweep_params), 1) * 16, A) / 8;
     const size_t o_xchg = carve((size_t)n_slots * a.sweep_xchg_stride * 8);
     a.sweep_rec_stride = gg::sweep_pair_rec_floats(ctx->sweep_params);
@@ -951,6 +997,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.front_sync2 = (uint32_t *)(base + o_fsync2);
     a.sweep_sync2 = (uint32_t *)(base + o_ssync2);
     a.scan_sync = (unsigned long long *)(base + o_scansync);
+    a.scan_sync2 = (unsigned long long *)(base + o_scansync2);
     {
         const uint32_t first_epoch[4] = {0u, 0u, 1u, 0u}; // (the exchange region starts zeroed: tag 0 is never current)
         CREATE_CHK(hipMemcpyAsync(a.sweep_sync, first_epoch, sizeof first_epoch, hipMemcpyHostToDevice, ctx->stream));
@@ -1982,7 +2029,12 @@ int gg_filter_cloud_layers(gg_context *ctx, int slot, const gg_point32 *cloud, s
     }
     int ticket = -1;
     const int rc = enqueue_ticket(ctx, slot, cloud, n, map_from_cloud, origin, base_z, &ticket, false, &plan);
-    if (rc != GG_OK) return rc;
+    if (rc != GG_OK) {
+        // the side branch may already copy into the caller's (registered) planes: nothing of this call is in flight when it returns
+        (void)hipStreamSynchronize(ctx->d2h_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
     // planes that came down into the staging block move on to the caller's: the early ones WHILE the device sweeps, the late ones at the end
     auto copy_staged = [&](unsigned group) {
         int want[GG_NUM_LAYERS], n_want = 0;
@@ -2003,6 +2055,11 @@ int gg_filter_cloud_layers(gg_context *ctx, int slot, const gg_point32 *cloud, s
     const int rc_wait = gg_filter_cloud_wait(ctx, ticket, out_cloud, out_n, out_label, out_index); // (assembles the returned cloud while the late layers travel)
     SYNCCHK(ctx, hipEventSynchronize(ctx->layers_event));
     if (rc_wait != GG_OK) return rc_wait;
+    if (ctx->layer_copy_failed) {
+        ctx->layer_copy_failed = false;
+        ctx->last_error = "gg_filter_cloud_layers: a layer download could not be enqueued";
+        return GG_ERR_HIP;
+    }
     copy_staged(~EARLY_LAYERS);
     return GG_OK;
 }

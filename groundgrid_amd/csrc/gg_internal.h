@@ -137,6 +137,7 @@ struct Arena {
     unsigned long long *scan_sync; // [n_slots][SCAN_SYNC_WORDS] k_scan as several work-groups per cloud (sort_core.h "PARTS"): ticket counter, then one
                                    // word per part; zeroed before every such launch
     uint32_t *front_sync2, *sweep_sync2; // the same two regions once more, for the half of a batch that runs on the library's side stream
+    unsigned long long *scan_sync2;      // ... and the scan's (its own region: consecutive divided batches need not have equal halves)
     uint32_t *sweep_sync; // [4] ticket counter, finished work-groups, epoch of k_sweep launches with several work-groups per cloud (k4_sweep.hip)
     unsigned long long *sweep_xchg; size_t sweep_xchg_stride; // [slot] exchange region between the work-groups of one sweep (sweep_core.h "Parts"), in 64-bit words
     float *sweep_rec; size_t sweep_rec_stride; int sweep_rec_clouds; // scratch of the pair sweep (k4p_sweep_pair.hip): the records of up to

@@ -185,7 +185,7 @@ GG_DEV bool ray_walk_hits_lane(const Arena &a, const CloudParams &cp, const floa
             const int step = base + k;
             const float sx = (float)step * vx, sy = (float)step * vy, sz = (float)step * vz;
             const double d2 = (double)sx * (double)sx + (double)sy * (double)sy + (double)sz * (double)sz;
-            on[k] = d2 < len2; // (monotonic in step: once false, false for every later step)
+            on[k] = d2 < len2 && step < WALK_MAX_STEP; // (monotonic in step: once false, false for every later step; the bound as in walk_packed and the oracle)
             const float ipx = sx + cp.ox, ipy = sy + cp.oy; // :260
             index_from_position(g, cp.pos_x, cp.pos_y, (double)ipx, (double)ipy, I0[k], I1[k]); // :261
             inside[k] = on[k] && !(I0[k] <= 0 || I1[k] <= 0 || I0[k] >= rows - 1 || I1[k] >= cols - 1); // :264-265

@@ -491,6 +491,54 @@ def test_batches_as_two_concurrent_halves_match_the_oracle(n_slots, B):
     seg.close()
 
 
+@pytest.mark.parametrize("n_slots,B,geometry", [(8, 8, (120.0, 0.33)), (9, 6, (120.0, 0.33)), (6, 6, (200.0, 0.2))])
+def test_unfenced_divided_batches_whose_halves_change(n_slots, B, geometry):
+    """Several divided batches in a row on one stream WITHOUT a fence between them, the clouds rotating over the slots so that the halves
+    change size and a row of the (reused) output buffers changes its half from step to step: the library has to order the two streams
+    itself where a row would otherwise be written from both (enqueue_batch: output ranges x row-to-half map of the last divided
+    batches), and the side stream's scan must not share its words with the caller stream's (a 1000 x 1000 map scans in parts).  Only the
+    LAST step's outputs are read -- after one fence -- and every map against the oracle."""
+    import torch
+
+    length, resolution = geometry
+    k = np.float32(length / 120.0)
+    clouds = []
+    for b in range(B):
+        c = synth.hdl64_cloud(seed=500 + b, n_az=90 + 37 * b)
+        c["x"] *= k
+        c["y"] *= k
+        clouds.append(c)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=n_slots, max_points=stride)
+    seg.set_flags(concurrent_halves=True)
+    seg.debug_set_tuning("halves_min_clouds", 2)
+    refs = [oracle.OracleMap(length, resolution) for _ in range(n_slots)]
+    pts = _halves_inputs(B, stride, clouds)
+    n, org, bz = [len(c) for c in clouds], np.zeros((B, 3), np.float32), np.full(B, -1.73)
+    side = torch.cuda.Stream()
+    outs = [None, None]
+    steps = 7
+    with torch.cuda.stream(side):
+        for step in range(steps):
+            slots = [(b * 2 + 3 * step) % n_slots if n_slots % 2 else (b + 3 * step) % n_slots for b in range(B)]
+            if len(set(slots)) < B:  # (keep the slots of a batch distinct)
+                slots = [(b + step) % n_slots for b in range(B)]
+            outs[step % 2] = seg.filter_batch(pts, n, org, bz, out=outs[step % 2], slots=np.asarray(slots, np.int32))
+            last = [refs[slots[b]].filter_cloud(c, ORIGIN0, -1.73) for b, c in enumerate(clouds)]
+        seg.batch_fence()
+        out = outs[(steps - 1) % 2]
+        labels, index, counts = out.labels.cpu().numpy(), out.out_index.cpu().numpy(), out.counts.cpu().numpy()
+    for b, c in enumerate(clouds):
+        assert np.array_equal(labels[b, : len(c)], last[b]["label"]), b
+        assert np.array_equal(index[b, : len(c)], last[b]["index"]), b
+        assert counts[b, 0] == len(last[b]["out_points"]), b
+    for s in range(n_slots):
+        for name in ("ground", "groundpatch", "points"):
+            assert nan_equal(seg.map(s)[name], refs[s].layer(name)), (s, name)
+    seg.synchronize()
+    seg.close()
+
+
 def test_new_entry_points_on_empty_and_all_outside_clouds():
     """The reference's edge cases (empty cloud, every point outside the map) through the round-5 entry points: the fused call, the
     PointCloud2-out call and the sensor-frame transform inside the fused call."""
