@@ -225,7 +225,10 @@ def ordered_line(result, world):
         "config4": {"clouds_per_s": pick(result, "config4", "clouds_per_s"), "all_kernels_frac_hbm": pick(result, "config4", "all_kernels_frac_hbm"),
                     "dominant_frac": pick(result, "config4", "roofline", "frac"), "single_cloud_latency_ms": pick(result, "config4", "single_cloud", "latency_ms"),
                     "cpu_clouds_per_s": pick(result, "config4", "cpu_baseline", "value")},
-        "parity_checked_in_run": {"headline": result.get("parity_checked_in_run"), "warm": pick(result, "warm_map", "parity_checked_in_run"),
+        "config5_synthetic": {"frames": pick(result, "config5_synthetic", "frames"), "clouds_per_s": pick(result, "config5_synthetic", "clouds_per_s"),
+                              "cpu_clouds_per_s": pick(result, "config5_synthetic", "cpu_baseline", "value"),
+                              "final_map_identical": pick(result, "config5_synthetic", "final_map_identical")},
+        "parity_checked_in_run": {"headline": result.get("parity_checked_in_run"), "config5_synthetic": pick(result, "config5_synthetic", "parity_checked_in_run"), "warm": pick(result, "warm_map", "parity_checked_in_run"),
                                   "config3": pick(result, "config3", "parity_checked_in_run"), "config4": pick(result, "config4", "parity_checked_in_run"),
                                   "lazy_layers": pick(result, "lazy_layers", "parity_checked_in_run"), "concurrent_halves": pick(result, "concurrent_halves", "parity_checked_in_run"),
                                   "config4_single": pick(result, "config4", "single_cloud", "parity_checked_in_run")},
@@ -283,6 +286,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (RCCL process group, all-gather per step) even with one rank")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the N ranks only (gloo when no GPU is visible): launch-path check")
     ap.add_argument("--only-config4", action="store_true", help="profiling runs: a token headline (8 clouds), then only the configs[3] leg")
+    ap.add_argument("--drive-frames", type=int, default=4540, help="frames of the configs[4]-shaped synthetic drive leg (0: skip it)")
     ap.add_argument("--kitti-dir", default=None, help="SemanticKITTI sequence directory: replay it instead of the synthetic bench")
     ap.add_argument("--kitti-max-frames", type=int, default=0)
     ap.add_argument("--kitti-euler-roundtrip", action="store_true", help="model the player's quaternion -> euler -> quaternion round trip")
@@ -874,6 +878,14 @@ def main():
         except Exception as e:  # the headline must not depend on the stress configuration
             result["config4"] = {"error": repr(e)}
 
+        # BASELINE configs[4]'s shape on synthetic data: thousands of consecutive full-size frames, the map scrolling in every one
+        if args.drive_frames > 0:
+            try:
+                seg.close()  # (the headline context's 12 GB are not needed any more)
+                result["config5_synthetic"] = drive_leg(args, local_rank)
+            except Exception as e:
+                result["config5_synthetic"] = {"error": repr(e)}
+
     if rank == 0 and world == 1 and args.only_config4:
         from oracle import oracle  # noqa: F401  (config4_leg checks its timed outputs)
 
@@ -964,6 +976,61 @@ def config4_leg(args, api, torch, dev, local_rank, seg_main, Pipeline, check_tim
     out["single_cloud"] = {"latency_ms": round(1e3 * e1 / 10, 4), "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kt1.items()},
                            "parity_checked_in_run": ok1}
     seg4.close()
+    return out
+
+
+class _OracleBackend:
+    """The CPU path behind the replay harness (groundgrid_amd.replay): the checker and the CPU baseline of the drive leg."""
+
+    def __init__(self):
+        self.m = None
+
+    def reset(self, pos, odom_z):
+        from oracle import oracle
+
+        self.m = oracle.OracleMap(120.0, 0.33, pos=pos, odom_z=float(odom_z))
+
+    def move(self, odom, base_to_map):
+        self.m.update(odom[0], odom[1], base_to_map)
+
+    def filter(self, cloud_map, origin, base_z):
+        r = self.m.filter_cloud(cloud_map, origin, base_z)
+        return r["label"], r["index"]
+
+
+def drive_leg(args, local_rank):
+    """BASELINE configs[4]'s SHAPE (SemanticKITTI sequence 00: 4540 consecutive clouds on ONE map that scrolls with the vehicle, the
+    evaluator's table at the end) on synthetic data -- the dataset is not in the image: groundgrid_amd.kitti.synthetic_drive, a closed
+    loop of 0.8 m per frame through eight seeded HDL-64E scenes, wired like a sequence directory.  Per frame GroundGrid::update on the
+    device (gg_move_map) and one synchronous gg_filter_cloud, host buffers both ways; the CPU path (the oracle, one thread) runs the same
+    frames side by side: labels and returned-cloud order compared in EVERY frame, ground / groundpatch after the LAST one (what decays
+    and scrolls for thousands of frames), the two evaluator tables against each other."""
+    import numpy as np
+
+    from groundgrid_amd import kitti, replay
+
+    n = args.drive_frames
+    dev_b, cpu_b = replay.DeviceBackend(device=local_rank, max_points=140000), _OracleBackend()
+    t0 = time.perf_counter()
+    ev, t_dev, t_cpu, n_cpu, same, first_bad = replay.replay_side_by_side(kitti.synthetic_drive(n), dev_b, cpu_b)
+    wall = time.perf_counter() - t0
+    final_same = True
+    for name in ("ground", "groundpatch"):
+        a, b = dev_b.map.get(name), cpu_b.m.layer(name)
+        final_same = final_same and bool(np.array_equal(a, b, equal_nan=True))
+    out = {
+        "workload": f"BASELINE configs[4] shape, synthetic: {n} consecutive ~125 k-point HDL-64E clouds (8 seeded scenes in turn) along a closed loop of "
+                    f"{0.8 * n / 1000.0:.2f} km, one 364 x 364 map scrolled by GroundGrid::update on the device every frame; SemanticKITTI itself is not in the image",
+        "frames": n, "clouds_per_s": round(n / t_dev, 1), "ms_per_frame": round(1e3 * t_dev / n, 4),
+        "call": "gg_move_map + synchronous gg_filter_cloud (host buffers both ways) per frame", "seconds_wall_incl_frame_synthesis_and_cpu": round(wall, 1),
+        "cpu_baseline": {"value": round(n_cpu / t_cpu, 1) if t_cpu > 0 else None, "unit": "clouds/s", "cores": 1, "kind": "port",
+                         "sample": f"the same {n_cpu} frames, GroundGrid::update + filter_cloud per frame, {t_cpu:.1f} s"},
+        "labels_and_order_identical_in_every_frame": bool(same), "first_frame_that_differed": first_bad, "final_map_identical": bool(final_same),
+        "map_position_after_the_loop": [round(float(v), 3) for v in dev_b.map.getPosition()], "evaluator": ev.rows(),
+        "parity_checked_in_run": bool(same and final_same),
+    }
+    print(ev.table(), file=sys.stderr)
+    dev_b.seg.close()
     return out
 
 

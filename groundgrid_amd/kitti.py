@@ -228,3 +228,39 @@ def write_synthetic_sequence(directory: str, clouds: List[np.ndarray], poses_cam
             c["ring"].astype(np.uint32).tofile(os.path.join(directory, "labels", f"{i:06d}.label"))
             fp.write(" ".join(f"{v:.12e}" for v in np.asarray(P, dtype=np.float64)[:3, :4].reshape(-1)) + "\n")
             ft.write(f"{0.1 * i:.6e}\n")
+
+
+def drive_poses(n_frames: int, metres_per_frame: float = 0.8) -> List[np.ndarray]:
+    """Vehicle poses (4 x 4, map <- kitti_base_link) of a closed loop driven once in n_frames steps: a circle with a slow
+    lateral weave, the heading along the path and a gentle climb and descent -- sequence 00's shape (3.7 km in 4540 frames,
+    README.md:57) without its data: the map scrolls two or three cells in every frame."""
+    radius = n_frames * metres_per_frame / (2.0 * np.pi)
+    poses = []
+    for i in range(n_frames):
+        th = 2.0 * np.pi * i / n_frames
+        rad = radius * (1.0 + 0.01 * np.sin(9.0 * th))
+        x, y = rad * np.cos(th) - radius, rad * np.sin(th)
+        yaw = th + np.pi / 2.0 + 0.02 * np.sin(31.0 * th)
+        T = np.eye(4)
+        T[:3, :3] = [[np.cos(yaw), -np.sin(yaw), 0.0], [np.sin(yaw), np.cos(yaw), 0.0], [0.0, 0.0, 1.0]]
+        T[:3, 3] = [x, y, 1.5 * np.sin(3.0 * th)]
+        poses.append(T)
+    return poses
+
+
+def synthetic_drive(n_frames: int = 4540, n_scenes: int = 8, n_az: int = 2083, seed: int = 20240113, euler_roundtrip: bool = False) -> Iterator[Frame]:
+    """BASELINE configs[4]'s SHAPE on synthetic data, in memory: n_frames consecutive full-size HDL-64E clouds (n_scenes seeded
+    scenes of groundgrid_amd.synth in turn, semantic labels faked from the height: `road` below, `building` above, some
+    `vegetation`) along drive_poses(), wired exactly like a sequence directory (make_frame).  The dataset itself is not in the
+    image; what this exercises is what the dataset would: thousands of dependent frames, the map scrolling in every one."""
+    from .synth import hdl64_cloud
+
+    scenes = []
+    for k in range(n_scenes):
+        c = hdl64_cloud(seed=seed + k, n_az=n_az)
+        lab = np.where(c["z"] < -1.4, 40, 50).astype(np.uint16)
+        lab[::17] = 70
+        c["ring"] = lab
+        scenes.append(c)
+    for i, pose in enumerate(drive_poses(n_frames)):
+        yield make_frame(i, scenes[i % n_scenes], pose, euler_roundtrip=euler_roundtrip)

@@ -53,3 +53,38 @@ def replay(frames, backend, evaluator: GroundEvaluator = None, on_frame=None):
         if on_frame:
             on_frame(fr, labels, index)
     return ev, spent
+
+
+def replay_side_by_side(frames, device, cpu, cpu_frames: int = 0):
+    """One pass over `frames` through two backends (`cpu`: the checker -- tests and bench.py pass the oracle's; None: device only), frame by frame: (evaluator of the device path, its seconds, the CPU path's
+    seconds and frames, labels_equal_in_every_frame, first frame that differed or -1).  cpu_frames > 0 stops the CPU path (and the
+    comparison) after that many frames."""
+    ev = GroundEvaluator()
+    t_dev = t_cpu = 0.0
+    n_cpu = 0
+    first_bad = -1
+    first = True
+    for k, fr in enumerate(frames):
+        with_cpu = cpu is not None and (cpu_frames <= 0 or k < cpu_frames)
+        t0 = time.perf_counter()
+        if first:
+            device.reset((fr.odom[0], fr.odom[1]), np.float32(fr.odom[2]))
+        else:
+            device.move((fr.odom[0], fr.odom[1]), fr.base_to_map)
+        labels, index = device.filter(fr.cloud_map, fr.origin, fr.map_to_base_z)
+        t_dev += time.perf_counter() - t0
+        if with_cpu:
+            t0 = time.perf_counter()
+            if first:
+                cpu.reset((fr.odom[0], fr.odom[1]), np.float32(fr.odom[2]))
+            else:
+                cpu.move((fr.odom[0], fr.odom[1]), fr.base_to_map)
+            lc, ic = cpu.filter(fr.cloud_map, fr.origin, fr.map_to_base_z)
+            t_cpu += time.perf_counter() - t0
+            n_cpu += 1
+            if first_bad < 0 and not (np.array_equal(labels, lc) and np.array_equal(index, ic)):
+                first_bad = k
+        first = False
+        emitted = index >= 0
+        ev.add_cloud(labels[emitted], fr.cloud_map["ring"][emitted])
+    return ev, t_dev, t_cpu, n_cpu, first_bad < 0, first_bad

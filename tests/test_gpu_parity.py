@@ -1383,3 +1383,24 @@ def test_pair_sweep_and_k_sweep_leave_the_same_map():
         assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"]), frame
         assert_same_state(seg.map(0), ref, f"frame {frame}")
     seg.close()
+
+
+def test_synthetic_drive_of_1200_frames_matches_the_cpu_path_to_the_last_map():
+    """BASELINE configs[4]'s shape (thousands of consecutive clouds on one scrolling map; the dataset is absent): 1200 frames of
+    groundgrid_amd.kitti.synthetic_drive -- a closed loop of 0.8 m per frame, the map scrolling two or three cells in every frame,
+    ~45 k points per cloud -- through the device path and the oracle side by side.  Labels and returned-cloud order in every frame,
+    ground / groundpatch after the last (confidence decay and scroll seeding accumulate over a drive: 70 frames do not show a drift),
+    the evaluator's table."""
+    from groundgrid_amd import kitti, replay
+    from tests.test_kitti_cpu import OracleBackend
+
+    n = 1200
+    dev_b, cpu_b = replay.DeviceBackend(max_points=60000), OracleBackend()
+    ev, t_dev, t_cpu, n_cpu, same, first_bad = replay.replay_side_by_side(kitti.synthetic_drive(n, n_scenes=5, n_az=760), dev_b, cpu_b)
+    assert same, f"labels / order differ first in frame {first_bad}"
+    assert n_cpu == n and ev.cloud_count == n
+    for name in ("ground", "groundpatch", "points", "variance"):
+        assert nan_equal(dev_b.map.get(name), cpu_b.m.layer(name)), name
+    # the loop closes: the map is back within a metre of where it started, after scrolling ~960 m
+    assert np.hypot(*dev_b.map.getPosition()) < 1.5
+    dev_b.seg.close()

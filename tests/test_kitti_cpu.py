@@ -153,3 +153,17 @@ def test_player_euler_round_trip_of_the_broadcast_quaternion():
     f0 = kitti.make_frame(0, cloud, pose)
     f1 = kitti.make_frame(0, cloud, pose, euler_roundtrip=True)
     assert np.max(np.abs(f0.cloud_map["x"] - f1.cloud_map["x"])) < 1e-4
+
+
+def test_synthetic_drive_is_a_closed_loop_wired_like_a_sequence():
+    """groundgrid_amd.kitti.synthetic_drive (the configs[4]-shaped leg of bench.py): frames in memory, wired by make_frame like a
+    sequence directory; 0.8 m per frame, back at the start after the last one; through the CPU path (plumbing, no GPU)."""
+    poses = kitti.drive_poses(300)
+    steps = [np.linalg.norm(poses[i + 1][:2, 3] - poses[i][:2, 3]) for i in range(299)]
+    assert 0.7 < min(steps) and max(steps) < 0.9
+    assert np.linalg.norm(poses[-1][:2, 3] - poses[0][:2, 3]) < 1.0
+    frames = list(kitti.synthetic_drive(6, n_scenes=2, n_az=200))
+    assert [f.index for f in frames] == list(range(6)) and frames[0].cloud_sensor is frames[2].cloud_sensor  # two scenes in turn
+    assert abs(frames[3].map_to_base_z - (kitti.drive_poses(6)[3][2, 3] - 1.73)) < 1e-9  # (a yaw-only pose: base_link sits 1.73 m below)
+    ev, _ = replay.replay(frames, OracleBackend())
+    assert ev.cloud_count == 6 and sum(ev.total.values()) > 0
