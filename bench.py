@@ -219,8 +219,10 @@ def ordered_line(result, world):
                                     "device_resident_binding": pick(result, "host_api", "device_resident_binding_vs_cpu_1thread")},
         "single_cloud_latency_ms": result.get("single_cloud_latency_ms"),
         "concurrent_halves_clouds_per_s": pick(result, "concurrent_halves", "clouds_per_s"),
-        "lazy_layers": {"clouds_per_s": pick(result, "lazy_layers", "clouds_per_s"), "reduce_ms": pick(result, "lazy_layers", "kernel_ms", "k_reduce"),
-                        "materialise_ms_per_map": pick(result, "lazy_layers", "materialise_ms_per_map")},
+        "eager_layers": {"clouds_per_s": pick(result, "eager_layers", "clouds_per_s"), "reduce_ms": pick(result, "eager_layers", "kernel_ms", "k_reduce")},
+        "lazy_read_materialise_ms_per_map": pick(result, "lazy_layers", "materialise_ms_per_map"),
+        "warm_map_unrelated_scenes": {"clouds_per_s": pick(result, "warm_map_unrelated_scenes", "clouds_per_s"), "k_classify_ms": pick(result, "warm_map_unrelated_scenes", "kernel_ms", "k_classify")},
+        "roofline_traffic_source": pick(result, "roofline", "traffic_source"),
         "config3_clouds_per_s": pick(result, "config3", "clouds_per_s"),
         "config4": {"clouds_per_s": pick(result, "config4", "clouds_per_s"), "all_kernels_frac_hbm": pick(result, "config4", "all_kernels_frac_hbm"),
                     "dominant_frac": pick(result, "config4", "roofline", "frac"), "single_cloud_latency_ms": pick(result, "config4", "single_cloud", "latency_ms"),
@@ -230,7 +232,7 @@ def ordered_line(result, world):
                               "final_map_identical": pick(result, "config5_synthetic", "final_map_identical")},
         "parity_checked_in_run": {"headline": result.get("parity_checked_in_run"), "config5_synthetic": pick(result, "config5_synthetic", "parity_checked_in_run"), "warm": pick(result, "warm_map", "parity_checked_in_run"),
                                   "config3": pick(result, "config3", "parity_checked_in_run"), "config4": pick(result, "config4", "parity_checked_in_run"),
-                                  "lazy_layers": pick(result, "lazy_layers", "parity_checked_in_run"), "concurrent_halves": pick(result, "concurrent_halves", "parity_checked_in_run"),
+                                  "lazy_layers": pick(result, "lazy_layers", "parity_checked_in_run"), "eager_layers": pick(result, "eager_layers", "parity_checked_in_run"), "concurrent_halves": pick(result, "concurrent_halves", "parity_checked_in_run"),
                                   "config4_single": pick(result, "config4", "single_cloud", "parity_checked_in_run")},
     }
     head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
@@ -273,7 +275,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="independent (cloud, map) pairs per GPU per step")
-    ap.add_argument("--minimal-layers", action="store_true", help="do not maintain the three layers nothing in the path reads")
+    ap.add_argument("--eager-layers", action="store_true", help="GG_FLAG_EAGER_LAYERS: maintain all nine per-call layers for every cloud (the library's default for "
+                    "gg_filter_batch leaves the three that nothing on the path reads to their first reader)")
+    ap.add_argument("--minimal-layers", action="store_true", help="(the default since round 6; kept for old command lines)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no warm / config3 / config4 / host_api / CPU legs)")
@@ -374,7 +378,7 @@ def main():
     n_points = [len(c) for c in clouds]
     stride = common_stride(max(n_points), device=dev)  # one shape on every rank; multiple of 64 (2-bit masks need 4)
     seg = api.GroundSegmentation().init(120.0, 0.33, n_slots=B, max_points=stride, device=local_rank)
-    seg.set_flags(minimal_layers=args.minimal_layers, profile=not args.no_profile)
+    seg.set_flags(eager_layers=args.eager_layers, profile=not args.no_profile)
 
     def to_device(cl, st):
         host = np.zeros((max(len(cl), 1), st), dtype=api.POINT16_DTYPE)
@@ -391,8 +395,9 @@ def main():
         kernels; buffer i % 2 is reused only after its gather completed.  shifts[i] = how far the clouds were rotated over the
         slots in step i (cloud b -> slot (b + shift) mod nb)."""
 
-        def __init__(self, seg_, pts, npts, org, bz, cold, rotate=True, first_shift=0):
+        def __init__(self, seg_, pts, npts, org, bz, cold, rotate=True, first_shift=0, within_halves=False):
             self.seg, self.pts, self.npts, self.org, self.bz, self.cold = seg_, pts, npts, org, bz, cold
+            self.within_halves = within_halves  # the clouds rotate over the slots of their own half (a row of the outputs keeps its half)
             self.outs, self.pending, self.step_no, self.out = [None, None], [None, None], 0, None
             self.nb = nb = pts.shape[0]
             self.rotate = rotate and not args.no_rotate and nb > 1
@@ -403,7 +408,13 @@ def main():
             self.abi = StreamGather(AbiLabelGather(seg_, rank, world)) if (dist and args.abi_collective) else None
 
         def slots_of(self, shift):
+            if self.within_halves:
+                h = self.nb // 2
+                return np.where(self.ids < h, (self.ids + shift) % h, h + (self.ids - h + shift) % (self.nb - h)).astype(np.int32)
             return ((self.ids + shift) % self.nb).astype(np.int32)
+
+        def slot_of(self, b, shift):
+            return int(self.slots_of(shift)[b])
 
         def step(self):
             k = self.step_no % 2
@@ -466,7 +477,7 @@ def main():
         labels, index, counts = pipe.out.labels, pipe.out.out_index, pipe.out.counts.cpu().numpy()
         ok, checked = True, []
         for b in sorted(rng.choice(nb, size=min(n_check, nb), replace=False).tolist()):
-            slot = int((b + last) % nb)
+            slot = pipe.slot_of(b, last)
             hist = history_of(slot) if history_of else [b]
             ref = oracle.OracleMap(length, resolution)
             r = None
@@ -513,7 +524,9 @@ def main():
             "grid": "364x364",
             "map_state": "cold",
             "point_format": "packed 16 B (x,y,z,ring) resident in HBM",
-            "layers": "minimal" if args.minimal_layers else "all 11",
+            "layers": "all 11 maintained for every cloud (GG_FLAG_EAGER_LAYERS)" if args.eager_layers else
+                      "gg_filter_batch's default: the eight layers the path reads or rewrites maintained per cloud; groundCandidates, planeDist, maxGroundHeight "
+                      "(read by nothing on the path) computed on their first read -- every getter returns the reference's values at all times",
             "parallelism": f"clouds sharded {B}/GPU x {world} GPU, no data-path collective"
                            + (", 1 all-gather of label masks per step overlapped with the next step" if world > 1 else ""),
         },
@@ -532,10 +545,10 @@ def main():
         n_in = float(np.mean(counts[:, 1] + counts[:, 2] + counts[:, 3]))  # emitted kept + ignored + outliers ~ in-map
         n_kept = float(np.mean(counts[:, 1]))
         pw = seg.debug_set_tuning("pw", 0)  # points per wave chunk of this context (K1 / scan / scatter / K5)
-        alg = algorithmic_bytes(n_mean, n_in, n_kept, C, T, (stride + pw - 1) // pw, full_layers=not args.minimal_layers)
+        alg = algorithmic_bytes(n_mean, n_in, n_kept, C, T, (stride + pw - 1) // pw, full_layers=args.eager_layers)
         table = kernel_table(ktimes, alg, B)
         traffic_source = "profiles/pmc_summary.json (the committed profile round, rescaled to this batch)"
-        if world == 1 and dist is None and not args.no_extras and not args.no_live_pmc and not args.only_config4 and not args.minimal_layers:
+        if world == 1 and dist is None and not args.no_extras and not args.no_live_pmc and not args.only_config4:
             live = live_pmc_passes(B)
             if "kernels" in live:
                 LIVE_PMC.update(live["kernels"])
@@ -621,43 +634,49 @@ def main():
         # slots as two launch sequences on two streams that never join between steps, so kernels of different kinds overlap.  Reported
         # BESIDE the headline, not as it: with two kernels sharing the device a per-kernel event pair times half a machine, so this leg
         # has no per-kernel table and no roofline.
-        seg.set_flags(minimal_layers=args.minimal_layers, profile=False, concurrent_halves=True)
+        seg.set_flags(eager_layers=args.eager_layers, profile=False, concurrent_halves=True)
         saved_no_profile, args.no_profile = args.no_profile, True
         h_steps = max(4, args.steps // 2)
         with torch.cuda.stream(torch.cuda.Stream(device=dev)):  # (a real stream: the flag is ignored on the legacy default one)
-            # halves / one sequence / halves again on the same stream, back to back: the like-for-like pair (the faster of the two
-            # divided runs is reported; the first also pays the side stream's first use)
-            halves = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=pipe.shifts[-1])
-            h_elapsed, _ = halves.timed(h_steps, 4)
-            seg.set_flags(minimal_layers=args.minimal_layers, profile=False)
-            plain = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=halves.shifts[-1])
-            one_seq, _ = plain.timed(h_steps, 2)
-            seg.set_flags(minimal_layers=args.minimal_layers, profile=False, concurrent_halves=True)
-            halves = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=plain.shifts[-1])
-            h_elapsed = min(h_elapsed, halves.timed(h_steps, 2)[0])
+            # halves / one sequence / halves / one sequence on the same stream, back to back, the same warm-up for each: the like-for-like
+            # pairs; the faster run of either kind is reported.  The clouds rotate over the slots of their own half: a row of the output
+            # buffers keeps its half, so the library need not join the two streams between steps (a row that changed its half would be
+            # written from both: enqueue_batch orders such batches itself, and the overlap is gone)
+            h_elapsed = one_seq = None
+            shift = pipe.shifts[-1]
+            for rep in range(2):
+                seg.set_flags(eager_layers=args.eager_layers, profile=False, concurrent_halves=True)
+                halves = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=shift, within_halves=True)
+                e, _ = halves.timed(h_steps, 3)
+                h_elapsed = e if h_elapsed is None else min(h_elapsed, e)
+                seg.set_flags(eager_layers=args.eager_layers, profile=False)
+                plain = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=halves.shifts[-1], within_halves=True)
+                e, _ = plain.timed(h_steps, 3)
+                one_seq = e if one_seq is None else min(one_seq, e)
+                shift = plain.shifts[-1]
+            seg.set_flags(eager_layers=args.eager_layers, profile=False, concurrent_halves=True)
+            halves = Pipeline(seg, points, n_points, origins, base_z, cold=True, first_shift=shift, within_halves=True)
+            halves.timed(2, 1)  # (the outputs check_timed_outputs reads: a divided run's)
         args.no_profile = saved_no_profile
-        seg.set_flags(minimal_layers=args.minimal_layers, profile=not args.no_profile)
+        seg.set_flags(eager_layers=args.eager_layers, profile=not args.no_profile)
         result["concurrent_halves"] = {
             "clouds_per_s": round(world * B * h_steps / h_elapsed, 1), "ms_per_step": round(1e3 * h_elapsed / h_steps, 4),
             "one_sequence_same_stream_ms_per_step": round(1e3 * one_seq / h_steps, 4), "one_sequence_same_stream_clouds_per_s": round(world * B * h_steps / one_seq, 1),
             "note": "the headline's cold steps under gg_set_flags(GG_FLAG_CONCURRENT_HALVES): the clouds whose maps are in the lower / upper half "
-                    "of the slots as two launch sequences on two streams, no join between steps (the caller fences before it reads outputs); "
-                    "results identical; per-kernel timing is not meaningful in this mode"}
+                    "of the slots as two launch sequences on two streams, no join between steps (the caller fences before it reads outputs; the "
+                    "clouds rotate over the slots of their own half, so that a row of the outputs keeps its half); each variant twice, "
+                    "interleaved, same warm-up, the faster run of either; results identical; per-kernel timing is not meaningful in this mode"}
         if do_checks:
             result["concurrent_halves"]["parity_checked_in_run"] = check_timed_outputs(halves, clouds, 120.0, 0.33, n_check=4, seed=9)[0]
 
-    # ---------------------------------------------------------------- lazily materialised layers (a separate leg, not the headline)
-    if extras and rank == 0 and world == 1 and not args.minimal_layers:
-        # SURVEY Appendix E / VERDICT r3 2(c): k_reduce maintains the six per-call layers the path reads; maxGroundHeight,
+    # ---------------------------------------------------------------- all nine per-call layers for every cloud (a separate leg), and what a lazy read costs
+    if extras and rank == 0 and world == 1 and not args.eager_layers:
+        # SURVEY Appendix E / VERDICT r3 2(c), r5 5(a): by default k_reduce maintains the six per-call layers the path reads; maxGroundHeight,
         # groundCandidates and planeDist are computed when a reader asks (gg_get_layer), from the records the call left behind.
-        seg.set_flags(minimal_layers=True, profile=not args.no_profile)
         lazy = Pipeline(seg, points, n_points, origins, base_z, cold=True)
-        l_steps = max(4, args.steps // 2)
-        l_elapsed, l_kt = lazy.timed(l_steps, 2)
-        leg = {"clouds_per_s": round(B * l_steps / l_elapsed, 1), "ms_per_step": round(1e3 * l_elapsed / l_steps, 4),
-               "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in l_kt.items()},
-               "note": "GG_FLAG_MINIMAL_LAYERS: per cloud only the six per-call layers the path reads; the three published-only ones are "
-                       "computed on the first read of one of them (`materialise_ms_per_map`: that read against a read of a maintained layer)"}
+        lazy.timed(2, 1)
+        leg = {"note": "the library's default for gg_filter_batch; `materialise_ms_per_map`: the first read of one of the three published-only layers of a map "
+                       "against a read of a maintained layer"}
         n_read = min(16, B)  # (a read = extract + 0.5 MB over PCIe; the lazy read also runs the three recurrences of that map first)
         t0 = time.perf_counter()
         for sl in range(n_read):
@@ -677,8 +696,17 @@ def main():
                 got = seg.map(c["slot"]).layers()
                 okl &= all(nan_equal(got[name], ref.layer(name)) for name in oracle.LAYERS)
             leg["parity_checked_in_run"] = bool(okl)
-        seg.set_flags(minimal_layers=False, profile=not args.no_profile)
         result["lazy_layers"] = leg
+        seg.set_flags(eager_layers=True, profile=not args.no_profile)
+        eager = Pipeline(seg, points, n_points, origins, base_z, cold=True)
+        l_steps = max(4, args.steps // 2)
+        l_elapsed, l_kt = eager.timed(l_steps, 2)
+        result["eager_layers"] = {"clouds_per_s": round(B * l_steps / l_elapsed, 1), "ms_per_step": round(1e3 * l_elapsed / l_steps, 4),
+                                  "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in l_kt.items()},
+                                  "note": "GG_FLAG_EAGER_LAYERS: all nine per-call layers written for every cloud (the headline of rounds 1-5)"}
+        if do_checks:
+            result["eager_layers"]["parity_checked_in_run"] = check_timed_outputs(eager, clouds, 120.0, 0.33, n_check=2, seed=14)[0]
+        seg.set_flags(eager_layers=False, profile=not args.no_profile)
 
     # ---------------------------------------------------------------- configs[2]: 64 clouds in total, 64 / N per GPU
     if extras:

@@ -24,7 +24,7 @@ STATUS = {
 
 GG_ABI_VERSION = 5  # include/groundgrid_hip.h
 GG_POINT32, GG_POINT16 = 0, 1
-GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE, GG_FLAG_CONCURRENT_HALVES = 1, 2, 4
+GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE, GG_FLAG_CONCURRENT_HALVES, GG_FLAG_EAGER_LAYERS = 1, 2, 4, 8
 GG_NUM_KERNELS = 7
 GG_NUM_LAYERS = 11
 

@@ -271,13 +271,14 @@ class GroundSegmentation:
         _check(self._L, self._ctx, self._L.gg_get_config(self._ctx, C.byref(c)), "gg_get_config")
         return c
 
-    def set_flags(self, minimal_layers: bool = False, profile: bool = False, concurrent_halves: bool = False):
+    def set_flags(self, minimal_layers: bool = False, profile: bool = False, concurrent_halves: bool = False, eager_layers: bool = False):
         """gg_set_flags.  minimal_layers: maxGroundHeight / groundCandidates / planeDist -- written by insert_cloud
         (src/GroundSegmentation.cpp:296,303,307) and read by nothing on the path -- are computed when a layer getter asks for one of
         them instead of for every cloud; every getter still returns what the reference's layer would hold.  profile: per-kernel
-        events (kernel_times)."""
+        events (kernel_times).  filter_batch (device-resident clouds) does that by default; eager_layers switches it back to all nine
+        per-call layers per cloud."""
         f = ((_lib.GG_FLAG_MINIMAL_LAYERS if minimal_layers else 0) | (_lib.GG_FLAG_PROFILE if profile else 0) |
-             (_lib.GG_FLAG_CONCURRENT_HALVES if concurrent_halves else 0))
+             (_lib.GG_FLAG_CONCURRENT_HALVES if concurrent_halves else 0) | (_lib.GG_FLAG_EAGER_LAYERS if eager_layers else 0))
         _check(self._L, self._ctx, self._L.gg_set_flags(self._ctx, f), "gg_set_flags")
 
     def expected_points(self) -> np.ndarray:

@@ -488,7 +488,7 @@ int launch_or_replay(gg_context *ctx, const Arena &a, const CloudParams *hp, Clo
     // the grids of a captured sequence cover the largest cloud the buffers can hold: work-groups beyond this cloud's chunks leave at once
     key.max_n = (int)std::min(ctx->max_points, io.cloud_stride);
     key.slot = hp[0].slot;
-    key.flags = ctx->flags;
+    key.flags = a.flags;
     key.eigen = a.eigen_reduction;
     key.generation = ctx->graph_generation;
     key.stream = s;
@@ -558,8 +558,12 @@ bool halves_enabled(const gg_context *ctx)
 }
 
 // enqueue the seven kernels of one batched filter_cloud call
-int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const LayerPlan *plan = nullptr)
+// batch_entry: the call is gg_filter_batch (device-resident clouds, no layer asked for): the three published-only layers are left to
+// their first reader unless GG_FLAG_EAGER_LAYERS says otherwise
+int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const LayerPlan *plan = nullptr, bool batch_entry = false)
 {
+    const bool lazy = (ctx->flags & GG_FLAG_MINIMAL_LAYERS) || (batch_entry && !(ctx->flags & GG_FLAG_EAGER_LAYERS));
+    const unsigned eff_flags = lazy ? (ctx->flags | GG_FLAG_MINIMAL_LAYERS) : (ctx->flags & ~(unsigned)GG_FLAG_MINIMAL_LAYERS);
     const int nb = b->n_clouds;
     if (nb == 0) return GG_OK;
     // parameter ring slot
@@ -601,8 +605,8 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
         p.label_shift = nb == 1 ? ctx->next_label_shift : 0;
         p.io_index = i;
         max_n[half] = std::max(max_n[half], p.n_points);
-        ctx->lazy_pending[slot] = (ctx->flags & GG_FLAG_MINIMAL_LAYERS) ? 1 : 0;
-        if (ctx->flags & GG_FLAG_MINIMAL_LAYERS) ctx->lazy_params[slot] = p;
+        ctx->lazy_pending[slot] = lazy ? 1 : 0;
+        if (lazy) ctx->lazy_params[slot] = p;
     }
     // order this batch after everything that touched map state on the context's stream, and after an earlier batch that ran
     // on another stream
@@ -668,7 +672,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
     io.d_out_pc2 = b->d_out_pc2;
 
     Arena a = ctx->arena;
-    a.flags = ctx->flags;
+    a.flags = eff_flags;
     a.eigen_reduction = ctx->conv.eigen_reduction;
     if (split) {
         // the side stream sees what the caller's stream holds up to here (its inputs, a re-initialisation of the maps on that stream)
@@ -1780,7 +1784,7 @@ int gg_filter_batch(gg_context *ctx, const gg_batch *b, void *stream)
         if (b->n_points[i] < 0 || (size_t)b->n_points[i] > ctx->max_points || (size_t)b->n_points[i] > b->cloud_stride)
             return fail(ctx, GG_ERR_CAPACITY, "n_points exceeds max_points / cloud_stride");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    return enqueue_batch(ctx, b, pick_stream(ctx, stream));
+    return enqueue_batch(ctx, b, pick_stream(ctx, stream), nullptr, true);
 }
 
 int gg_device_error(gg_context *ctx, int clear)

@@ -116,14 +116,20 @@ enum {
                                    src/GroundSegmentation.cpp:296,303,307) are not maintained per cloud; a reader of one of them
                                    (gg_get_layer, gg_get_layers, gg_get_layer_image_u8, gg_set_layer) has them computed first, from
                                    the tile-sorted records the slot's last cloud left on the device -- so every layer reads at all
-                                   times as the reference's would; default off */
+                                   times as the reference's would.  Default: off for the calls that take or return host buffers (the
+                                   binding publishes every layer), ON for gg_filter_batch -- device-resident clouds, nobody has asked
+                                   for a layer -- unless GG_FLAG_EAGER_LAYERS is set */
     GG_FLAG_PROFILE = 2,        /* bracket every kernel with events on the launch stream (gg_get_kernel_times) */
+    GG_FLAG_EAGER_LAYERS = 8,   /* gg_filter_batch maintains all nine per-call layers for every cloud as well (the behaviour up to ABI v5:
+                                   k_reduce 1.27 instead of 1.12 ms per 1024 clouds) */
     GG_FLAG_CONCURRENT_HALVES = 4 /* a gg_filter_batch of at least 256 clouds runs as TWO independent launch sequences side by side: the
                                    clouds whose map slot is in the lower half of the context's slots on the caller's stream, the others
                                    on a stream of the library's own, and gg_reset_maps on a caller stream divides its fills the same way.
                                    A map slot is only ever touched from "its" stream, so the two sequences never wait for each other:
                                    they drift apart, kernels of different kinds overlap and fill each other's tails (+4 % clouds/s at
-                                   1024 clouds per call).  The price: the CALLER'S STREAM IS NOT ORDERED AFTER THE SECOND HALF.  Work the
+                                   1024 clouds per call).  An OUTPUT row follows a cloud's position in the batch, its half the cloud's slot: while
+                                   every row keeps its half from batch to batch (or the output buffers are fresh) nothing joins; a batch that
+                                   would write a row from the other stream than the batch before is ordered behind both first.  The price: the CALLER'S STREAM IS NOT ORDERED AFTER THE SECOND HALF.  Work the
                                    caller enqueues itself behind the call (copies of the outputs, its own kernels) must follow
                                    gg_batch_fence(ctx, stream) first; every gg_* entry point orders itself (getters, gg_synchronize,
                                    gg_allgather_label_masks, batches on other streams).  Ignored on the legacy default stream (its implicit synchronisation
