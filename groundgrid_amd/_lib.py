@@ -22,7 +22,7 @@ STATUS = {
     -6: "GG_ERR_NO_DEVICE",
 }
 
-GG_ABI_VERSION = 5  # include/groundgrid_hip.h
+GG_ABI_VERSION = 6  # include/groundgrid_hip.h
 GG_POINT32, GG_POINT16 = 0, 1
 GG_FLAG_MINIMAL_LAYERS, GG_FLAG_PROFILE, GG_FLAG_CONCURRENT_HALVES, GG_FLAG_EAGER_LAYERS = 1, 2, 4, 8
 GG_NUM_KERNELS = 7
@@ -41,7 +41,7 @@ SYMBOLS = [
     "gg_filter_cloud", "gg_filter_cloud_tf", "gg_filter_cloud_pc2", "gg_get_layer_image_u8", "gg_get_terrain_image", "gg_filter_batch", "gg_synchronize", "gg_get_point_classes", "gg_get_kernel_times",
     "gg_set_conventions", "gg_get_conventions", "gg_rotation_from_quaternion", "gg_transform_from_pose",
     "gg_filter_cloud_async", "gg_filter_cloud_wait", "gg_debug_emulate_ring_sweep", "gg_debug_sweep_sync_selftest",
-    "gg_batch_fence", "gg_device_error", "gg_filter_cloud_layers", "gg_host_register", "gg_host_unregister", "gg_run_stage", "gg_filter_cloud_pc2_out", "gg_get_gridmap_message",
+    "gg_batch_fence", "gg_device_error", "gg_filter_cloud_layers", "gg_host_register", "gg_host_unregister", "gg_run_stage", "gg_insert_cloud", "gg_filter_cloud_pc2_out", "gg_get_gridmap_message",
     "gg_collective_available", "gg_comm_unique_id", "gg_comm_init_rank", "gg_comm_init_rank_for", "gg_comm_destroy", "gg_allgather_label_masks",
 ]
 
@@ -174,6 +174,7 @@ def load():
     L.gg_filter_cloud_pc2_out.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, vp, P(C.c_size_t)]
     L.gg_get_gridmap_message.argtypes = [vp, C.c_int, C.c_uint, P(GGGridMapHeader), vp, C.c_size_t, P(C.c_size_t)]
     L.gg_run_stage.argtypes = [vp, C.c_int, C.c_int, P(GGStageArgs)]
+    L.gg_insert_cloud.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, P(C.c_float), vp, vp]
     L.gg_filter_cloud_layers.argtypes = [vp, C.c_int, vp, C.c_size_t, P(C.c_double), P(C.c_float), C.c_double, vp, P(C.c_size_t), vp, vp, P(vp)]
     L.gg_host_register.argtypes = [vp, vp, C.c_size_t]
     L.gg_host_unregister.argtypes = [vp, vp]

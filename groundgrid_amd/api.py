@@ -180,6 +180,20 @@ class GridMap:
     def interpolate_cell(self, x: int, y: int):
         self._stage(_lib.GG_STAGE_INTERPOLATE_CELL, i=x, j=y)
 
+    def insert_cloud(self, cloud: np.ndarray, start: int, end: int, cloudOrigin: Sequence[float]):
+        """GroundSegmentation::insert_cloud(cloud, start, end, cloudOrigin, point_index, ignored, outliers, map)
+        (include/groundgrid/GroundSegmentation.h:55, src/GroundSegmentation.cpp:200-311) on this map as it stands (no per-call reset).
+        Returns (class, cell) per point of [start, end) in cloud order; the three lists the reference appends to are the points of class
+        KEPT / IGNORED (with their cells) / OUTLIER in that order."""
+        L, ctx = self._seg._L, self._seg._ctx
+        cloud = np.ascontiguousarray(cloud)
+        assert cloud.dtype.itemsize == 32 and 0 <= start <= end <= len(cloud)
+        n = end - start
+        cls, cell = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.int32)
+        org = (C.c_float * 3)(*[float(v) for v in cloudOrigin])
+        _check(L, ctx, L.gg_insert_cloud(ctx, self.slot, cloud.ctypes.data, start, end, org, cls.ctypes.data, cell.ctypes.data), "gg_insert_cloud")
+        return cls, cell
+
     def terrain_image(self) -> np.ndarray:
         """The 32FC3 terrain image of Nodelet.cpp:247-268: rows x cols x (ground, visited flag, pointsRaw)."""
         L, ctx = self._seg._L, self._seg._ctx

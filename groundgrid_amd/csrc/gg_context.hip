@@ -2247,6 +2247,65 @@ int gg_run_stage(gg_context *ctx, int slot, int stage, const gg_stage_args *args
     return GG_OK;
 }
 
+// GroundSegmentation::insert_cloud on the slot's map as it stands (include/groundgrid_hip.h): k_classify -> scan -> scatter on the range,
+// then k_stage_insert continues the recurrences in the (densified) layers.
+int gg_insert_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t start, size_t end, const float origin[3], uint8_t *out_class, int32_t *out_cell)
+{
+    if (!slot_ok(ctx, slot)) return GG_ERR_CAPACITY;
+    if (!origin || end < start || (end > start && !cloud)) return fail(ctx, GG_ERR_INVALID, "gg_insert_cloud: null cloud / origin or end < start");
+    const size_t n = end - start;
+    if (n > ctx->max_points) return fail(ctx, GG_ERR_CAPACITY, "gg_insert_cloud: range larger than max_points");
+    if (n == 0) return GG_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
+    const hipStream_t s = ctx->stream;
+    // the per-call layers dense: the three lazily kept ones computed, the reset values written into the dead half columns
+    if (const int rc = ensure_lazy_layers(ctx, slot, true)) return rc;
+    Arena a = ctx->arena;
+    a.flags = ctx->flags & ~(unsigned)GG_FLAG_MINIMAL_LAYERS;
+    a.eigen_reduction = ctx->conv.eigen_reduction;
+    launch_materialise_layers(a, slot, s);
+    HIPCHK(ctx, hipGetLastError());
+    for (size_t i = 0; i < n; ++i) {
+        const gg_point32 &p = cloud[start + i];
+        gg_point16 &d = ctx->h_stage_pts[i];
+        d.x = p.x, d.y = p.y, d.z = p.z, d.ring = p.ring, d.pad = 0;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage_pts, ctx->h_stage_pts, n * sizeof(gg_point16), hipMemcpyHostToDevice, s));
+    const int r = ctx->ring_next;
+    ctx->ring_next = (r + 1) % PARAM_RING;
+    if (ctx->ring_used[r]) HIPCHK(ctx, hipEventSynchronize(ctx->ring_done[r]));
+    CloudParams *hp = ctx->h_params + (size_t)r * ctx->n_slots, *dp = ctx->d_params + (size_t)r * ctx->n_slots;
+    hp[0] = CloudParams{};
+    hp[0].slot = slot;
+    hp[0].n_points = (int)n;
+    hp[0].ox = origin[0], hp[0].oy = origin[1], hp[0].oz = origin[2];
+    hp[0].pos_x = ctx->pos_x[slot];
+    hp[0].pos_y = ctx->pos_y[slot];
+    hp[0].no_confidence = ctx->no_confidence[slot] ? 1 : 0;
+    HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams), hipMemcpyHostToDevice, s));
+    BatchIO io{};
+    io.d_points = ctx->d_stage_pts;
+    io.cloud_stride = ctx->max_points;
+    io.point_format = GG_POINT16;
+    const int front = launch_classify(a, dp, io, 1, (int)n, s);
+    if (front == FRONT_THREE_LAUNCHES) launch_scan(a, dp, 1, s);
+    if (front != FRONT_ONE_LAUNCH) launch_scatter(a, dp, 1, (int)n, s);
+    launch_stage_insert(a, dp, s);
+    // (k_scan dropped the liveness masks of the tiles this range left empty; their values are all still there: every half column holds its values)
+    launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)slot * a.tile_live_stride), (size_t)a.g.T * 4, 0xFF, s);
+    launch_decode_classes(a, slot, n, ctx->d_stage_class, ctx->d_stage_cell, s);
+    HIPCHK(ctx, hipGetLastError());
+    if (out_class) HIPCHK(ctx, hipMemcpyAsync(out_class, ctx->d_stage_class, n, hipMemcpyDeviceToHost, s));
+    if (out_cell) HIPCHK(ctx, hipMemcpyAsync(out_cell, ctx->d_stage_cell, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ring_done[r], s));
+    ctx->ring_used[r] = true;
+    ctx->lazy_pending[slot] = 0; // (all nine layers are maintained and dense)
+    if (const int rc = own_stream_mutated_map(ctx)) return rc;
+    SYNCCHK(ctx, hipStreamSynchronize(s));
+    return GG_OK;
+}
+
 // tools and tests only (not in the header): override the launch geometry the library would pick from the batch size (0 = back
 // to the default).  key: "sweep_waves", "k2_per_cloud", "k2_dense_share".  Returns the chunk size PW for key "pw" (read-only:
 // the arena is carved for it at gg_create; set GG_PW in the environment before gg_create to change it).

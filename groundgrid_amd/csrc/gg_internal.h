@@ -281,6 +281,7 @@ int launch_classify(const Arena &a, const CloudParams *d_params, const BatchIO &
 void launch_scan(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_scatter(const Arena &a, const CloudParams *d_params, int n_clouds, int max_n, hipStream_t s);
 void launch_reduce(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
+void launch_stage_insert(const Arena &a, const CloudParams *d_params, hipStream_t s); // gg_insert_cloud: :282-309 continued from the layers as they stand (one slot, dense layers)
 void launch_reduce_lazy(const Arena &a, const CloudParams &cp, hipStream_t s); // (GG_FLAG_MINIMAL_LAYERS: the other three layers, one slot)
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s);
 void launch_patch_stage(const Arena &a, const CloudParams *d_params, int slot, int section, hipStream_t s); // gg_run_stage: :323 + one quadrant (-1: all) on the slot's layers as they stand

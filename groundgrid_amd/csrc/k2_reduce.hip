@@ -839,6 +839,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     reduce_share<K2_LAZY3>(a, &cp, lds, 0, (int)blockIdx.x, (int)gridDim.x, n_dense_groups);
 }
 
+// GroundSegmentation::insert_cloud as a member of its own (gg_insert_cloud; include/groundgrid/GroundSegmentation.h:55,
+// src/GroundSegmentation.cpp:282-309 and the count of :234): the recurrences CONTINUE from what the layers hold -- no reset (:61-75 is
+// filter_cloud's), a cell's count starts wherever an earlier range left it -- so none of k_reduce's shortcuts apply (a wave-uniform
+// count, quotients from a table, the sparse half columns).  One work-group per tile that received records, one thread per cell: it
+// walks the tile's records in cloud order (k_scatter's stable order) and applies the reference's expressions as they stand to its own.
+// A stage entry, not the hot path: the layers of the slot are dense when this runs (launch_materialise_layers).
+__global__ __launch_bounds__(256) void k_stage_insert(const Arena a, const CloudParams *__restrict__ params)
+{
+    const CloudParams &cp = params[0];
+    const int rank = (int)blockIdx.x;
+    const uint32_t *tile_start = a.tile_start + (size_t)cp.slot * a.tile_start_stride;
+    const uint32_t first = tile_start[rank], end = tile_start[rank + 1];
+    if (first == end) return;
+    const uint2 *sorted = a.sorted + (size_t)cp.slot * a.point_stride;
+    float *blk = percall_ptr(a, cp.slot) + percall_index(rank, 0, 0);
+    const uint32_t cell = threadIdx.x; // row in tile + 16 * column in tile
+    const uint32_t c0 = a.rank_cell0[rank];
+    const bool inside = (int)(c0 & 0xFFFFu) + (int)(cell & 15u) < a.g.rows && (int)(c0 >> 16) + (int)(cell >> 4) < a.g.cols;
+    CellState st;
+    float count = 0.f, raw = 0.f;
+    if (inside) {
+        count = blk[PL_POINTS * TILE_CELLS + cell];
+        raw = blk[PL_POINTSRAW * TILE_CELLS + cell];
+        st.gc = blk[PL_GROUNDCANDIDATES * TILE_CELLS + cell];
+        st.mean = blk[PL_MEANVARIANCE * TILE_CELLS + cell];
+        st.pdm = blk[PL_PLANEDIST * TILE_CELLS + cell];
+        st.m2 = blk[PL_M2 * TILE_CELLS + cell];
+        st.mx = blk[PL_MAXGROUNDHEIGHT * TILE_CELLS + cell];
+        st.mn = blk[PL_MINGROUNDHEIGHT * TILE_CELLS + cell];
+    }
+    for (uint32_t i = first; i < end; ++i) {
+        const uint2 r = sorted[i]; // (every thread reads the same record: one broadcast load)
+        if (!inside || (r.y & 0xFFu) != cell) continue;
+        raw += 1.0f; // :234
+        if (((r.y >> KEY_CLASS_SHIFT) & 3u) != (uint32_t)GG_CLASS_KEPT) continue;
+        // (the expressions of :295-309 letter by letter, binary64 divisions included: a count that gg_set_layer put there need not be an integer)
+        const float z = __uint_as_float(r.x);
+        const float planeDist = z - cp.oz;                                                       // :295
+        st.gc = (float)((double)(z + count * st.gc) / ((double)count + 1.0));                    // :296
+        if ((double)st.mean == 0.0) st.mean = planeDist;                                         // :298-299
+        if (!isnan(planeDist)) {                                                                 // :300
+            const float delta = planeDist - st.mean;                                             // :301
+            st.mean += delta / (count + 1);                                                      // :302
+            st.pdm = (float)((double)(planeDist + count * st.pdm) / ((double)count + 1.0));      // :303
+            st.m2 += delta * (planeDist - st.mean);                                              // :304
+        }
+        st.mx = std_max(st.mx, z);                                                               // :307
+        st.mn = std_min(st.mn, z - 0.0001f);                                                     // :308
+        count = (float)((double)count + 1.0);                                                    // :309
+    }
+    if (inside) {
+        blk[PL_POINTS * TILE_CELLS + cell] = count;
+        blk[PL_POINTSRAW * TILE_CELLS + cell] = raw;
+        blk[PL_GROUNDCANDIDATES * TILE_CELLS + cell] = st.gc;
+        blk[PL_MEANVARIANCE * TILE_CELLS + cell] = st.mean;
+        blk[PL_PLANEDIST * TILE_CELLS + cell] = st.pdm;
+        blk[PL_M2 * TILE_CELLS + cell] = st.m2;
+        blk[PL_MAXGROUNDHEIGHT * TILE_CELLS + cell] = st.mx;
+        blk[PL_MINGROUNDHEIGHT * TILE_CELLS + cell] = st.mn;
+    }
+}
+
+void launch_stage_insert(const Arena &a, const CloudParams *d_params, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_stage_insert, dim3(a.g.T), dim3(256), 0, s, a, d_params);
+}
+
 void launch_reduce_lazy(const Arena &a, const CloudParams &cp, hipStream_t s)
 {
     const int per_cloud = std::min(4096, 2 * a.g.T);

@@ -132,21 +132,35 @@ class GroundSegmentation {
         return filter_cloud(cloud, cloudOrigin, mapToBase_z, map);
     }
 
-    // GroundSegmentation::insert_cloud's outputs (src/GroundSegmentation.cpp:200-311) for the cloud last passed to
-    // filter_cloud on `map`, restricted to [start, end): point_index (kept), ignored, outliers, in cloud order.
-    void insert_cloud(const size_t start, const size_t end, std::vector<std::pair<size_t, Index>> &point_index,
-                      std::vector<std::pair<size_t, Index>> &ignored, std::vector<size_t> &outliers, GridMap &map)
+    // GroundSegmentation::insert_cloud (include/groundgrid/GroundSegmentation.h:55, src/GroundSegmentation.cpp:200-311): the points
+    // cloud[start, end) INTO `map` as it stands -- pointsRaw and the recurrences of :296-309 continue from what the layers hold, no reset
+    // -- and appended to the three lists in cloud order (gg_insert_cloud).
+    void insert_cloud(const std::vector<PCLPoint> &cloud, const size_t start, const size_t end, const PCLPoint &cloudOrigin,
+                      std::vector<std::pair<size_t, Index>> &point_index, std::vector<std::pair<size_t, Index>> &ignored, std::vector<size_t> &outliers,
+                      GridMap &map)
+    {
+        const size_t last = end < cloud.size() ? end : cloud.size();
+        if (start >= last) return;
+        std::vector<uint8_t> cls(last - start);
+        std::vector<int32_t> cell(last - start);
+        const float origin[3] = {cloudOrigin.x, cloudOrigin.y, cloudOrigin.z};
+        if (gg_insert_cloud(ctx_, map.slot(), reinterpret_cast<const gg_point32 *>(cloud.data()), start, last, origin, cls.data(), cell.data()) != GG_OK)
+            throw std::runtime_error(std::string("gg_insert_cloud: ") + gg_last_error(ctx_));
+        append_lists(cls, cell, start, map.rows(), point_index, ignored, outliers);
+    }
+    // ... and the per-point decisions of the LAST filter_cloud call on `map`, restricted to [start, end), in the same three lists (nothing
+    // is inserted: gg_get_point_classes)
+    void last_call_lists(const size_t start, const size_t end, std::vector<std::pair<size_t, Index>> &point_index,
+                         std::vector<std::pair<size_t, Index>> &ignored, std::vector<size_t> &outliers, GridMap &map)
     {
         std::vector<uint8_t> cls(last_n_);
         std::vector<int32_t> cell(last_n_);
         if (gg_get_point_classes(ctx_, map.slot(), last_n_, cls.data(), cell.data()) != GG_OK)
             throw std::runtime_error("gg_get_point_classes");
-        for (size_t i = start; i < end && i < last_n_; ++i) {
-            const Index gi = {cell[i] % map.rows(), cell[i] / map.rows()};
-            if (cls[i] == GG_CLASS_KEPT) point_index.emplace_back(i, gi);
-            else if (cls[i] == GG_CLASS_IGNORED) ignored.emplace_back(i, gi);
-            else if (cls[i] == GG_CLASS_OUTLIER) outliers.push_back(i);
-        }
+        const size_t last = end < last_n_ ? end : last_n_;
+        if (start >= last) return;
+        append_lists(std::vector<uint8_t>(cls.begin() + start, cls.begin() + last), std::vector<int32_t>(cell.begin() + start, cell.begin() + last), start,
+                     map.rows(), point_index, ignored, outliers);
     }
 
     // The stage members (include/groundgrid/GroundSegmentation.h:59-62), each on `map` as it stands (gg_run_stage)
@@ -165,6 +179,16 @@ class GroundSegmentation {
     gg_context *context() { return ctx_; }
 
   private:
+    static void append_lists(const std::vector<uint8_t> &cls, const std::vector<int32_t> &cell, size_t start, int rows,
+                             std::vector<std::pair<size_t, Index>> &point_index, std::vector<std::pair<size_t, Index>> &ignored, std::vector<size_t> &outliers)
+    {
+        for (size_t k = 0; k < cls.size(); ++k) {
+            const Index gi = {cell[k] % rows, cell[k] / rows};
+            if (cls[k] == GG_CLASS_KEPT) point_index.emplace_back(start + k, gi);
+            else if (cls[k] == GG_CLASS_IGNORED) ignored.emplace_back(start + k, gi);
+            else if (cls[k] == GG_CLASS_OUTLIER) outliers.push_back(start + k);
+        }
+    }
     void stage(GridMap &map, int which, int section, int i, int j, double base_z) const
     {
         gg_stage_args a{};

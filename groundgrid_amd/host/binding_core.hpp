@@ -208,6 +208,34 @@ class Core {
         return rc_down;
     }
 
+    // GroundSegmentation::insert_cloud (.h:55, :200-311) on the caller's map as it stands: a host-managed map's ground / groundpatch and the
+    // eight layers the insertion reads and continues are uploaded first, what it wrote comes back into the view's planes; per point of
+    // [start, end) the GG_CLASS_* and the cell (gg_insert_cloud).
+    int insert(const MapView &view, const gg_point32 *cloud, size_t start, size_t end, const float origin[3], uint8_t *cls, int32_t *cell)
+    {
+        if (!ctx_) return GG_ERR_INVALID;
+        if (end > start && !ensure_capacity(end - start)) return GG_ERR_CAPACITY;
+        const unsigned writes = (1u << GG_LAYER_POINTS) | (1u << GG_LAYER_POINTSRAW) | (1u << GG_LAYER_GROUNDCANDIDATES) | (1u << GG_LAYER_MEANVARIANCE) |
+                                (1u << GG_LAYER_PLANEDIST) | (1u << GG_LAYER_M2) | (1u << GG_LAYER_MAXGROUNDHEIGHT) | (1u << GG_LAYER_MINGROUNDHEIGHT);
+        const unsigned reads = writes | (1u << GG_LAYER_GROUND) | (1u << GG_LAYER_GROUNDPATCH);
+        if (!device_resident_) {
+            int rc = gg_set_map_position(ctx_, 0, view.pos_x, view.pos_y);
+            for (int l = 0; l < GG_NUM_LAYERS && rc == GG_OK; ++l)
+                if (((reads >> l) & 1u) && view.layer[l]) rc = gg_set_layer(ctx_, 0, l, view.layer[l]);
+            if (rc != GG_OK) return note("uploading the layers of insert_cloud"), rc;
+            have_position_ = true;
+            pos_x_ = view.pos_x;
+            pos_y_ = view.pos_y;
+        }
+        const int rc = gg_insert_cloud(ctx_, 0, cloud, start, end, origin, cls, cell);
+        if (rc != GG_OK) return note("gg_insert_cloud"), rc;
+        float *dst[GG_NUM_LAYERS];
+        for (int l = 0; l < GG_NUM_LAYERS; ++l) dst[l] = ((writes >> l) & 1u) ? view.layer[l] : nullptr;
+        const int rc_down = gg_get_layers(ctx_, 0, dst);
+        if (rc_down != GG_OK) note("downloading the layers of insert_cloud");
+        return rc_down;
+    }
+
     // a cloud larger than the context was created for: re-create it with headroom.  A device-resident map is carried over
     // (ground, groundpatch and the position take the round trip through the host once); a host-managed one is uploaded again
     // by the next filter() anyway.

@@ -139,32 +139,47 @@ pcl::PointCloud<GroundSegmentation::PCLPoint>::Ptr GroundSegmentation::filter_cl
     return filtered_cloud;
 }
 
-// src/GroundSegmentation.cpp:200-311.  The reference calls this from its own filter_cloud only; here the per-point
-// decisions of the LAST filter_cloud call are handed out in the same three lists, restricted to [start, end).
+// src/GroundSegmentation.cpp:200-311, the member itself: cloud[start, end) is classified against `map` as it stands and INSERTED -- pointsRaw
+// and the recurrences of :296-309 continue in the map's layers, which a host-managed map sends up and gets back -- and the three lists
+// receive the range's points in cloud order (gg_insert_cloud).  (The per-point decisions of the last filter_cloud call, without
+// inserting anything, are gg_get_point_classes.)
 void GroundSegmentation::insert_cloud(const pcl::PointCloud<PCLPoint>::Ptr cloud, const size_t start, const size_t end,
                                       const PCLPoint &cloudOrigin, std::vector<std::pair<size_t, grid_map::Index>> &point_index,
                                       std::vector<std::pair<size_t, grid_map::Index>> &ignored, std::vector<size_t> &outliers,
                                       grid_map::GridMap &map)
 {
-    (void)cloudOrigin;
     Core *core = Registry::instance().core_of_map(&map);
     if (!core) core = Registry::instance().core_of_object(this, false);
-    if (!core || !core->ok()) return;
-    const size_t n = cloud->points.size();
-    std::vector<uint8_t> cls(n);
-    std::vector<int32_t> cell(n);
-    if (gg_get_point_classes(core->context(), 0, n, cls.data(), cell.data()) != GG_OK) return;
+    if (!core || !core->ok()) {
+        ROS_ERROR("groundgrid_hip: insert_cloud was called before a successful init");
+        return;
+    }
+    const size_t last = std::min(end, cloud->points.size());
+    if (start >= last) return;
+    const char *const *names = groundgrid_hip::layer_names();
+    groundgrid_hip::MapView view;
+    view.pos_x = map.getPosition().x();
+    view.pos_y = map.getPosition().y();
+    for (int l = 0; l < GG_NUM_LAYERS; ++l) view.layer[l] = map.exists(names[l]) ? map[names[l]].data() : nullptr;
+    std::vector<uint8_t> cls(last - start);
+    std::vector<int32_t> cell(last - start);
+    const float origin[3] = {cloudOrigin.x, cloudOrigin.y, cloudOrigin.z};
+    const int rc = core->insert(view, reinterpret_cast<const gg_point32 *>(cloud->points.data()), start, last, origin, cls.data(), cell.data());
+    if (rc != GG_OK) {
+        ROS_ERROR("groundgrid_hip: insert_cloud failed with status %d (%s)", rc, core->last_error().c_str());
+        return;
+    }
     int rows = 0, cols = 0;
     gg_get_size(core->context(), &rows, &cols);
-    for (size_t i = start; i < end && i < n; ++i) {
-        if (cls[i] == GG_CLASS_OUTSIDE) continue;
-        const grid_map::Index gi(cell[i] % rows, cell[i] / rows);
-        if (cls[i] == GG_CLASS_KEPT)
-            point_index.push_back(std::make_pair(i, gi));
-        else if (cls[i] == GG_CLASS_IGNORED)
-            ignored.push_back(std::make_pair(i, gi));
+    for (size_t k = 0; k < cls.size(); ++k) {
+        if (cls[k] == GG_CLASS_OUTSIDE) continue;
+        const grid_map::Index gi(cell[k] % rows, cell[k] / rows);
+        if (cls[k] == GG_CLASS_KEPT)
+            point_index.push_back(std::make_pair(start + k, gi));
+        else if (cls[k] == GG_CLASS_IGNORED)
+            ignored.push_back(std::make_pair(start + k, gi));
         else
-            outliers.push_back(i);
+            outliers.push_back(start + k);
     }
 }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 5
+#define GG_ABI_VERSION 6
 
 typedef enum gg_status {
     GG_OK = 0,
@@ -439,6 +439,15 @@ typedef struct gg_stage_args {
     double base_z; /* GG_STAGE_SPIRAL_GROUND_INTERPOLATION */
 } gg_stage_args;
 int gg_run_stage(gg_context *ctx, int slot, int stage, const gg_stage_args *args);
+
+/* GroundSegmentation::insert_cloud as the member it is (include/groundgrid/GroundSegmentation.h:55, src/GroundSegmentation.cpp:200-311):
+ * the points cloud[start, end) against the slot's map AS IT STANDS -- no per-call reset (:61-75 is filter_cloud's): `pointsRaw` and the seven
+ * recurrences of :296-309 continue from what the layers hold, a cell's count from wherever an earlier range left it; the outlier test of
+ * :243-279 reads ground / groundpatch as they are.  out_class / out_cell (each end - start entries, either may be null) = per point of the
+ * range, in cloud order, its GG_CLASS_* and its cell (row + col * rows; -1 outside the map): the three lists the reference appends to
+ * are the points of class KEPT (`point_index`, with their cells), IGNORED (`ignored`, with their cells) and OUTLIER (`outliers`), each
+ * in cloud order -- the host mirrors build them from these two arrays.  Synchronous; ABI v6. */
+int gg_insert_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t start, size_t end, const float origin[3], uint8_t *out_class, int32_t *out_cell);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 

@@ -72,7 +72,7 @@ int main()
         }
         std::vector<std::pair<size_t, groundgrid_hip::GroundSegmentation::Index>> pi, ig;
         std::vector<size_t> outl;
-        seg.insert_cloud(0, cloud.size(), pi, ig, outl, seg.map());
+        seg.last_call_lists(0, cloud.size(), pi, ig, outl, seg.map()); // (the decisions of the call above; nothing is inserted)
         size_t nk = 0, ni = 0, no = 0;
         for (size_t i = 0; i < cloud.size(); ++i) {
             nk += rcls[i] == GGO_KEPT;
@@ -81,6 +81,31 @@ int main()
         }
         ok &= pi.size() == nk && ig.size() == ni && outl.size() == no;
         std::printf("frame %d: %zu points returned, kept %zu ignored %zu outliers %zu -> %s\n", frame, out.size(), nk, ni, no, ok ? "identical" : "MISMATCH");
+    }
+    // GroundSegmentation::insert_cloud as the member it is: two ranges of the cloud INTO the map as the three frames left it (the second range
+    // continues the counts of the first), lists and all eleven layers against the oracle's insert_cloud on the same state
+    {
+        const size_t half = cloud.size() / 2;
+        std::vector<std::pair<size_t, groundgrid_hip::GroundSegmentation::Index>> pi, ig;
+        std::vector<size_t> outl;
+        seg.insert_cloud(cloud, 0, half, origin, pi, ig, outl, seg.map());
+        seg.insert_cloud(cloud, half, cloud.size(), origin, pi, ig, outl, seg.map());
+        std::vector<uint8_t> rcls(cloud.size());
+        std::vector<int32_t> rcell(cloud.size());
+        ggo_stage_insert(ref, &rcfg, reinterpret_cast<const ggo_point *>(cloud.data()), half, org, rcls.data(), rcell.data());
+        ggo_stage_insert(ref, &rcfg, reinterpret_cast<const ggo_point *>(cloud.data()) + half, cloud.size() - half, org, rcls.data() + half, rcell.data() + half);
+        size_t k = 0, g = 0, o = 0;
+        for (size_t i = 0; i < cloud.size() && ok; ++i) {
+            if (rcls[i] == GGO_KEPT) ok &= k < pi.size() && pi[k].first == i && pi[k].second[0] + pi[k].second[1] * seg.map().rows() == rcell[i], ++k;
+            else if (rcls[i] == GGO_IGNORED) ok &= g < ig.size() && ig[g].first == i && ig[g].second[0] + ig[g].second[1] * seg.map().rows() == rcell[i], ++g;
+            else if (rcls[i] == GGO_OUTLIER) ok &= o < outl.size() && outl[o] == i, ++o;
+        }
+        ok &= k == pi.size() && g == ig.size() && o == outl.size();
+        for (int l = 0; l < GG_NUM_LAYERS && ok; ++l) {
+            const std::vector<float> a = seg.map().layer((gg_layer)l);
+            ok &= same_floats(a.data(), ref->layer[l], a.size());
+        }
+        std::printf("insert_cloud in two ranges: kept %zu ignored %zu outliers %zu -> %s\n", k, g, o, ok ? "identical" : "MISMATCH");
     }
     ggo_map_destroy(ref);
     return ok ? 0 : 1;

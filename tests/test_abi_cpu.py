@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_abi_version_and_kernel_names(lib):
     # v2: gg_move_map takes matrix entries, conventions, async host call; v3: gg_batch.slots; v4: gg_comm_init_rank_for;
     # v5: gg_batch.d_out_pc2, gg_run_stage, gg_filter_cloud_pc2_out, gg_get_gridmap_message, gg_device_error
-    assert lib.gg_abi_version() == 5
+    assert lib.gg_abi_version() == 6
     names = [lib.gg_kernel_name(k).decode() for k in range(_lib.GG_NUM_KERNELS)]
     assert names == ["k_classify", "k_scan", "k_scatter", "k_reduce", "k_patch", "k_sweep", "k_label"]
 

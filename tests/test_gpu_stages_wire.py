@@ -590,3 +590,53 @@ def test_pc2_records_and_fused_layers_at_full_size():
                 assert nan_equal(v, ref.layer(name)), (length, f, name)
         seg.release_layers(planes)
         seg.close()
+
+
+# ---------------------------------------------------------------- GroundSegmentation::insert_cloud as a member of its own (gg_insert_cloud)
+
+@pytest.mark.parametrize("length,resolution", [(120.0, 0.33), (33.0, 0.33), (200.0, 0.2)])
+def test_insert_cloud_in_ranges_continues_the_layers_as_they_stand(length, resolution):
+    """GroundSegmentation::insert_cloud (include/groundgrid/GroundSegmentation.h:55, src/GroundSegmentation.cpp:200-311) called the way the
+    header allows: sub-ranges of a cloud, one after the other, INTO a map that filter_cloud and earlier ranges already wrote -- no
+    per-call reset, a cell's count continues from c > 0, the outlier test reads the terrain as it stands.  Per range the classes and
+    cells (= the reference's three lists) and after every range all eleven layers against the oracle's insert_cloud on the same state."""
+    k = np.float32(length / 120.0)
+    cloud = synth.hdl64_cloud(seed=83, n_az=700)
+    cloud["x"] *= k
+    cloud["y"] *= k
+    low = synth.clone_cloud(cloud)
+    low["z"][::3] -= np.float32(0.9)                      # a third of the returns dive under the terrain: outliers once the map is warm
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=2, max_points=len(cloud))
+    ref = oracle.OracleMap(length, resolution)
+    m = seg.map(1)
+    for _ in range(2):                                    # a warm map first (slot 1: the stage entry takes any slot)
+        seg.filter_cloud(cloud, ORIGIN0, -1.73, map=m)
+        ref.filter_cloud(cloud, ORIGIN0, -1.73)
+    n = len(low)
+    origin = (0.5, -0.25, 0.1)
+    for start, end in ((0, n // 3), (n // 3, n // 3), (n // 3, n - 5), (n - 5, n), (0, n)):   # (an empty range; the whole cloud once more on top)
+        cls, cell = m.insert_cloud(low, start, end, origin)
+        rcls, rcell = ref.stage_insert(low[start:end], origin)
+        assert np.array_equal(cls, rcls), (start, end)
+        inside = rcls != oracle.OUTSIDE
+        assert np.array_equal(cell[inside], rcell[inside]), (start, end)
+        for name in oracle.LAYERS:
+            assert nan_equal(m.get(name), ref.layer(name)), (start, end, name)
+    assert (rcls == oracle.OUTLIER).sum() > 0 and ref.layer("points").max() > 3
+    # a layer the host put there (counts that are not integers): the reference's expressions as they stand
+    pts = ref.layer("points").copy()
+    pts[pts > 0] += np.float32(0.25)
+    m.set("points", pts)
+    ref.set_layer("points", pts)
+    cls, cell = m.insert_cloud(cloud, 0, n // 2, ORIGIN0)
+    rcls, rcell = ref.stage_insert(cloud[: n // 2], ORIGIN0)
+    assert np.array_equal(cls, rcls)
+    for name in oracle.LAYERS:
+        assert nan_equal(m.get(name), ref.layer(name)), name
+    # and filter_cloud afterwards starts from its own reset as always
+    out, labels, index = seg.filter_cloud(cloud, ORIGIN0, -1.73, map=m, return_details=True)
+    r = ref.filter_cloud(cloud, ORIGIN0, -1.73)
+    assert np.array_equal(labels, r["label"]) and np.array_equal(index, r["index"])
+    for name in oracle.LAYERS:
+        assert nan_equal(m.get(name), ref.layer(name)), name
+    seg.close()

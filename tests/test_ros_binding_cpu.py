@@ -26,7 +26,7 @@ def test_binding_compiles_against_the_reference_class_declaration(tmp_path):
                  "spiral_ground_interpolation(", "interpolate_cell("):
         assert re.search(r"groundgrid::GroundSegmentation::" + re.escape(name.split("groundgrid::GroundSegmentation::")[-1]), syms), name
     undefined = subprocess.check_output(["nm", "-C", "--undefined-only", obj], text=True)
-    for entry in ("gg_create", "gg_set_config", "gg_filter_cloud_layers", "gg_run_stage", "gg_get_layers", "gg_set_layer", "gg_set_map_position", "gg_get_point_classes", "gg_abi_version"):
+    for entry in ("gg_create", "gg_set_config", "gg_filter_cloud_layers", "gg_run_stage", "gg_get_layers", "gg_set_layer", "gg_set_map_position", "gg_insert_cloud", "gg_abi_version"):
         assert re.search(r"\bU " + entry + r"\b", undefined), entry  # ... and forwards to the C ABI
 
 

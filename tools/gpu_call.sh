@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stages_wire.py -m gpu -x -q -k "synthetic_drive or unfenced" 2>&1 | grep -v "RCCL\|HIP version\|ROCm\|Hostname\|Librccl" | tail -8 | tee gpurun_out/tests_new.log
-timeout 1500 python bench.py > gpurun_out/bench_r06a.json 2> gpurun_out/bench_r06a.err; tail -c 3000 gpurun_out/bench_r06a.json; tail -5 gpurun_out/bench_r06a.err
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm\|Hostname\|Librccl" | tail -6 | tee gpurun_out/tests.log
+timeout 1500 python bench.py > gpurun_out/bench_r06b.json 2> gpurun_out/bench_r06b.err; tail -c 2600 gpurun_out/bench_r06b.json; tail -3 gpurun_out/bench_r06b.err
