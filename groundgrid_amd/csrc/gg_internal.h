@@ -152,7 +152,8 @@ struct Arena {
     int tune_sweep_waves;   // chain wavefronts per side of k_sweep
     int tune_sweep_gpw;     // ring groups per work-group of k_sweep (sweep_core.h "Parts"); default min(groups, 3)
     int tune_sweep_split;   // k_sweep "split steps": 0 = when a launch has one ring group per work-group and at most 256 work-groups, 1 = whenever gpw == 1, 2 = never
-    int tune_sweep_pair;    // the pair sweep (sweep_pair.h) for launches of at most sweep_rec_clouds clouds: 0 = yes, 2 = never (k_sweep always)
+    int tune_sweep_pair;    // the pair sweeps: 0 = sweep_pair.h for launches of at most sweep_rec_clouds clouds, k_sweep for larger ones; 2 = never (k_sweep
+                            // always); 4 = sweep_pairb.h (the pair sweep on the layer in place) for every launch
     int tune_sweep_pair_wgs; // work-groups per cloud of the pair sweep: 0 / 2 = one per pair of sides (two CUs), 1 = both pairs in one
     int tune_sweep_pair_waves; // chain wavefronts per pair (0 = one per 32-ring group, as many as fit)
     int tune_sweep_poll_cap; // tests: polls after which k_sweep's waits give up (0 = about a second)
@@ -293,6 +294,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
 void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s,
                   unsigned long long *dbg = nullptr); // k4_sweep.hip; dbg: 16 x 4 cycle counters of cloud 0's wavefronts (tools)
 bool launch_sweep_pair(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4p_sweep_pair.hip; false: not this launch
+bool launch_sweep_pair_batch(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4b_sweep_pair_batch.hip; false: not this launch
 size_t sweep_pair_rec_floats(const sweep::Params &P); // scratch floats per cloud of a launch (0: the geometry cannot take the pair sweep)
 constexpr int SWEEP_PAIR_MAX_CLOUDS = 16;              // launches of more clouds keep k_sweep
 size_t sweep_lds_bytes(const sweep::Params &P);

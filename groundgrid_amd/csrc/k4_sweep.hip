@@ -759,7 +759,12 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
     // latency launches: the pair sweep (sweep_pair.h) -- both sides of a ring hand-over in one wavefront, old values from records
     // (a context whose k_sweep shape is forced -- wavefronts per side, groups per work-group, split steps, a fault to inject -- means k_sweep)
     const bool k_sweep_forced = a.tune_sweep_waves || a.tune_sweep_gpw || a.tune_sweep_split || a.tune_sweep_fault;
-    if (!dbg && a.tune_sweep_pair != 2 && !k_sweep_forced && launch_sweep_pair(a, P_in, d_params, n_clouds, s)) return;
+    // (the pair sweep on the layer in place, sweep_pairb.h / k4b_sweep_pair_batch.hip, takes a launch only when asked to -- tuning
+    // sweep_pair = 4: correct on every geometry, but at 1024 clouds per launch 1.12 ms where k_sweep takes 0.89 ms)
+    if (!dbg && a.tune_sweep_pair != 2 && !k_sweep_forced) {
+        if (a.tune_sweep_pair == 4 && launch_sweep_pair_batch(a, P_in, d_params, n_clouds, s)) return;
+        if (a.tune_sweep_pair != 4 && launch_sweep_pair(a, P_in, d_params, n_clouds, s)) return;
+    }
     Params P = P_in;
     // Work-groups ("parts", sweep_core.h) per cloud.  The sweep of one cloud is a dependency chain, so a launch that leaves CUs idle
     // spreads every cloud over as many work-groups as there are CUs to take them (measured, k_sweep per launch: n = 1000, 1 / 8

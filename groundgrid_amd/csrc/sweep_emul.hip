@@ -866,3 +866,271 @@ extern "C" int gg_debug_emulate_pair_sweep(int n, double resolution, float min_d
         }
     return rc;
 }
+
+// =====================================================================================================================
+// The throughput pair sweep (sweep_pairb.h): the lanes load their own cells from the in-place layer -- `late` resolves every load at its
+// use, the worst case for write-after-read hazards -- one work-group with both pairs and the two corner wavefronts.
+// =====================================================================================================================
+#include "sweep_pairb.h"
+
+namespace {
+
+struct PairBHostMem {
+    Cell *layer;
+    std::vector<int32_t> lds;
+    bool late = false, fault = false;
+    long loads = 0, stores = 0;
+    Cell load_issue(bool valid, int cell)
+    {
+        if (!valid) return Cell{0.f, 0.f};
+        ++loads;
+        return layer[cell];
+    }
+    Cell load_value(const Cell &queued, bool valid, int cell) { return (late && valid) ? layer[cell] : queued; }
+    void store(bool valid, int cell, Cell v)
+    {
+        if (!valid) return;
+        ++stores;
+        layer[cell] = v;
+    }
+    WP lds_wp(int word)
+    {
+        WP v;
+        memcpy(&v, &lds[(size_t)word], 8);
+        return v;
+    }
+    void lds_put_wp(int word, WP v) { memcpy(&lds[(size_t)word], &v, 8); }
+    void entry_write(int word, WP v) // (w, tag, p, tag): one 16-byte write on the device
+    {
+        if (word & 3) fault = true;
+        memcpy(&lds[(size_t)word], &v.w, 4);
+        memcpy(&lds[(size_t)word + 2], &v.p, 4);
+        lds[(size_t)word + 1] = lds[(size_t)word + 3] = 1;
+    }
+    bool entry_read(int word, WP &v)
+    {
+        if (word & 3) fault = true;
+        memcpy(&v.w, &lds[(size_t)word], 4);
+        memcpy(&v.p, &lds[(size_t)word + 2], 4);
+        return lds[(size_t)word + 1] != 0 && lds[(size_t)word + 3] != 0;
+    }
+    int lds_i(int word) { return lds[(size_t)word]; }
+    void lds_set(int word, int v) { lds[(size_t)word] = v; }
+};
+
+template <int PAIR> struct PairWaveB : WaveBase {
+    const Params &P;
+    const gp::Plan &pl;
+    const gp::LdsB &L;
+    PairBHostMem &mem;
+    WP centre;
+    int W, group, t, t_end;
+    gp::Group G;
+    gp::PairLaneB<PAIR> lane[64];
+    bool plan_mismatch = false;
+    PairWaveB(const Params &p, const gp::Plan &pl_, const gp::LdsB &l, PairBHostMem &m, WP c, int w, int W_) : P(p), pl(pl_), L(l), mem(m), centre(c), W(W_), group(w - W_) { next_group(); }
+    void next_group()
+    {
+        group += W;
+        if (group >= pl.groups) return;
+        G = gp::group_of(PAIR, group, P.rings);
+        for (int k = 0; k < 64; ++k) {
+            lane[k].init(k, group, G, P, pl, L);
+            const gp::PairLaneB<PAIR> &c = lane[k];
+            const int side = c.is_x ? gp::side_x(PAIR) : gp::side_y(PAIR), k0 = gp::k0_of(side);
+            for (int s = 0; s < c.len; ++s) { // the stride-64 addressing of the three lines against gp_index(), visit by visit
+                int x, y;
+                gp::side_xy(side, P.c, c.r, 0, k0 + s, x, y);
+                if (c.st_base + 64 * (c.start + s) != gp_index(P.gl, x, y)) plan_mismatch = true;
+                gp::side_xy(side, P.c, c.r, 1, k0 + s + 1, x, y);
+                if (c.outA + 64 * (c.start + s) != gp_index(P.gl, x, y)) plan_mismatch = true;
+                if (s + 1 < c.len) {
+                    gp::side_xy(side, P.c, c.r, 0, k0 + s + 1, x, y);
+                    if (c.ownA + 64 * (c.start + s) != gp_index(P.gl, x, y)) plan_mismatch = true;
+                }
+            }
+        }
+        t = G.t_first;
+        t_end = G.t_first + G.steps;
+        for (int k = 0; k < 64; ++k) lane[k].prime(G.t_first, mem);
+    }
+    bool done() const override { return group >= pl.groups; }
+    bool bad() const override { return plan_mismatch || mem.fault; }
+    template <int RES> void steps(int slot, const bool (&first)[64], const WP (&x_in)[64], const WP (&j_in)[64], const WP (&c0)[64], const WP (&c1)[64], WP (&res)[64])
+    {
+        for (int k = 0; k < 64; ++k) res[k] = lane[k].template step<RES>(t, slot, x_in[k], j_in[k], first[k], c0[k], c1[k], P, mem);
+    }
+    bool try_step() override
+    {
+        if (done()) return false;
+        WP imp[64], jl[64];
+        for (int k = 0; k < 64; ++k) { // everything the step takes from other wavefronts must be there
+            const gp::PairLaneB<PAIR> &c = lane[k];
+            if (c.first_at(t) && mem.lds_i(L.cnt_corner + c.cd) < c.r) return false;
+            if (c.imports_at(t, group) && !mem.entry_read(c.import_entry(t), imp[k])) return false;
+            if (c.join_from_lds_at(t, group) && !mem.entry_read(c.a_jl, jl[k])) return false;
+        }
+        bool first[64];
+        WP c0[64], c1[64];
+        for (int k = 0; k < 64; ++k) {
+            first[k] = lane[k].first_at(t);
+            c0[k] = mem.lds_wp(lane[k].a_s0);
+            c1[k] = mem.lds_wp(lane[k].a_s1);
+            lane[k].pre(first[k], mem.lds_wp(lane[k].a_pred));
+        }
+        WP x_in[64], j_in[64], res[64];
+        for (int k = 0; k < 64; ++k) {
+            const gp::PairLaneB<PAIR> &c = lane[k];
+            x_in[k] = c.imports_at(t, group) ? imp[k] : (k ? lane[k - 1].h2 : WP{0.f, 0.f});
+            j_in[k] = k < 32 ? (k ? lane[32 + k - 1].h1 : WP{0.f, 0.f}) : lane[k - 32].h1;
+            if (c.jl_lane) j_in[k] = group > 0 ? (c.join_from_lds_at(t, group) ? jl[k] : WP{0.f, 0.f}) : centre;
+        }
+        const int slot = (t - G.t_first) % (int)gp::PFB;
+        switch ((t - G.t_first) & 3) {
+        case 0: steps<0>(slot, first, x_in, j_in, c0, c1, res); break;
+        case 1: steps<1>(slot, first, x_in, j_in, c0, c1, res); break;
+        case 2: steps<2>(slot, first, x_in, j_in, c0, c1, res); break;
+        default: steps<3>(slot, first, x_in, j_in, c0, c1, res); break;
+        }
+        for (int k = 0; k < 64; ++k)
+            if (lane[k].exports_at(t)) mem.entry_write(lane[k].export_entry(t), res[k]);
+        // B_1 of ring 1 for the CD corner wavefront (the B chain of ring 1 is one visit, at wave-step 0 of group 0)
+        if (PAIR == gp::PAIR_BC && group == 0 && t == 0) mem.entry_write(L.b1, lane[0].h1);
+        if (++t >= t_end) next_group();
+        return true;
+    }
+};
+
+template <int CD> struct PairCornerWaveB : WaveBase {
+    const Params &P;
+    const gp::LdsB &L;
+    PairBHostMem &mem;
+    int r = 1;
+    gp::CornerLaneB<CD> lane[64];
+    gp::CornerHeld held[64]; // the batch before: stored after this batch's loads
+    bool have_held = false;
+    float in_corner, in_x1 = 0.f;
+    PairCornerWaveB(const Params &p, const gp::LdsB &l, PairBHostMem &m, float centre_p) : P(p), L(l), mem(m), in_corner(centre_p) {}
+    bool done() const override { return r > P.rings; }
+    bool try_step() override
+    {
+        if (done()) return false;
+        if (CD && r == 1) {
+            WP b1;
+            if (!mem.entry_read(L.b1, b1)) return false;
+            in_x1 = b1.p;
+        }
+        const int k = (r - 1) % 64;
+        if (k == 0) {
+            for (int j = 0; j < 64; ++j) lane[j].init(r + j, P, mem);
+            if (have_held)
+                for (int j = 0; j < 64; ++j) held[j].flush(mem);
+            have_held = false;
+        }
+        float x1g, x1, y0g, y0;
+        lane[k].c.visits(in_corner, in_x1, x1g, x1, y0g, y0);
+        lane[k].c.keep(true, x1g, y0g);
+        gp::CornerLaneB<CD>::publish(r, WP{lane[k].c.R.wn[1], x1}, WP{lane[k].c.R.wn[2], y0}, P, L, mem);
+        in_corner = y0;
+        in_x1 = x1;
+        if (k == 63 || r == P.rings) { // the batch is done
+            for (int j = 0; j < 64; ++j) held[j] = lane[j].hold(j <= k);
+            have_held = true;
+            if (r == P.rings)
+                for (int j = 0; j < 64; ++j) held[j].flush(mem);
+        }
+        ++r;
+        return true;
+    }
+};
+
+} // namespace
+
+extern "C" int gg_debug_emulate_pair_sweep_batch(int n, double resolution, float min_dist_squared, float *gp2, float base_z, double decrease, unsigned seed, int late_loads,
+                                                 int waves_per_pair, long *stats)
+{
+    if (n < 8 || !gp2) return GG_ERR_INVALID;
+    const Params P = gg::sweep::make_params(n, resolution, min_dist_squared, decrease);
+    const gp::Plan pl = gp::make_plan(P.rings);
+    if (pl.groups <= 0) return GG_ERR_INVALID;
+    std::vector<Cell> sheared((size_t)P.gl.elems, Cell{0.f, 0.f});
+    for (int col = 0; col < n; ++col)
+        for (int row = 0; row < n; ++row) sheared[(size_t)gp_index(P.gl, row, col)] = Cell{gp2[2 * ((size_t)row + (size_t)col * n)], gp2[2 * ((size_t)row + (size_t)col * n) + 1]};
+    sheared[(size_t)gp_index(P.gl, P.c, P.c)] = Cell{base_z, 1.0f}; // :405-411
+    const WP centre{1.0f, 1.0f * base_z};
+    const gp::LdsB L = gp::ldsb_of(P.c, pl, true);
+    const int W = std::max(1, std::min(waves_per_pair > 0 ? waves_per_pair : pl.groups, pl.groups));
+    PairBHostMem mem;
+    mem.layer = sheared.data();
+    mem.late = late_loads != 0;
+    mem.lds.assign((size_t)L.words, 0);
+    for (int k = 0; k < 64; ++k) mem.lds[(size_t)L.scratch + 4 * k + 1] = mem.lds[(size_t)L.scratch + 4 * k + 3] = 1;
+    for (int cd = 0; cd < 2; ++cd) mem.lds_put_wp(gp::cornerb_word(L, P.c, cd, 0, 1), centre);
+    std::vector<WaveBase *> waves;
+    for (int w = 0; w < W; ++w) {
+        waves.push_back(new PairWaveB<gp::PAIR_AD>(P, pl, L, mem, centre, w, W));
+        waves.push_back(new PairWaveB<gp::PAIR_BC>(P, pl, L, mem, centre, w, W));
+    }
+    waves.push_back(new PairCornerWaveB<0>(P, L, mem, centre.p));
+    waves.push_back(new PairCornerWaveB<1>(P, L, mem, centre.p));
+    uint32_t rng = seed * 2654435761u + 12345u;
+    auto rnd = [&]() { return rng = rng * 1664525u + 1013904223u; };
+    long total_steps = 0, stalls = 0;
+    int rc = GG_OK;
+    for (;;) {
+        bool all_done = true, progress = false;
+        for (auto *w : waves) all_done &= w->done();
+        if (all_done) break;
+        if (seed == 0) {
+            for (auto *w : waves)
+                if (w->try_step()) {
+                    progress = true;
+                    ++total_steps;
+                } else if (!w->done())
+                    ++stalls;
+        } else {
+            for (int tries = 0; tries < 4 * (int)waves.size() && !progress; ++tries) {
+                WaveBase *w = waves[(rnd() >> 8) % waves.size()];
+                const uint32_t mode = (rnd() >> 8) % 8;
+                int burst = mode == 0 ? 1 << 30 : mode < 4 ? 1 + (int)((rnd() >> 8) % 64) : 1;
+                while (burst-- > 0 && w->try_step()) {
+                    progress = true;
+                    ++total_steps;
+                }
+                if (!progress && !w->done()) ++stalls;
+            }
+            if (!progress)
+                for (auto *w : waves)
+                    if (w->try_step()) {
+                        progress = true;
+                        ++total_steps;
+                        break;
+                    }
+        }
+        if (!progress) {
+            rc = -10;
+            break;
+        }
+    }
+    if (stats) {
+        stats[0] = total_steps;
+        stats[1] = stalls;
+        stats[2] = mem.loads;
+        stats[3] = mem.stores;
+        stats[4] = (long)L.words * 4;
+        stats[5] = (long)waves.size();
+        stats[6] = pl.total_steps;
+        stats[7] = pl.groups;
+    }
+    for (auto *w : waves) {
+        if (w->bad() && rc == GG_OK) rc = -11;
+        delete w;
+    }
+    for (int col = 0; col < n; ++col)
+        for (int row = 0; row < n; ++row) {
+            const Cell v = sheared[(size_t)gp_index(P.gl, row, col)];
+            gp2[2 * ((size_t)row + (size_t)col * n)] = v.g;
+            gp2[2 * ((size_t)row + (size_t)col * n) + 1] = v.w;
+        }
+    return rc;
+}

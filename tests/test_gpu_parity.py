@@ -1370,6 +1370,34 @@ def test_pair_sweep_shapes(length, resolution, batch, wgs, waves):
     seg.close()
 
 
+@pytest.mark.parametrize("waves", [0, 1, 2])
+@pytest.mark.parametrize("length,resolution,batch", [(4.0, 0.33, 2), (22.0, 0.33, 3), (23.0, 0.33, 1), (50.0, 0.33, 24), (61.0, 0.25, 5), (120.0, 0.33, 2), (240.0, 0.33, 1)])
+def test_throughput_pair_sweep_shapes(length, resolution, batch, waves):
+    """Launches of more than 16 clouds sweep with k_sweep_pair_batch (sweep_pairb.h: the pair sweep on the layer in place, one work-group
+    per cloud); here it takes every launch (tuning sweep_pair = 4), with up to three wavefronts per pair of sides or fewer, on maps from a
+    single ring group to 23.  Three frames, labels of every cloud and all layers of some against the oracle."""
+    import torch
+
+    clouds = _rotated_clouds(batch, length)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
+    seg.debug_set_tuning("sweep_pair", 4)
+    seg.debug_set_tuning("sweep_pair_waves", waves)
+    refs = [oracle.OracleMap(length, resolution) for _ in clouds]
+    pts = _batch_inputs(16, clouds, stride)
+    out = None
+    for frame in range(3):
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((batch, 3), np.float32), np.full(batch, -1.73 + 0.01 * frame), out=out)
+        torch.cuda.synchronize()
+        labels = out.labels.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, ORIGIN0, -1.73 + 0.01 * frame)
+            assert np.array_equal(labels[b, : len(c)], r["label"]), (frame, b)
+            if b in (0, 1, batch // 2, batch - 1):
+                assert_same_state(seg.map(b), refs[b], f"frame {frame} cloud {b}")
+    seg.close()
+
+
 def test_pair_sweep_and_k_sweep_leave_the_same_map():
     """The two sweeps are interchangeable launch by launch: a map swept alternately by either (the pair sweep switched off for every
     other frame) stays bit-identical to the oracle's."""

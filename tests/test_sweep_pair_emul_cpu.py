@@ -102,3 +102,61 @@ def test_special_values_travel_unchanged(lib):
     for wgs in (1, 2):
         g, w, _ = emulate(lib, n, ref.resolution, ground, conf, -1.0, 5.0, 4, wgs)
         assert np.array_equal(g, ref.layer("ground"), equal_nan=True) and np.array_equal(w, ref.layer("groundpatch"), equal_nan=True)
+
+
+# ---------------------------------------------------------------- the throughput launches' variant (sweep_pairb.h)
+
+def emulate_batch(L, n, resolution, ground, conf, base_z, decrease, seed, late, waves=0, min_dist_sq=12.0):
+    L.gg_debug_emulate_pair_sweep_batch.restype = C.c_int
+    L.gg_debug_emulate_pair_sweep_batch.argtypes = [C.c_int, C.c_double, C.c_float, C.c_void_p, C.c_float, C.c_double, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_long)]
+    gp2 = np.empty((n * n, 2), dtype=np.float32)
+    gp2[:, 0] = ground.ravel(order="F")
+    gp2[:, 1] = conf.ravel(order="F")
+    stats = (C.c_long * 8)()
+    rc = L.gg_debug_emulate_pair_sweep_batch(n, resolution, min_dist_sq, gp2.ctypes.data, base_z, decrease, seed, int(late), waves, stats)
+    assert rc == 0, f"deadlock (-10) or a plan / publication fault (-11): {rc}"
+    return gp2[:, 0].reshape((n, n), order="F"), gp2[:, 1].reshape((n, n), order="F"), list(stats)
+
+
+@pytest.mark.parametrize("length,resolution", [(4.0, 0.33), (5.0, 0.5), (10.0, 0.5), (22.0, 0.33), (23.0, 0.33), (33.0, 0.33), (43.0, 0.33), (61.0, 0.25),
+                                               (120.0, 0.33), (150.0, 0.25), (240.0, 0.33)])
+def test_throughput_pair_sweep_reproduces_the_serial_sweep(lib, length, resolution):
+    """sweep_pairb.h: the lanes of a pair wavefront load their own cells from the in-place layer, two steps ahead of their use -- or, in
+    the emulation's `late` mode, at the very moment of use: if a cell could be rewritten before a visit that must still see its OLD
+    value has read it, this finds it.  (confidence, product) pairs through the lane exchanges, LDS and the corner tables."""
+    ref, n, ground, conf = reference(length, resolution, 13 * int(length))
+    decrease = float(ref.cfg.occupied_cells_decrease_factor)
+    for seed in ((0, 1, 2, 3) if n <= 400 else (0, 5)):
+        for late in (False, True):
+            g, w, stats = emulate_batch(lib, n, ref.resolution, ground, conf, -1.73, decrease, seed, late)
+            assert np.array_equal(g, ref.layer("ground")), (seed, late, np.argwhere(g != ref.layer("ground"))[:5].tolist())
+            assert np.array_equal(w, ref.layer("groundpatch")), (seed, late, np.argwhere(w != ref.layer("groundpatch"))[:5].tolist())
+    visits = oracle.lib().ggo_spiral_visit_count(n)
+    rings = n // 2 - 2
+    assert stats[3] == visits - 2 * rings  # every visited cell is stored once (the corners: the revisit only)
+
+
+@pytest.mark.parametrize("waves", [1, 2, 3])
+def test_throughput_pair_sweep_with_fewer_wavefronts_than_groups(lib, waves):
+    ref, n, ground, conf = reference(120.0, 0.33, 93)
+    for seed in (0, 7, 8):
+        for late in (False, True):
+            g, w, _ = emulate_batch(lib, n, ref.resolution, ground, conf, -1.73, 5.0, seed, late, waves)
+            assert np.array_equal(g, ref.layer("ground")) and np.array_equal(w, ref.layer("groundpatch")), (seed, late)
+
+
+def test_throughput_pair_sweep_special_values_and_decay_factors(lib):
+    ref = oracle.OracleMap(61.0, 0.25)
+    n = ref.layer("ground").shape[0]
+    ground, conf = random_state(n, 5)
+    rng = np.random.default_rng(6)
+    ground[rng.random((n, n)) < 0.02] = np.nan
+    ground[rng.random((n, n)) < 0.01] = np.inf
+    conf[rng.random((n, n)) < 0.01] = np.float32(1e-30)
+    for decrease in (5.0, 1.1, 0.5):
+        ref.cfg.occupied_cells_decrease_factor = decrease
+        ref.set_layer("ground", ground)
+        ref.set_layer("groundpatch", conf)
+        ref.stage_spiral(-1.0)
+        g, w, _ = emulate_batch(lib, n, ref.resolution, ground, conf, -1.0, decrease, 4, True)
+        assert np.array_equal(g, ref.layer("ground"), equal_nan=True) and np.array_equal(w, ref.layer("groundpatch"), equal_nan=True), decrease
