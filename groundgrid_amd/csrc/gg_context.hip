@@ -59,6 +59,11 @@ struct gg_context {
     std::vector<double> pos_x, pos_y; // per slot map position
     std::vector<char> slot_seen;      // scratch of gg_filter_batch's check of gg_batch.slots
     std::vector<char> no_confidence;  // per slot: groundpatch <= 0.01 everywhere for sure (set by gg_reset_map, cleared by any writer)
+    // per slot: the map is FRESH -- gg_reset_maps left the interior of its (ground, confidence) layer unwritten (gg_internal.h Arena::gp_bits);
+    // a batch of at least FRESH_MIN_CLOUDS fresh maps sweeps them as they are, anything else that touches the layer fills it first (make_real)
+    std::vector<char> fresh;
+    std::vector<float> fresh_z;       // ... and the ground height its cells hold by definition
+    bool fresh_enabled = true;        // env GG_FRESH_MAPS=0 / tuning "fresh_maps": gg_reset_maps writes every cell, as before
     // GG_FLAG_MINIMAL_LAYERS: the slot's last cloud left maxGroundHeight / groundCandidates / planeDist unwritten; a reader of one of
     // them has them computed first, from what that call left in the slot's buffers and with its parameters (ensure_lazy_layers)
     bool probe_unordered_streams = false; // measurement only: batches and resets on different caller streams are NOT ordered by the library
@@ -283,11 +288,39 @@ int stream_waits_for_second_half(gg_context *ctx, hipStream_t st)
 }
 // Entry points that read or write map state on ctx->stream call this first: the context's stream waits for the last batch
 // that ran on another stream (gg_get_layer after a batch on a caller stream read stale layers).
+// FRESH maps (gg_context::fresh) among the slots [first, first + n) become real on stream `st`: the fill gg_reset_maps left out (:71-75).
+// The caller has ordered `st` behind the reset.
+int make_real(gg_context *ctx, int first, int n, hipStream_t st)
+{
+    const Arena &a = ctx->arena;
+    for (int s = first; s < first + n;) {
+        if (!ctx->fresh[s]) {
+            ++s;
+            continue;
+        }
+        int e = s + 1;
+        while (e < first + n && ctx->fresh[e] && ctx->fresh_z[e] == ctx->fresh_z[s]) ++e; // one strided fill per run of equal heights
+        launch_fill2_strided(gp2_ptr(a, s), (size_t)a.gpl.elems, a.gp2_stride, e - s, ctx->fresh_z[s], (float)0.0000001, a.gp_valid, st);
+        for (int k = s; k < e; ++k) ctx->fresh[k] = 0;
+        s = e;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return GG_OK;
+}
+
 int own_stream_waits_for_batches(gg_context *ctx)
 {
     if (ctx->have_batch_event && ctx->last_batch_stream != ctx->stream)
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_event, 0));
-    return stream_waits_for_second_half(ctx, ctx->stream);
+    if (const int rc = stream_waits_for_second_half(ctx, ctx->stream)) return rc;
+    // whatever the context's own stream does next with map state (getters, setters, scrolls, stages, single clouds) finds real layers
+    bool any = false;
+    for (int s = 0; s < ctx->n_slots && !any; ++s) any = ctx->fresh[s] != 0;
+    if (!any) return GG_OK;
+    if (const int rc = make_real(ctx, 0, ctx->n_slots, ctx->stream)) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->map_event, ctx->stream)); // (own_stream_mutated_map: a batch on another stream waits for the fill)
+    ctx->map_event_pending = true;
+    return GG_OK;
 }
 // ... and this after enqueueing a mutation of map state on ctx->stream (reset, move, set_layer): the next batch on any
 // other stream waits for it.
@@ -600,6 +633,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
         p.pos_y = ctx->pos_y[slot];
         p.has_tf = b->transforms ? 1 : 0;
         p.no_confidence = ctx->no_confidence[slot] ? 1 : 0;
+        p.fresh = 0;
         ctx->no_confidence[slot] = 0; // the sweep of this call writes confidences
         for (int k = 0; k < 12; ++k) p.tf[k] = b->transforms ? b->transforms[(size_t)i * 12 + k] : 0.0;
         p.label_shift = nb == 1 ? ctx->next_label_shift : 0;
@@ -608,6 +642,23 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
         ctx->lazy_pending[slot] = lazy ? 1 : 0;
         if (lazy) ctx->lazy_params[slot] = p;
     }
+    // FRESH maps (gg_context::fresh): a (half) launch whose maps are all fresh, and large enough for the plain k_sweep, takes them as they
+    // are -- k_patch marks what it writes, the sweep reads nothing else of the layer --; in any other launch they are filled first
+    bool fresh_half[2] = {false, false};
+    for (int h = 0; h < (split ? 2 : 1); ++h) {
+        const int lo = h ? n_first : 0, hi = h ? nb : n_first;
+        bool all = ctx->fresh_enabled && !plan && !ctx->d_sweep_dbg && sweep_takes_fresh(ctx->arena, ctx->sweep_params, hi - lo);
+        for (int i = lo; i < hi && all; ++i) all = ctx->fresh[hp[i].slot] != 0;
+        fresh_half[h] = all;
+        if (all)
+            for (int i = lo; i < hi; ++i) hp[i].fresh = 1, ctx->fresh[hp[i].slot] = 0;
+    }
+    auto fill_fresh = [&](int lo, int hi, hipStream_t on) -> int { // (the stream is ordered behind the reset by now)
+        for (int i = lo; i < hi; ++i)
+            if (ctx->fresh[hp[i].slot])
+                if (const int rc = make_real(ctx, hp[i].slot, 1, on)) return rc;
+        return GG_OK;
+    };
     // order this batch after everything that touched map state on the context's stream, and after an earlier batch that ran
     // on another stream
     if (s != ctx->stream && ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->map_event, 0));
@@ -674,6 +725,7 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
     Arena a = ctx->arena;
     a.flags = eff_flags;
     a.eigen_reduction = ctx->conv.eigen_reduction;
+    a.fresh_launch = 0;
     if (split) {
         // the side stream sees what the caller's stream holds up to here (its inputs, a re-initialisation of the maps on that stream)
         if (!ctx->probe_no_fork) {
@@ -685,6 +737,10 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
         a2.sweep_sync = a.sweep_sync2;
         a2.sweep_rec_clouds = 0; // (one scratch region: the side stream's half keeps k_sweep)
         a2.scan_sync = a.scan_sync2; // (its own region: the halves of consecutive divided batches need not be the same size)
+        a.fresh_launch = fresh_half[0] ? 1 : 0;
+        a2.fresh_launch = fresh_half[1] ? 1 : 0;
+        if (const int rc = fill_fresh(0, n_first, s)) return rc;
+        if (const int rc = fill_fresh(n_first, nb, ctx->half_stream)) return rc;
         HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams) * n_first, hipMemcpyHostToDevice, s));
         HIPCHK(ctx, hipMemcpyAsync(dp + n_first, hp + n_first, sizeof(CloudParams) * (nb - n_first), hipMemcpyHostToDevice, ctx->half_stream));
         launch_sequence(ctx, a, dp, io, n_first, max_n[0], s, nullptr, hp[0].slot, false);
@@ -695,6 +751,8 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
         HIPCHK(ctx, hipEventRecord(ctx->half_done, ctx->half_stream));
         ctx->have_half_event = true;
     } else {
+        a.fresh_launch = fresh_half[0] ? 1 : 0;
+        if (const int rc = fill_fresh(0, nb, s)) return rc;
         if (const int rc = launch_or_replay(ctx, a, hp, dp, io, nb, max_n[0], s, plan)) return rc;
         HIPCHK(ctx, hipGetLastError());
     }
@@ -802,6 +860,9 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     gg_default_config(&ctx->cfg);
     ctx->pos_x.assign(n_slots, 0.0);
     ctx->no_confidence.assign(n_slots, 0); // layers start as zeros, but only gg_reset_map makes a slot usable
+    ctx->fresh.assign(n_slots, 0);
+    ctx->fresh_z.assign(n_slots, 0.0f);
+    ctx->fresh_enabled = !(getenv("GG_FRESH_MAPS") && atoi(getenv("GG_FRESH_MAPS")) == 0);
     ctx->lazy_pending.assign(n_slots, 0);
     ctx->lazy_params.assign(n_slots, CloudParams{});
     ctx->pos_y.assign(n_slots, 0.0);
@@ -918,7 +979,11 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t percall_slot_floats = align_up((size_t)g.T * PERCALL_BLOCK * 4, A) / 4;
     const size_t o_layers = carve((size_t)n_slots * percall_slot_floats * 4);
     a.gpl = make_gp_layout(n);
-    a.gp2_stride = align_up((size_t)a.gpl.elems * 8, A) / 8;
+    // (a slot's written-cell bits -- FRESH maps, gg_internal.h -- live behind its layer: one buffer descriptor reaches both)
+    a.gp_bits_off = (int)align_up((size_t)a.gpl.elems, 16);
+    a.gp_bits_words = a.gpl.elems / 64 + 2;
+    a.gp2_stride = align_up(((size_t)a.gp_bits_off + (size_t)a.gp_bits_words) * 8, A) / 8;
+    a.gp_bits_stride = a.gp2_stride;
     const size_t o_gp2 = carve((size_t)n_slots * a.gp2_stride * 8);
     const size_t o_rec = carve((size_t)n_slots * Npad * 8);
     const size_t o_sorted = carve((size_t)n_slots * Npad * 8);
@@ -968,6 +1033,14 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_bounds = carve(64);
     const size_t gp_valid_words = ((size_t)a.gpl.elems + 31) / 32;
     const size_t o_gpvalid = carve(gp_valid_words * 4);
+    const size_t o_gpbits_border = carve(align_up((size_t)a.gp_bits_words * 8, A));
+    std::vector<int> gp_border; // the cells no sweep visits: ring >= c
+    for (int col = 0; col < n; ++col)
+        for (int row = 0; row < n; ++row)
+            if (std::max(std::abs(row - a.gpl.c), std::abs(col - a.gpl.c)) >= a.gpl.c) gp_border.push_back(gp_index(a.gpl, row, col));
+    a.gp_border_n = (int)gp_border.size();
+    const size_t o_gpborder = carve(std::max<size_t>(gp_border.size() * 4, 64));
+    a.gp_fresh_cell = 1 + (a.gpl.VS - 1) * 64; // side 0, group 0, the last sheared position of ring 1: beyond the map's last column
     const size_t o_dbg = carve(64 * 8); // sweep timing
     const size_t o_pdbg = carve(2048 * 8); // pair sweep timing
     const bool k2_timing = getenv("GG_K2_DEBUG") && (atoi(getenv("GG_K2_DEBUG")) == 9 || atoi(getenv("GG_K2_DEBUG")) == 5 || atoi(getenv("GG_K2_DEBUG")) == 6);
@@ -984,6 +1057,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.rank_cell0 = (const uint32_t *)(base + o_rcell0);
     a.layers = (float *)(base + o_layers);
     a.gp2 = (float2 *)(base + o_gp2);
+    a.gp_bits = (unsigned long long *)(base + o_gp2) + a.gp_bits_off;
     a.slot_layer_stride = percall_slot_floats;
     a.rec = (uint2 *)(base + o_rec);
     a.sorted = (uint2 *)(base + o_sorted);
@@ -1044,6 +1118,20 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_image = (float *)(base + o_image);
     ctx->d_bounds = (float *)(base + o_bounds);
     a.gp_valid = (const uint32_t *)(base + o_gpvalid);
+    a.gp_bits_border = (const unsigned long long *)(base + o_gpbits_border);
+    a.gp_border = (const int *)(base + o_gpborder);
+    {
+        std::vector<unsigned long long> tmpl((size_t)a.gp_bits_words, 0ull);
+        for (int e : gp_border) tmpl[(size_t)(e - 1) >> 6] |= 1ull << ((e - 1) & 63);
+        int row, col;
+        if (gp_cell_of(a.gpl, a.gp_fresh_cell, row, col)) { // (cannot happen: sheared position VS - 1 of ring 1 is column n + 125)
+            gg_destroy(ctx);
+            return GG_ERR_INVALID;
+        }
+        CREATE_CHK(hipMemcpyAsync(base + o_gpbits_border, tmpl.data(), tmpl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        CREATE_CHK(hipMemcpyAsync(base + o_gpborder, gp_border.data(), gp_border.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        CREATE_CHK(hipStreamSynchronize(ctx->stream)); // (the vectors go out of scope)
+    }
     if (getenv("GG_SWEEP_TIMING")) {
         ctx->d_sweep_dbg = (unsigned long long *)(base + o_dbg);
         const unsigned long long mode = getenv("GG_SWEEP_DEBUG") ? strtoull(getenv("GG_SWEEP_DEBUG"), nullptr, 0) : 0ull;
@@ -1340,6 +1428,7 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
     if (n == 0) return GG_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const hipStream_t st = pick_stream(ctx, stream);
+    for (int s = first_slot; s < first_slot + n; ++s) ctx->fresh[s] = 0; // (whatever they were: rewritten now)
     // GG_FLAG_CONCURRENT_HALVES: on a caller stream the maps of the upper half of the slots are re-initialised on the side stream, where
     // their batches run -- the caller's stream never has to wait for the second half of the batch before
     const int boundary = (ctx->n_slots + 1) / 2;
@@ -1369,7 +1458,13 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
             // these are GroundGrid's initial values, not filter_cloud's per-call reset values: the next cloud rewrites every tile
             launch_fill_bytes((uint8_t *)(a.tile_live + (size_t)first * a.tile_live_stride), (size_t)count * a.tile_live_stride * 4, 0xFF, on);
         }
-        launch_fill2_strided(gp2_ptr(a, first), (size_t)a.gpl.elems, a.gp2_stride, count, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], a.gp_valid, on);
+        if (ctx->fresh_enabled) { // the interior stays unwritten: the next batch's sweep rewrites it anyway (make_real() for everybody else)
+            static const bool probe_all = getenv("GG_FRESH_MAPS") && atoi(getenv("GG_FRESH_MAPS")) == 2; // (measurement: every cell written AND marked)
+            if (probe_all) launch_fill2_strided(gp2_ptr(a, first), (size_t)a.gpl.elems, a.gp2_stride, count, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], a.gp_valid, on);
+            launch_reset_fresh(a, first, count, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], on, probe_all ? 1 : 0);
+            for (int s = first; s < first + count; ++s) ctx->fresh[s] = 1, ctx->fresh_z[s] = odom_z;
+        } else
+            launch_fill2_strided(gp2_ptr(a, first), (size_t)a.gpl.elems, a.gp2_stride, count, init[GG_LAYER_GROUND], init[GG_LAYER_GROUNDPATCH], a.gp_valid, on);
     };
     if (split) {
         if (!ctx->probe_no_fork) {
@@ -2283,6 +2378,7 @@ int gg_insert_cloud(gg_context *ctx, int slot, const gg_point32 *cloud, size_t s
     hp[0].pos_x = ctx->pos_x[slot];
     hp[0].pos_y = ctx->pos_y[slot];
     hp[0].no_confidence = ctx->no_confidence[slot] ? 1 : 0;
+    hp[0].fresh = 0;
     HIPCHK(ctx, hipMemcpyAsync(dp, hp, sizeof(CloudParams), hipMemcpyHostToDevice, s));
     BatchIO io{};
     io.d_points = ctx->d_stage_pts;
@@ -2326,6 +2422,7 @@ extern "C" int gg_debug_set_tuning(gg_context *ctx, const char *key, int value)
     else if (!strcmp(key, "sweep_pair")) ctx->arena.tune_sweep_pair = value;
     else if (!strcmp(key, "sweep_pair_wgs")) ctx->arena.tune_sweep_pair_wgs = value;
     else if (!strcmp(key, "sweep_pair_waves")) ctx->arena.tune_sweep_pair_waves = value;
+    else if (!strcmp(key, "fresh_maps")) ctx->fresh_enabled = value != 0;
     else if (!strcmp(key, "front")) ctx->arena.tune_front = std::min(value, 3);
     else if (!strcmp(key, "sweep_poll_cap")) ctx->arena.tune_sweep_poll_cap = value;
     else if (!strcmp(key, "scan_parts")) ctx->arena.tune_scan_parts = value;

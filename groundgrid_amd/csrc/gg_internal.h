@@ -80,6 +80,8 @@ struct CloudParams {
     float base_z;   // (float)translation.z
     double pos_x, pos_y;
     int has_tf;     // points are in the sensor frame: p_map = (float)(R p + t) first (src/GroundGridNodelet.cpp:166-181)
+    int fresh;      // the slot's (ground, confidence) layer holds the reset values by DEFINITION -- only its never-swept border, Arena::gp_fresh_cell
+                    // and what k_patch writes in this call (Arena::gp_bits) are in memory; the sweep of this call makes the layer real
     int no_confidence; // the slot's groundpatch layer is known to hold nothing above 0.01 (fresh or only scrolled since
                     // gg_reset_map): the line-of-sight test (:269 needs groundpatch(I) > 0.01f) cannot fire, K1 skips the walks
     double tf[12];  // map <- cloud frame, 3x4 row-major (R | t)
@@ -107,6 +109,15 @@ struct Arena {
     float *layers;  size_t slot_layer_stride;  // the nine per-call layers of slot s, TILE BY TILE (percall_block below): layers + s*slot_layer_stride
     const uint32_t *gp_valid;     // one bit per element of the gp2 order: does gg_reset_maps fill it (the 128-byte lines that hold cells; the rest is padding)
     float2 *gp2;    size_t gp2_stride;    GpLayout gpl;              // (ground, confidence) of slot s: gp2 + s*gp2_stride, element order gp_layout.h
+    // FRESH maps (gg_reset_maps did not write the interior: CloudParams::fresh).  gp_bits: per slot one bit per element of the gp2 order, bit
+    // (e - 1) of the slot's words -- a wave-step of k_sweep (64 consecutive elements from 1 + 64 k) is ONE 64-bit word; zeroed by the reset,
+    // set by k_patch for the cells it writes.  gp_fresh_cell: a padding element that holds the reset values (ground = odom_z, confidence
+    // = 1e-7): where a fresh map's unwritten cells are read from
+    unsigned long long *gp_bits;  size_t gp_bits_stride;  int gp_fresh_cell;
+    int gp_bits_off, gp_bits_words;           // the bits of a slot sit behind its layer: 8-byte element gp_bits_off of the slot's gp2 region (gp_bits = gp2 + that)
+    const unsigned long long *gp_bits_border; // [gp_bits_stride] the bits of the cells no sweep visits (ring >= c)
+    const int *gp_border;  int gp_border_n;   // ... and their elements
+    int fresh_launch;                         // this launch's maps are all fresh (CloudParams::fresh): k_sweep's FRESH variant
     uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
     float *zcell;   size_t zcell_stride;  // per slot: the KEPT heights grouped by cell (K2's stable cell sort), Nmax + 32 T + 64
     uint32_t *hist;        size_t hist_stride;   // NCH * hist_pitch
@@ -294,6 +305,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
 void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s,
                   unsigned long long *dbg = nullptr); // k4_sweep.hip; dbg: 16 x 4 cycle counters of cloud 0's wavefronts (tools)
 bool launch_sweep_pair(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4p_sweep_pair.hip; false: not this launch
+bool sweep_takes_fresh(const Arena &a, const sweep::Params &P, int n_clouds); // k4_sweep.hip: would launch_sweep run the plain k_sweep (one work-group per cloud, no split steps)?
 bool launch_sweep_pair_batch(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4b_sweep_pair_batch.hip; false: not this launch
 size_t sweep_pair_rec_floats(const sweep::Params &P); // scratch floats per cloud of a launch (0: the geometry cannot take the pair sweep)
 constexpr int SWEEP_PAIR_MAX_CLOUDS = 16;              // launches of more clouds keep k_sweep
@@ -307,6 +319,7 @@ void launch_fill_percall(const Arena &a, int first_slot, int n_slots, const floa
 void launch_layer_insert(const Arena &a, int slot, int layer, const float *src, hipStream_t s);    // dense column-major plane -> per-call layer (all columns live)
 void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float x, float y, const uint32_t *valid, hipStream_t s);
 void launch_fill2(float2 *dst, size_t n, float x, float y, hipStream_t s);
+void launch_reset_fresh(const Arena &a, int first_slot, int count, float x, float y, hipStream_t s, int all_ones = 0); // k1_classify.hip k_reset_fresh
 void launch_plane_extract(const Arena &a, int slot, int comp, float *dst, hipStream_t s); // sheared layer -> column-major plane
 void launch_plane_insert(const Arena &a, int slot, int comp, const float *src, hipStream_t s);
 void launch_layer_extract(const Arena &a, int slot, int layer, float *dst, hipStream_t s);

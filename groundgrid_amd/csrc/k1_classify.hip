@@ -591,6 +591,26 @@ void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float
     hipLaunchKernelGGL(k_fill2_strided, dim3(blocks, count), dim3(256), 0, s, dst, n, stride, x, y, valid);
 }
 
+// gg_reset_maps for maps that stay FRESH (gg_internal.h Arena::gp_bits): the interior of the (ground, confidence) layer is not written --
+// the next batch's sweep rewrites every cell of rings 1 .. c - 1 and reads the reset's pair from ONE padding element instead --; what is
+// written are the cells the sweep never visits (ring >= c: row 0 and the last rows, column 0 and the last columns; Arena::gp_border
+// lists their elements), the padding element, and the written-cell bits: a copy of the template that has the border's bits set.
+__global__ __launch_bounds__(256) void k_reset_fresh(const Arena a, int first_slot, float x, float y, int all_ones)
+{
+    const int slot = first_slot + (int)blockIdx.y;
+    float2 *gp2 = gp2_ptr(a, slot);
+    unsigned long long *bits = a.gp_bits + (size_t)slot * a.gp_bits_stride;
+    const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x), nt = (int)(gridDim.x * blockDim.x);
+    for (int w = tid; w < a.gp_bits_words; w += nt) bits[w] = all_ones ? ~0ull : a.gp_bits_border[w]; // (all_ones: measurements, GG_FRESH_MAPS=2)
+    for (int k = tid; k < a.gp_border_n; k += nt) gp2[a.gp_border[k]] = make_float2(x, y);
+    if (tid == 0) gp2[a.gp_fresh_cell] = make_float2(x, y);
+}
+void launch_reset_fresh(const Arena &a, int first_slot, int count, float x, float y, hipStream_t s, int all_ones)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_reset_fresh, dim3(count >= 64 ? 12 : 24, count), dim3(256), 0, s, a, first_slot, x, y, all_ones);
+}
+
 __global__ void k_fill_bytes(uint8_t *dst, size_t n, uint8_t v)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;

@@ -111,7 +111,8 @@ GG_DEV void patch_sums(const Arena &a, const float (*pts)[LR], const float (*var
 }
 
 // second half (:360-393): the decision against the old cell, one block later
-GG_DEV void detect_ground_patch_b(const Arena &a, const PatchCarry &pc, float2 *gp2)
+// bits: the fresh map's written-cell bits (Arena::gp_bits of the slot), or null
+GG_DEV void detect_ground_patch_b(const Arena &a, const PatchCarry &pc, float2 *gp2, unsigned long long *bits)
 {
     if (!pc.live) return;
     const DevConfig &cfg = a.cfg;
@@ -133,6 +134,11 @@ GG_DEV void detect_ground_patch_b(const Arena &a, const PatchCarry &pc, float2 *
         gp2[pc.gidx] = make_float2(G, Cf);
     } else if (pc.localmin < oldGroundheight) { // :389
         gp2[pc.gidx] = make_float2(pc.localmin, std_min(oldConfidence + 0.1f, 0.5f)); // :391, :393
+    } else
+        return;
+    if (bits) { // (the centre cell, element 0, is the sweep's own: :405-411 overwrite it)
+        const unsigned e = (unsigned)pc.gidx - 1u;
+        if (pc.gidx > 0) __hip_atomic_fetch_or(bits + (e >> 6), 1ull << (e & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -209,6 +215,10 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
     const float *gp_var = L + percall_index(0, PL_VARIANCE, 0);
     const float *gp_min = L + percall_index(0, PL_MINGROUNDHEIGHT, 0);
     float2 *gp2 = gp2_ptr(a, cp.slot);
+    // a FRESH map: every cell's old (ground, confidence) is the reset's pair -- read from the one padding element that holds it --, and the
+    // cells written here are marked for the sweep, which reads nothing else of the layer
+    const bool fresh = !STAGE && (cp.fresh != 0 || GG_DEBUG_SWITCH(a, k3_debug) == 7);
+    unsigned long long *bits = fresh ? a.gp_bits + (size_t)cp.slot * a.gp_bits_stride : nullptr;
 
     // staging registers: LC columns x LR rows = 12 x 9 QUADS of four rows, the three layers of one quad per thread (threads
     // 0 .. 107): a tile's block of a layer holds a column's 16 rows contiguously and the window starts at a tile row, so a quad
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         req_cols = nb == b + 1 ? PC : LC;
         request(nb, req_first, req_cols);
         __syncthreads();
-        detect_ground_patch_b(a, consume, gp2); // the previous block's cell: its old (ground, confidence) has arrived meanwhile
+        detect_ground_patch_b(a, consume, gp2, bits); // the previous block's cell: its old (ground, confidence) has arrived meanwhile
         consume.live = false;
 
         const int base = (PC * b) & (RING - 1); // 0, 8, 16 or 24: the window is slots base .. base + LC - 1
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         // :364-365 (count and threshold are integer-valued floats: the comparison is the reference's binary64 one)
         const bool pass = !(pointsblockSum < threshold) && GG_DEBUG_SWITCH(a, k3_debug) != 3;
         produce.gidx = pass ? __float_as_int(cell_const.w) : 0; // the (ground, confidence) layer has its own element order (gp_layout.h)
-        produce.old = gp2[produce.gidx];           // :360-361, used one block later
+        produce.old = gp2[(cp.fresh != 0 && !STAGE) ? a.gp_fresh_cell : produce.gidx]; // :360-361, used one block later
         produce.live = pass;
         produce.S = S;
         produce.pointsblockSum = pointsblockSum;
@@ -346,8 +356,8 @@ __global__ __launch_bounds__(256) void k_patch(const Arena a, const CloudParams 
         if (b >= n_blocks) break;
         block_step(c1, c0);
     }
-    detect_ground_patch_b(a, c0, gp2);
-    detect_ground_patch_b(a, c1, gp2);
+    detect_ground_patch_b(a, c0, gp2, bits);
+    detect_ground_patch_b(a, c1, gp2, bits);
 }
 
 void launch_patch(const Arena &a, const CloudParams *d_params, int n_clouds, hipStream_t s)

@@ -131,6 +131,17 @@ template <bool DBG> struct DevMemT {
         return Cell{__uint_as_float(v.x), __uint_as_float(v.y)};
     }
     GG_DEV Cell load_value(const Cell &queued, bool, int) const { return queued; }
+    // FRESH maps (gg_internal.h Arena::gp_bits): is the cell's element in memory?  The slot's bit words lie behind its layer, inside the
+    // same buffer descriptor, from byte bits_byte0.  (Per-lane gather: the corner lanes' cells and the two cells of a chain that lie off its
+    // lines; the cells ON the lines are looked up a wave-step at a time, run_chain)
+    uint32_t bits_byte0 = 0u;
+    GG_DEV uint32_t bits_dword(uint32_t voffset, uint32_t soffset) const { return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0); }
+    GG_DEV bool bit_of(int cell) const
+    {
+        const unsigned e = (unsigned)cell - 1u;
+        const uint32_t w = bits_dword(bits_byte0 + (e >> 5) * 4u, 0u);
+        return cell <= 0 || ((w >> (e & 31u)) & 1u) != 0u; // (element 0, the centre cell, is written when the kernel starts)
+    }
     GG_DEV Cell fresh(const Cell &v) const
     {
         Cell o;
@@ -263,9 +274,10 @@ template <bool S, int B, int J> struct TripKind {
 };
 
 // SPLIT: a preparing wavefront (run_prep) does the layer half of every step (sweep_core.h "Split steps")
-template <int SIDE, bool DBG, bool SPLIT>
+template <int SIDE, bool DBG, bool SPLIT, bool FRESH = false>
 GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int wave_of_side, int lane, WaveClockT<DBG> &clk, int g0, int g1)
 {
+    static_assert(!(FRESH && SPLIT), "fresh maps: the plain chain only");
     ChainLane<SIDE> st;
     int have_prep = 0; // (split steps) cached count of prepared wave-steps
     // a counter only lane 0 writes: the other lanes write to their scratch words instead of being masked off (an exec-mask round trip
@@ -277,6 +289,27 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
         st.init(lane, r0, nl, group, P, L);
         const int t_first = group_first_step(), t_last = group_last_step<SIDE>(r0, nl);
         const int has_next = __builtin_amdgcn_readfirstlane(group + 1 < P.groups ? 1 : 0);
+        // FRESH: the requests of wave-step t name elements ownA + 64 (t + 1 + PF) and outA + 64 (t + 1 + PF): bit (X - 1) & 63 of word
+        // ((X - 1) >> 6) + t + 1 + PF of the slot's bit map (a wave-step of the own line is one word, gp_layout.h; of the outer line bits 1 .. 63
+        // of a word and, for lane 63, bit 0 of a word of the next storage group).  Each lane fetches the 32-bit half that holds its bit, two
+        // steps ahead and BEFORE that step's cell requests: loads return in order, and by then only cells the step needs anyway are older.
+        // (Measured per 1024 clouds, k_sweep 0.88 ms on written maps: this 0.98 ms; the words as scalar loads a step ahead, or 64 steps' words
+        // in one coalesced load and v_readlane per step -- lane masks in scalar registers either way -- 1.06 ms: scalar-register spills.)
+        uint32_t fo_own = 0u, fo_out = 0u, sh_own = 0u, sh_out = 0u, mq_own[2] = {0u, 0u}, mq_out[2] = {0u, 0u};
+        if constexpr (FRESH) {
+            const unsigned eo = (unsigned)st.ownA - 1u, eu = (unsigned)st.outA - 1u;
+            fo_own = mem.bits_byte0 + 8u * (unsigned)((int)(eo >> 6) + t_first + 1 + (int)PF) + 4u * ((eo & 63u) >> 5);
+            fo_out = mem.bits_byte0 + 8u * (unsigned)((int)(eu >> 6) + t_first + 1 + (int)PF) + 4u * ((eu & 63u) >> 5);
+            sh_own = eo & 31u;
+            sh_out = eu & 31u;
+            st.xold_bit = mem.bit_of(st.xold_cell);
+            st.end_bit = mem.bit_of(st.own_end);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                mq_own[k] = mem.bits_dword(fo_own, 8u * (unsigned)k);
+                mq_out[k] = mem.bits_dword(fo_out, 8u * (unsigned)k);
+            }
+        }
         // TRIP steps per trip, no per-step condition: a step past t_last finds every lane idle (no loads, no stores, nothing
         // to wait for), and without a conditional around it the queue registers of a slot never meet a control-flow join --
         // a join makes the compiler copy freshly loaded registers, i.e. wait for the loads it has just issued
@@ -375,6 +408,14 @@ GG_DEV void run_chain(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int w
                     if (AHEAD) rec_ahead = mem.ring_get(rec_word + (u + 1) * (int)LANES * (int)PREP_WORDS);
                     st.template take<STARTS, K::bnd>(t, tmod, rec, x_in, group > 0, mem);
                     mem.set_counter(w_take, step_no + 1 + AHEAD); // (after the reads above: the DS queue is in order)
+                } else if constexpr (FRESH) {
+                    static_assert((int)TRIP % 2 == 0, "the bit queue's slot is a constant of the unrolled trip");
+                    const uint32_t w_own = mq_own[u & 1], w_out = mq_out[u & 1]; // (requested two steps ago)
+                    const uint32_t ahead = 8u * (unsigned)(t + 2 - t_first);
+                    mq_own[u & 1] = mem.bits_dword(fo_own, ahead);
+                    mq_out[u & 1] = mem.bits_dword(fo_out, ahead);
+                    const bool own_bit = ((w_own >> sh_own) & 1u) != 0u, out_bit = ((w_out >> sh_out) & 1u) != 0u;
+                    st.template step_a<STARTS, K::bnd, true>(t, u % (int)PF, tmod, x_in, P, L, K::bnd == 3 ? trip_bnd : group > 0, mem, own_bit, out_bit);
                 } else {
                     st.template step_a<STARTS, K::bnd>(t, u % (int)PF, tmod, x_in, P, L, K::bnd == 3 ? trip_bnd : group > 0, mem);
                 }
@@ -439,7 +480,7 @@ template <int SIDE, bool DBG> GG_DEV void run_prep(const Params &P, const LdsMap
     }
 }
 
-template <int CD, bool DBG> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, WaveClockT<DBG> &clk, int g0, int g1)
+template <int CD, bool DBG, bool FRESH = false> GG_DEV void run_corner(const Params &P, const LdsMap &L, DevMemT<DBG> &mem, int lane, WaveClockT<DBG> &clk, int g0, int g1)
 {
     (void)clk;
     CornerRing<CD> st;
@@ -447,7 +488,7 @@ template <int CD, bool DBG> GG_DEV void run_corner(const Params &P, const LdsMap
         const int r0 = LANES * group + 1;
         const int nl = min(P.rings - (r0 - 1), (int)LANES);
         // prepare: 64 rings at once
-        st.issue(r0 + lane, P, mem);
+        st.template issue<FRESH>(r0 + lane, P, mem);
         st.finish(P, mem);
         // a part that does not start at the centre: the ring before its first one comes from another work-group (the importer
         // wavefront sets the counter once the two corner values of that ring are in this work-group's table)
@@ -591,7 +632,9 @@ template <bool DBG> GG_DEV void run_export(const Params &P, const LdsMap &L, Dev
 // per CU spills and is 1.6x slower at 1024 clouds per launch.)
 // PARTS: the launch cuts every cloud into several work-groups (tickets, importer / exporter wavefronts, the exchange region); the
 // throughput launches -- one work-group per cloud -- are compiled without any of that.
-template <bool DBG, bool PARTS>
+// FRESH: every map of the launch is fresh (gg_internal.h Arena::gp_bits; one work-group per cloud, no split steps): a variant of its own --
+// the work-groups of a throughput launch share the instruction cache, a kernel that carried both step codes was the slower one for both
+template <bool DBG, bool PARTS, bool FRESH = false>
 __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const CloudParams *__restrict__ params, int n_clouds, int n_parts_rt,
                                                    unsigned long long *dbg)
 {
@@ -675,10 +718,11 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     __syncthreads(); // the only barrier of the sweep
 
     DevMemT<DBG> mem;
-    mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, P.gl.elems * 8, 0x00020000);
+    mem.rsrc = __builtin_amdgcn_make_buffer_rsrc(gp2, 0, FRESH ? (a.gp_bits_off + a.gp_bits_words) * 8 : P.gl.elems * 8, 0x00020000); // (FRESH: the layer and its bit words)
     mem.lds = (lds_int *)lds;
     mem.xchg = a.sweep_xchg + (size_t)cp.slot * a.sweep_xchg_stride;
     mem.seq = epoch;
+    if (FRESH) mem.bits_byte0 = (uint32_t)a.gp_bits_off * 8u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const int W = P.waves_per_side;
     WaveClockT<DBG> clk;
@@ -690,7 +734,7 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
     // a work-group go to the CU's four SIMDs round-robin, so ids 4 w + side put them on four different SIMDs (with the sides'
     // wavefronts numbered consecutively, A_w and C_w shared one SIMD and B_w and D_w another while two SIMDs idled)
     const int side = wave & 3, w_of_side = wave >> 2;
-    if (P.split_steps) { // one ring group per work-group: wavefronts 0..3 chains, 4..7 their preparing wavefronts, 8 / 9 corners, 10 importer, 11 exporter
+    if (!FRESH && P.split_steps) { // one ring group per work-group: wavefronts 0..3 chains, 4..7 their preparing wavefronts, 8 / 9 corners, 10 importer, 11 exporter
         if (wave < 4) {
             if (side == SIDE_A) run_chain<SIDE_A, DBG, true>(P, L, mem, 0, lane, clk, g0, g1);
             else if (side == SIDE_B) run_chain<SIDE_B, DBG, true>(P, L, mem, 0, lane, clk, g0, g1);
@@ -710,17 +754,17 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
         } else if (PARTS && g1 < P.groups)
             run_export<DBG>(P, L, mem, lane, g1);
     } else if (wave < 4 * W && side == SIDE_A)
-        run_chain<SIDE_A, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
+        run_chain<SIDE_A, DBG, false, FRESH>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W && side == SIDE_B)
-        run_chain<SIDE_B, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
+        run_chain<SIDE_B, DBG, false, FRESH>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W && side == SIDE_C)
-        run_chain<SIDE_C, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
+        run_chain<SIDE_C, DBG, false, FRESH>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave < 4 * W)
-        run_chain<SIDE_D, DBG, false>(P, L, mem, w_of_side, lane, clk, g0, g1);
+        run_chain<SIDE_D, DBG, false, FRESH>(P, L, mem, w_of_side, lane, clk, g0, g1);
     else if (wave == 4 * W)
-        run_corner<0, DBG>(P, L, mem, lane, clk, g0, g1);
+        run_corner<0, DBG, FRESH>(P, L, mem, lane, clk, g0, g1);
     else if (wave == 4 * W + 1)
-        run_corner<1, DBG>(P, L, mem, lane, clk, g0, g1);
+        run_corner<1, DBG, FRESH>(P, L, mem, lane, clk, g0, g1);
     else if (PARTS && wave == 4 * W + 2) {
         if (part > 0) run_import<DBG>(P, L, mem, lane, g0);
     } else if (PARTS && g1 < P.groups)
@@ -752,6 +796,22 @@ static size_t parts_lds_bytes(const Params &P, int gpw, bool split = false)
 // what gg_create checks: the sweep must fit in LDS at least when every work-group takes a single ring group per side
 size_t sweep_lds_bytes(const Params &P) { return parts_lds_bytes(P, 1); }
 size_t sweep_xchg_entries(const Params &P) { return (size_t)xchg_entries(P.groups); }
+
+// Would launch_sweep give this launch the plain k_sweep -- one work-group per cloud, no split steps, nothing forced?  (What a launch of FRESH
+// maps needs, gg_internal.h Arena::gp_bits: decided before k_patch runs.)
+bool sweep_takes_fresh(const Arena &a, const Params &P_in, int n_clouds)
+{
+    if (P_in.rings <= 0 || n_clouds <= SWEEP_PAIR_MAX_CLOUDS || a.tune_sweep_gpw || a.tune_sweep_split == 1 || a.tune_sweep_fault || a.tune_sweep_pair == 4) return false;
+    // (launch_sweep's shape, below)
+    Params P = P_in;
+    const int n_groups = std::max(P.groups, 1);
+    int n_parts = std::max(1, std::min(n_groups, SWEEP_LATENCY_MAX_CLOUDS / std::max(n_clouds, 1)));
+    P.gpw = (n_groups + n_parts - 1) / n_parts;
+    while (P.gpw > 1 && parts_lds_bytes(P, P.gpw) > 158 * 1024) --P.gpw;
+    n_parts = (n_groups + P.gpw - 1) / P.gpw;
+    const bool split = P.gpw == 1 && a.tune_sweep_split != 2 && n_clouds * n_parts <= SWEEP_LATENCY_MAX_CLOUDS && parts_lds_bytes(P, 1, true) <= 158 * 1024;
+    return n_parts == 1 && !split;
+}
 
 void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_params, int n_clouds, hipStream_t s, unsigned long long *dbg)
 {
@@ -800,12 +860,16 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
             hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
             hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
             hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         });
+    P.fresh_cell = a.gp_fresh_cell;
     P.poll_cap = a.tune_sweep_poll_cap > 0 ? a.tune_sweep_poll_cap : 1 << 22; // (x ~0.2 us: about a second)
     P.debug_fault = a.tune_sweep_fault;
     const int threads = P.split_steps ? 12 * 64 : (4 * P.waves_per_side + 2 + (n_parts > 1 ? 2 : 0)) * 64; // (+ importer and exporter)
     if (dbg) // (GG_SWEEP_TIMING: the instrumented twin)
         hipLaunchKernelGGL((k_sweep<true, true>), dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
+    else if (a.fresh_launch && n_parts == 1 && !P.split_steps)
+        hipLaunchKernelGGL((k_sweep<false, false, true>), dim3(n_clouds), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
     else if (n_parts > 1)
         hipLaunchKernelGGL((k_sweep<false, true>), dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
     else

@@ -83,6 +83,7 @@ struct Params {
     int waves_per_side;
     int gpw;    // ring groups per work-group ("part"); >= groups: one work-group sweeps the whole map (see "Parts" below)
     int split_steps; // 1: every chain wavefront has a PREPARING wavefront next to it (see "Split steps"; needs gpw == 1)
+    int fresh_cell; // FRESH maps (gg_internal.h Arena::gp_bits): the layer element that holds the reset's (ground, confidence)
     int r2min;  // the confidence decay (:463-464) applies to cell (x, y) iff (x-c)^2 + (y-c)^2 >= r2min (host-computed, exact)
     double decrease, inv_decrease;
     int decay_fast;
@@ -461,6 +462,7 @@ template <int SIDE> struct ChainLane {
     // handed from the first half of a step to the second
     WP xa, cs0, cs1, cpred;
     float w_new_;
+    bool xold_bit = true, end_bit = true; // FRESH maps: are the two cells off the lines (xold_cell, own_end) in memory
 
     SW_HD void init(int lane, int r0, int nl, int group, const Params &P, const LdsMap &L)
     {
@@ -540,8 +542,11 @@ template <int SIDE> struct ChainLane {
     //                    step outside a range that its trip touches reads a value no lane selects, and publishes from no active lane)
     // (1 = test per step).  A range test is seven scalar instructions and a taken branch, the blocks meet the step at control-flow
     // joins that cost register copies, and a lone wavefront pays ~5 cycles for an instruction of any kind.
-    template <bool STARTS = true, int BND = 1, class Mem>
-    SW_HD void step_a(int t, int slot, int tmod, WP x_in, const Params &P, const LdsMap &L, bool has_prev_group, Mem &mem)
+    // FRESH (device only; gg_internal.h Arena::gp_bits): the map's layer holds the reset's pair by definition, only the cells marked in the
+    // bit map are in memory -- own_bit / out_bit say so for the cells this step REQUESTS on the own and the outer line; the others are read
+    // from P.fresh_cell, the one element that holds the reset's pair
+    template <bool STARTS = true, int BND = 1, bool FRESH = false, class Mem>
+    SW_HD void step_a(int t, int slot, int tmod, WP x_in, const Params &P, const LdsMap &L, bool has_prev_group, Mem &mem, bool own_bit = true, bool out_bit = true)
     {
         (void)L;
         // ---- the visited cell's new confidence depends on its old one only (its rare exact path is the step's only branch
@@ -575,8 +580,15 @@ template <int SIDE> struct ChainLane {
         const int own_colq = ownA + 64 * (t + 1 + PF);
         int own_req = (int)uq == len + 1 ? own_end : own_colq; // (two selects on ready values: no branch)
         own_req = uq == 0u ? xold_cell : own_req;
+        int out_req = outA + 64 * (t + 1 + PF);
+        if (FRESH) {
+            bool ob = (int)uq == len + 1 ? end_bit : own_bit;
+            ob = uq == 0u ? xold_bit : ob;
+            own_req = ob ? own_req : P.fresh_cell;
+            out_req = out_bit ? out_req : P.fresh_cell;
+        }
         q_own[slot] = mem.load_issue(colq, own_req);
-        q_out[slot] = mem.load_issue(colq, outA + 64 * (t + 1 + PF));
+        q_out[slot] = mem.load_issue(colq, out_req);
         // ---- advance the window
         Sg = Ng;
         Sw = Nw;
@@ -792,12 +804,16 @@ template <int CD> struct CornerRing {
     }
 
     // ---- prepare, part 1: request the ring's old cells
-    template <class Mem> SW_HD void issue(int ring, const Params &P, Mem &mem)
+    template <bool FRESH = false, class Mem> SW_HD void issue(int ring, const Params &P, Mem &mem)
     {
         live = ring <= P.rings;
         r = live ? ring : P.rings; // (idle lanes keep valid addresses)
         for (int a = -1; a <= 1; ++a)
-            for (int b = -2; b <= 1; ++b) q[a + 1][b + 2] = mem.load_issue(live && is_old(r, a, b), cell_at(P, r, a, b));
+            for (int b = -2; b <= 1; ++b) {
+                int cell = cell_at(P, r, a, b);
+                if constexpr (FRESH) cell = mem.bit_of(cell) ? cell : P.fresh_cell; // (a FRESH map: step_a)
+                q[a + 1][b + 2] = mem.load_issue(live && is_old(r, a, b), cell);
+            }
         e00 = cell_at(P, r, 0, 0);
         e0m1 = cell_at(P, r, 0, -1);
     }

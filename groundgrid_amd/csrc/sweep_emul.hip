@@ -385,6 +385,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
     P.poll_cap = 1 << 22;
     P.debug_fault = 0;
     P.keep_points = 0;
+    P.fresh_cell = 0;
     P.gpw = P.groups > 1 ? P.groups : 1; // one work-group unless the launcher (or the emulation's GG_SWEEP_GPW) cuts the map into parts
     if (getenv("GG_SWEEP_WAVES")) P.waves_per_side = std::max(1, std::min(std::min(P.groups, 3), atoi(getenv("GG_SWEEP_WAVES")))); // (the host emulation: tests/test_sweep_emul_cpu.py)
     // :463 (pow((float)x - center, 2.0) + pow((float)y - center, 2.0)) * pow(resolution, 2.0f) > minDistSquared: the left side is a

@@ -1398,6 +1398,123 @@ def test_throughput_pair_sweep_shapes(length, resolution, batch, waves):
     seg.close()
 
 
+def _reset_persistent(ref, odom_z):
+    """gg_reset_maps(persistent_only) on the oracle's map: the two layers that outlive a cloud take GroundGrid.cpp:71-75's values."""
+    ref.set_layer("ground", np.full((ref.rows, ref.cols), np.float32(odom_z)))
+    ref.set_layer("groundpatch", np.full((ref.rows, ref.cols), np.float32(0.0000001)))
+
+
+def _fresh_batch(length, resolution, batch, n_az, halves=False):
+    """batch maps, three calls: on fresh maps (the reset left their interior unwritten), on the maps that call left (warm), and after a
+    second reset (persistent state only, another height) -- labels of every cloud, all layers of some, against the oracle."""
+    import torch
+
+    clouds = _rotated_clouds(batch, length, n_az=n_az)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
+    if halves:
+        seg.set_flags(concurrent_halves=True)
+    refs = [oracle.OracleMap(length, resolution, odom_z=0.25) for _ in clouds]
+    seg.reset_maps(odom_z=0.25)
+    pts = _batch_inputs(16, clouds, stride)
+    out = None
+    watched = sorted({0, 1, batch // 2 - 1, batch // 2, batch - 1})
+    for call in range(3):
+        if call == 2:
+            seg.reset_maps(odom_z=-0.5, persistent_only=True, on_torch_stream=True)
+            for r in refs:
+                _reset_persistent(r, -0.5)
+        out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((batch, 3), np.float32), np.full(batch, -1.73 + 0.01 * call), out=out)
+        if halves:
+            seg.batch_fence()
+        torch.cuda.synchronize()
+        labels = out.labels.cpu().numpy()
+        for b, c in enumerate(clouds):
+            r = refs[b].filter_cloud(c, ORIGIN0, -1.73 + 0.01 * call)
+            assert np.array_equal(labels[b, : len(c)], r["label"]), (call, b)
+            if b in watched:
+                assert_same_state(seg.map(b), refs[b], f"call {call} cloud {b}")
+    seg.close()
+
+
+@pytest.mark.parametrize("length,resolution,batch,n_az", [(22.0, 0.33, 260, 60), (61.0, 0.25, 258, 100), (61.0, 0.25, 130, 100), (120.0, 0.33, 257, 120)])
+def test_fresh_maps_are_swept_as_they_are(length, resolution, batch, n_az):
+    """gg_reset_maps leaves the interior of the (ground, confidence) layer unwritten (only the never-swept border, one padding element with
+    the reset's pair and the written-cell bits); a batch of such maps that is large enough for one work-group per cloud (more than 256, or
+    more than 128 on maps of several ring groups) runs k_patch and k_sweep in their FRESH variants: one ring group (66 x 66), two
+    (244 x 244) and three with a partial last one (364 x 364)."""
+    _fresh_batch(length, resolution, batch, n_az)
+
+
+def test_fresh_maps_in_concurrent_halves():
+    _fresh_batch(22.0, 0.33, 520, 60, halves=True)
+
+
+def test_fresh_maps_read_or_mixed_with_warm_ones_are_filled_first():
+    """Anything but a large all-fresh launch fills a fresh map before touching it: the getters return the reset's values, a launch that
+    mixes fresh and warm maps sees both right, and so does a single cloud."""
+    import torch
+
+    length, resolution, batch = 22.0, 0.33, 260
+    clouds = _rotated_clouds(batch, length, n_az=60)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
+    refs = [oracle.OracleMap(length, resolution, odom_z=0.125) for _ in clouds]
+    seg.reset_maps(odom_z=0.125)
+    g = seg.map(3)["ground"]
+    assert np.all(g == np.float32(0.125)) and np.all(seg.map(3)["groundpatch"] == np.float32(0.0000001))
+    assert_same_state(seg.map(batch - 1), refs[batch - 1], "fresh, never filtered")
+    pts = _batch_inputs(16, clouds, stride)
+    n = [len(c) for c in clouds]
+    zero = np.zeros((batch, 3), np.float32)
+    out = seg.filter_batch(pts, n, zero, np.full(batch, -1.73))
+    torch.cuda.synchronize()
+    for b, c in enumerate(clouds):
+        refs[b].filter_cloud(c, ORIGIN0, -1.73)
+    # every second pair of maps re-initialised: the next launch holds fresh and warm maps
+    for b in range(0, batch, 4):
+        seg.reset_maps(first_slot=b, n_slots=2, odom_z=-0.25, persistent_only=True, on_torch_stream=True)
+        _reset_persistent(refs[b], -0.25)
+        _reset_persistent(refs[b + 1], -0.25)
+    out = seg.filter_batch(pts, n, zero, np.full(batch, -1.7), out=out)
+    torch.cuda.synchronize()
+    labels = out.labels.cpu().numpy()
+    for b, c in enumerate(clouds):
+        r = refs[b].filter_cloud(c, ORIGIN0, -1.7)
+        assert np.array_equal(labels[b, : len(c)], r["label"]), b
+    for b in (0, 1, 2, 3, batch - 1):
+        assert_same_state(seg.map(b), refs[b], f"mixed launch, cloud {b}")
+    # a single cloud on a fresh map
+    seg.reset_maps(first_slot=5, n_slots=1, odom_z=0.5)
+    ref = oracle.OracleMap(length, resolution, odom_z=0.5)
+    _, labels1, _ = seg.filter_cloud(clouds[5], ORIGIN0, -1.73, map=seg.map(5), return_details=True)
+    assert np.array_equal(labels1, ref.filter_cloud(clouds[5], ORIGIN0, -1.73)["label"])
+    assert_same_state(seg.map(5), ref, "single cloud on a fresh map")
+    seg.close()
+
+
+def test_fresh_maps_switched_off_write_every_cell():
+    """tuning fresh_maps = 0: gg_reset_maps fills the layer as before; the results are the same."""
+    import torch
+
+    length, resolution, batch = 22.0, 0.33, 260
+    clouds = _rotated_clouds(batch, length, n_az=60)
+    stride = (max(len(c) for c in clouds) + 63) // 64 * 64
+    seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
+    seg.debug_set_tuning("fresh_maps", 0)
+    seg.reset_maps(odom_z=0.25)
+    pts = _batch_inputs(16, clouds, stride)
+    out = seg.filter_batch(pts, [len(c) for c in clouds], np.zeros((batch, 3), np.float32), np.full(batch, -1.73))
+    torch.cuda.synchronize()
+    labels = out.labels.cpu().numpy()
+    for b in (0, 7, batch - 1):
+        ref = oracle.OracleMap(length, resolution, odom_z=0.25)
+        r = ref.filter_cloud(clouds[b], ORIGIN0, -1.73)
+        assert np.array_equal(labels[b, : len(clouds[b])], r["label"]), b
+        assert_same_state(seg.map(b), ref, f"cloud {b}")
+    seg.close()
+
+
 def test_pair_sweep_and_k_sweep_leave_the_same_map():
     """The two sweeps are interchangeable launch by launch: a map swept alternately by either (the pair sweep switched off for every
     other frame) stays bit-identical to the oracle's."""
