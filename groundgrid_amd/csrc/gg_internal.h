@@ -305,7 +305,7 @@ Params make_params(int n, double resolution, float min_dist_squared, double decr
 void launch_sweep(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s,
                   unsigned long long *dbg = nullptr); // k4_sweep.hip; dbg: 16 x 4 cycle counters of cloud 0's wavefronts (tools)
 bool launch_sweep_pair(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4p_sweep_pair.hip; false: not this launch
-bool sweep_takes_fresh(const Arena &a, const sweep::Params &P, int n_clouds); // k4_sweep.hip: would launch_sweep run the plain k_sweep (one work-group per cloud, no split steps)?
+bool sweep_takes_fresh(const Arena &a, const sweep::Params &P, int n_clouds); // k4_sweep.hip: would launch_sweep run k_sweep without split steps (what a launch of fresh maps needs)?
 bool launch_sweep_pair_batch(const Arena &a, const sweep::Params &P, const CloudParams *d_params, int n_clouds, hipStream_t s); // k4b_sweep_pair_batch.hip; false: not this launch
 size_t sweep_pair_rec_floats(const sweep::Params &P); // scratch floats per cloud of a launch (0: the geometry cannot take the pair sweep)
 constexpr int SWEEP_PAIR_MAX_CLOUDS = 16;              // launches of more clouds keep k_sweep

@@ -632,7 +632,7 @@ template <bool DBG> GG_DEV void run_export(const Params &P, const LdsMap &L, Dev
 // per CU spills and is 1.6x slower at 1024 clouds per launch.)
 // PARTS: the launch cuts every cloud into several work-groups (tickets, importer / exporter wavefronts, the exchange region); the
 // throughput launches -- one work-group per cloud -- are compiled without any of that.
-// FRESH: every map of the launch is fresh (gg_internal.h Arena::gp_bits; one work-group per cloud, no split steps): a variant of its own --
+// FRESH: every map of the launch is fresh (gg_internal.h Arena::gp_bits; no split steps): a variant of its own --
 // the work-groups of a throughput launch share the instruction cache, a kernel that carried both step codes was the slower one for both
 template <bool DBG, bool PARTS, bool FRESH = false>
 __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P, const CloudParams *__restrict__ params, int n_clouds, int n_parts_rt,
@@ -810,7 +810,7 @@ bool sweep_takes_fresh(const Arena &a, const Params &P_in, int n_clouds)
     while (P.gpw > 1 && parts_lds_bytes(P, P.gpw) > 158 * 1024) --P.gpw;
     n_parts = (n_groups + P.gpw - 1) / P.gpw;
     const bool split = P.gpw == 1 && a.tune_sweep_split != 2 && n_clouds * n_parts <= SWEEP_LATENCY_MAX_CLOUDS && parts_lds_bytes(P, 1, true) <= 158 * 1024;
-    return n_parts == 1 && !split;
+    return !split; // (one work-group per cloud or several: the chains are the same)
 }
 
 void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_params, int n_clouds, hipStream_t s, unsigned long long *dbg)
@@ -861,6 +861,7 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
             hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
             hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
             hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         });
     P.fresh_cell = a.gp_fresh_cell;
     P.poll_cap = a.tune_sweep_poll_cap > 0 ? a.tune_sweep_poll_cap : 1 << 22; // (x ~0.2 us: about a second)
@@ -868,8 +869,10 @@ void launch_sweep(const Arena &a, const Params &P_in, const CloudParams *d_param
     const int threads = P.split_steps ? 12 * 64 : (4 * P.waves_per_side + 2 + (n_parts > 1 ? 2 : 0)) * 64; // (+ importer and exporter)
     if (dbg) // (GG_SWEEP_TIMING: the instrumented twin)
         hipLaunchKernelGGL((k_sweep<true, true>), dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
-    else if (a.fresh_launch && n_parts == 1 && !P.split_steps)
+    else if (a.fresh_launch && !P.split_steps && n_parts == 1)
         hipLaunchKernelGGL((k_sweep<false, false, true>), dim3(n_clouds), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
+    else if (a.fresh_launch && !P.split_steps)
+        hipLaunchKernelGGL((k_sweep<false, true, true>), dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
     else if (n_parts > 1)
         hipLaunchKernelGGL((k_sweep<false, true>), dim3(n_clouds * n_parts), dim3(threads), lds, s, a, P, d_params, n_clouds, n_parts, dbg);
     else

@@ -1437,12 +1437,12 @@ def _fresh_batch(length, resolution, batch, n_az, halves=False):
     seg.close()
 
 
-@pytest.mark.parametrize("length,resolution,batch,n_az", [(22.0, 0.33, 260, 60), (61.0, 0.25, 258, 100), (61.0, 0.25, 130, 100), (120.0, 0.33, 257, 120)])
+@pytest.mark.parametrize("length,resolution,batch,n_az", [(22.0, 0.33, 260, 60), (61.0, 0.25, 258, 100), (61.0, 0.25, 130, 100), (120.0, 0.33, 257, 120), (120.0, 0.33, 100, 120), (200.0, 0.2, 40, 200)])
 def test_fresh_maps_are_swept_as_they_are(length, resolution, batch, n_az):
     """gg_reset_maps leaves the interior of the (ground, confidence) layer unwritten (only the never-swept border, one padding element with
-    the reset's pair and the written-cell bits); a batch of such maps that is large enough for one work-group per cloud (more than 256, or
-    more than 128 on maps of several ring groups) runs k_patch and k_sweep in their FRESH variants: one ring group (66 x 66), two
-    (244 x 244) and three with a partial last one (364 x 364)."""
+    the reset's pair and the written-cell bits); a batch of such maps that k_sweep takes without split steps -- one work-group per cloud,
+    or several (364 x 364: 100 clouds in two parts each; 1000 x 1000: 40 clouds in three or four) -- runs k_patch and k_sweep in their
+    FRESH variants: one ring group (66 x 66), two (244 x 244), three with a partial last one (364 x 364), eight (1000 x 1000)."""
     _fresh_batch(length, resolution, batch, n_az)
 
 
