@@ -287,6 +287,9 @@ def main():
     ap.add_argument("--config4-batch", type=int, default=128, help="clouds per launch of the configs[3] leg (GPU-filling)")
     ap.add_argument("--abi-collective", action="store_true", help="all-gather through the C ABI (gg_allgather_label_masks, RCCL bound by the "
                     "library itself) instead of torch.distributed")
+    ap.add_argument("--gather", choices=["all", "config3-only"], default="all",
+                    help="N > 1: 'all' = every headline step ends with the all-gather of its label masks (overlapped with the next step); "
+                         "'config3-only' = the headline steps run without a collective (kernel scaling alone), only the configs[2] leg gathers")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (RCCL process group, all-gather per step) even with one rank")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the N ranks only (gloo when no GPU is visible): launch-path check")
     ap.add_argument("--only-config4", action="store_true", help="profiling runs: a token headline (8 clouds), then only the configs[3] leg")
@@ -395,8 +398,9 @@ def main():
         kernels; buffer i % 2 is reused only after its gather completed.  shifts[i] = how far the clouds were rotated over the
         slots in step i (cloud b -> slot (b + shift) mod nb)."""
 
-        def __init__(self, seg_, pts, npts, org, bz, cold, rotate=True, first_shift=0, within_halves=False):
+        def __init__(self, seg_, pts, npts, org, bz, cold, rotate=True, first_shift=0, within_halves=False, gather=True):
             self.seg, self.pts, self.npts, self.org, self.bz, self.cold = seg_, pts, npts, org, bz, cold
+            self.gather = gather and dist is not None  # (--gather config3-only: the headline's steps end without the collective)
             self.within_halves = within_halves  # the clouds rotate over the slots of their own half (a row of the outputs keeps its half)
             self.outs, self.pending, self.step_no, self.out = [None, None], [None, None], 0, None
             self.nb = nb = pts.shape[0]
@@ -404,8 +408,8 @@ def main():
             self.shift = first_shift
             self.shifts = []
             self.ids = np.arange(nb, dtype=np.int64)
-            self.gathered = [torch.empty((world * nb, pts.shape[1] // 4), dtype=torch.uint8, device=dev) for _ in range(2)] if dist else None
-            self.abi = StreamGather(AbiLabelGather(seg_, rank, world)) if (dist and args.abi_collective) else None
+            self.gathered = [torch.empty((world * nb, pts.shape[1] // 4), dtype=torch.uint8, device=dev) for _ in range(2)] if self.gather else None
+            self.abi = StreamGather(AbiLabelGather(seg_, rank, world)) if (self.gather and args.abi_collective) else None
 
         def slots_of(self, shift):
             if self.within_halves:
@@ -426,12 +430,12 @@ def main():
             if self.rotate:
                 self.shift = (self.shift + ROT) % self.nb
             self.shifts.append(self.shift)
-            self.outs[k] = self.seg.filter_batch(self.pts, self.npts, self.org, self.bz, out=self.outs[k], want_masks=dist is not None,
+            self.outs[k] = self.seg.filter_batch(self.pts, self.npts, self.org, self.bz, out=self.outs[k], want_masks=self.gather,
                                                  slots=self.slots_of(self.shift) if (self.rotate or self.shift) else None)
             self.out = self.outs[k]
             if self.abi:
                 self.pending[k] = self.abi(self.gathered[k], self.outs[k].label_masks)
-            elif dist:
+            elif self.gather:
                 self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.outs[k].label_masks, async_op=True)
             self.step_no += 1
 
@@ -495,7 +499,8 @@ def main():
         return ok, checked
 
     # ---------------------------------------------------------------- headline: cold maps, K timed steps
-    pipe = Pipeline(seg, points, n_points, origins, base_z, cold=True)
+    gather_headline = args.gather == "all"
+    pipe = Pipeline(seg, points, n_points, origins, base_z, cold=True, gather=gather_headline)
     elapsed, ktimes = pipe.timed(args.steps, args.warmup)
     total_clouds = world * B * args.steps
     value = total_clouds / elapsed
@@ -518,7 +523,8 @@ def main():
                         f"{B} independent (cloud, map-state) pairs per GPU per step, COLD maps (each step re-initialises the persistent "
                         "state of its maps -- ground 0, groundpatch 1e-7 -- inside the timed region, then filters)"
                         + ("" if args.no_rotate else f"; the clouds rotate over the map slots by {ROT} per step")
-                        + ("; + RCCL all-gather of the 2-bit label masks per step (configs[2])" if world > 1 else ""),
+                        + ("; + RCCL all-gather of the 2-bit label masks per step (configs[2])" if (world > 1 and gather_headline) else "")
+                        + ("; NO collective in these steps (--gather config3-only: the configs[2] leg carries it)" if (world > 1 and not gather_headline) else ""),
             "clouds_per_gpu_per_step": B,
             "points_per_cloud_mean": int(np.mean(n_points)),
             "grid": "364x364",
@@ -528,13 +534,14 @@ def main():
                       "gg_filter_batch's default: the eight layers the path reads or rewrites maintained per cloud; groundCandidates, planeDist, maxGroundHeight "
                       "(read by nothing on the path) computed on their first read -- every getter returns the reference's values at all times",
             "parallelism": f"clouds sharded {B}/GPU x {world} GPU, no data-path collective"
-                           + (", 1 all-gather of label masks per step overlapped with the next step" if world > 1 else ""),
+                           + (", 1 all-gather of label masks per step overlapped with the next step" if (world > 1 and gather_headline) else ""),
         },
     }
     if dist:
         result["collective"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
                                 "issued_by": "gg_allgather_label_masks (C ABI, RCCL bound by the library)" if args.abi_collective else "torch.distributed",
-                                "bytes_per_rank_per_step": int(B * stride // 4)}
+                                "bytes_per_rank_per_step": int(B * stride // 4), "bytes_received_per_rank_per_step": int((world - 1) * B * stride // 4),
+                                "in_headline_steps": bool(gather_headline)}
 
     rows, C = seg.rows, seg.rows * seg.rows
     T = ((rows + 15) // 16) ** 2

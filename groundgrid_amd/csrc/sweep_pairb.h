@@ -23,7 +23,10 @@ namespace gg {
 namespace sweep {
 namespace pair {
 
-enum { PFB = 2 }; // wave-steps a layer cell is requested ahead (other wavefronts hide the latency; the queue is 4 registers per step)
+#ifndef GG_PAIRB_PF
+#define GG_PAIRB_PF 2
+#endif
+enum { PFB = GG_PAIRB_PF }; // wave-steps a layer cell is requested ahead (the queue is 4 registers per step)
 
 // LDS image of one work-group (4-byte words): entries are (w, tag, p, tag) = 16 bytes -- each half one 8-byte unit that is written and read
 // whole, so a reader that finds both tags set has both values however the 16 bytes travel --, the corner table holds plain pairs
