@@ -654,9 +654,12 @@ int enqueue_batch(gg_context *ctx, const gg_batch *b, hipStream_t s, const Layer
             for (int i = lo; i < hi; ++i) hp[i].fresh = 1, ctx->fresh[hp[i].slot] = 0;
     }
     auto fill_fresh = [&](int lo, int hi, hipStream_t on) -> int { // (the stream is ordered behind the reset by now)
-        for (int i = lo; i < hi; ++i)
-            if (ctx->fresh[hp[i].slot])
-                if (const int rc = make_real(ctx, hp[i].slot, 1, on)) return rc;
+        for (int i = lo; i < hi;) { // one fill per run of consecutive slots (make_real cuts a run where the heights differ)
+            int e = i + 1;
+            while (e < hi && hp[e].slot == hp[e - 1].slot + 1) ++e;
+            if (const int rc = make_real(ctx, hp[i].slot, e - i, on)) return rc;
+            i = e;
+        }
         return GG_OK;
     };
     // order this batch after everything that touched map state on the context's stream, and after an earlier batch that ran

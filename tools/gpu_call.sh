@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm\|Hostname\|Librccl" | tail -6 | tee gpurun_out/tests.log
-timeout 1500 python bench.py > gpurun_out/bench_r06b.json 2> gpurun_out/bench_r06b.err; tail -c 2600 gpurun_out/bench_r06b.json; tail -3 gpurun_out/bench_r06b.err
+F='RCCL\|HIP version\|ROCm\|Hostname\|Librccl\|amdgpu'
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stages_wire.py -m gpu -x -q -k "fresh or halves or divided or batch" 2>&1 | grep -v "$F" | tail -5
+python bench.py --steps 6 --warmup 2 --no-live-pmc --drive-frames 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['config3']['clouds_per_s'], d['config3']['ms_per_step'], d['summary']['config4'])"
