@@ -57,6 +57,33 @@ def test_stand_ins_define_no_functions():
 
 
 def test_integration_doc_matches_the_code():
+    import glob
+    import json
+    import re
+
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "GG_SPIRAL_CAPS" not in doc and "GG_DEBUG_SCHEDULE" not in doc  # knobs of the retired level-scheduled sweep
     assert "GroundSegmentationHip.cpp" in doc and "base_plane" in doc  # ABI v2 move_map in the device-resident binding
+    # the default layer masks of the two bindings, as the code has them
+    core = open(os.path.join(ROOT, "groundgrid_amd", "host", "binding_core.hpp")).read()
+    shell = open(os.path.join(ROOT, "groundgrid_amd", "host", "ros", "GroundSegmentationHip.cpp")).read()
+    assert re.search(r"layers_from_env\(core->device_resident\(\) \? groundgrid_hip::LAYERS_STATE : groundgrid_hip::LAYERS_ALL\)", shell)
+    assert "LAYERS_STATE = (1u << GG_LAYER_GROUND) | (1u << GG_LAYER_GROUNDPATCH) | (1u << GG_LAYER_POINTS) | (1u << GG_LAYER_POINTSRAW)" in core
+    assert "Default `state` for a device-resident map" in doc and "`all` for a host-managed one" in doc
+    assert "`state` (ground, groundpatch, points, pointsRaw)" in doc
+    assert "Default `none`" not in doc
+    # entry points and flags of ABI v6 are named
+    header = open(os.path.join(ROOT, "include", "groundgrid_hip.h")).read()
+    for name in ("gg_insert_cloud", "GG_FLAG_EAGER_LAYERS", "GG_FLAG_CONCURRENT_HALVES", "GG_FLAG_MINIMAL_LAYERS", "gg_batch_fence"):
+        assert name in header and name in doc, name
+    # the quoted host_api figures are those of the last committed profile round
+    rounds = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default.json")))
+    assert rounds
+    last = rounds[-1]
+    line = json.loads(open(last).read().strip().splitlines()[-1])
+    api = line["host_api"]
+    assert os.path.basename(os.path.dirname(last)) in doc, "INTEGRATION.md names another profile round than the last committed one"
+    quoted = {"binding_like_ms": api["binding_like_ms"], "binding_like_two_calls_ms": api["binding_like_two_calls_ms"], "sync_ms": api["sync_ms"]}
+    for key, ms in quoted.items():
+        assert f"{ms:.2f}" in doc, (key, ms)
+    assert f"{api['binding_like_clouds_per_s']:.0f}" in doc and f"{api['device_resident_binding_clouds_per_s']:.0f}" in doc
