@@ -984,7 +984,7 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     a.gpl = make_gp_layout(n);
     // (a slot's written-cell bits -- FRESH maps, gg_internal.h -- live behind its layer: one buffer descriptor reaches both)
     a.gp_bits_off = (int)align_up((size_t)a.gpl.elems, 16);
-    a.gp_bits_words = a.gpl.elems / 64 + 2;
+    a.gp_bits_words = (a.gpl.elems / 64 + 2 + 1) & ~1; // (8-byte words; even: k_reset_fresh copies 16 bytes at a time)
     a.gp2_stride = align_up(((size_t)a.gp_bits_off + (size_t)a.gp_bits_words) * 8, A) / 8;
     a.gp_bits_stride = a.gp2_stride;
     const size_t o_gp2 = carve((size_t)n_slots * a.gp2_stride * 8);
@@ -1036,7 +1036,6 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     const size_t o_bounds = carve(64);
     const size_t gp_valid_words = ((size_t)a.gpl.elems + 31) / 32;
     const size_t o_gpvalid = carve(gp_valid_words * 4);
-    const size_t o_gpbits_border = carve(align_up((size_t)a.gp_bits_words * 8, A));
     std::vector<int> gp_border; // the cells no sweep visits: ring >= c
     for (int col = 0; col < n; ++col)
         for (int row = 0; row < n; ++row)
@@ -1121,17 +1120,13 @@ int gg_create(const gg_geometry *geom_in, int n_slots, size_t max_points, int de
     ctx->d_image = (float *)(base + o_image);
     ctx->d_bounds = (float *)(base + o_bounds);
     a.gp_valid = (const uint32_t *)(base + o_gpvalid);
-    a.gp_bits_border = (const unsigned long long *)(base + o_gpbits_border);
     a.gp_border = (const int *)(base + o_gpborder);
     {
-        std::vector<unsigned long long> tmpl((size_t)a.gp_bits_words, 0ull);
-        for (int e : gp_border) tmpl[(size_t)(e - 1) >> 6] |= 1ull << ((e - 1) & 63);
         int row, col;
         if (gp_cell_of(a.gpl, a.gp_fresh_cell, row, col)) { // (cannot happen: sheared position VS - 1 of ring 1 is column n + 125)
             gg_destroy(ctx);
             return GG_ERR_INVALID;
         }
-        CREATE_CHK(hipMemcpyAsync(base + o_gpbits_border, tmpl.data(), tmpl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         CREATE_CHK(hipMemcpyAsync(base + o_gpborder, gp_border.data(), gp_border.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         CREATE_CHK(hipStreamSynchronize(ctx->stream)); // (the vectors go out of scope)
     }

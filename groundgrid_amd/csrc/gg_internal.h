@@ -115,8 +115,7 @@ struct Arena {
     // = 1e-7): where a fresh map's unwritten cells are read from
     unsigned long long *gp_bits;  size_t gp_bits_stride;  int gp_fresh_cell;
     int gp_bits_off, gp_bits_words;           // the bits of a slot sit behind its layer: 8-byte element gp_bits_off of the slot's gp2 region (gp_bits = gp2 + that)
-    const unsigned long long *gp_bits_border; // [gp_bits_stride] the bits of the cells no sweep visits (ring >= c)
-    const int *gp_border;  int gp_border_n;   // ... and their elements
+    const int *gp_border;  int gp_border_n;   // the elements of the cells no sweep visits (ring >= c): k_sweep<FRESH> writes the reset's pair into them
     int fresh_launch;                         // this launch's maps are all fresh (CloudParams::fresh): k_sweep's FRESH variant
     uint2 *rec;     uint2 *sorted;  size_t point_stride;            // per slot Nmax
     float *zcell;   size_t zcell_stride;  // per slot: the KEPT heights grouped by cell (K2's stable cell sort), Nmax + 32 T + 64

@@ -591,24 +591,26 @@ void launch_fill2_strided(float2 *dst, size_t n, size_t stride, int count, float
     hipLaunchKernelGGL(k_fill2_strided, dim3(blocks, count), dim3(256), 0, s, dst, n, stride, x, y, valid);
 }
 
-// gg_reset_maps for maps that stay FRESH (gg_internal.h Arena::gp_bits): the interior of the (ground, confidence) layer is not written --
-// the next batch's sweep rewrites every cell of rings 1 .. c - 1 and reads the reset's pair from ONE padding element instead --; what is
-// written are the cells the sweep never visits (ring >= c: row 0 and the last rows, column 0 and the last columns; Arena::gp_border
-// lists their elements), the padding element, and the written-cell bits: a copy of the template that has the border's bits set.
+// gg_reset_maps for maps that stay FRESH (gg_internal.h Arena::gp_bits): the (ground, confidence) layer is not written at all -- the next
+// batch's sweep rewrites every cell of rings 1 .. c - 1, reads the reset's pair from ONE padding element instead, and writes the cells no
+// sweep visits (ring >= c) itself while it runs (k_sweep<FRESH>, Arena::gp_border).  What is written here: that padding element and the
+// slot's written-cell bits, all 0.  (Writing the 2.2 k border cells of every map here -- each in a 128-byte line of its own -- took
+// 0.04 of this kernel's 0.05 ms per 1024 maps.)
 __global__ __launch_bounds__(256) void k_reset_fresh(const Arena a, int first_slot, float x, float y, int all_ones)
 {
     const int slot = first_slot + (int)blockIdx.y;
     float2 *gp2 = gp2_ptr(a, slot);
-    unsigned long long *bits = a.gp_bits + (size_t)slot * a.gp_bits_stride;
+    // (the slot's bit words are 16-byte aligned and a multiple of 16 bytes long: gg_create)
+    uint4 *bits = reinterpret_cast<uint4 *>(a.gp_bits + (size_t)slot * a.gp_bits_stride);
     const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x), nt = (int)(gridDim.x * blockDim.x);
-    for (int w = tid; w < a.gp_bits_words; w += nt) bits[w] = all_ones ? ~0ull : a.gp_bits_border[w]; // (all_ones: measurements, GG_FRESH_MAPS=2)
-    for (int k = tid; k < a.gp_border_n; k += nt) gp2[a.gp_border[k]] = make_float2(x, y);
+    const uint32_t v = all_ones ? ~0u : 0u; // (all_ones: measurements, GG_FRESH_MAPS=2 -- every cell written by a fill AND marked)
+    for (int w = tid; w < a.gp_bits_words / 2; w += nt) bits[w] = make_uint4(v, v, v, v);
     if (tid == 0) gp2[a.gp_fresh_cell] = make_float2(x, y);
 }
 void launch_reset_fresh(const Arena &a, int first_slot, int count, float x, float y, hipStream_t s, int all_ones)
 {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_reset_fresh, dim3(count >= 64 ? 12 : 24, count), dim3(256), 0, s, a, first_slot, x, y, all_ones);
+    hipLaunchKernelGGL(k_reset_fresh, dim3(count >= 64 ? 2 : 12, count), dim3(256), 0, s, a, first_slot, x, y, all_ones);
 }
 
 __global__ void k_fill_bytes(uint8_t *dst, size_t n, uint8_t v)

@@ -698,6 +698,18 @@ __global__ __launch_bounds__(1024, 5) void k_sweep(const Arena a, const Params P
             f[L.join + 2 * (side * P.c + 0) + 1] = centre.p;
         }
     }
+    // FRESH maps: the cells no sweep visits (ring >= c) were not written by the reset either: unless k_patch has written them (maps with an
+    // odd number of rows: its quadrant loops reach one line into ring c, :325-328) they take the reset's pair now, from the padding element
+    // that holds it.  (Nobody reads these before the launch ends: where the bit is 0 the sweep reads the padding element.)
+    if (FRESH) {
+        const float2 init = gp2[a.gp_fresh_cell];
+        const unsigned long long *bw = a.gp_bits + (size_t)cp.slot * a.gp_bits_stride;
+        for (int k = (int)threadIdx.x + part * nthreads; k < a.gp_border_n; k += nthreads * n_parts) {
+            const int e = a.gp_border[k];
+            const unsigned q = (unsigned)e - 1u;
+            if (((bw[q >> 6] >> (q & 63u)) & 1ull) == 0ull) gp2[e] = init;
+        }
+    }
     // :147 map["points"].setConstant(0.0) -- K3 was the last reader of the KEPT counts; K5 re-counts non-ground points.  Only the
     // half columns of tiles that received records hold anything but 0 (K2's tile_live invariant): one wavefront per such tile, 4 cells
     // per lane

@@ -201,8 +201,8 @@ int gg_reset_map(gg_context *ctx, int slot, double pos_x, double pos_y, float od
  * fills there, ordered like a batch on that stream -- a server that re-initialises maps between batches on its own stream
  * then has no cross-stream hand-over in its loop.
  * Fresh maps (ABI v6, nothing to do for the caller): the (ground, groundpatch) layer of a re-initialised map is not written cell by cell
- * -- the library notes that it holds the reset's values, writes the border no terrain sweep visits, and a large gg_filter_batch of such
- * maps sweeps them as they are (0.05 instead of 0.35 ms per 1024 maps of 364 x 364); every other entry point that reads or edits the
+ * -- the library notes that it holds the reset's values, and a large gg_filter_batch of such maps sweeps them as they are (0.01 instead
+ * of 0.35 ms per 1024 maps of 364 x 364); every other entry point that reads or edits the
  * layer (getters, setters, gg_move_map, the stage calls, single clouds, small or mixed batches) fills it first.  Every getter returns
  * the values above at all times.  Environment GG_FRESH_MAPS=0: write every cell, as before. */
 int gg_reset_maps(gg_context *ctx, int first_slot, int n_slots, double pos_x, double pos_y, float odom_z, int persistent_only, void *stream);
