@@ -308,11 +308,13 @@ int make_real(gg_context *ctx, int first, int n, hipStream_t st)
     return GG_OK;
 }
 
-int own_stream_waits_for_batches(gg_context *ctx)
+// (maps_real = false: the caller touches no layer -- a re-initialisation leaves the other maps as they are)
+int own_stream_waits_for_batches(gg_context *ctx, bool maps_real = true)
 {
     if (ctx->have_batch_event && ctx->last_batch_stream != ctx->stream)
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_event, 0));
     if (const int rc = stream_waits_for_second_half(ctx, ctx->stream)) return rc;
+    if (!maps_real) return GG_OK;
     // whatever the context's own stream does next with map state (getters, setters, scrolls, stages, single clouds) finds real layers
     bool any = false;
     for (int s = 0; s < ctx->n_slots && !any; ++s) any = ctx->fresh[s] != 0;
@@ -1432,7 +1434,7 @@ int gg_reset_maps(gg_context *ctx, int first_slot, int n, double pos_x, double p
     const int boundary = (ctx->n_slots + 1) / 2;
     const bool split = halves_enabled(ctx) && st != ctx->stream && st != ctx->half_stream && st != nullptr && first_slot < boundary && first_slot + n > boundary;
     if (st == ctx->stream) {
-        if (const int rc = own_stream_waits_for_batches(ctx)) return rc;
+        if (const int rc = own_stream_waits_for_batches(ctx, false)) return rc;
     } else { // ordered like a batch on the caller's stream
         if (ctx->map_event_pending) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->map_event, 0));
         if (ctx->have_batch_event && ctx->last_batch_stream != st && !ctx->probe_unordered_streams) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->batch_event, 0));
