@@ -20,6 +20,8 @@ using namespace gg::sweep;
 
 struct HostMem { // one per emulated work-group ("part"): its own LDS, the layer and the exchange region shared with the others
     Cell *gp2;
+    const std::vector<uint64_t> *bits = nullptr; // FRESH maps (gg_internal.h Arena::gp_bits): bit e - 1 = element e is in memory; null: a written map
+    bool bit_of(int cell) const { return cell <= 0 || (((*bits)[(size_t)(cell - 1) >> 6] >> ((cell - 1) & 63)) & 1ull) != 0ull; }
     std::vector<int32_t> lds;
     bool late;
     long loads = 0, stores = 0, lds_ops = 0;
@@ -140,6 +142,11 @@ template <int SIDE> struct ChainWave : WaveBase {
                 if (c.outA + 64 * (c.l3 + j - k0) != side_cell<SIDE>(P, c.r, 1, j)) plan_mismatch = true;
             if (l > 0 && l < nl && c.len > 0 && lane[l - 1].len > 0 && c.ownA != lane[l - 1].ownA + 1) plan_mismatch = true; // one wave-step = 64 consecutive elements
         }
+        if (mem.bits)
+            for (int l = 0; l < LANES; ++l) {
+                lane[l].xold_bit = mem.bit_of(lane[l].xold_cell);
+                lane[l].end_bit = mem.bit_of(lane[l].own_end);
+            }
         t = group_first_step();
         t_last = group_last_step<SIDE>(r0, nl);
         t_last += (TRIP - (t_last - t + 1) % TRIP) % TRIP; // the device runs whole trips of TRIP steps
@@ -179,6 +186,12 @@ template <int SIDE> struct ChainWave : WaveBase {
                 for (int l = 0; l < LANES; ++l)
                     lane[l].take(t, tmod, mem.ring_get(L.prep + ((SIDE * PREP_DEPTH + (step_no % PREP_DEPTH)) * LANES + l) * PREP_WORDS), x_in[l], group > 0, mem);
                 mem.set_counter(L.take_done + SIDE, step_no + 1);
+            } else if (mem.bits) { // a FRESH map (k4_sweep.hip run_chain<FRESH>): the bits of the two cells this step REQUESTS on its lines
+                for (int l = 0; l < LANES; ++l) {
+                    const int eo = lane[l].ownA + 64 * (t + 1 + (int)PF), eu = lane[l].outA + 64 * (t + 1 + (int)PF);
+                    const bool in_o = eo >= 1 && eo < P.gl.elems, in_u = eu >= 1 && eu < P.gl.elems; // (outside: requests of idle steps)
+                    lane[l].template step_a<true, 1, true>(t, slot, tmod, x_in[l], P, L, group > 0, mem, in_o && mem.bit_of(eo), in_u && mem.bit_of(eu));
+                }
             } else {
                 for (int l = 0; l < LANES; ++l) lane[l].step_a(t, slot, tmod, x_in[l], P, L, group > 0, mem);
             }
@@ -223,7 +236,10 @@ template <int CD> struct CornerWave : WaveBase {
         const int l = (r - 1) % LANES, r0 = r - l;
         if (!prepared) { // like the device: the whole group's old cells, requested and consumed at the start of the group
             if (g0 > 0 && r0 == LANES * g0 + 1 && mem.counter(L.corner_done + CD) < r0 - 1) return false; // the importer has not delivered the ring before the part yet
-            for (int k = 0; k < LANES; ++k) lane[k].issue(r0 + k, P, mem);
+            for (int k = 0; k < LANES; ++k) {
+                if (mem.bits) lane[k].template issue<true>(r0 + k, P, mem);
+                else lane[k].issue(r0 + k, P, mem);
+            }
             for (int k = 0; k < LANES; ++k) lane[k].finish(P, mem);
             const int prev = L.corner + 2 * ((CD * P.c + r0 - 1) * 2);
             in_corner = mem.get(prev + 2);
@@ -440,11 +456,14 @@ extern "C" long gg_debug_sweep_sync_selftest(int n)
     return sync_mismatches<SIDE_A>(P) + sync_mismatches<SIDE_B>(P) + sync_mismatches<SIDE_C>(P) + sync_mismatches<SIDE_D>(P);
 }
 
-extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z, double decrease,
-                                           unsigned seed, int late_loads, long *stats)
+// patched (nullable): a FRESH map (gg_internal.h Arena::gp_bits) -- n x n bytes, column-major like gp2: which cells are in memory (what k_patch
+// wrote); every other cell holds (fresh_ground, 1e-7) by definition, and its memory is POISON (NaN): a read of it spoils the result
+static int emulate_ring_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z, double decrease, unsigned seed, int late_loads, long *stats,
+                              const unsigned char *patched, float fresh_ground)
 {
     if (n < 8 || !gp2) return GG_ERR_INVALID;
     Params P = gg::sweep::make_params(n, resolution, min_dist_squared, decrease);
+    P.fresh_cell = 1 + (P.gl.VS - 1) * 64; // (gg_create: a padding element)
     if (getenv("GG_SWEEP_GPW")) { // emulate the multi-work-group sweep (sweep_core.h "Parts")
         P.gpw = std::max(1, std::min(atoi(getenv("GG_SWEEP_GPW")), std::max(P.groups, 1)));
         P.waves_per_side = std::max(1, std::min(P.waves_per_side, P.gpw));
@@ -455,6 +474,24 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
     std::vector<Cell> sheared((size_t)P.gl.elems, Cell{0.f, 0.f});
     for (int col = 0; col < n; ++col)
         for (int row = 0; row < n; ++row) sheared[(size_t)gp_index(P.gl, row, col)] = Cell{gp2[2 * ((size_t)row + (size_t)col * n)], gp2[2 * ((size_t)row + (size_t)col * n) + 1]};
+    std::vector<uint64_t> bits;
+    if (patched) {
+        if (late_loads) return GG_ERR_INVALID; // (the late-load check re-reads a request's CELL, not the element the fresh step asked for)
+        bits.assign((size_t)P.gl.elems / 64 + 2, 0ull);
+        const float poison = __builtin_nanf("");
+        for (int col = 0; col < n; ++col)
+            for (int row = 0; row < n; ++row) {
+                const int e = gp_index(P.gl, row, col);
+                if (patched[(size_t)row + (size_t)col * n] && e > 0) bits[(size_t)(e - 1) >> 6] |= 1ull << ((e - 1) & 63);
+                else sheared[(size_t)e] = Cell{poison, poison};
+            }
+        sheared[(size_t)P.fresh_cell] = Cell{fresh_ground, (float)0.0000001};
+        // k_sweep<FRESH>'s first lines: the cells no sweep visits take the reset's pair unless they are marked
+        for (int col = 0; col < n; ++col)
+            for (int row = 0; row < n; ++row)
+                if (std::max(std::abs(row - P.c), std::abs(col - P.c)) >= P.c && !patched[(size_t)row + (size_t)col * n])
+                    sheared[(size_t)gp_index(P.gl, row, col)] = sheared[(size_t)P.fresh_cell];
+    }
     std::vector<uint64_t> xchg(2 * (size_t)std::max(xchg_entries(P.groups), 1), 0ull);
     std::vector<LdsMap> maps((size_t)n_parts);
     std::vector<HostMem> mems((size_t)n_parts);
@@ -470,6 +507,7 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
         L = lds_layout(P.c, P.groups, g0, g1, P.split_steps != 0);
         lds_words = std::max(lds_words, (size_t)L.words);
         mem.gp2 = sheared.data();
+        mem.bits = patched ? &bits : nullptr;
         mem.lds.assign((size_t)L.words, 0);
         mem.late = late_loads != 0;
         mem.xchg = &xchg;
@@ -560,6 +598,20 @@ extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_d
             gp2[2 * ((size_t)row + (size_t)col * n) + 1] = v.w;
         }
     return rc;
+}
+
+extern "C" int gg_debug_emulate_ring_sweep(int n, double resolution, float min_dist_squared, float *gp2, float base_z, double decrease,
+                                           unsigned seed, int late_loads, long *stats)
+{
+    return emulate_ring_sweep(n, resolution, min_dist_squared, gp2, base_z, decrease, seed, late_loads, stats, nullptr, 0.0f);
+}
+// the same on a FRESH map: gp2 holds the values of the cells marked in `patched` (anything elsewhere: those cells are (fresh_ground, 1e-7) by
+// definition and their memory is poisoned); on return every cell is real
+extern "C" int gg_debug_emulate_ring_sweep_fresh(int n, double resolution, float min_dist_squared, float *gp2, const unsigned char *patched, float fresh_ground, float base_z,
+                                                 double decrease, unsigned seed, long *stats)
+{
+    if (!patched) return GG_ERR_INVALID;
+    return emulate_ring_sweep(n, resolution, min_dist_squared, gp2, base_z, decrease, seed, 0, stats, patched, fresh_ground);
 }
 
 // =====================================================================================================================

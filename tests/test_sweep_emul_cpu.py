@@ -148,3 +148,52 @@ def test_one_compare_wait_test_is_the_inverse_of_the_closed_form_needs(lib, n):
     lib.gg_debug_sweep_sync_selftest.restype = C.c_long
     lib.gg_debug_sweep_sync_selftest.argtypes = [C.c_int]
     assert lib.gg_debug_sweep_sync_selftest(n) == 0
+
+
+# ---------------------------------------------------------------- FRESH maps (k4_sweep.hip run_chain<FRESH>, sweep_core.h step_a<.., FRESH>)
+
+def emulate_fresh(L, n, resolution, ground, conf, patched, fresh_ground, base_z, decrease, seed, min_dist_sq=12.0):
+    L.gg_debug_emulate_ring_sweep_fresh.restype = C.c_int
+    L.gg_debug_emulate_ring_sweep_fresh.argtypes = [C.c_int, C.c_double, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_double, C.c_uint, C.POINTER(C.c_long)]
+    gp2 = np.empty((n * n, 2), dtype=np.float32)
+    gp2[:, 0] = ground.ravel(order="F")
+    gp2[:, 1] = conf.ravel(order="F")
+    mask = np.ascontiguousarray(patched.astype(np.uint8).ravel(order="F"))
+    stats = (C.c_long * 8)()
+    rc = L.gg_debug_emulate_ring_sweep_fresh(n, resolution, min_dist_sq, gp2.ctypes.data, mask.ctypes.data, fresh_ground, base_z, decrease, seed, stats)
+    assert rc == 0, f"deadlock (-10) or a plan fault (-11): {rc}"
+    return gp2[:, 0].reshape((n, n), order="F"), gp2[:, 1].reshape((n, n), order="F"), list(stats)
+
+
+@pytest.mark.parametrize("length,resolution", [(4.0, 0.33), (10.0, 0.5), (22.0, 0.33), (23.0, 0.33), (43.0, 0.33), (61.0, 0.25), (120.0, 0.33), (150.0, 0.25)])
+def test_fresh_map_sweep_reads_only_marked_cells(lib, length, resolution):
+    """A FRESH map (gg_reset_maps wrote no cell): only the cells k_patch marked are in memory, every other cell holds the reset's pair by
+    definition and the emulation POISONS its memory (NaN).  The sweep -- chains and corner lanes -- must take marked cells from memory and
+    everything else from the one padding element, never the poison; the cells no sweep visits (ring >= c) come out real as well, with the
+    reset's pair unless they are marked (an odd number of rows: the patch loops reach one line into that ring).  Result = the oracle's
+    serial sweep of the layer as defined, bit for bit; even and odd sizes, one to four ring groups."""
+    ref = oracle.OracleMap(length, resolution)
+    n = ref.layer("ground").shape[0]
+    rng = np.random.default_rng(1000 + n)
+    fresh_ground = np.float32(rng.uniform(-0.5, 0.5))
+    ground, conf = random_state(n, n + 1)
+    # what k_patch may have written: rows and columns 2 .. n - 3, in clusters
+    patched = np.zeros((n, n), dtype=bool)
+    for _ in range(max(3, n // 6)):
+        r0, c0 = rng.integers(2, n - 2, size=2)
+        h, w = rng.integers(1, max(2, n // 4), size=2)
+        patched[r0:min(r0 + h, n - 2), c0:min(c0 + w, n - 2)] = True
+    patched &= rng.random((n, n)) < 0.8
+    patched[:2, :] = patched[n - 2:, :] = False
+    patched[:, :2] = patched[:, n - 2:] = False
+    defined_g = np.where(patched, ground, fresh_ground).astype(np.float32)
+    defined_w = np.where(patched, conf, np.float32(0.0000001)).astype(np.float32)
+    decrease = float(ref.cfg.occupied_cells_decrease_factor)
+    ref.set_layer("ground", defined_g)
+    ref.set_layer("groundpatch", defined_w)
+    ref.stage_spiral(-1.73)
+    for seed in ((0, 1, 2, 3) if n <= 400 else (0, 5)):
+        g, w, _ = emulate_fresh(lib, n, ref.resolution, ground, conf, patched, float(fresh_ground), -1.73, decrease, seed)
+        assert not np.isnan(g).any() and not np.isnan(w).any(), (seed, "poison came through", np.argwhere(np.isnan(g))[:5].tolist())
+        assert np.array_equal(g, ref.layer("ground")), (seed, np.argwhere(g != ref.layer("ground"))[:5].tolist())
+        assert np.array_equal(w, ref.layer("groundpatch")), seed

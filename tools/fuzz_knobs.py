@@ -14,7 +14,10 @@ bad = 0
 for seed in range(first, last):
     rng = np.random.default_rng(5000 + seed)
     knobs = {"pw": int(rng.choice([0, 64, 256, 1024, 2048])), "front": int(rng.choice([1, 2, 3])), "scan_parts": int(rng.choice([0, 2, 5, 16])),
-             "sweep_gpw": int(rng.choice([0, 1, 2])), "minimal": bool(rng.integers(0, 2)), "k2_per_cloud": int(rng.choice([0, 16, 64]))}
+             "sweep_gpw": int(rng.choice([0, 1, 2])), "minimal": bool(rng.integers(0, 2)), "k2_per_cloud": int(rng.choice([0, 16, 64])),
+             # round 6: which sweep takes the (single-cloud) launch -- the pair sweep (0; with sweep_gpw set: k_sweep), k_sweep (2), the throughput
+             # pair sweep (4) -- and the pair sweeps' shapes
+             "sweep_pair": int(rng.choice([0, 0, 2, 4])), "sweep_pair_wgs": int(rng.choice([0, 1])), "sweep_pair_waves": int(rng.choice([0, 1, 2, 3]))}
     length, resolution = [(20.0, 0.2), (40.0, 0.33), (64.0, 0.33), (120.0, 0.33), (150.0, 0.25), (200.0, 0.2)][int(rng.integers(0, 6))]
     parts = []
     for k in range(int(rng.integers(3, 8))):
@@ -32,7 +35,7 @@ for seed in range(first, last):
         os.environ.pop("GG_PW", None)
     try:
         seg = api.GroundSegmentation().init(length, resolution, n_slots=1, max_points=len(cloud))
-        for key in ("front", "scan_parts", "sweep_gpw", "k2_per_cloud"):
+        for key in ("front", "scan_parts", "sweep_gpw", "k2_per_cloud", "sweep_pair", "sweep_pair_wgs", "sweep_pair_waves"):
             if knobs[key]:
                 seg.debug_set_tuning(key, knobs[key])
         seg.set_flags(minimal_layers=knobs["minimal"])

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
 F='RCCL\|HIP version\|ROCm\|Hostname\|Librccl\|amdgpu'
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stages_wire.py -m gpu -x -q -k "fresh or halves or divided or batch" 2>&1 | grep -v "$F" | tail -5
-python bench.py --steps 6 --warmup 2 --no-live-pmc --drive-frames 0 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['config3']['clouds_per_s'], d['config3']['ms_per_step'], d['summary']['config4'])"
+timeout 2400 python tools/fuzz_fresh.py 400 2400 2>&1 | grep -v "$F" > gpurun_out/r06_fuzz_fresh_2.log; tail -2 gpurun_out/r06_fuzz_fresh_2.log
+timeout 2400 python tools/fuzz_knobs.py 400 2000 2>&1 | grep -v "$F" > gpurun_out/r06_fuzz_knobs_2.log; tail -2 gpurun_out/r06_fuzz_knobs_2.log
+timeout 2400 python tools/fuzz_more.py 600 3000 2>&1 | grep -v "$F" > gpurun_out/r06_fuzz_more_2.log; tail -2 gpurun_out/r06_fuzz_more_2.log
+timeout 1200 python tools/fuzz_walk.py 0 300 2>&1 | grep -v "$F" > gpurun_out/r06_fuzz_walk.log; tail -2 gpurun_out/r06_fuzz_walk.log
