@@ -32,8 +32,13 @@ for seed in range(first, last):
     stride = (max(len(c) for c in clouds) + 63) // 64 * 64
     try:
         seg = api.GroundSegmentation().init(length, resolution, n_slots=batch, max_points=stride)
-        if rng.integers(0, 2):
-            seg.set_flags(concurrent_halves=True)
+        halves, eager = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        seg.set_flags(concurrent_halves=halves, eager_layers=eager)
+        knobs = {"sweep_waves": int(rng.choice([0, 1, 2, 3])), "front": int(rng.choice([0, 1, 2, 3])), "scan_parts": int(rng.choice([0, 2, 5])),
+                 "halves_min_clouds": int(rng.choice([0, 64, 200]))}
+        for key, value in knobs.items():
+            if value:
+                seg.debug_set_tuning(key, value)
         host = np.zeros((batch, stride), dtype=api.POINT16_DTYPE)
         for b, c in enumerate(clouds):
             host[b, : len(c)] = api.pack16(c)
@@ -73,4 +78,8 @@ for seed in range(first, last):
     except Exception as e:
         bad += 1
         print("seed", seed, (length, resolution, batch), "FAILED:", str(e)[:300], flush=True)
+        try:
+            print("   knobs", halves, eager, knobs, flush=True)
+        except NameError:
+            pass
 print("done, failures:", bad)
